@@ -1,0 +1,44 @@
+"""Shared builders for tests: model configs, synthetic state_dicts, deterministic noise."""
+import functools
+
+import torch
+
+from moleculediffusiontransformer_amd.netspec import (forward_unet_config, inverse_unet_config,
+                                                      unet_manifest)
+from moleculediffusiontransformer_amd.synth import synth_normal, synth_state_dict
+from oracle import unet_oracle as O
+
+# name -> (kind, wrapper kwargs)
+CASES = {
+    "cfg1": ("inverse", dict(max_length=64, pred_dim=16, channels=64, context_embedding_max_length=12)),
+    "cfg3": ("forward", dict(max_length=64, pred_dim=1, channels=64, context_embedding_max_length=64)),
+    "tiny": ("inverse", dict(max_length=32, pred_dim=16, channels=16, context_embedding_max_length=12)),
+    "pd22": ("inverse", dict(max_length=32, pred_dim=22, channels=32, context_embedding_max_length=12)),
+}
+
+
+def oracle_cfg(case):
+    kind, kw = CASES[case]
+    f = O.inverse_config if kind == "inverse" else O.forward_config
+    return f(kw["max_length"], kw["channels"], kw["pred_dim"], kw["context_embedding_max_length"])
+
+
+@functools.lru_cache(maxsize=None)
+def synth_sd(case):
+    """Reference-format state_dict (canonical 'unet.' prefix + fc1 + p_enc_1d) with synthetic weights."""
+    kind, kw = CASES[case]
+    mk = inverse_unet_config if kind == "inverse" else forward_unet_config
+    ucfg = mk(kw["pred_dim"], kw["channels"], 128, kw["context_embedding_max_length"])
+    keys = [("fc1.weight", (64, 1)), ("fc1.bias", (64,)), ("p_enc_1d.inv_freq", (32,))]
+    keys += unet_manifest(ucfg, "unet.")
+    return synth_state_dict(keys)
+
+
+def noise_fns(tag, shape):
+    """(init_noise, step_noise(i, x)) reproducing tests/golden/make_golden.py's NoiseInjector order."""
+    init = synth_normal(f"{tag}/draw0", shape)
+    return init, (lambda i, x: synth_normal(f"{tag}/draw{i + 1}", tuple(x.shape)))
+
+
+def to_t(a):
+    return torch.from_numpy(a)

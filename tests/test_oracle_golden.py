@@ -1,0 +1,98 @@
+"""Pins oracle/unet_oracle.py against golden vectors produced by the real reference."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from helpers import CASES, noise_fns, oracle_cfg, synth_sd, to_t
+from oracle import unet_oracle as O
+
+TOL = 2e-6   # oracle and reference issue the same ATen ops; observed difference is exactly 0
+
+
+@pytest.mark.parametrize("case", ["cfg1", "cfg3", "tiny", "pd22"])
+def test_unet_eval_matches_reference(case):
+    g = load_golden(f"{case}_unet.npz")
+    sd, cfg = synth_sd(case), oracle_cfg(case)
+    with torch.no_grad():
+        emb = O.cond_embed(sd, cfg, to_t(g["seq"]))
+        assert (emb - to_t(g["emb"])).abs().max() <= TOL
+        mp = O.time_mapping(sd, "unet.", to_t(g["t"]))
+        assert (mp - to_t(g["mapping"])).abs().max() <= TOL
+        taps = {}
+        y = O.unet_forward(sd, cfg, to_t(g["x"]), to_t(g["t"]), emb, taps=taps)
+        assert (y - to_t(g["y_scale1"])).abs().max() <= TOL
+        y = O.unet_cfg_forward(sd, cfg, to_t(g["x"]), to_t(g["t"]), emb, 7.5)
+        assert (y - to_t(g["y_scale7p5"])).abs().max() <= 4 * TOL
+        d = O.denoise(sd, cfg, to_t(g["x"]) * 2.5, torch.tensor(2.5), emb, 1.0)
+        assert (d - to_t(g["denoise_sigma2p5"])).abs().max() <= TOL
+        for ours, theirs in (("to_in", "out:to_in"), ("down0", "out:downsamples.0"),
+                             ("down1", "out:downsamples.1"), ("bottleneck", "out:bottleneck"),
+                             ("up0", "out:upsamples.0"), ("up1", "out:upsamples.1")):
+            if theirs in g:
+                assert (taps[ours] - to_t(g[theirs])).abs().max() <= TOL, ours
+
+
+@pytest.mark.parametrize("name,case,want", [
+    ("cfg1_b4_t64", "cfg1", (1, 2, 32, 63)),
+    ("cfg1_b2_t12_cfg7p5", "cfg1", ()),
+    ("cfg3_b2_t10", "cfg3", ()),
+    ("tiny_b3_t8", "tiny", (1, 7)),
+    ("tiny_b3_t8_cfg2", "tiny", ()),
+    ("pd22_b2_t6", "pd22", ()),
+])
+def test_sample_matches_reference(name, case, want):
+    g = load_golden(f"{name}_sample.npz")
+    sd, cfg = synth_sd(case), oracle_cfg(case)
+    out_ref = to_t(g["out"])
+    init, step = noise_fns(name, tuple(out_ref.shape))
+    trace = {"want": want}
+    out = O.sample(sd, cfg, to_t(g["seq"]), init, step, int(g["timesteps"]), float(g["cond_scale"]),
+                   False, trace)
+    assert out.shape == out_ref.shape and not out.requires_grad
+    assert (out - out_ref).abs().max() <= TOL
+    for s in want:
+        assert (trace[s] - to_t(g[f"x_step{s}"])).abs().max() <= TOL
+
+
+def test_inpaint_matches_reference():
+    g = load_golden("tiny_inpaint.npz")
+    sd, cfg = synth_sd("tiny"), oracle_cfg("tiny")
+    n = {"i": 0}
+
+    def draw(like):
+        from moleculediffusiontransformer_amd.synth import synth_normal
+        t = synth_normal(f"tiny_inpaint/draw{n['i']}", tuple(like.shape))
+        n["i"] += 1
+        return t
+    with torch.no_grad():
+        emb = O.cond_embed(sd, cfg, to_t(g["seq"]))
+    src, mask = to_t(g["src"]), to_t(g["mask"])
+    out = O.adpm2_inpaint(sd, cfg, src, mask, emb, int(g["timesteps"]), int(g["num_resamples"]), draw,
+                          float(g["cond_scale"]))
+    assert n["i"] == int(g["ndraws"])
+    assert (out - to_t(g["out"])).abs().max() <= TOL
+    assert torch.equal(out[mask], src[mask])      # kept region is returned bit-equal (diffusion.py:549)
+
+
+def test_schedule_and_scalars_kats():
+    g = load_golden("scalars.npz")
+    for T in (64, 100, 12):
+        sig = O.karras_sigmas(T)
+        assert np.array_equal(sig.numpy(), g[f"sigmas_{T}"])
+        for i in range(T - 1):
+            up, down, mid = O.adpm2_sigmas(sig[i], sig[i + 1])
+            assert up == g[f"up_{T}"][i] and down == g[f"down_{T}"][i]
+            assert np.float32(float(mid)) == g[f"mid_{T}"][i]
+    # SURVEY §8a known answers (measured on the reference)
+    s64 = O.karras_sigmas(64)
+    assert s64[1].item() == 8.598163604736328 and s64[62].item() == 0.0022702966816723347
+    assert s64[63].item() == 0.0010000006295740604 and s64[64].item() == 0.0
+    up, down, mid = O.adpm2_sigmas(s64[0], s64[1])
+    assert up == 2.5405128444864213 and down == 8.214268844302843
+    for row, s in zip(g["scale_weights"], (9.0, 1.0, 0.001)):
+        w = O.scale_weights(torch.full((4,), s))
+        assert np.array_equal(np.array([float(c.flatten()[0]) for c in w], dtype=np.float32), row)
+    w = O.scale_weights(torch.full((4,), 9.0))
+    assert float(w[0].flatten()[0]) == 0.000123441539471969
+    assert float(w[3][0]) == 0.5493061542510986
