@@ -1,0 +1,220 @@
+/*
+ * mdt_hip.h -- C ABI of libmdt_hip.so, the MI355X (gfx950) kernels behind
+ * QMDiffusion.sample / QMDiffusionForward.sample.
+ *
+ * The reference (lamm-mit/MoleculeDiffusionTransformer) is pure Python/PyTorch and has
+ * no FFI of its own; the drop-in surface is the Python class pair QMDiffusion /
+ * QMDiffusionForward (generative.py:718-914, :31-225).  This header is the native
+ * boundary underneath that surface: plain device pointers, sizes and a hipStream_t
+ * (passed as void*), no torch types.  Every entry point names the reference code
+ * it replaces.  All pointers are DEVICE pointers to fp32 unless stated otherwise;
+ * every call only enqueues work on `stream` (no allocation, no synchronisation), so
+ * calls may be captured into a HIP graph.  Return value: 0 on success, non-zero on
+ * error (message via mdt_last_error()).
+ *
+ * Layouts
+ *   sampler state / noise / result : (B, C, L)   channel-major, as the reference
+ *   U-Net activations              : (B, L, Cp)  token-major, Cp = C padded to 16
+ *   context embedding              : (B, n, F)   as the reference
+ */
+#ifndef MDT_HIP_H
+#define MDT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDT_ABI_VERSION 1
+
+int mdt_abi_version(void);
+const char *mdt_last_error(void);
+
+/* ------------------------------------------------------------------ */
+/* U-Net evaluation as an op program                                   */
+/* ------------------------------------------------------------------ */
+/* The network (UNet1d.forward, modules.py:1144-1180) is lowered by the
+ * Python host (moleculediffusiontransformer_amd/compiler.py) into a flat
+ * list of fused ops over packed weights; mdt_program_run enqueues them.  */
+
+enum mdt_space {
+  MDT_SP_NONE = 0,
+  MDT_SP_WEIGHT = 1, /* off = absolute float offset into the packed weight buffer            */
+  MDT_SP_ACT = 2,    /* off = float offset PER SAMPLE; address = act + off * B               */
+  MDT_SP_SHR = 3,    /* off = absolute float offset into the batch-invariant (shared) arena   */
+  MDT_SP_EXT0 = 4    /* MDT_SP_EXT0 + i : off floats into bindings.ext[i]                      */
+};
+#define MDT_N_EXT 8
+
+typedef struct mdt_ref {
+  int32_t space;
+  int32_t reserved;
+  int64_t off;
+} mdt_ref;
+
+enum mdt_op_kind {
+  MDT_OP_GEMM = 1,     /* nn.Linear / nn.Conv1d / nn.ConvTranspose1d phase as implicit GEMM with
+                          fused norm-apply/FiLM/SiLU prologue and bias/GELU/residual epilogue
+                          (modules.py:114-122, :135, :188, :317-319, :386-391, :486-516, :40-81) */
+  MDT_OP_GN_STATS = 2, /* nn.GroupNorm statistics (modules.py:99-103, :485)                     */
+  MDT_OP_ATTN = 3,     /* AttentionBase.forward core: softmax(q k^T * scale) v (modules.py:350-363) */
+  MDT_OP_CONCAT = 4,   /* UpsampleBlock1d.add_skip: cat([x, skip * s], channel) (modules.py:828-829) */
+  MDT_OP_PATCH = 5,    /* Patcher / Unpatcher rearrange (modules.py:230, :255)                   */
+  MDT_OP_TIME_EMBED = 6 /* LearnedPositionalEmbedding.forward (modules.py:554-559)               */
+};
+
+/* prologue applied to the A operand of MDT_OP_GEMM while it is staged into LDS */
+enum mdt_prologue {
+  MDT_PRO_NONE = 0,
+  MDT_PRO_LAYERNORM = 1, /* nn.LayerNorm over the K features of each row; p0 = gain, p1 = bias   */
+  MDT_PRO_GROUPNORM = 2, /* normalise with stats from MDT_OP_GN_STATS (p2), p0 = gain, p1 = bias;
+                            optional FiLM x*(scale+1)+shift (p3 = [scale(C) | shift(C)]); optional SiLU */
+  MDT_PRO_SILU = 3       /* plain SiLU (MappingToScaleShift, modules.py:133-136)                 */
+};
+
+/* integer / float parameter slots of mdt_op, per kind */
+enum mdt_gemm_i {
+  MDT_G_R_OUT = 0,   /* M rows per sample of this GEMM                                           */
+  MDT_G_R_IN = 1,    /* rows per sample of the A tensor                                           */
+  MDT_G_LDA = 2,     /* floats per A row                                                          */
+  MDT_G_CIN = 3,     /* channels consumed per tap (multiple of 16); K = taps * cin                */
+  MDT_G_TAPS = 4,
+  MDT_G_T_STRIDE = 5, /* source row of tap j for output row r: r*stride + j*dj + off; rows outside */
+  MDT_G_T_DJ = 6,     /* [0, R_IN) read as zero AFTER the prologue (conv zero padding)             */
+  MDT_G_T_OFF = 7,
+  MDT_G_N = 8,       /* output features (multiple of 16)                                          */
+  MDT_G_LDC = 9,     /* floats per output row                                                     */
+  MDT_G_O_ROWS = 10, /* rows per sample of the output tensor                                      */
+  MDT_G_O_STRIDE = 11, /* output row of GEMM row r: r*o_stride + o_off                             */
+  MDT_G_O_OFF = 12,
+  MDT_G_LDR = 13,    /* floats per residual row (residual uses the output row mapping)            */
+  MDT_G_PRO = 14,    /* enum mdt_prologue                                                         */
+  MDT_G_GROUPS = 15, /* GroupNorm groups                                                          */
+  MDT_G_GSIZE = 16,  /* channels per group                                                        */
+  MDT_G_PRO_SILU = 17, /* GROUPNORM prologue: apply SiLU after norm/FiLM                           */
+  MDT_G_ACT = 18,    /* epilogue: 0 none, 1 exact-erf GELU                                         */
+  MDT_G_M_MODE = 19, /* 0: M = B * R_OUT; 1: M = n_shared_rows * R_OUT; 2: M = R_OUT               */
+  MDT_G_A_COL = 20,  /* first channel of the A row to consume                                     */
+  MDT_G_O_COL = 21   /* first column of the output row to write                                   */
+};
+enum mdt_gemm_f { MDT_GF_EPS = 0 };
+
+enum mdt_gn_i { MDT_N_ROWS = 0, MDT_N_LD = 1, MDT_N_GROUPS = 2, MDT_N_GSIZE = 3 };
+enum mdt_gn_f { MDT_NF_EPS = 0 };
+
+enum mdt_attn_i {
+  MDT_A_T = 0, MDT_A_TK = 1, MDT_A_HEADS = 2, MDT_A_LDQ = 3, MDT_A_LDKV = 4, MDT_A_LDO = 5,
+  MDT_A_KV_BSTRIDE = 6 /* rows between consecutive samples' K/V (TK, or 0 for a batch-invariant context) */
+};
+enum mdt_attn_f { MDT_AF_SCALE = 0 };
+
+enum mdt_concat_i { MDT_C_ROWS = 0, MDT_C_CA = 1, MDT_C_CB = 2 };
+enum mdt_concat_f { MDT_CF_SCALE_B = 0 };
+
+enum mdt_patch_i { MDT_P_ROWS_IN = 0, MDT_P_C_IN = 1, MDT_P_LD_IN = 2, MDT_P_LD_OUT = 3, MDT_P_PATCH = 4,
+                   MDT_P_INVERSE = 5 };
+
+enum mdt_time_i { MDT_T_HALF = 0, MDT_T_LD = 1 };
+
+typedef struct mdt_op {
+  int32_t kind;
+  int32_t reserved;
+  mdt_ref a;    /* GEMM A / GN input / ATTN q / CONCAT a / PATCH in / TIME c_noise values        */
+  mdt_ref a2;   /* ATTN k (v = k + heads*64 floats) / CONCAT b                                   */
+  mdt_ref w;    /* GEMM weights [N][K], K contiguous / TIME fourier weights                       */
+  mdt_ref bias; /* GEMM bias [N]                                                                  */
+  mdt_ref out;
+  mdt_ref res;  /* GEMM residual                                                                  */
+  mdt_ref p0, p1, p2, p3;
+  int32_t i[24];
+  float f[8];
+} mdt_op;
+
+typedef struct mdt_bindings {
+  const float *weights;
+  float *act; /* per-sample arena, act_floats_per_sample * B floats                               */
+  float *shr; /* batch-invariant arena                                                            */
+  float *ext[MDT_N_EXT];
+} mdt_bindings;
+
+typedef struct mdt_program mdt_program;
+
+/* Validates and copies `n_ops` ops.  Returns NULL on error. */
+mdt_program *mdt_program_create(const mdt_op *ops, int32_t n_ops);
+void mdt_program_destroy(mdt_program *p);
+int32_t mdt_program_num_ops(const mdt_program *p);
+/* Enqueue ops [first, first+count) for batch size B (count < 0: to the end). */
+int mdt_program_run(const mdt_program *p, const mdt_bindings *b, int32_t B, int32_t n_shared_rows,
+                    int32_t first, int32_t count, void *stream);
+
+/* ------------------------------------------------------------------ */
+/* conditioning prelude                                                */
+/* ------------------------------------------------------------------ */
+/* generative.py:838-850 (QMDiffusion.sample) / :149-161 (QMDiffusionForward.sample):
+ *   e[b,i,0:D1]      = gelu(fc1_w[d] * seq[b,i] + fc1_b[d])
+ *   e[b,i,D1:D1+D2]  = PositionalEncoding1D: [sin(i*f_j) | cos(i*f_j)], f = inv_freq (D2/2 values)
+ * (transformer.py:3456-3470).  out is (B, n, D1+D2). */
+int mdt_cond_embed(const float *seq, const float *fc1_w, const float *fc1_b, const float *inv_freq,
+                   float *out, int32_t B, int32_t n, int32_t D1, int32_t D2, void *stream);
+
+/* ------------------------------------------------------------------ */
+/* k-diffusion preconditioning + ADPM2 sampler update                   */
+/* ------------------------------------------------------------------ */
+/* KDiffusion_mod.denoise_fn input scaling (diffusion.py:810): xin[b,l,c] = c_in * x[b,c,l],
+ * written token-major with channels padded to Cp (pad = 0). */
+int mdt_precond_in(const float *x, float *xin, float c_in, int32_t B, int32_t C, int32_t L, int32_t Cp,
+                   void *stream);
+/* KDiffusion_mod.denoise_fn output (diffusion.py:811-814, clip :75-77):
+ *   D = clamp(c_skip * x + c_out * pred, -1, 1);   pred is token-major (B, L, Cp). */
+int mdt_precond_out(const float *x, const float *pred, float *D, float c_skip, float c_out, int32_t B,
+                    int32_t C, int32_t L, int32_t Cp, void *stream);
+/* UNetCFG1d.forward guidance mix (modules.py:1253): out = um + (cond - um) * scale, token-major. */
+int mdt_cfg_mix(const float *cond, const float *uncond, float *out, float scale, int64_t n, void *stream);
+/* First half of ADPM2Sampler.step (diffusion.py:506-508) fused with the denoise output:
+ *   D = clamp(c_skip*x + c_out*pred, -1, 1); d = (x - D) / sigma; x_mid = x + d * dt_mid
+ * and, for the next U-Net call, xin_mid = c_in_mid * x_mid (token-major, padded). */
+int mdt_adpm2_mid(const float *x, const float *pred, float *x_mid, float *xin_mid, float c_skip,
+                  float c_out, float sigma, float dt_mid, float c_in_mid, int32_t B, int32_t C, int32_t L,
+                  int32_t Cp, void *stream);
+/* Second half (diffusion.py:510-515):
+ *   D = clamp(c_skip*x_mid + c_out*pred, -1, 1); d_mid = (x_mid - D) / sigma_mid;
+ *   x = x + d_mid * dt_down;  x = x + noise * sigma_up   (in place on x)
+ * and xin_next = c_in_next * x.  noise == NULL selects the counter-based generator:
+ * Philox4x32-10 keyed by (seed, step), counter = global element index
+ * (sample0 + b) * C * L + c * L + l, Box-Muller -- independent of how the batch is sharded. */
+int mdt_adpm2_next(float *x, const float *x_mid, const float *pred, const float *noise, float *xin_next,
+                   float c_skip, float c_out, float sigma_mid, float dt_down, float sigma_up,
+                   float c_in_next, uint64_t seed, uint32_t step, int64_t sample0, int32_t B, int32_t C,
+                   int32_t L, int32_t Cp, void *stream);
+/* x = sigma0 * noise (diffusion.py:520); noise == NULL: counter-based generator as above. */
+int mdt_init_noise(float *x, const float *noise, float sigma0, uint64_t seed, uint32_t step,
+                   int64_t sample0, int32_t B, int32_t C, int32_t L, void *stream);
+/* DiffusionSampler final clamp (diffusion.py:590). */
+int mdt_clamp(float *x, float lo, float hi, int64_t n, void *stream);
+/* Inpainting merge (diffusion.py:539-542, :549): out = where(mask, src + sigma*noise, x);
+ * mask is uint8 (B,C,L); noise may be NULL when sigma == 0. */
+int mdt_inpaint_merge(float *x, const float *src, const uint8_t *mask, const float *noise, float sigma,
+                      uint64_t seed, uint32_t step, int64_t sample0, int32_t B, int32_t C, int32_t L,
+                      void *stream);
+/* x += s * noise (inpaint re-noise, diffusion.py:546-547). */
+int mdt_add_noise(float *x, const float *noise, float s, uint64_t seed, uint32_t step, int64_t sample0,
+                  int32_t B, int32_t C, int32_t L, void *stream);
+/* Decode step after the path (generative.py:1212-1213): tokens[b,l] = argmax_c x[b,c,l] (int32). */
+int mdt_argmax_tokens(const float *x, int32_t *tokens, int32_t B, int32_t C, int32_t L, void *stream);
+
+/* ------------------------------------------------------------------ */
+/* measurement helpers (HIP events on the caller's stream)             */
+/* ------------------------------------------------------------------ */
+typedef struct mdt_timer mdt_timer;
+mdt_timer *mdt_timer_create(int32_t max_intervals);
+void mdt_timer_destroy(mdt_timer *t);
+int mdt_timer_start(mdt_timer *t, void *stream); /* records the start event of the next interval */
+int mdt_timer_stop(mdt_timer *t, void *stream);  /* records its stop event                         */
+/* Synchronises the stop events and returns the number of intervals; ms[i] = duration of interval i. */
+int32_t mdt_timer_collect(mdt_timer *t, float *ms, int32_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDT_HIP_H */

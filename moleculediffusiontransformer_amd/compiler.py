@@ -1,0 +1,576 @@
+"""Lowers the 1-D conditional U-Net (UNet1d.forward, modules.py:1144-1180) to mdt_op programs.
+
+Input: a UNetConfig, the sequence length, the conditioning length and a reference-format
+state_dict (keys relative to the U-Net, e.g. ``downsamples.0.blocks.1.block1.project.weight``).
+Output (CompiledUNet): one packed fp32 weight buffer plus five programs
+
+  time        rows = all timesteps of a sampling call: LearnedPositionalEmbedding -> to_time -> to_mapping
+              -> every ResnetBlock1d's MappingToScaleShift in ONE GEMM   (modules.py:545-566, :996-1010, :125-142)
+  ctx         per call: cross-attention norm_context + to_kv on the conditioning embedding for every
+              cross-attention layer (the context never changes inside DiffusionSampler.forward, diffusion.py:587)
+  ctx_fixed   the same on UNetCFG1d's FixedEmbedding (batch-invariant; modules.py:1239, :1251)
+  eval        one U-Net evaluation for the batch (conditional)
+  eval_fixed  the same attending to the fixed embedding (classifier-free-guidance second pass)
+
+Activations are token-major (B, L, Cp) with channels padded to a multiple of 16; every conv/linear is
+an MDT_OP_GEMM with fused prologue/epilogue (see csrc/k_gemm.hip).  Buffers live at per-sample offsets
+in one arena that is scaled by the batch size at run time, so a compiled model serves any batch size.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import runtime as rt
+from .netspec import UNetConfig
+
+EXT_XIN, EXT_CTX, EXT_OUT = 0, 1, 2      # bindings.ext slots used by the programs
+
+
+def pad16(c: int) -> int:
+    return (c + 15) // 16 * 16
+
+
+@dataclass
+class Ten:
+    """A token-major tensor: `rows` per sample, `ld` floats per row, at `off` in `space`."""
+    space: int
+    off: int
+    rows: int
+    ld: int
+    c: int = 0           # real (unpadded) channel count
+
+    def ref(self) -> rt.MdtRef:
+        return rt.MdtRef(self.space, 0, self.off)
+
+
+def _ref(space: int = 0, off: int = 0) -> rt.MdtRef:
+    return rt.MdtRef(space, 0, off)
+
+
+class _Arena:
+    """First-fit allocator over per-sample float offsets (64-float granules)."""
+
+    def __init__(self):
+        self.free: List[Tuple[int, int]] = []   # (off, size)
+        self.top = 0
+
+    def alloc(self, n: int) -> int:
+        n = (n + 63) // 64 * 64
+        for i, (o, s) in enumerate(self.free):
+            if s >= n:
+                if s == n:
+                    self.free.pop(i)
+                else:
+                    self.free[i] = (o + n, s - n)
+                return o
+        o = self.top
+        self.top += n
+        return o
+
+    def release(self, off: int, n: int) -> None:
+        n = (n + 63) // 64 * 64
+        self.free.append((off, n))
+        self.free.sort()
+        merged: List[Tuple[int, int]] = []
+        for o, s in self.free:
+            if merged and merged[-1][0] + merged[-1][1] == o:
+                merged[-1] = (merged[-1][0], merged[-1][1] + s)
+            else:
+                merged.append((o, s))
+        self.free = merged
+
+
+class _Weights:
+    def __init__(self):
+        self.chunks: List[torch.Tensor] = []
+        self.n = 0
+        self.index: Dict[str, int] = {}
+
+    def add(self, name: str, t: torch.Tensor) -> int:
+        t = t.detach().to(torch.float32).contiguous().reshape(-1).cpu()
+        off = self.n
+        pad = (-t.numel()) % 64
+        self.chunks.append(t)
+        if pad:
+            self.chunks.append(torch.zeros(pad))
+        self.n += t.numel() + pad
+        self.index[name] = off
+        return off
+
+    def pack(self) -> torch.Tensor:
+        return torch.cat(self.chunks) if self.chunks else torch.zeros(0)
+
+
+@dataclass
+class CompiledUNet:
+    cfg: UNetConfig
+    length: int
+    cond_len: int
+    in_pad: int                      # padded in/out channels of the token-major U-Net input/output
+    weights: torch.Tensor            # packed fp32 (CPU); moved to the device by the runtime
+    programs: Dict[str, List[rt.MdtOp]]
+    act_floats: int                  # per-sample arena size
+    shr_floats: int                  # batch-invariant arena size for `max_time_rows`
+    max_time_rows: int
+    shr: Dict[str, int]              # named offsets in the shared arena
+    ss_total: int                    # floats of one row of all (scale, shift) vectors
+    n_cross: int
+    flops_per_sample_eval: int       # 2*MACs of one conditional U-Net evaluation (dense contractions + attention)
+    flops_ctx_per_sample: int
+    weight_index: Dict[str, int] = field(default_factory=dict)
+
+
+class UNetCompiler:
+    def __init__(self, cfg: UNetConfig, length: int, cond_len: int, sd: Dict[str, torch.Tensor],
+                 max_time_rows: int = 512):
+        if cfg.channels % 16:
+            raise ValueError("channels must be a multiple of 16")
+        if length % (cfg.patch_size * _prod(cfg.factors)):
+            raise ValueError("max_length must be divisible by patch_size * prod(factors)")
+        if cfg.head_features != 64:
+            raise ValueError("attention kernel is specialised for head_features == 64")
+        if cfg.ctx_features % 16:
+            raise ValueError("context features must be a multiple of 16")
+        self.cfg, self.L, self.n_ctx, self.sd = cfg, length, cond_len, sd
+        self.W = _Weights()
+        self.arena = _Arena()
+        self.ops: List[rt.MdtOp] = []
+        self.flops = 0
+        self.max_time_rows = max_time_rows
+        self.kv_slots: List[int] = []        # ACT offsets of the hoisted K/V per cross-attention layer
+        self.kv_fixed: List[int] = []        # SHR offsets for the fixed embedding
+        self.cross_layers: List[str] = []    # key prefixes, in evaluation order
+        self.ss_offsets: Dict[str, int] = {}
+        self.ss_total = 0
+        self.shr_top = 0
+        self.shr: Dict[str, int] = {}
+
+    # ------------------------------------------------------------------ helpers
+    def _shr_alloc(self, name: str, n: int) -> int:
+        off = self.shr_top
+        self.shr_top += (n + 63) // 64 * 64
+        self.shr[name] = off
+        return off
+
+    def _new(self, rows: int, ld: int, c: int = 0) -> Ten:
+        return Ten(rt.SP_ACT, self.arena.alloc(rows * ld), rows, ld, c or ld)
+
+    def _free(self, t: Ten) -> None:
+        if t.space == rt.SP_ACT:
+            self.arena.release(t.off, t.rows * t.ld)
+
+    def _vec(self, key: str, pad_to: int) -> int:
+        v = self.sd[key]
+        out = torch.zeros(pad_to)
+        out[: v.numel()] = v
+        return self.W.add(key, out)
+
+    def _lin_w(self, key: str, n_pad: Optional[int] = None, k_pad: Optional[int] = None) -> int:
+        w = self.sd[key]                       # [N, K]
+        n, k = w.shape
+        out = torch.zeros(n_pad or pad16(n), k_pad or pad16(k))
+        out[:n, :k] = w
+        return self.W.add(key, out)
+
+    def _conv_w(self, key: str, cin_pad: int, n_pad: int) -> int:
+        w = self.sd[key]                       # [Cout, Cin, k] -> [Np][k][Cin_p]
+        co, ci, k = w.shape
+        out = torch.zeros(n_pad, k, cin_pad)
+        out[:co, :, :ci] = w.permute(0, 2, 1)
+        return self.W.add(key, out)
+
+    def _emit(self, op: rt.MdtOp) -> None:
+        self.ops.append(op)
+
+    def gemm(self, a: Ten, w_off: int, n: int, out: Ten, *, cin: int, bias_off: Optional[int] = None,
+             taps: int = 1, t_stride: int = 1, t_dj: int = 0, t_off: int = 0, r_out: Optional[int] = None,
+             o_stride: int = 1, o_off: int = 0, res: Optional[Ten] = None, pro: int = rt.PRO_NONE,
+             gain: Optional[int] = None, nbias: Optional[int] = None, stats: Optional[Ten] = None,
+             film: Optional[rt.MdtRef] = None, groups: int = 0, gsize: int = 0, pro_silu: int = 0,
+             act: int = 0, eps: float = 0.0, m_mode: int = 0, a_col: int = 0, o_col: int = 0,
+             count_flops: bool = True) -> None:
+        op = rt.MdtOp()
+        op.kind = rt.OP_GEMM
+        op.a, op.w, op.out = a.ref(), _ref(rt.SP_WEIGHT, w_off), out.ref()
+        if bias_off is not None:
+            op.bias = _ref(rt.SP_WEIGHT, bias_off)
+        if res is not None:
+            op.res = res.ref()
+        if gain is not None:
+            op.p0 = _ref(rt.SP_WEIGHT, gain)
+        if nbias is not None:
+            op.p1 = _ref(rt.SP_WEIGHT, nbias)
+        if stats is not None:
+            op.p2 = stats.ref()
+        if isinstance(film, tuple):      # ("ss", offset inside the shared scale/shift row): resolved in build()
+            op._film = film
+        elif film is not None:
+            op.p3 = film
+        r_out = a.rows if r_out is None else r_out
+        i = op.i
+        i[rt.G_R_OUT], i[rt.G_R_IN], i[rt.G_LDA], i[rt.G_CIN], i[rt.G_TAPS] = r_out, a.rows, a.ld, cin, taps
+        i[rt.G_T_STRIDE], i[rt.G_T_DJ], i[rt.G_T_OFF] = t_stride, t_dj, t_off
+        i[rt.G_N], i[rt.G_LDC], i[rt.G_O_ROWS], i[rt.G_O_STRIDE], i[rt.G_O_OFF] = n, out.ld, out.rows, o_stride, o_off
+        i[rt.G_LDR] = res.ld if res is not None else 0
+        i[rt.G_PRO], i[rt.G_GROUPS], i[rt.G_GSIZE], i[rt.G_PRO_SILU] = pro, groups, gsize, pro_silu
+        i[rt.G_ACT], i[rt.G_M_MODE], i[rt.G_A_COL], i[rt.G_O_COL] = act, m_mode, a_col, o_col
+        op.f[0] = eps
+        self._emit(op)
+        if count_flops:
+            self.flops += 2 * r_out * n * taps * cin
+
+    def gn_stats(self, x: Ten, groups: int, gsize: int, eps: float) -> Ten:
+        st = self._new(1, 2 * groups)
+        op = rt.MdtOp()
+        op.kind = rt.OP_GN_STATS
+        op.a, op.out = x.ref(), st.ref()
+        op.i[rt.N_ROWS], op.i[rt.N_LD], op.i[rt.N_GROUPS], op.i[rt.N_GSIZE] = x.rows, x.ld, groups, gsize
+        op.f[0] = eps
+        self._emit(op)
+        return st
+
+    def attn(self, q: Ten, kv: rt.MdtRef, tk: int, kv_bstride: int, out: Ten) -> None:
+        cfg = self.cfg
+        op = rt.MdtOp()
+        op.kind = rt.OP_ATTN
+        op.a, op.out = q.ref(), out.ref()
+        if isinstance(kv, tuple):        # ("kv", cross-attention layer index): resolved in build()
+            op._kv = kv
+            op.a2 = _ref(rt.SP_ACT, 0)
+        else:
+            op.a2 = kv
+        i = op.i
+        i[rt.A_T], i[rt.A_TK], i[rt.A_HEADS] = q.rows, tk, cfg.heads
+        i[rt.A_LDQ], i[rt.A_LDKV], i[rt.A_LDO], i[rt.A_KV_BSTRIDE] = q.ld, 2 * cfg.mid_features, out.ld, kv_bstride
+        op.f[0] = float(cfg.head_features) ** -0.5
+        self._emit(op)
+        self.flops += 2 * 2 * q.rows * tk * cfg.mid_features
+
+    # ------------------------------------------------------------------ blocks
+    def resnet(self, x: Ten, p: str, cin: int, cout: int, groups: int, free_input: bool = True) -> Ten:
+        """ResnetBlock1d.forward (modules.py:193-205); x has `cin` real channels."""
+        cin_p, cout_p = pad16(cin), pad16(cout)
+        assert x.ld == cin_p, (p, x.ld, cin_p)
+        st1 = self.gn_stats(x, groups, cin // groups, 1e-5)
+        h = self._new(x.rows, cout_p, cout)
+        self.gemm(x, self._conv_w(p + "block1.project.weight", cin_p, cout_p), cout_p, h, cin=cin_p,
+                  bias_off=self._vec(p + "block1.project.bias", cout_p), taps=3, t_dj=1, t_off=-1,
+                  pro=rt.PRO_GROUPNORM, gain=self._vec(p + "block1.groupnorm.weight", cin_p),
+                  nbias=self._vec(p + "block1.groupnorm.bias", cin_p), stats=st1, groups=groups,
+                  gsize=cin // groups, pro_silu=1)
+        self._free(st1)
+        st2 = self.gn_stats(h, groups, cout // groups, 1e-5)
+        if (p + "to_out.weight") in self.sd:
+            r = self._new(x.rows, cout_p, cout)
+            self.gemm(x, self._conv_w(p + "to_out.weight", cin_p, cout_p), cout_p, r, cin=cin_p,
+                      bias_off=self._vec(p + "to_out.bias", cout_p))
+        else:
+            r = x
+        # FiLM vectors of this block inside the shared (scale | shift) row
+        ss_off = self.ss_total
+        self.ss_offsets[p] = ss_off
+        self.ss_total += 2 * cout_p
+        y = self._new(x.rows, cout_p, cout)
+        self.gemm(h, self._conv_w(p + "block2.project.weight", cout_p, cout_p), cout_p, y, cin=cout_p,
+                  bias_off=self._vec(p + "block2.project.bias", cout_p), taps=3, t_dj=1, t_off=-1,
+                  pro=rt.PRO_GROUPNORM, gain=self._vec(p + "block2.groupnorm.weight", cout_p),
+                  nbias=self._vec(p + "block2.groupnorm.bias", cout_p), stats=st2, groups=groups,
+                  gsize=cout // groups, pro_silu=1, film=("ss", ss_off), res=r)
+        self._free(st2)
+        self._free(h)
+        if r is not x:
+            self._free(r)
+        if free_input:
+            self._free(x)
+        return y
+
+    def attention_layer(self, t: Ten, p: str, cross_index: Optional[int]) -> None:
+        """x = Attention(x[, context]) + x, in place on t (modules.py:401-410, :457-459)."""
+        cfg = self.cfg
+        c, mid = t.ld, cfg.mid_features
+        q = self._new(t.rows, mid)
+        self.gemm(t, self._lin_w(p + "to_q.weight"), mid, q, cin=c, pro=rt.PRO_LAYERNORM,
+                  gain=self._vec(p + "norm.weight", c), nbias=self._vec(p + "norm.bias", c), eps=1e-5)
+        ao = self._new(t.rows, mid)
+        if cross_index is None:
+            kv = self._new(t.rows, 2 * mid)
+            self.gemm(t, self._lin_w(p + "to_kv.weight"), 2 * mid, kv, cin=c, pro=rt.PRO_LAYERNORM,
+                      gain=self._vec(p + "norm_context.weight", c), nbias=self._vec(p + "norm_context.bias", c),
+                      eps=1e-5)
+            self.attn(q, kv.ref(), t.rows, t.rows, ao)
+            self._free(kv)
+        else:
+            self.attn(q, ("kv", cross_index), self.n_ctx, self.n_ctx, ao)
+        self._free(q)
+        self.gemm(ao, self._lin_w(p + "attention.to_out.weight"), c, t, cin=mid,
+                  bias_off=self._vec(p + "attention.to_out.bias", c), res=t)
+        self._free(ao)
+
+    def transformer(self, x: Ten, p: str, c: int, layers: int, cross: bool, free_input: bool = True) -> Ten:
+        """Transformer1d.forward (modules.py:519-524)."""
+        cfg = self.cfg
+        assert x.ld == c and c % 32 == 0
+        st = self.gn_stats(x, 32, c // 32, 1e-6)
+        t = self._new(x.rows, c)
+        self.gemm(x, self._conv_w(p + "to_in.1.weight", c, c), c, t, cin=c, bias_off=self._vec(p + "to_in.1.bias", c),
+                  pro=rt.PRO_GROUPNORM, gain=self._vec(p + "to_in.0.weight", c), nbias=self._vec(p + "to_in.0.bias", c),
+                  stats=st, groups=32, gsize=c // 32, pro_silu=0)
+        self._free(st)
+        if free_input:
+            self._free(x)
+        for i in range(layers):
+            bp = p + f"blocks.{i}."
+            self.attention_layer(t, bp + "attention.", None)
+            if cross:
+                self.cross_layers.append(bp + "cross_attention.")
+                self.attention_layer(t, bp + "cross_attention.", len(self.cross_layers) - 1)
+            h = self._new(t.rows, c * cfg.ff_mult)
+            self.gemm(t, self._lin_w(bp + "feed_forward.0.weight"), c * cfg.ff_mult, h, cin=c,
+                      bias_off=self._vec(bp + "feed_forward.0.bias", c * cfg.ff_mult), act=1)
+            self.gemm(h, self._lin_w(bp + "feed_forward.2.weight"), c, t, cin=c * cfg.ff_mult,
+                      bias_off=self._vec(bp + "feed_forward.2.bias", c), res=t)
+            self._free(h)
+        y = self._new(t.rows, c)
+        self.gemm(t, self._conv_w(p + "to_out.1.weight", c, c), c, y, cin=c, bias_off=self._vec(p + "to_out.1.bias", c))
+        self._free(t)
+        return y
+
+    def concat(self, a: Ten, b: Ten, scale_b: float) -> Ten:
+        out = self._new(a.rows, a.ld + b.ld)
+        op = rt.MdtOp()
+        op.kind = rt.OP_CONCAT
+        op.a, op.a2, op.out = a.ref(), b.ref(), out.ref()
+        op.i[rt.C_ROWS], op.i[rt.C_CA], op.i[rt.C_CB] = a.rows, a.ld, b.ld
+        op.f[0] = scale_b
+        self._emit(op)
+        return out
+
+    def patch(self, x: Ten, patch: int, inverse: bool) -> Ten:
+        if inverse:                       # (L/p, C*p) -> (L, C)
+            out = self._new(x.rows * patch, x.ld // patch)
+            rows_long, c_long, ld_in, ld_out = out.rows, out.ld, x.ld, out.ld
+        else:                             # (L, C) -> (L/p, C*p)
+            out = self._new(x.rows // patch, x.ld * patch)
+            rows_long, c_long, ld_in, ld_out = x.rows, x.ld, x.ld, out.ld
+        op = rt.MdtOp()
+        op.kind = rt.OP_PATCH
+        op.a, op.out = x.ref(), out.ref()
+        i = op.i
+        i[rt.P_ROWS_IN], i[rt.P_C_IN], i[rt.P_LD_IN], i[rt.P_LD_OUT] = rows_long, c_long, ld_in, ld_out
+        i[rt.P_PATCH], i[rt.P_INVERSE] = patch, int(inverse)
+        self._emit(op)
+        return out
+
+    # ------------------------------------------------------------------ programs
+    def build_eval(self) -> None:
+        cfg, L = self.cfg, self.L
+        ps, g = cfg.patch_size, cfg.resnet_groups
+        cin, c0 = cfg.in_channels, cfg.level_channels(0)
+        self.in_pad = pad16(cin)
+        x = Ten(rt.SP_EXT0 + EXT_XIN, 0, L, self.in_pad, cin)
+        x = self.resnet(x, "to_in.block.", cin, c0 // ps, 1, free_input=False)
+        if ps > 1:
+            if (c0 // ps) % 16:
+                raise ValueError("channels // patch_size must be a multiple of 16")
+            y = self.patch(x, ps, inverse=False)
+            self._free(x)
+            x = y
+        skips_list = [[x]]
+        for i in range(cfg.num_layers):
+            dp = f"downsamples.{i}."
+            ci, co, f = cfg.level_channels(i), cfg.level_channels(i + 1), cfg.factors[i]
+            y = self._new(x.rows // f, co)
+            self.gemm(x, self._conv_w(dp + "downsample.weight", ci, co), co, y, cin=ci,
+                      bias_off=self._vec(dp + "downsample.bias", co), taps=2 * f + 1, t_stride=f, t_dj=1, t_off=-f,
+                      r_out=x.rows // f)
+            x = y                         # the block input stays alive as a skip of the previous level
+            skips: List[Ten] = []
+            x_is_skip = False
+            if cfg.pre_transformer > 0:
+                y = self.transformer(x, dp + "pre_transformer_block.", co, cfg.pre_transformer, False)
+                skips.append(y)
+                x, x_is_skip = y, True
+            for j in range(cfg.num_blocks[i]):
+                x = self.resnet(x, dp + f"blocks.{j}.", co, co, g, free_input=not x_is_skip)
+                skips.append(x)
+                x_is_skip = True
+            if cfg.attentions[i] > 0:
+                x = self.transformer(x, dp + "transformer.", co, cfg.attentions[i], True, free_input=False)
+                skips.append(x)
+            skips_list.append(skips)
+        cb = cfg.level_channels(cfg.num_layers)
+        keep = x in skips_list[-1]
+        x = self.resnet(x, "bottleneck.pre_block.", cb, cb, g, free_input=not keep)
+        if cfg.attentions[-1] > 0:
+            x = self.transformer(x, "bottleneck.transformer.", cb, cfg.attentions[-1], True)
+        x = self.resnet(x, "bottleneck.post_block.", cb, cb, g)
+        for u, i in enumerate(reversed(range(cfg.num_layers))):
+            up = f"upsamples.{u}."
+            ci, co, f = cfg.level_channels(i + 1), cfg.level_channels(i), cfg.factors[i]
+            skips = skips_list.pop()
+            n_res = cfg.num_blocks[i] + (1 if cfg.attentions[i] else 0)
+            for j in range(n_res):
+                s = skips.pop()
+                cat = self.concat(x, s, 2 ** -0.5)
+                self._free(x)
+                self._free(s)
+                x = self.resnet(cat, up + f"blocks.{j}.", 2 * ci, ci, g)
+            for s in skips:               # DownsampleBlock1d emits one more skip than is consumed (:702, :843-845)
+                self._free(s)
+            if cfg.pre_transformer > 0:
+                x = self.transformer(x, up + "pre_transformer_block.", ci, cfg.pre_transformer, False)
+            if cfg.attentions[i] > 0:
+                x = self.transformer(x, up + "transformer.", ci, cfg.attentions[i], True)
+            # ConvTranspose1d k=2f s=f p=f/2 as f output phases of 2 taps each (modules.py:74-81)
+            if f % 2:
+                raise ValueError("odd upsample factors are not supported")
+            wt = self.sd[up + "upsample.weight"]          # [Cin, Cout, 2f]
+            bias = self._vec(up + "upsample.bias", co)
+            y = self._new(x.rows * f, co)
+            last = u == cfg.num_layers - 1
+            res = skips_list[0][0] if last else None       # `x += skips_list.pop()` (modules.py:1176)
+            for ph in range(f):
+                shift = 1 if ph < f // 2 else 0
+                wp = torch.stack((wt[:, :, ph], wt[:, :, ph + f]), dim=0).permute(2, 0, 1)   # [Cout][2][Cin]
+                self.gemm(x, self.W.add(f"{up}upsample.weight/phase{ph}", wp), co, y, cin=ci, bias_off=bias, taps=2,
+                          t_stride=1, t_dj=-1, t_off=shift, r_out=x.rows, o_stride=f, o_off=f * shift + ph - f // 2,
+                          res=res)
+            self._free(x)
+            x = y
+        self._free(skips_list.pop()[0])
+        if ps > 1:
+            y = self.patch(x, ps, inverse=True)
+            self._free(x)
+            x = y
+        out = Ten(rt.SP_EXT0 + EXT_OUT, 0, L, self.in_pad, cin)
+        y = self.resnet(x, "to_out.block.", c0 // ps, cin, 1)
+        # the final resnet wrote into an arena buffer; retarget its last GEMM to the bound output tensor
+        last_op = self.ops[-1]
+        assert last_op.kind == rt.OP_GEMM
+        last_op.out = out.ref()
+        self._free(y)
+
+    def build(self) -> CompiledUNet:
+        cfg = self.cfg
+        # K/V slots live at the bottom of the per-sample arena (written by `ctx`, read by `eval`)
+        mid2 = 2 * cfg.mid_features
+        self.build_eval()
+        eval_ops = self.ops
+        flops_eval = self.flops
+        n_cross = len(self.cross_layers)
+        kv_base = self.arena.top
+        self.kv_slots = [kv_base + i * self.n_ctx * mid2 for i in range(n_cross)]
+        act_floats = kv_base + n_cross * self.n_ctx * mid2
+
+        # ---- shared arena layout ----
+        rows = self.max_time_rows
+        mapf = cfg.mapping_features
+        ldt = pad16(cfg.channels + 1)
+        cn = self._shr_alloc("c_noise", rows)
+        temb = self._shr_alloc("time_embed", rows * ldt)
+        m1 = self._shr_alloc("map1", rows * mapf)
+        m2 = self._shr_alloc("map2", rows * mapf)
+        m3 = self._shr_alloc("map3", rows * mapf)
+        ss_all = self._shr_alloc("ss_all", rows * self.ss_total)
+        ss_cur = self._shr_alloc("ss_cur", self.ss_total)
+        kvf = self._shr_alloc("kv_fixed", n_cross * self.n_ctx * mid2)
+        self.kv_fixed = [kvf + i * self.n_ctx * mid2 for i in range(n_cross)]
+
+        # ---- resolve symbolic refs of the eval program; derive the fixed-embedding twin ----
+        def resolve(ops, fixed: bool):
+            out = []
+            for op in ops:
+                o = rt.MdtOp()
+                C_memmove(o, op)
+                if op.kind == rt.OP_GEMM and isinstance(getattr(op, "_film", None), tuple):
+                    o.p3 = _ref(rt.SP_SHR, ss_cur + op._film[1])
+                if op.kind == rt.OP_ATTN and isinstance(getattr(op, "_kv", None), tuple):
+                    idx = op._kv[1]
+                    if fixed:
+                        o.a2 = _ref(rt.SP_SHR, self.kv_fixed[idx])
+                        o.i[rt.A_KV_BSTRIDE] = 0
+                    else:
+                        o.a2 = _ref(rt.SP_ACT, self.kv_slots[idx])
+                out.append(o)
+            return out
+
+        programs = {"eval": resolve(eval_ops, False), "eval_fixed": resolve(eval_ops, True)}
+
+        # ---- time program (m_mode 1) ----
+        self.ops, self.flops = [], 0
+        t_cn = Ten(rt.SP_SHR, cn, 1, 1)
+        t_emb = Ten(rt.SP_SHR, temb, 1, ldt)
+        op = rt.MdtOp()
+        op.kind = rt.OP_TIME_EMBED
+        op.a, op.w, op.out = t_cn.ref(), _ref(rt.SP_WEIGHT, self.W.add("to_time.0.0.weights", self.sd["to_time.0.0.weights"])), t_emb.ref()
+        op.i[rt.T_HALF], op.i[rt.T_LD] = cfg.channels // 2, ldt
+        self._emit(op)
+        t1, t2, t3 = Ten(rt.SP_SHR, m1, 1, mapf), Ten(rt.SP_SHR, m2, 1, mapf), Ten(rt.SP_SHR, m3, 1, mapf)
+        self.gemm(t_emb, self._lin_w("to_time.0.1.weight", mapf, ldt), mapf, t1, cin=ldt,
+                  bias_off=self._vec("to_time.0.1.bias", mapf), act=1, m_mode=1)
+        self.gemm(t1, self._lin_w("to_mapping.0.weight"), mapf, t2, cin=mapf,
+                  bias_off=self._vec("to_mapping.0.bias", mapf), act=1, m_mode=1)
+        self.gemm(t2, self._lin_w("to_mapping.2.weight"), mapf, t3, cin=mapf,
+                  bias_off=self._vec("to_mapping.2.bias", mapf), act=1, m_mode=1)
+        # all MappingToScaleShift linears as one GEMM: rows laid out [scale(Cp) | shift(Cp)] per block
+        w_all = torch.zeros(self.ss_total, mapf)
+        b_all = torch.zeros(self.ss_total)
+        for p, off in self.ss_offsets.items():
+            w = self.sd[p + "to_scale_shift.to_scale_shift.1.weight"]      # [2C, mapf]
+            b = self.sd[p + "to_scale_shift.to_scale_shift.1.bias"]
+            c = w.shape[0] // 2
+            cp = pad16(c)
+            w_all[off: off + c] = w[:c]
+            w_all[off + cp: off + cp + c] = w[c:]
+            b_all[off: off + c] = b[:c]
+            b_all[off + cp: off + cp + c] = b[c:]
+        t_ss = Ten(rt.SP_SHR, ss_all, 1, self.ss_total)
+        self.gemm(t3, self.W.add("scale_shift_all.weight", w_all), self.ss_total, t_ss, cin=mapf,
+                  bias_off=self.W.add("scale_shift_all.bias", b_all), pro=rt.PRO_SILU, m_mode=1)
+        programs["time"] = self.ops
+
+        # ---- context programs ----
+        self.ops, self.flops = [], 0
+        ctx = Ten(rt.SP_EXT0 + EXT_CTX, 0, self.n_ctx, cfg.ctx_features)
+        fixed = Ten(rt.SP_WEIGHT, self.W.add("fixed_embedding.embedding.weight",
+                                             self.sd["fixed_embedding.embedding.weight"][: self.n_ctx]),
+                    self.n_ctx, cfg.ctx_features)
+        ctx_ops, fixed_ops = [], []
+        for idx, p in enumerate(self.cross_layers):
+            w = self._lin_w(p + "to_kv.weight")
+            gain = self._vec(p + "norm_context.weight", cfg.ctx_features)
+            nb = self._vec(p + "norm_context.bias", cfg.ctx_features)
+            self.ops = ctx_ops
+            self.gemm(ctx, w, mid2, Ten(rt.SP_ACT, self.kv_slots[idx], self.n_ctx, mid2), cin=cfg.ctx_features,
+                      pro=rt.PRO_LAYERNORM, gain=gain, nbias=nb, eps=1e-5)
+            self.ops = fixed_ops
+            self.gemm(fixed, w, mid2, Ten(rt.SP_SHR, self.kv_fixed[idx], self.n_ctx, mid2), cin=cfg.ctx_features,
+                      pro=rt.PRO_LAYERNORM, gain=gain, nbias=nb, eps=1e-5, m_mode=2, count_flops=False)
+        programs["ctx"], programs["ctx_fixed"] = ctx_ops, fixed_ops
+        flops_ctx = self.flops
+
+        return CompiledUNet(cfg=cfg, length=self.L, cond_len=self.n_ctx, in_pad=self.in_pad, weights=self.W.pack(),
+                            programs=programs, act_floats=act_floats, shr_floats=self.shr_top,
+                            max_time_rows=rows, shr=dict(self.shr), ss_total=self.ss_total, n_cross=n_cross,
+                            flops_per_sample_eval=flops_eval, flops_ctx_per_sample=flops_ctx,
+                            weight_index=dict(self.W.index))
+
+
+def C_memmove(dst: rt.MdtOp, src: rt.MdtOp) -> None:
+    import ctypes
+    ctypes.memmove(ctypes.byref(dst), ctypes.byref(src), ctypes.sizeof(rt.MdtOp))
+
+
+def _prod(xs) -> int:
+    r = 1
+    for x in xs:
+        r *= x
+    return r
+
+
+def compile_unet(cfg: UNetConfig, length: int, cond_len: int, sd: Dict[str, torch.Tensor],
+                 max_time_rows: int = 512) -> CompiledUNet:
+    return UNetCompiler(cfg, length, cond_len, sd, max_time_rows).build()

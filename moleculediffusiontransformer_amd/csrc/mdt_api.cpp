@@ -1,0 +1,280 @@
+// C ABI of libmdt_hip.so: op-program executor, error reporting, HIP-event timers.
+// Entry points are declared (with the reference code each one replaces) in include/mdt_hip.h.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mdt_hip.h"
+#include "mdt_kernels.h"
+
+namespace {
+thread_local std::string g_err;
+
+int fail(const std::string& m) {
+  g_err = m;
+  return 1;
+}
+
+int hip_fail(const char* what, hipError_t e) {
+  return fail(std::string(what) + ": " + hipGetErrorString(e));
+}
+}  // namespace
+
+struct mdt_program {
+  std::vector<mdt_op> ops;
+};
+
+struct mdt_timer {
+  std::vector<hipEvent_t> start, stop;
+  int n = 0;
+  bool open = false;
+};
+
+extern "C" {
+
+void mdt_set_error(const char* msg) { g_err = msg ? msg : ""; }
+const char* mdt_last_error(void) { return g_err.c_str(); }
+int mdt_abi_version(void) { return MDT_ABI_VERSION; }
+
+// ------------------------------------------------------------------------------------------------
+static const char* validate(const mdt_op& o, int idx, char* buf, size_t nbuf) {
+  auto bad = [&](const char* why) {
+    snprintf(buf, nbuf, "op %d (kind %d): %s", idx, o.kind, why);
+    return buf;
+  };
+  auto space_ok = [](const mdt_ref& r) { return r.space >= 0 && r.space < MDT_SP_EXT0 + MDT_N_EXT; };
+  for (const mdt_ref* r : {&o.a, &o.a2, &o.w, &o.bias, &o.out, &o.res, &o.p0, &o.p1, &o.p2, &o.p3})
+    if (!space_ok(*r) || r->off < 0) return bad("bad operand reference");
+  switch (o.kind) {
+    case MDT_OP_GEMM: {
+      const int32_t* i = o.i;
+      if (i[MDT_G_CIN] <= 0 || i[MDT_G_CIN] % 16) return bad("cin must be a positive multiple of 16");
+      if (i[MDT_G_N] <= 0 || i[MDT_G_TAPS] <= 0 || i[MDT_G_R_OUT] <= 0 || i[MDT_G_R_IN] <= 0) return bad("bad dims");
+      if (i[MDT_G_LDA] % 4 || i[MDT_G_A_COL] % 4) return bad("A rows must be 16-byte aligned");
+      if (i[MDT_G_LDA] < i[MDT_G_A_COL] + i[MDT_G_CIN]) return bad("lda < a_col + cin");
+      if (!o.a.space || !o.w.space || !o.out.space) return bad("missing A / W / out");
+      if (i[MDT_G_PRO] < 0 || i[MDT_G_PRO] > 3) return bad("bad prologue");
+      if (i[MDT_G_PRO] == MDT_PRO_LAYERNORM) {
+        if (i[MDT_G_TAPS] != 1) return bad("LayerNorm prologue needs taps == 1");
+        if (i[MDT_G_CIN] > 2048) return bad("LayerNorm prologue supports <= 2048 features");
+        if (!o.p0.space || !o.p1.space) return bad("LayerNorm prologue needs gain and bias");
+      }
+      if (i[MDT_G_PRO] == MDT_PRO_GROUPNORM) {
+        if (!o.p0.space || !o.p1.space || !o.p2.space) return bad("GroupNorm prologue needs gain, bias, stats");
+        if (i[MDT_G_GROUPS] <= 0 || i[MDT_G_GSIZE] <= 0) return bad("bad groups");
+      }
+      if (i[MDT_G_M_MODE] < 0 || i[MDT_G_M_MODE] > 2) return bad("bad m_mode");
+      if (o.res.space && i[MDT_G_LDR] <= 0) return bad("residual without ldr");
+      break;
+    }
+    case MDT_OP_GN_STATS:
+      if (o.i[MDT_N_ROWS] <= 0 || o.i[MDT_N_GROUPS] <= 0 || o.i[MDT_N_GSIZE] <= 0) return bad("bad dims");
+      if (!o.a.space || !o.out.space) return bad("missing operand");
+      break;
+    case MDT_OP_ATTN:
+      if (o.i[MDT_A_T] <= 0 || o.i[MDT_A_T] > 64 || o.i[MDT_A_TK] <= 0 || o.i[MDT_A_TK] > 64)
+        return bad("attention supports 1..64 queries and keys per sample");
+      if (!o.a.space || !o.a2.space || !o.out.space) return bad("missing operand");
+      break;
+    case MDT_OP_CONCAT:
+      if (o.i[MDT_C_CA] % 4 || o.i[MDT_C_CB] % 4 || o.i[MDT_C_ROWS] <= 0) return bad("bad dims");
+      break;
+    case MDT_OP_PATCH:
+      if (o.i[MDT_P_PATCH] <= 0 || o.i[MDT_P_ROWS_IN] % o.i[MDT_P_PATCH]) return bad("bad patch");
+      break;
+    case MDT_OP_TIME_EMBED:
+      if (o.i[MDT_T_LD] < 2 * o.i[MDT_T_HALF] + 1) return bad("ld too small");
+      break;
+    default:
+      return bad("unknown op kind");
+  }
+  return nullptr;
+}
+
+mdt_program* mdt_program_create(const mdt_op* ops, int32_t n_ops) {
+  if (!ops || n_ops < 0) {
+    fail("mdt_program_create: bad arguments");
+    return nullptr;
+  }
+  char buf[256];
+  for (int i = 0; i < n_ops; ++i) {
+    if (const char* why = validate(ops[i], i, buf, sizeof buf)) {
+      fail(std::string("mdt_program_create: ") + why);
+      return nullptr;
+    }
+  }
+  mdt_program* p = new mdt_program();
+  p->ops.assign(ops, ops + n_ops);
+  return p;
+}
+
+void mdt_program_destroy(mdt_program* p) { delete p; }
+int32_t mdt_program_num_ops(const mdt_program* p) { return p ? (int32_t)p->ops.size() : 0; }
+
+int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int32_t n_shared_rows, int32_t first,
+                    int32_t count, void* stream_) {
+  if (!p || !bd) return fail("mdt_program_run: null program or bindings");
+  if (B <= 0) return fail("mdt_program_run: B must be positive");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int n = (int)p->ops.size();
+  if (first < 0 || first > n) return fail("mdt_program_run: bad op range");
+  const int last = count < 0 ? n : first + count;
+  if (last > n) return fail("mdt_program_run: bad op range");
+
+  bool missing = false;
+  auto ptr = [&](const mdt_ref& r) -> float* {
+    switch (r.space) {
+      case MDT_SP_NONE: return nullptr;
+      case MDT_SP_WEIGHT:
+        if (!bd->weights) missing = true;
+        return const_cast<float*>(bd->weights) + r.off;
+      case MDT_SP_ACT:
+        if (!bd->act) missing = true;
+        return bd->act + r.off * (int64_t)B;
+      case MDT_SP_SHR:
+        if (!bd->shr) missing = true;
+        return bd->shr + r.off;
+      default: {
+        float* e = bd->ext[r.space - MDT_SP_EXT0];
+        if (!e) missing = true;
+        return e + r.off;
+      }
+    }
+  };
+
+  for (int idx = first; idx < last; ++idx) {
+    const mdt_op& o = p->ops[idx];
+    hipError_t e = hipSuccess;
+    switch (o.kind) {
+      case MDT_OP_GEMM: {
+        const int32_t* i = o.i;
+        mdt::GemmArgs g;
+        g.A = ptr(o.a); g.W = ptr(o.w); g.bias = ptr(o.bias); g.out = ptr(o.out); g.res = ptr(o.res);
+        g.p0 = ptr(o.p0); g.p1 = ptr(o.p1); g.p2 = ptr(o.p2); g.p3 = ptr(o.p3);
+        const int batches = i[MDT_G_M_MODE] == 0 ? B : (i[MDT_G_M_MODE] == 1 ? n_shared_rows : 1);
+        g.M = batches * i[MDT_G_R_OUT];
+        g.r_out = i[MDT_G_R_OUT]; g.r_in = i[MDT_G_R_IN]; g.lda = i[MDT_G_LDA]; g.cin = i[MDT_G_CIN];
+        g.taps = i[MDT_G_TAPS]; g.t_stride = i[MDT_G_T_STRIDE]; g.t_dj = i[MDT_G_T_DJ]; g.t_off = i[MDT_G_T_OFF];
+        g.N = i[MDT_G_N]; g.ldc = i[MDT_G_LDC]; g.o_rows = i[MDT_G_O_ROWS]; g.o_stride = i[MDT_G_O_STRIDE];
+        g.o_off = i[MDT_G_O_OFF]; g.ldr = i[MDT_G_LDR]; g.pro = i[MDT_G_PRO]; g.groups = i[MDT_G_GROUPS];
+        g.gsize = i[MDT_G_GSIZE]; g.pro_silu = i[MDT_G_PRO_SILU]; g.act = i[MDT_G_ACT]; g.a_col = i[MDT_G_A_COL];
+        g.o_col = i[MDT_G_O_COL]; g.eps = o.f[MDT_GF_EPS];
+        if (!missing) e = mdt::launch_gemm(g, stream);
+        break;
+      }
+      case MDT_OP_GN_STATS: {
+        mdt::GnStatsArgs g;
+        g.x = ptr(o.a); g.stats = ptr(o.out); g.batch = B; g.rows = o.i[MDT_N_ROWS]; g.ld = o.i[MDT_N_LD];
+        g.groups = o.i[MDT_N_GROUPS]; g.gsize = o.i[MDT_N_GSIZE]; g.eps = o.f[MDT_NF_EPS];
+        if (!missing) e = mdt::launch_gn_stats(g, stream);
+        break;
+      }
+      case MDT_OP_ATTN: {
+        mdt::AttnArgs a;
+        a.q = ptr(o.a); a.k = ptr(o.a2); a.out = ptr(o.out); a.batch = B; a.T = o.i[MDT_A_T]; a.Tk = o.i[MDT_A_TK];
+        a.heads = o.i[MDT_A_HEADS]; a.ldq = o.i[MDT_A_LDQ]; a.ldkv = o.i[MDT_A_LDKV]; a.ldo = o.i[MDT_A_LDO];
+        a.kv_bstride = o.i[MDT_A_KV_BSTRIDE]; a.scale = o.f[MDT_AF_SCALE];
+        if (!missing) e = mdt::launch_attn(a, stream);
+        break;
+      }
+      case MDT_OP_CONCAT: {
+        float *a = ptr(o.a), *b2 = ptr(o.a2), *out = ptr(o.out);
+        if (!missing)
+          e = mdt::launch_concat(a, b2, out, (int64_t)B * o.i[MDT_C_ROWS], o.i[MDT_C_CA], o.i[MDT_C_CB],
+                                 o.f[MDT_CF_SCALE_B], stream);
+        break;
+      }
+      case MDT_OP_PATCH: {
+        float *in = ptr(o.a), *out = ptr(o.out);
+        if (!missing)
+          e = mdt::launch_patch(in, out, B, o.i[MDT_P_ROWS_IN], o.i[MDT_P_C_IN], o.i[MDT_P_LD_IN], o.i[MDT_P_LD_OUT],
+                                o.i[MDT_P_PATCH], o.i[MDT_P_INVERSE], stream);
+        break;
+      }
+      case MDT_OP_TIME_EMBED: {
+        float *cn = ptr(o.a), *w = ptr(o.w), *out = ptr(o.out);
+        if (!missing) e = mdt::launch_time_embed(cn, w, out, n_shared_rows, o.i[MDT_T_HALF], o.i[MDT_T_LD], stream);
+        break;
+      }
+      default:
+        return fail("mdt_program_run: unknown op kind");
+    }
+    if (missing) {
+      char buf[128];
+      snprintf(buf, sizeof buf, "mdt_program_run: op %d references an unbound buffer", idx);
+      return fail(buf);
+    }
+    if (e != hipSuccess) {
+      char buf[128];
+      snprintf(buf, sizeof buf, "mdt_program_run: op %d (kind %d) launch failed", idx, o.kind);
+      return hip_fail(buf, e);
+    }
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+mdt_timer* mdt_timer_create(int32_t max_intervals) {
+  if (max_intervals <= 0) {
+    fail("mdt_timer_create: max_intervals must be positive");
+    return nullptr;
+  }
+  mdt_timer* t = new mdt_timer();
+  t->start.resize(max_intervals);
+  t->stop.resize(max_intervals);
+  for (int i = 0; i < max_intervals; ++i) {
+    if (hipEventCreate(&t->start[i]) != hipSuccess || hipEventCreate(&t->stop[i]) != hipSuccess) {
+      fail("mdt_timer_create: hipEventCreate failed");
+      delete t;
+      return nullptr;
+    }
+  }
+  return t;
+}
+
+void mdt_timer_destroy(mdt_timer* t) {
+  if (!t) return;
+  for (auto e : t->start) (void)hipEventDestroy(e);
+  for (auto e : t->stop) (void)hipEventDestroy(e);
+  delete t;
+}
+
+int mdt_timer_start(mdt_timer* t, void* stream) {
+  if (!t || t->open || t->n >= (int)t->start.size()) return fail("mdt_timer_start: timer full or interval open");
+  hipError_t e = hipEventRecord(t->start[t->n], (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail("mdt_timer_start", e);
+  t->open = true;
+  return 0;
+}
+
+int mdt_timer_stop(mdt_timer* t, void* stream) {
+  if (!t || !t->open) return fail("mdt_timer_stop: no open interval");
+  hipError_t e = hipEventRecord(t->stop[t->n], (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail("mdt_timer_stop", e);
+  t->open = false;
+  t->n++;
+  return 0;
+}
+
+int32_t mdt_timer_collect(mdt_timer* t, float* ms, int32_t cap) {
+  if (!t || t->open) {
+    fail("mdt_timer_collect: interval still open");
+    return -1;
+  }
+  const int n = t->n < cap ? t->n : cap;
+  for (int i = 0; i < n; ++i) {
+    hipError_t e = hipEventSynchronize(t->stop[i]);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms[i], t->start[i], t->stop[i]);
+    if (e != hipSuccess) {
+      hip_fail("mdt_timer_collect", e);
+      return -1;
+    }
+  }
+  t->n = 0;
+  return n;
+}
+
+}  // extern "C"

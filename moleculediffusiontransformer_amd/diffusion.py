@@ -1,0 +1,265 @@
+"""k-diffusion runtime of the sampling path: Karras schedule, ADPM2 sampler, KDiffusion_mod
+preconditioning, kept behind the reference's class seams (diffusion.py:324-342, :486-549, :554-625,
+:706-814) while the per-step arithmetic runs in the fused HIP kernels of libmdt_hip.so.
+
+Host side = scalar bookkeeping only.  All per-step scalars are computed up front in exactly the mixed
+precision the reference uses (0-dim fp32 tensors, Python doubles through math.sqrt), which
+removes the >= 4 device->host synchronisations per step of the reference loop.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import runtime as rt
+
+Tensor = torch.Tensor
+
+
+# ----------------------------------------------------------------------------------------------
+# distributions / schedules / samplers (constructor-compatible with the reference classes)
+# ----------------------------------------------------------------------------------------------
+class LogNormalDistribution:
+    """diffusion.py:29-38 (training-time sigma sampling; not used by sample())."""
+
+    def __init__(self, mean: float, std: float):
+        self.mean, self.std = mean, std
+
+    def __call__(self, num_samples: int, device=torch.device("cpu")) -> Tensor:
+        return (self.mean + self.std * torch.randn((num_samples,), device=device)).exp()
+
+
+class KarrasSchedule(nn.Module):
+    """diffusion.py:324-342.  Evaluated on the host (CPU fp32), as the reference's CPU path does."""
+
+    def __init__(self, sigma_min: float, sigma_max: float, rho: float = 7.0):
+        super().__init__()
+        self.sigma_min, self.sigma_max, self.rho = sigma_min, sigma_max, rho
+
+    def forward(self, num_steps: int, device=None) -> Tensor:
+        rho_inv = 1.0 / self.rho
+        steps = torch.arange(num_steps, dtype=torch.float32)
+        sigmas = (self.sigma_max ** rho_inv
+                  + (steps / (num_steps - 1)) * (self.sigma_min ** rho_inv - self.sigma_max ** rho_inv)) ** self.rho
+        return F.pad(sigmas, pad=(0, 1), value=0.0)
+
+
+class ADPM2Sampler(nn.Module):
+    """diffusion.py:486-549.  Holds rho; the update itself is mdt_adpm2_mid / mdt_adpm2_next."""
+
+    def __init__(self, rho: float = 1.0):
+        super().__init__()
+        self.rho = rho
+
+    def get_sigmas(self, sigma, sigma_next):
+        r = self.rho
+        sigma_up = math.sqrt(sigma_next ** 2 * (sigma ** 2 - sigma_next ** 2) / sigma ** 2)
+        sigma_down = math.sqrt(sigma_next ** 2 - sigma_up ** 2)
+        sigma_mid = ((sigma ** (1 / r) + sigma_down ** (1 / r)) / 2) ** r
+        return sigma_up, sigma_down, sigma_mid
+
+
+@dataclass
+class ScaleWeights:
+    c_skip: float
+    c_out: float
+    c_in: float
+    c_noise: float
+
+
+def scale_weights(sigma: Tensor, sigma_data: float) -> ScaleWeights:
+    """KDiffusion_mod.get_scale_weights (diffusion.py:789-796) for one sigma (0-dim fp32 tensor),
+    evaluated as the reference does on a to_batch()-ed fp32 vector (diffusion.py:91-102)."""
+    sigmas = torch.as_tensor(sigma, dtype=torch.float32).reshape(1).expand(16).clone()
+    c_noise = torch.log(sigmas) * 0.25
+    s = sigmas.view(-1, 1, 1)
+    c_skip = (sigma_data ** 2) / (s ** 2 + sigma_data ** 2)
+    c_out = s * sigma_data * (sigma_data ** 2 + s ** 2) ** -0.5
+    c_in = (s ** 2 + sigma_data ** 2) ** -0.5
+    return ScaleWeights(float(c_skip.flatten()[0]), float(c_out.flatten()[0]), float(c_in.flatten()[0]),
+                        float(c_noise[0]))
+
+
+@dataclass
+class StepScalars:
+    """Everything one ADPM2 step needs, as fp32-exact Python floats."""
+    sigma: float
+    sigma_mid: float
+    sigma_up: float          # fp32(sigma_up): `randn * sigma_up` multiplies by the double cast to fp32
+    dt_mid: float            # fp32(sigma_mid - sigma)
+    dt_down: float           # fp32(sigma_down - sigma)
+    w: ScaleWeights          # at sigma
+    w_mid: ScaleWeights      # at sigma_mid
+    renoise: float           # sqrt(sigma^2 - sigma_next^2) for inpaint resampling (diffusion.py:546)
+
+
+def adpm2_plan(num_steps: int, schedule: KarrasSchedule, sampler: ADPM2Sampler, sigma_data: float):
+    """Per-step scalars of ADPM2Sampler.forward/step (diffusion.py:502-524), bit-for-bit as the reference
+    computes them on CPU."""
+    sigmas = schedule(num_steps)
+    steps: List[StepScalars] = []
+    for i in range(num_steps - 1):
+        sigma, sigma_next = sigmas[i], sigmas[i + 1]
+        sigma_up, sigma_down, sigma_mid = sampler.get_sigmas(sigma, sigma_next)
+        dt_mid = sigma_mid - sigma                       # 0-dim fp32
+        dt_down = sigma_down - sigma                     # python double - fp32 tensor -> fp32 tensor
+        up32 = torch.tensor(sigma_up, dtype=torch.float32)
+        renoise = math.sqrt(sigmas[i] ** 2 - sigmas[i + 1] ** 2)
+        steps.append(StepScalars(float(sigma), float(sigma_mid), float(up32), float(dt_mid), float(dt_down),
+                                 scale_weights(sigma, sigma_data), scale_weights(sigma_mid, sigma_data),
+                                 float(torch.tensor(renoise, dtype=torch.float32))))
+    return sigmas, steps
+
+
+class NoiseSource:
+    """Where torch.randn / torch.randn_like of the reference come from.
+
+    * explicit tensors (parity mode): ``init`` is the (B, C, L) draw of generative.py:853, ``steps(i)``
+      returns the torch.randn_like draw of step i (diffusion.py:514) already on the device;
+    * ``seed`` (throughput mode): on-device Philox4x32-10 keyed by (seed, draw index) with the counter
+      taken from the GLOBAL sample index ``sample0 + b`` so results do not depend on the sharding.
+    """
+
+    def __init__(self, init: Optional[Tensor] = None, steps: Optional[Callable[[int], Tensor]] = None,
+                 seed: Optional[int] = None, sample0: int = 0):
+        if (init is None) != (steps is None) or (init is None) == (seed is None):
+            raise ValueError("give either (init, steps) tensors or a seed")
+        self.init, self.steps, self.seed, self.sample0 = init, steps, seed, sample0
+
+
+# ----------------------------------------------------------------------------------------------
+# the fused sampling loop
+# ----------------------------------------------------------------------------------------------
+def _f32(t: Tensor, device) -> Tensor:
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+def run_adpm2(engine, embedding: Tensor, pred_dim: int, num_steps: int, noise: NoiseSource,
+              schedule: KarrasSchedule, sampler: ADPM2Sampler, sigma_data: float, embedding_scale: float = 1.0,
+              clamp: bool = False, trace: Optional[dict] = None, timer=None) -> Tensor:
+    """DiffusionSampler.forward (diffusion.py:577-591) + ADPM2Sampler.forward (:517-524) +
+    KDiffusion_mod.denoise_fn (:798-814) + UNetCFG1d.forward (modules.py:1228-1255) on the GPU."""
+    lib = rt.load_library()
+    dev = engine.device
+    B = embedding.shape[0]
+    C, L, Cp = pred_dim, engine.c.length, engine.c.in_pad
+    sigmas, steps = adpm2_plan(num_steps, schedule, sampler, sigma_data)
+    guided = embedding_scale != 1.0
+
+    with torch.cuda.device(dev):
+        st = rt.current_stream()
+        engine.reserve(B)
+        engine.prepare_context(embedding)
+        c_noise = torch.tensor([v for s in steps for v in (s.w.c_noise, s.w_mid.c_noise)], dtype=torch.float32)
+        engine.prepare_times(c_noise)
+
+        x = torch.empty(B, C, L, device=dev)
+        x_mid = torch.empty_like(x)
+        seed = noise.seed or 0
+        init = None if noise.init is None else _f32(noise.init, dev)
+        rt.check(lib.mdt_init_noise(rt.ptr(x), rt.ptr(init), float(sigmas[0]), seed, 0, noise.sample0, B, C, L, st))
+        if not steps:
+            return x.clamp(-1.0, 1.0) if clamp else x
+        rt.check(lib.mdt_precond_in(rt.ptr(x), rt.ptr(engine.xin), steps[0].w.c_in, B, C, L, Cp, st))
+
+        def unet(row: int) -> Tensor:
+            engine.select_time(row)
+            if timer is not None:
+                timer.start()
+            pred = engine.eval(False)
+            if guided:
+                um = engine.eval(True)
+                rt.check(lib.mdt_cfg_mix(rt.ptr(pred), rt.ptr(um), rt.ptr(pred), float(embedding_scale),
+                                         pred.numel(), st))
+            if timer is not None:
+                timer.stop()
+            return pred
+
+        for i, s in enumerate(steps):
+            pred = unet(2 * i)
+            rt.check(lib.mdt_adpm2_mid(rt.ptr(x), rt.ptr(pred), rt.ptr(x_mid), rt.ptr(engine.xin), s.w.c_skip,
+                                       s.w.c_out, s.sigma, s.dt_mid, s.w_mid.c_in, B, C, L, Cp, st))
+            pred = unet(2 * i + 1)
+            nz = None if noise.steps is None else _f32(noise.steps(i), dev)
+            last = i + 1 == len(steps)
+            c_in_next = 0.0 if last else steps[i + 1].w.c_in
+            rt.check(lib.mdt_adpm2_next(rt.ptr(x), rt.ptr(x_mid), rt.ptr(pred), rt.ptr(nz),
+                                        0 if last else rt.ptr(engine.xin), s.w_mid.c_skip, s.w_mid.c_out,
+                                        s.sigma_mid, s.dt_down, s.sigma_up, c_in_next, seed, i + 1, noise.sample0,
+                                        B, C, L, Cp, st))
+            if trace is not None and (i + 1) in trace.get("want", ()):
+                trace[i + 1] = x.clone()
+        if clamp:
+            rt.check(lib.mdt_clamp(rt.ptr(x), -1.0, 1.0, x.numel(), st))
+    return x
+
+
+def run_adpm2_inpaint(engine, embedding: Tensor, source: Tensor, mask: Tensor, num_steps: int, num_resamples: int,
+                      draw: Optional[Callable[[], Tensor]], seed: Optional[int], schedule: KarrasSchedule,
+                      sampler: ADPM2Sampler, sigma_data: float, embedding_scale: float = 1.0,
+                      sample0: int = 0) -> Tensor:
+    """ADPM2Sampler.inpaint (diffusion.py:526-549) behind DiffusionInpainter.forward (:612-625).
+    ``draw()`` returns the next torch.randn_like tensor in the reference's call order (parity mode);
+    otherwise draws come from the counter-based generator keyed by (seed, draw index)."""
+    lib = rt.load_library()
+    dev = engine.device
+    B, C, L = source.shape
+    Cp = engine.c.in_pad
+    sigmas, steps = adpm2_plan(num_steps, schedule, sampler, sigma_data)
+    guided = embedding_scale != 1.0
+    if mask.dtype != torch.bool or tuple(mask.shape) != tuple(source.shape):
+        raise ValueError("in_paint_mask must be a bool tensor of the same shape as inpaint")
+
+    counter = {"n": 0}
+
+    def next_draw():
+        counter["n"] += 1
+        return (None if draw is None else _f32(draw(), dev)), counter["n"] - 1
+
+    with torch.cuda.device(dev):
+        st = rt.current_stream()
+        engine.reserve(B)
+        engine.prepare_context(embedding)
+        c_noise = torch.tensor([v for s in steps for v in (s.w.c_noise, s.w_mid.c_noise)], dtype=torch.float32)
+        engine.prepare_times(c_noise)
+        src = _f32(source, dev)
+        mk = mask.to(device=dev).to(torch.uint8).contiguous()
+        x = torch.empty(B, C, L, device=dev)
+        x_mid = torch.empty_like(x)
+        sd = seed or 0
+        nz, k = next_draw()
+        rt.check(lib.mdt_init_noise(rt.ptr(x), rt.ptr(nz), float(sigmas[0]), sd, k, sample0, B, C, L, st))
+
+        def unet(row: int) -> Tensor:
+            engine.select_time(row)
+            pred = engine.eval(False)
+            if guided:
+                um = engine.eval(True)
+                rt.check(lib.mdt_cfg_mix(rt.ptr(pred), rt.ptr(um), rt.ptr(pred), float(embedding_scale),
+                                         pred.numel(), st))
+            return pred
+
+        for i, s in enumerate(steps):
+            src_nz, src_k = next_draw()                   # source_noisy = source + sigmas[i] * randn_like(source)
+            for r in range(num_resamples):
+                rt.check(lib.mdt_inpaint_merge(rt.ptr(x), rt.ptr(src), rt.ptr(mk), rt.ptr(src_nz), s.sigma, sd,
+                                               src_k, sample0, B, C, L, st))
+                rt.check(lib.mdt_precond_in(rt.ptr(x), rt.ptr(engine.xin), s.w.c_in, B, C, L, Cp, st))
+                pred = unet(2 * i)
+                rt.check(lib.mdt_adpm2_mid(rt.ptr(x), rt.ptr(pred), rt.ptr(x_mid), rt.ptr(engine.xin), s.w.c_skip,
+                                           s.w.c_out, s.sigma, s.dt_mid, s.w_mid.c_in, B, C, L, Cp, st))
+                pred = unet(2 * i + 1)
+                nz, k = next_draw()
+                rt.check(lib.mdt_adpm2_next(rt.ptr(x), rt.ptr(x_mid), rt.ptr(pred), rt.ptr(nz), 0, s.w_mid.c_skip,
+                                            s.w_mid.c_out, s.sigma_mid, s.dt_down, s.sigma_up, 0.0, sd, k, sample0,
+                                            B, C, L, Cp, st))
+                if r < num_resamples - 1:
+                    nz, k = next_draw()
+                    rt.check(lib.mdt_add_noise(rt.ptr(x), rt.ptr(nz), s.renoise, sd, k, sample0, B, C, L, st))
+        rt.check(lib.mdt_inpaint_merge(rt.ptr(x), rt.ptr(src), rt.ptr(mk), 0, 0.0, sd, 0, sample0, B, C, L, st))
+    return x

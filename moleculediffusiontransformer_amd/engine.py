@@ -1,0 +1,124 @@
+"""Device-side state of one compiled U-Net: packed weights, arenas, programs, HIP-graph replay.
+
+PyTorch supplies device memory and the current HIP stream only; all arithmetic is in
+libmdt_hip.so (see include/mdt_hip.h).  There is no CPU path: constructing an engine on a
+machine without a HIP device raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional
+
+import torch
+
+from . import runtime as rt
+from .compiler import EXT_CTX, EXT_OUT, EXT_XIN, CompiledUNet
+
+
+def _require_gpu(device: torch.device) -> None:
+    if device.type != "cuda" or not torch.cuda.is_available():
+        raise RuntimeError(
+            "moleculediffusiontransformer_amd runs its sampling path only on an AMD GPU through libmdt_hip.so; "
+            f"device '{device}' is not a HIP device (there is no CPU fallback by design)")
+
+
+class UNetEngine:
+    """Runs the `time`, `ctx`, `eval` and `eval_fixed` programs of a CompiledUNet for a batch."""
+
+    def __init__(self, compiled: CompiledUNet, device, use_graph: Optional[bool] = None):
+        device = torch.device(device)
+        _require_gpu(device)
+        rt.load_library()
+        self.c = compiled
+        self.device = device
+        with torch.cuda.device(device):
+            self.weights = compiled.weights.to(device)
+            self.shr = torch.zeros(compiled.shr_floats, device=device)
+            self.programs: Dict[str, rt.Program] = {k: rt.Program(v) for k, v in compiled.programs.items()}
+        if use_graph is None:
+            use_graph = os.environ.get("MDT_GRAPH", "1") != "0"
+        self.use_graph = use_graph
+        self.B = 0
+        self.act = None
+        self.xin = None           # (B, L, Cp) token-major U-Net input
+        self.pred = None          # (B, L, Cp) token-major U-Net output
+        self.pred_fixed = None
+        self._graphs: Dict[str, torch.cuda.CUDAGraph] = {}
+        self._time_rows = 0
+        self._fixed_ready = False
+
+    # ------------------------------------------------------------------ buffers
+    def reserve(self, B: int) -> None:
+        """(Re)allocate per-batch buffers.  Invalidates captured graphs when B changes."""
+        if B == self.B:
+            return
+        c = self.c
+        self._graphs.clear()
+        self.act = self.xin = self.pred = self.pred_fixed = None
+        self.act = torch.empty(c.act_floats * B, device=self.device)
+        self.xin = torch.zeros(B, c.length, c.in_pad, device=self.device)
+        self.pred = torch.zeros(B, c.length, c.in_pad, device=self.device)
+        self.pred_fixed = torch.zeros(B, c.length, c.in_pad, device=self.device)
+        self.B = B
+
+    def _bind(self, xin=None, ctx=None, out=None) -> rt.MdtBindings:
+        b = rt.MdtBindings()
+        b.weights, b.act, b.shr = rt.ptr(self.weights), rt.ptr(self.act), rt.ptr(self.shr)
+        b.ext[EXT_XIN], b.ext[EXT_CTX], b.ext[EXT_OUT] = rt.ptr(xin), rt.ptr(ctx), rt.ptr(out)
+        return b
+
+    # ------------------------------------------------------------------ per-call preparation
+    def prepare_times(self, c_noise: torch.Tensor) -> None:
+        """Time mapping + all FiLM (scale, shift) rows for every U-Net call of a sampling run at once
+        (rows are identical across the batch: sigma is a scalar broadcast by to_batch, diffusion.py:91-102)."""
+        n = c_noise.numel()
+        if n > self.c.max_time_rows:
+            raise ValueError(f"{n} timesteps exceed max_time_rows={self.c.max_time_rows}")
+        off = self.c.shr["c_noise"]
+        self.shr[off: off + n].copy_(c_noise.to(device=self.device, dtype=torch.float32), non_blocking=True)
+        self.programs["time"].run(self._bind(), max(self.B, 1), n)
+        self._time_rows = n
+
+    def select_time(self, row: int) -> None:
+        """Make row `row` of the precomputed FiLM table current for the next eval()."""
+        assert 0 <= row < self._time_rows
+        c = self.c
+        src = c.shr["ss_all"] + row * c.ss_total
+        dst = c.shr["ss_cur"]
+        self.shr[dst: dst + c.ss_total].copy_(self.shr[src: src + c.ss_total], non_blocking=True)
+
+    def prepare_context(self, embedding: torch.Tensor) -> None:
+        """Hoisted cross-attention K/V of every layer for this batch's conditioning embedding."""
+        B = embedding.shape[0]
+        self.reserve(B)
+        emb = embedding.to(device=self.device, dtype=torch.float32).contiguous()
+        assert emb.shape[1] == self.c.cond_len and emb.shape[2] == self.c.cfg.ctx_features, emb.shape
+        self.programs["ctx"].run(self._bind(ctx=emb), B)
+
+    def prepare_fixed(self) -> None:
+        if not self._fixed_ready:
+            self.programs["ctx_fixed"].run(self._bind(), max(self.B, 1))
+            self._fixed_ready = True
+
+    # ------------------------------------------------------------------ evaluation
+    def eval(self, fixed: bool = False) -> torch.Tensor:
+        """One U-Net evaluation of self.xin for the whole batch -> self.pred (or self.pred_fixed)."""
+        name = "eval_fixed" if fixed else "eval"
+        out = self.pred_fixed if fixed else self.pred
+        if fixed:
+            self.prepare_fixed()
+        if not self.use_graph:
+            self.programs[name].run(self._bind(xin=self.xin, out=out), self.B)
+            return out
+        g = self._graphs.get(name)
+        if g is None:
+            # warm-up launch outside capture, then capture the ~350 launches of one evaluation
+            self.programs[name].run(self._bind(xin=self.xin, out=out), self.B)
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.programs[name].run(self._bind(xin=self.xin, out=out), self.B)
+            self._graphs[name] = g
+        g.replay()
+        return out

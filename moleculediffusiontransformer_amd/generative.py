@@ -1,0 +1,290 @@
+"""Drop-in class surface: QMDiffusion (generative.py:718-914) and QMDiffusionForward (:31-225).
+
+Same constructor keywords, attributes (.unet, .diffusion, .fc1, .GELUact, .p_enc_1d, .max_length,
+.pred_dim, ...), state_dict key layout (the U-Net appears under unet.*, diffusion.net.* and
+diffusion.diffusion.net.*, as in the reference) and sample()/inpaint() signatures.  The sampling
+path runs on an MI355X through libmdt_hip.so; there is no CPU implementation behind these classes.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import torch
+import torch.nn as nn
+
+from . import runtime as rt
+from .compiler import compile_unet
+from .diffusion import (ADPM2Sampler, KarrasSchedule, LogNormalDistribution, NoiseSource, run_adpm2,
+                        run_adpm2_inpaint, scale_weights)
+from .engine import UNetEngine, _require_gpu
+from .modules import PositionalEncoding1D, UNetCFG1d
+from .netspec import forward_unet_config, inverse_unet_config
+
+Tensor = torch.Tensor
+
+
+class KDiffusion_mod(nn.Module):
+    """diffusion.py:770-844: Karras preconditioning around the net (alias 'k')."""
+
+    alias = "k"
+
+    def __init__(self, net: nn.Module, *, sigma_distribution, sigma_data: float, dynamic_threshold: float = 0.0):
+        super().__init__()
+        if dynamic_threshold != 0.0:
+            raise NotImplementedError("dynamic thresholding is not on the sampling path of QMDiffusion*")
+        self.net = net
+        self.sigma_data = sigma_data
+        self.sigma_distribution = sigma_distribution
+        self.dynamic_threshold = dynamic_threshold
+        self._owner = None
+
+    def denoise_fn(self, x_noisy: Tensor, sigmas: Optional[Tensor] = None, sigma=None, *, embedding: Tensor,
+                   embedding_scale: float = 1.0) -> Tensor:
+        """diffusion.py:798-814 for a scalar sigma (the sampling case)."""
+        if sigma is None:
+            raise NotImplementedError("per-sample sigmas belong to the training path, which is out of scope")
+        return self._owner._denoise(x_noisy, sigma, embedding, embedding_scale)
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("training loss (KDiffusion_mod.forward) is outside the MI355X sampling path")
+
+
+class XDiffusion_x(nn.Module):
+    """diffusion.py:706-767: picks the diffusion class by alias ('k' -> KDiffusion_mod) and exposes
+    sample()/inpaint() with sampler and schedule objects."""
+
+    def __init__(self, type: str, net: nn.Module, **kwargs):
+        super().__init__()
+        if type != "k":
+            raise NotImplementedError(f"type='{type}': only the 'k' diffusion used by QMDiffusion* is built")
+        self.net = net
+        self.diffusion = KDiffusion_mod(net=net, **kwargs)
+
+    def forward(self, *args, **kwargs):
+        return self.diffusion(*args, **kwargs)
+
+    def sample(self, noise, num_steps: int, sigma_schedule: KarrasSchedule, sampler: ADPM2Sampler, clamp: bool,
+               *, embedding: Tensor, embedding_scale: float = 1.0, **extra) -> Tensor:
+        return self.diffusion._owner._sample(noise, num_steps, sigma_schedule, sampler, clamp, embedding,
+                                             embedding_scale, **extra)
+
+    def inpaint(self, sigma_schedule, sampler, inpaint, in_paint_mask, num_steps: int, num_resamples: int, *,
+                embedding: Tensor, embedding_scale: float = 1.0, **extra) -> Tensor:
+        return self.diffusion._owner._inpaint(inpaint, in_paint_mask, num_steps, num_resamples, sigma_schedule,
+                                              sampler, embedding, embedding_scale, **extra)
+
+
+class _QMBase(nn.Module):
+    _inverse = True
+
+    def _init_common(self, max_length, channels, pred_dim, unet, context_embedding_max_length, unet_type,
+                     pos_emb_fourier, pos_emb_fourier_add, text_embed_dim, embed_dim_position):
+        self.unet_type = unet_type
+        self.fc1 = nn.Linear(1, text_embed_dim)
+        self.GELUact = nn.GELU()
+        self.pos_emb_fourier = pos_emb_fourier
+        self.pos_emb_fourier_add = pos_emb_fourier_add
+        self._text_dim = text_embed_dim
+        self._pos_dim = 0
+        if pos_emb_fourier:
+            if pos_emb_fourier_add:
+                raise NotImplementedError("pos_emb_fourier_add=True is not supported by the MI355X path")
+            text_embed_dim = text_embed_dim + embed_dim_position
+            self._pos_dim = embed_dim_position
+            self.p_enc_1d = PositionalEncoding1D(embed_dim_position)
+        self.max_length = max_length
+        self.pred_dim = pred_dim
+        if unet_type != "cfg":
+            raise NotImplementedError("only unet_type='cfg' (UNetCFG1d) is on the MI355X sampling path")
+        if unet is not None:
+            if not isinstance(unet, UNetCFG1d):
+                raise TypeError("unet must be a moleculediffusiontransformer_amd UNetCFG1d")
+            self.unet = unet
+        else:
+            mk = inverse_unet_config if self._inverse else forward_unet_config
+            self.unet = UNetCFG1d(mk(pred_dim, channels, text_embed_dim, context_embedding_max_length))
+        self.diffusion = XDiffusion_x(type="k", net=self.unet,
+                                      sigma_distribution=LogNormalDistribution(mean=-1.2, std=1.2),
+                                      sigma_data=0.1, dynamic_threshold=0.0)
+        object.__setattr__(self.diffusion.diffusion, "_owner", self)
+        self.unet._evaluator = self._unet_call
+        self._engine: Optional[UNetEngine] = None
+        self._engine_key = None
+        self.sampler_stats = {}
+
+    # ------------------------------------------------------------------ engine management
+    def _param_key(self, device, n_ctx):
+        return (str(device), n_ctx, tuple((p.data_ptr(), p._version) for p in self.unet.parameters()))
+
+    def engine(self, device, n_ctx: Optional[int] = None) -> UNetEngine:
+        """Compiled-program engine for the current parameter values on `device` (rebuilt after an
+        optimiser step or load_state_dict) and `n_ctx` conditioning tokens."""
+        device = torch.device(device)
+        _require_gpu(device)
+        n_ctx = self.unet.config.ctx_max_length if n_ctx is None else n_ctx
+        if n_ctx > self.unet.config.ctx_max_length:
+            raise AssertionError("Input sequence length must be <= max_length")   # FixedEmbedding, modules.py:1194
+        key = self._param_key(device, n_ctx)
+        if self._engine is None or self._engine_key != key:
+            sd = {k: v.detach().float().cpu() for k, v in self.unet.state_dict().items()}
+            compiled = compile_unet(self.unet.config, self.max_length, n_ctx, sd)
+            self._engine = UNetEngine(compiled, device)
+            self._engine_key = key
+        return self._engine
+
+    # ------------------------------------------------------------------ conditioning prelude
+    def _embed(self, sequences: Tensor, device) -> Tensor:
+        """generative.py:838-850 / :149-161 on the device (mdt_cond_embed)."""
+        device = torch.device(device)
+        _require_gpu(device)
+        lib = rt.load_library()
+        seq = sequences.detach().float().to(device).contiguous()
+        B, n = seq.shape
+        out = torch.empty(B, n, self._text_dim + self._pos_dim, device=device)
+        w = self.fc1.weight.detach().float().to(device).contiguous().view(-1)
+        b = self.fc1.bias.detach().float().to(device).contiguous()
+        inv = self.p_enc_1d.inv_freq.detach().float().to(device).contiguous() if self._pos_dim else w
+        with torch.cuda.device(device):
+            rt.check(lib.mdt_cond_embed(rt.ptr(seq), rt.ptr(w), rt.ptr(b), rt.ptr(inv), rt.ptr(out), B, n,
+                                        self._text_dim, self._pos_dim, rt.current_stream()))
+        return out
+
+    # ------------------------------------------------------------------ seams used by the wrappers above
+    def _noise_source(self, noise, B, device, sample0=0):
+        if isinstance(noise, NoiseSource):
+            return noise
+        # default: initial noise from the CPU global generator exactly as generative.py:853 does; the
+        # per-step draws come from the counter-based device generator seeded from the same CPU generator
+        init = torch.randn(B, self.pred_dim, self.max_length) if noise is None else noise
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        ns = NoiseSource(seed=seed, sample0=sample0)
+        ns.init = init
+        return ns
+
+    def _sample(self, noise, num_steps, sigma_schedule, sampler, clamp, embedding, embedding_scale, trace=None,
+                timer=None):
+        if not isinstance(sampler, ADPM2Sampler) or not isinstance(sigma_schedule, KarrasSchedule):
+            raise NotImplementedError("the MI355X path implements ADPM2Sampler with KarrasSchedule")
+        device = embedding.device
+        eng = self.engine(device, embedding.shape[1])
+        ns = self._noise_source(noise, embedding.shape[0], device)
+        with torch.no_grad():
+            return run_adpm2(eng, embedding, self.pred_dim, num_steps, ns, sigma_schedule, sampler,
+                             self.diffusion.diffusion.sigma_data, embedding_scale, clamp, trace, timer)
+
+    def _inpaint(self, source, mask, num_steps, num_resamples, sigma_schedule, sampler, embedding, embedding_scale,
+                 draw: Optional[Callable[[], Tensor]] = None, seed: Optional[int] = None):
+        if not isinstance(sampler, ADPM2Sampler) or not isinstance(sigma_schedule, KarrasSchedule):
+            raise NotImplementedError("the MI355X path implements ADPM2Sampler with KarrasSchedule")
+        eng = self.engine(embedding.device, embedding.shape[1])
+        if draw is None and seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        with torch.no_grad():
+            return run_adpm2_inpaint(eng, embedding, source, mask, num_steps, num_resamples, draw, seed,
+                                     sigma_schedule, sampler, self.diffusion.diffusion.sigma_data, embedding_scale)
+
+    def _unet_call(self, x: Tensor, time, embedding: Tensor, embedding_scale: float = 1.0) -> Tensor:
+        """net(x, time, embedding=..., embedding_scale=...) (modules.py:1228-1255) for a time value shared
+        by the batch; x is (B, C, L) as in the reference."""
+        lib = rt.load_library()
+        device = x.device
+        eng = self.engine(device, embedding.shape[1])
+        t = torch.as_tensor(time, dtype=torch.float32).flatten().cpu()
+        if t.numel() > 1 and not bool((t == t[0]).all()):
+            raise NotImplementedError("the MI355X path evaluates one time value per batch")
+        B, C, L = x.shape
+        Cp = eng.c.in_pad
+        with torch.no_grad(), torch.cuda.device(device):
+            st = rt.current_stream()
+            eng.reserve(B)
+            eng.prepare_context(embedding)
+            eng.prepare_times(t[:1])
+            eng.select_time(0)
+            xc = x.detach().float().contiguous()
+            rt.check(lib.mdt_precond_in(rt.ptr(xc), rt.ptr(eng.xin), 1.0, B, C, L, Cp, st))
+            pred = eng.eval(False)
+            if embedding_scale != 1.0:
+                um = eng.eval(True)
+                rt.check(lib.mdt_cfg_mix(rt.ptr(pred), rt.ptr(um), rt.ptr(pred), float(embedding_scale),
+                                         pred.numel(), st))
+            return pred[:, :, :C].transpose(1, 2).contiguous()
+
+    def _denoise(self, x_noisy: Tensor, sigma, embedding: Tensor, embedding_scale: float = 1.0) -> Tensor:
+        lib = rt.load_library()
+        device = x_noisy.device
+        eng = self.engine(device, embedding.shape[1])
+        w = scale_weights(torch.as_tensor(sigma, dtype=torch.float32).cpu(), self.diffusion.diffusion.sigma_data)
+        B, C, L = x_noisy.shape
+        Cp = eng.c.in_pad
+        with torch.no_grad(), torch.cuda.device(device):
+            st = rt.current_stream()
+            eng.reserve(B)
+            eng.prepare_context(embedding)
+            eng.prepare_times(torch.tensor([w.c_noise]))
+            eng.select_time(0)
+            xc = x_noisy.detach().float().contiguous()
+            rt.check(lib.mdt_precond_in(rt.ptr(xc), rt.ptr(eng.xin), w.c_in, B, C, L, Cp, st))
+            pred = eng.eval(False)
+            if embedding_scale != 1.0:
+                um = eng.eval(True)
+                rt.check(lib.mdt_cfg_mix(rt.ptr(pred), rt.ptr(um), rt.ptr(pred), float(embedding_scale),
+                                         pred.numel(), st))
+            out = torch.empty_like(xc)
+            rt.check(lib.mdt_precond_out(rt.ptr(xc), rt.ptr(pred), rt.ptr(out), w.c_skip, w.c_out, B, C, L, Cp, st))
+            return out
+
+    # ------------------------------------------------------------------ public API (reference signatures)
+    def forward(self, sequences, output):
+        raise NotImplementedError(
+            "training loss (QMDiffusion*.forward, generative.py:812-833 / :120-143) is outside the MI355X "
+            "sampling path; train with the reference and load the checkpoint with load_state_dict()")
+
+    def _do_sample(self, sequences, device, cond_scale, timesteps, clamp, noise=None, trace=None, timer=None):
+        emb = self._embed(sequences, device)
+        return self.diffusion.sample(num_steps=timesteps, sampler=ADPM2Sampler(rho=1),
+                                     sigma_schedule=KarrasSchedule(sigma_min=0.001, sigma_max=9.0, rho=3.0),
+                                     clamp=clamp, noise=noise, embedding=emb, embedding_scale=cond_scale,
+                                     trace=trace, timer=timer)
+
+    def inpaint(self, sequences, device, cond_scale=7.5, timesteps=100, num_resamples=1, inpaint=None,
+                in_paint_mask=None, *, draw=None, seed=None):
+        emb = self._embed(sequences, device)
+        return self.diffusion.inpaint(num_steps=timesteps, num_resamples=num_resamples, sampler=ADPM2Sampler(rho=1),
+                                      sigma_schedule=KarrasSchedule(sigma_min=0.001, sigma_max=9.0, rho=3.0),
+                                      inpaint=inpaint, in_paint_mask=in_paint_mask, embedding=emb,
+                                      embedding_scale=cond_scale, draw=draw, seed=seed)
+
+
+class QMDiffusion(_QMBase):
+    """Generative inverse diffusion model (generative.py:718-914)."""
+
+    _inverse = True
+
+    def __init__(self, max_length=1024, channels=128, pred_dim=1, context_embedding_max_length=32, unet_type="cfg",
+                 pos_emb_fourier=True, pos_emb_fourier_add=False, text_embed_dim=1024, embed_dim_position=64,
+                 unet=None):
+        super().__init__()
+        print("Using unet type: ", unet_type)
+        self._init_common(max_length, channels, pred_dim, unet, context_embedding_max_length, unet_type,
+                          pos_emb_fourier, pos_emb_fourier_add, text_embed_dim, embed_dim_position)
+
+    def sample(self, sequences, device, cond_scale=7.5, timesteps=100, clamp=False, *, noise=None, trace=None,
+               timer=None):
+        return self._do_sample(sequences, device, cond_scale, timesteps, clamp, noise, trace, timer)
+
+
+class QMDiffusionForward(_QMBase):
+    """Forward diffusion property predictor (generative.py:31-225); note `unet` is the 4th positional."""
+
+    _inverse = False
+
+    def __init__(self, max_length=1024, channels=128, pred_dim=1, unet=None, context_embedding_max_length=32,
+                 unet_type="cfg", pos_emb_fourier=True, pos_emb_fourier_add=False, text_embed_dim=1024,
+                 embed_dim_position=64):
+        super().__init__()
+        self._init_common(max_length, channels, pred_dim, unet, context_embedding_max_length, unet_type,
+                          pos_emb_fourier, pos_emb_fourier_add, text_embed_dim, embed_dim_position)
+
+    def sample(self, sequences, device, cond_scale=1.0, timesteps=100, clamp=False, *, noise=None, trace=None,
+               timer=None):
+        return self._do_sample(sequences, device, cond_scale, timesteps, clamp, noise, trace, timer)

@@ -1,0 +1,143 @@
+"""CPU interpreter of mdt_op programs (TEST INFRASTRUCTURE).
+
+Executes the op list produced by moleculediffusiontransformer_amd/compiler.py with plain PyTorch CPU
+ops over flat fp32 buffers, following the op semantics documented in include/mdt_hip.h.  It lets the
+-m "not gpu" tests check the lowering (buffer offsets, tap/row mappings, weight packing, channel
+padding) against oracle/unet_oracle.py without a GPU; the HIP kernels are then checked against the
+same oracle on the GPU box.  Never imported by the product path.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+from moleculediffusiontransformer_amd import runtime as rt
+
+
+class Buffers:
+    def __init__(self, weights: torch.Tensor, act: torch.Tensor, shr: torch.Tensor, ext: Dict[int, torch.Tensor]):
+        self.weights, self.act, self.shr, self.ext = weights, act, shr, ext
+
+    def view(self, ref, B: int, n: int) -> Optional[torch.Tensor]:
+        if ref.space == rt.SP_NONE:
+            return None
+        if ref.space == rt.SP_WEIGHT:
+            buf, off = self.weights, ref.off
+        elif ref.space == rt.SP_ACT:
+            buf, off = self.act, ref.off * B
+        elif ref.space == rt.SP_SHR:
+            buf, off = self.shr, ref.off
+        else:
+            buf, off = self.ext[ref.space - rt.SP_EXT0], ref.off
+        assert off + n <= buf.numel(), (ref.space, off, n, buf.numel())
+        return buf[off: off + n]
+
+
+def _silu(x):
+    return x / (1.0 + torch.exp(-x))
+
+
+def run_program(ops, bufs: Buffers, B: int, n_shared_rows: int = 0) -> None:
+    for op in ops:
+        i, f = op.i, op.f
+        if op.kind == rt.OP_GEMM:
+            batches = B if i[rt.G_M_MODE] == 0 else (n_shared_rows if i[rt.G_M_MODE] == 1 else 1)
+            r_out, r_in, lda, cin, taps = i[rt.G_R_OUT], i[rt.G_R_IN], i[rt.G_LDA], i[rt.G_CIN], i[rt.G_TAPS]
+            n, ldc, o_rows = i[rt.G_N], i[rt.G_LDC], i[rt.G_O_ROWS]
+            a = bufs.view(op.a, B, batches * r_in * lda).view(batches, r_in, lda)
+            a = a[:, :, i[rt.G_A_COL]: i[rt.G_A_COL] + cin]
+            pro = i[rt.G_PRO]
+            if pro == rt.PRO_LAYERNORM:
+                g, b = bufs.view(op.p0, B, cin), bufs.view(op.p1, B, cin)
+                a = F.layer_norm(a, (cin,), g, b, eps=float(f[0]))
+            elif pro == rt.PRO_GROUPNORM:
+                G, gs = i[rt.G_GROUPS], i[rt.G_GSIZE]
+                g, b = bufs.view(op.p0, B, cin), bufs.view(op.p1, B, cin)
+                st = bufs.view(op.p2, B, batches * G * 2).view(batches, G, 2)
+                grp = torch.clamp(torch.arange(cin) // gs, max=G - 1)
+                mean, rstd = st[:, grp, 0].unsqueeze(1), st[:, grp, 1].unsqueeze(1)
+                a = (a - mean) * rstd * g + b
+                if op.p3.space != rt.SP_NONE:
+                    ss = bufs.view(op.p3, B, 2 * cin)
+                    a = a * (ss[:cin] + 1.0) + ss[cin:]
+                if i[rt.G_PRO_SILU]:
+                    a = _silu(a)
+            elif pro == rt.PRO_SILU:
+                a = _silu(a)
+            w = bufs.view(op.w, B, n * taps * cin).view(n, taps, cin)
+            r = torch.arange(r_out)
+            acc = torch.zeros(batches, r_out, n)
+            for t in range(taps):
+                src = r * i[rt.G_T_STRIDE] + t * i[rt.G_T_DJ] + i[rt.G_T_OFF]
+                ok = (src >= 0) & (src < r_in)
+                rows = a[:, src.clamp(0, r_in - 1), :] * ok.view(1, -1, 1)
+                acc = acc + rows @ w[:, t, :].T
+            if op.bias.space != rt.SP_NONE:
+                acc = acc + bufs.view(op.bias, B, n)
+            if i[rt.G_ACT] == 1:
+                acc = F.gelu(acc)
+            orow = r * i[rt.G_O_STRIDE] + i[rt.G_O_OFF]
+            if op.res.space != rt.SP_NONE:
+                ldr = i[rt.G_LDR]
+                res = bufs.view(op.res, B, batches * o_rows * ldr).view(batches, o_rows, ldr)
+                acc = acc + res[:, orow, :n]
+            out = bufs.view(op.out, B, batches * o_rows * ldc).view(batches, o_rows, ldc)
+            out[:, orow, i[rt.G_O_COL]: i[rt.G_O_COL] + n] = acc
+        elif op.kind == rt.OP_GN_STATS:
+            rows, ld, G, gs = i[rt.N_ROWS], i[rt.N_LD], i[rt.N_GROUPS], i[rt.N_GSIZE]
+            x = bufs.view(op.a, B, B * rows * ld).view(B, rows, ld)[:, :, : G * gs].reshape(B, rows, G, gs)
+            mean = x.mean(dim=(1, 3))
+            var = x.var(dim=(1, 3), unbiased=False)
+            st = bufs.view(op.out, B, B * G * 2).view(B, G, 2)
+            st[:, :, 0] = mean
+            st[:, :, 1] = 1.0 / torch.sqrt(var + float(f[0]))
+        elif op.kind == rt.OP_ATTN:
+            T, Tk, H = i[rt.A_T], i[rt.A_TK], i[rt.A_HEADS]
+            ldq, ldkv, ldo, bs = i[rt.A_LDQ], i[rt.A_LDKV], i[rt.A_LDO], i[rt.A_KV_BSTRIDE]
+            D = 64
+            q = bufs.view(op.a, B, B * T * ldq).view(B, T, ldq)[:, :, : H * D].reshape(B, T, H, D).transpose(1, 2)
+            if bs == 0:
+                kv = bufs.view(op.a2, B, Tk * ldkv).view(1, Tk, ldkv).expand(B, -1, -1)
+            else:
+                assert bs == Tk
+                kv = bufs.view(op.a2, B, B * Tk * ldkv).view(B, Tk, ldkv)
+            k = kv[:, :, : H * D].reshape(B, Tk, H, D).transpose(1, 2)
+            v = kv[:, :, H * D: 2 * H * D].reshape(B, Tk, H, D).transpose(1, 2)
+            sim = (q @ k.transpose(-1, -2)) * float(f[0])
+            o = (sim.softmax(-1) @ v).transpose(1, 2).reshape(B, T, H * D)
+            out = bufs.view(op.out, B, B * T * ldo).view(B, T, ldo)
+            out[:, :, : H * D] = o
+        elif op.kind == rt.OP_CONCAT:
+            rows, ca, cb = i[rt.C_ROWS], i[rt.C_CA], i[rt.C_CB]
+            a = bufs.view(op.a, B, B * rows * ca).view(B * rows, ca)
+            b = bufs.view(op.a2, B, B * rows * cb).view(B * rows, cb)
+            out = bufs.view(op.out, B, B * rows * (ca + cb)).view(B * rows, ca + cb)
+            out[:, :ca] = a
+            out[:, ca:] = b * float(f[0])
+        elif op.kind == rt.OP_PATCH:
+            rl, cl, ld_in, ld_out, p, inv = (i[rt.P_ROWS_IN], i[rt.P_C_IN], i[rt.P_LD_IN], i[rt.P_LD_OUT],
+                                             i[rt.P_PATCH], i[rt.P_INVERSE])
+            if not inv:      # y[b, l, c*p + q] = x[b, l*p + q, c]
+                x = bufs.view(op.a, B, B * rl * ld_in).view(B, rl // p, p, ld_in)[:, :, :, :cl]
+                out = bufs.view(op.out, B, B * (rl // p) * ld_out).view(B, rl // p, ld_out)
+                out[:, :, : cl * p] = x.permute(0, 1, 3, 2).reshape(B, rl // p, cl * p)
+            else:            # x[b, l*p + q, c] = y[b, l, c*p + q]
+                y = bufs.view(op.a, B, B * (rl // p) * ld_in).view(B, rl // p, ld_in)[:, :, : cl * p]
+                out = bufs.view(op.out, B, B * rl * ld_out).view(B, rl // p, p, ld_out)
+                out[:, :, :, :cl] = y.reshape(B, rl // p, cl, p).permute(0, 1, 3, 2)
+        elif op.kind == rt.OP_TIME_EMBED:
+            half, ld = i[rt.T_HALF], i[rt.T_LD]
+            n = n_shared_rows
+            t = bufs.view(op.a, B, n).view(n, 1)
+            w = bufs.view(op.w, B, half).view(1, half)
+            fr = t * w * 2 * math.pi
+            out = bufs.view(op.out, B, n * ld).view(n, ld)
+            out.zero_()
+            out[:, 0:1] = t
+            out[:, 1: 1 + half] = fr.sin()
+            out[:, 1 + half: 1 + 2 * half] = fr.cos()
+        else:
+            raise ValueError(f"unknown op kind {op.kind}")

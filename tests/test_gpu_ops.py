@@ -1,0 +1,269 @@
+"""-m gpu: every kernel class through the C ABI against the CPU interpreter / closed-form torch expressions."""
+import math
+
+import pytest
+import torch
+
+from gpu_util import DEV, ref, rnd, run_both
+from moleculediffusiontransformer_amd import runtime as rt
+
+pytestmark = pytest.mark.gpu
+
+W, A, S, E0 = rt.SP_WEIGHT, rt.SP_ACT, rt.SP_SHR, rt.SP_EXT0
+
+
+def gemm_op(**kw):
+    op = rt.MdtOp()
+    op.kind = rt.OP_GEMM
+    for k in ("a", "w", "bias", "out", "res", "p0", "p1", "p2", "p3"):
+        if k in kw:
+            setattr(op, k, kw.pop(k))
+    i = op.i
+    i[rt.G_T_STRIDE], i[rt.G_O_STRIDE] = 1, 1
+    names = dict(r_out=rt.G_R_OUT, r_in=rt.G_R_IN, lda=rt.G_LDA, cin=rt.G_CIN, taps=rt.G_TAPS, t_stride=rt.G_T_STRIDE,
+                 t_dj=rt.G_T_DJ, t_off=rt.G_T_OFF, n=rt.G_N, ldc=rt.G_LDC, o_rows=rt.G_O_ROWS,
+                 o_stride=rt.G_O_STRIDE, o_off=rt.G_O_OFF, ldr=rt.G_LDR, pro=rt.G_PRO, groups=rt.G_GROUPS,
+                 gsize=rt.G_GSIZE, pro_silu=rt.G_PRO_SILU, act=rt.G_ACT, m_mode=rt.G_M_MODE, a_col=rt.G_A_COL,
+                 o_col=rt.G_O_COL)
+    op.f[0] = kw.pop("eps", 0.0)
+    for k, v in kw.items():
+        i[names[k]] = v
+    return op
+
+
+@pytest.mark.parametrize("B,R,cin,N,taps", [(3, 16, 128, 512, 1), (5, 64, 16, 64, 3), (2, 4, 512, 256, 3),
+                                            (7, 16, 48, 32, 1), (1, 1, 80, 256, 1), (9, 64, 64, 16, 3)])
+def test_gemm_plain_bias_gelu_residual(B, R, cin, N, taps):
+    K = taps * cin
+    weights = torch.cat([rnd(N, K, seed=1, scale=K ** -0.5).view(-1), rnd(N, seed=2)])
+    act = torch.cat([rnd(B * R * cin, seed=3), torch.zeros(B * R * N), rnd(B * R * N, seed=4)])
+    ops = [gemm_op(a=ref(A, 0), w=ref(W, 0), bias=ref(W, N * K), out=ref(A, R * cin), res=ref(A, R * cin + R * N),
+                   r_out=R, r_in=R, lda=cin, cin=cin, taps=taps, t_dj=1 if taps > 1 else 0,
+                   t_off=-(taps // 2), n=N, ldc=N, o_rows=R, ldr=N, act=0)]
+    (ga, _, _), (ca, _, _) = run_both(ops, weights, act, torch.zeros(4), {}, B)
+    assert (ga - ca).abs().max() < 2e-5
+    ops[0].i[rt.G_ACT] = 1
+    ops[0].res = ref(rt.SP_NONE)
+    (ga, _, _), (ca, _, _) = run_both(ops, weights, act, torch.zeros(4), {}, B)
+    assert (ga - ca).abs().max() < 2e-5
+
+
+def test_gemm_strided_conv_and_transposed_phases():
+    B, Lin, cin, N, f = 3, 16, 64, 128, 4
+    # Conv1d k=9 s=4 p=4 (modules.py:40-51)
+    weights = torch.cat([rnd(N, 9 * cin, seed=1, scale=0.05).view(-1), rnd(N, seed=2)])
+    act = torch.cat([rnd(B * Lin * cin, seed=3), torch.zeros(B * (Lin // f) * N)])
+    ops = [gemm_op(a=ref(A, 0), w=ref(W, 0), bias=ref(W, N * 9 * cin), out=ref(A, Lin * cin), r_out=Lin // f,
+                   r_in=Lin, lda=cin, cin=cin, taps=9, t_stride=f, t_dj=1, t_off=-f, n=N, ldc=N, o_rows=Lin // f)]
+    (ga, _, _), (ca, _, _) = run_both(ops, weights, act, torch.zeros(4), {}, B)
+    assert (ga - ca).abs().max() < 2e-5
+    x = act[: B * Lin * cin].view(B, Lin, cin).transpose(1, 2)
+    wt = weights[: N * 9 * cin].view(N, 9, cin).permute(0, 2, 1)
+    y = torch.nn.functional.conv1d(x, wt, weights[N * 9 * cin:], stride=f, padding=f)
+    assert (ga[B * Lin * cin:].view(B, Lin // f, N) - y.transpose(1, 2)).abs().max() < 2e-5
+    # ConvTranspose1d k=8 s=4 p=2 as 4 phases (modules.py:74-81), with a residual on the output rows
+    wt = rnd(cin, N, 2 * f, seed=5, scale=0.05)
+    bias = rnd(N, seed=6)
+    chunks, offs, o = [], [], 0
+    for ph in range(f):
+        wp = torch.stack((wt[:, :, ph], wt[:, :, ph + f]), 0).permute(2, 0, 1).contiguous().view(-1)
+        chunks.append(wp)
+        offs.append(o)
+        o += wp.numel()
+    weights = torch.cat(chunks + [bias])
+    Lout = Lin * f
+    act = torch.cat([rnd(B * Lin * cin, seed=7), torch.zeros(B * Lout * N), rnd(B * Lout * N, seed=8)])
+    ops = []
+    for ph in range(f):
+        shift = 1 if ph < f // 2 else 0
+        ops.append(gemm_op(a=ref(A, 0), w=ref(W, offs[ph]), bias=ref(W, o), out=ref(A, Lin * cin),
+                           res=ref(A, Lin * cin + Lout * N), r_out=Lin, r_in=Lin, lda=cin, cin=cin, taps=2, t_dj=-1,
+                           t_off=shift, n=N, ldc=N, o_rows=Lout, o_stride=f, o_off=f * shift + ph - f // 2, ldr=N))
+    (ga, _, _), (ca, _, _) = run_both(ops, weights, act, torch.zeros(4), {}, B)
+    assert (ga - ca).abs().max() < 2e-5
+    x = act[: B * Lin * cin].view(B, Lin, cin).transpose(1, 2)
+    y = torch.nn.functional.conv_transpose1d(x, wt, bias, stride=f, padding=f // 2)
+    y = y.transpose(1, 2) + act[B * Lin * cin + B * Lout * N:].view(B, Lout, N)
+    assert (ga[B * Lin * cin: B * Lin * cin + B * Lout * N].view(B, Lout, N) - y).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("B,R,C,N", [(4, 16, 128, 512), (3, 12, 128, 1024), (2, 4, 256, 512), (130, 1, 64, 64)])
+def test_gemm_layernorm_prologue(B, R, C, N):
+    weights = torch.cat([rnd(N, C, seed=1, scale=C ** -0.5).view(-1), 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)])
+    act = torch.cat([rnd(B * R * C, seed=4) * 2 + 0.5, torch.zeros(B * R * N)])
+    ops = [gemm_op(a=ref(A, 0), w=ref(W, 0), out=ref(A, R * C), p0=ref(W, N * C), p1=ref(W, N * C + C), r_out=R,
+                   r_in=R, lda=C, cin=C, taps=1, n=N, ldc=N, o_rows=R, pro=rt.PRO_LAYERNORM, eps=1e-5)]
+    (ga, _, _), (ca, _, _) = run_both(ops, weights, act, torch.zeros(4), {}, B)
+    assert (ga - ca).abs().max() < 3e-5
+    x = act[: B * R * C].view(B * R, C)
+    y = torch.nn.functional.layer_norm(x, (C,), weights[N * C: N * C + C], weights[N * C + C:], 1e-5) @ \
+        weights[: N * C].view(N, C).T
+    assert (ga[B * R * C:].view(B * R, N) - y).abs().max() < 3e-5
+
+
+@pytest.mark.parametrize("B,R,C,G,N,film,silu,eps", [(3, 64, 64, 1, 64, False, True, 1e-5),
+                                                      (2, 16, 128, 8, 128, True, True, 1e-5),
+                                                      (5, 4, 512, 8, 256, True, True, 1e-5),
+                                                      (3, 16, 128, 32, 128, False, False, 1e-6),
+                                                      (2, 32, 32, 32, 32, False, False, 1e-6)])
+def test_gn_stats_and_groupnorm_prologue(B, R, C, G, N, film, silu, eps):
+    gs = C // G
+    taps = 3 if silu else 1
+    K = taps * C
+    weights = torch.cat([rnd(N, K, seed=1, scale=K ** -0.5).view(-1), 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)])
+    shr = 0.3 * rnd(2 * C, seed=9)
+    xoff, stoff, ooff = 0, R * C, R * C + 64
+    act = torch.zeros(B * (R * C + 64 + R * N))
+    act[: B * R * C] = rnd(B * R * C, seed=4) * 1.5 + 0.3
+    st = rt.MdtOp()
+    st.kind = rt.OP_GN_STATS
+    st.a, st.out = ref(A, xoff), ref(A, stoff)
+    st.i[rt.N_ROWS], st.i[rt.N_LD], st.i[rt.N_GROUPS], st.i[rt.N_GSIZE] = R, C, G, gs
+    st.f[0] = eps
+    ops = [st, gemm_op(a=ref(A, xoff), w=ref(W, 0), out=ref(A, ooff), p0=ref(W, N * K), p1=ref(W, N * K + C),
+                       p2=ref(A, stoff), p3=ref(S, 0) if film else ref(rt.SP_NONE), r_out=R, r_in=R, lda=C, cin=C,
+                       taps=taps, t_dj=1 if taps > 1 else 0, t_off=-(taps // 2), n=N, ldc=N, o_rows=R,
+                       pro=rt.PRO_GROUPNORM, groups=G, gsize=gs, pro_silu=int(silu))]
+    # NB: stats are per-sample 2G floats at ACT offset stoff (scaled by B at run time) -> needs 2G <= 64
+    (ga, _, _), (ca, _, _) = run_both(ops, weights, act, shr, {}, B)
+    assert (ga - ca).abs().max() < 5e-5
+    # independent check against torch's GroupNorm + conv
+    x = act[: B * R * C].view(B, R, C).transpose(1, 2)
+    h = torch.nn.functional.group_norm(x, G, weights[N * K: N * K + C], weights[N * K + C:], eps)
+    if film:
+        h = h * (shr[:C].view(1, C, 1) + 1) + shr[C:].view(1, C, 1)
+    if silu:
+        h = torch.nn.functional.silu(h)
+    y = torch.nn.functional.conv1d(h, weights[: N * K].view(N, taps, C).permute(0, 2, 1), padding=taps // 2)
+    assert (ga[B * ooff:].view(B, R, N) - y.transpose(1, 2)).abs().max() < 5e-5
+
+
+@pytest.mark.parametrize("B,T,Tk,shared", [(3, 16, 16, False), (2, 16, 12, False), (5, 4, 4, False), (2, 4, 12, True),
+                                           (2, 1, 64, False), (1, 32, 32, False), (3, 16, 12, True)])
+def test_attention(B, T, Tk, shared):
+    H, D = 8, 64
+    act = torch.cat([rnd(B * T * H * D, seed=1), rnd(B * Tk * 2 * H * D, seed=2), torch.zeros(B * T * H * D)])
+    shr = rnd(Tk * 2 * H * D, seed=3)
+    op = rt.MdtOp()
+    op.kind = rt.OP_ATTN
+    op.a, op.out = ref(A, 0), ref(A, T * H * D + Tk * 2 * H * D)
+    op.a2 = ref(S, 0) if shared else ref(A, T * H * D)
+    i = op.i
+    i[rt.A_T], i[rt.A_TK], i[rt.A_HEADS], i[rt.A_LDQ], i[rt.A_LDKV], i[rt.A_LDO] = T, Tk, H, H * D, 2 * H * D, H * D
+    i[rt.A_KV_BSTRIDE] = 0 if shared else Tk
+    op.f[0] = D ** -0.5
+    (ga, _, _), (ca, _, _) = run_both([op], torch.zeros(4), act, shr, {}, B)
+    assert (ga - ca).abs().max() < 1e-5
+
+
+def test_concat_patch_time_embed():
+    B, R, Ca, Cb = 3, 16, 128, 128
+    act = torch.cat([rnd(B * R * Ca, seed=1), rnd(B * R * Cb, seed=2), torch.zeros(B * R * (Ca + Cb))])
+    op = rt.MdtOp()
+    op.kind = rt.OP_CONCAT
+    op.a, op.a2, op.out = ref(A, 0), ref(A, R * Ca), ref(A, R * (Ca + Cb))
+    op.i[rt.C_ROWS], op.i[rt.C_CA], op.i[rt.C_CB] = R, Ca, Cb
+    op.f[0] = 2 ** -0.5
+    (ga, _, _), (ca, _, _) = run_both([op], torch.zeros(4), act, torch.zeros(4), {}, B)
+    assert torch.equal(ga, ca)
+    # Patcher / Unpatcher round trip
+    L, C, p = 64, 16, 4
+    act = torch.cat([rnd(B * L * C, seed=3), torch.zeros(B * L * C), torch.zeros(B * L * C)])
+    fwd, inv = rt.MdtOp(), rt.MdtOp()
+    for o, (src, dst, inverse) in ((fwd, (0, L * C, 0)), (inv, (L * C, 2 * L * C, 1))):
+        o.kind = rt.OP_PATCH
+        o.a, o.out = ref(A, src), ref(A, dst)
+        o.i[rt.P_ROWS_IN], o.i[rt.P_C_IN], o.i[rt.P_PATCH], o.i[rt.P_INVERSE] = L, C, p, inverse
+        o.i[rt.P_LD_IN], o.i[rt.P_LD_OUT] = (C * p, C) if inverse else (C, C * p)
+    (ga, _, _), (ca, _, _) = run_both([fwd, inv], torch.zeros(4), act, torch.zeros(4), {}, B)
+    assert torch.equal(ga, ca)
+    assert torch.equal(ga[2 * B * L * C:], ga[: B * L * C])
+    x = act[: B * L * C].view(B, L, C).transpose(1, 2)                      # b c (l p)
+    y = x.reshape(B, C, L // p, p).permute(0, 1, 3, 2).reshape(B, C * p, L // p)   # 'b c (l p) -> b (c p) l'
+    assert torch.equal(ga[B * L * C: 2 * B * L * C].view(B, L // p, C * p), y.transpose(1, 2))
+    # LearnedPositionalEmbedding
+    n, half, ld = 7, 32, 80
+    shr = torch.cat([torch.linspace(-1.7, 0.55, n), torch.zeros(57), torch.zeros(n * ld)])
+    weights = rnd(half, seed=5)
+    t = rt.MdtOp()
+    t.kind = rt.OP_TIME_EMBED
+    t.a, t.w, t.out = ref(S, 0), ref(W, 0), ref(S, 64)
+    t.i[rt.T_HALF], t.i[rt.T_LD] = half, ld
+    (_, gs, _), (_, cs, _) = run_both([t], weights, torch.zeros(4), shr, {}, 1, n)
+    assert (gs - cs).abs().max() < 2e-6
+
+
+def test_sampler_kernels_match_reference_arithmetic():
+    lib = rt.load_library()
+    B, C, L, Cp = 5, 22, 32, 32
+    x, xm, nz = rnd(B, C, L, seed=1) * 3, rnd(B, C, L, seed=2) * 3, rnd(B, C, L, seed=3)
+    pred = rnd(B, L, Cp, seed=4)
+    c_skip, c_out, c_in, sigma, sigma_mid, dt_mid, dt_down, up = 0.31, 0.095, 3.3, 0.29, 0.21, -0.08, -0.11, 0.17
+    gx, gxm, gnz, gp = (t.to(DEV).contiguous() for t in (x, xm, nz, pred))
+    with torch.cuda.device(DEV):
+        st = rt.current_stream()
+        xin = torch.full((B, L, Cp), 7.0, device=DEV)
+        rt.check(lib.mdt_precond_in(rt.ptr(gx), rt.ptr(xin), c_in, B, C, L, Cp, st))
+        want = torch.zeros(B, L, Cp)
+        want[:, :, :C] = (c_in * x).transpose(1, 2)
+        assert torch.equal(xin.cpu(), want)
+        D = torch.empty_like(gx)
+        rt.check(lib.mdt_precond_out(rt.ptr(gx), rt.ptr(gp), rt.ptr(D), c_skip, c_out, B, C, L, Cp, st))
+        p = pred[:, :, :C].transpose(1, 2)
+        den = (c_skip * x + c_out * p).clamp(-1.0, 1.0)
+        assert torch.equal(D.cpu(), den)
+        out_mid, xin_mid = torch.empty_like(gx), torch.empty_like(xin)
+        rt.check(lib.mdt_adpm2_mid(rt.ptr(gx), rt.ptr(gp), rt.ptr(out_mid), rt.ptr(xin_mid), c_skip, c_out, sigma,
+                                   dt_mid, c_in, B, C, L, Cp, st))
+        sg = torch.tensor(sigma)
+        x_mid = x + ((x - den) / sg) * torch.tensor(dt_mid)
+        assert torch.equal(out_mid.cpu(), x_mid)
+        assert torch.equal(xin_mid.cpu()[:, :, :C], (torch.tensor(c_in) * x_mid).transpose(1, 2))
+        assert float(xin_mid[:, :, C:].abs().max()) == 0.0
+        x2 = gx.clone()
+        rt.check(lib.mdt_adpm2_next(rt.ptr(x2), rt.ptr(gxm), rt.ptr(gp), rt.ptr(gnz), rt.ptr(xin_mid), c_skip, c_out,
+                                    sigma_mid, dt_down, up, c_in, 0, 0, 0, B, C, L, Cp, st))
+        den2 = (c_skip * xm + c_out * p).clamp(-1.0, 1.0)
+        want = x + ((xm - den2) / torch.tensor(sigma_mid)) * torch.tensor(dt_down)
+        want = want + nz * torch.tensor(up)
+        assert torch.equal(x2.cpu(), want)
+        assert torch.equal(xin_mid.cpu()[:, :, :C], (torch.tensor(c_in) * want).transpose(1, 2))
+        # guidance mix, clamp, argmax, inpaint merge
+        a, b = rnd(B, L, Cp, seed=5).to(DEV), rnd(B, L, Cp, seed=6).to(DEV)
+        o = torch.empty_like(a)
+        rt.check(lib.mdt_cfg_mix(rt.ptr(a), rt.ptr(b), rt.ptr(o), 7.5, a.numel(), st))
+        assert torch.equal(o.cpu(), b.cpu() + (a.cpu() - b.cpu()) * 7.5)
+        c = gx.clone()
+        rt.check(lib.mdt_clamp(rt.ptr(c), -1.0, 1.0, c.numel(), st))
+        assert torch.equal(c.cpu(), x.clamp(-1, 1))
+        tok = torch.empty(B, L, dtype=torch.int32, device=DEV)
+        rt.check(lib.mdt_argmax_tokens(rt.ptr(gx), rt.ptr(tok), B, C, L, st))
+        assert torch.equal(tok.cpu().long(), x.permute(0, 2, 1).argmax(dim=2))
+        mask = (rnd(B, C, L, seed=8) > 0)
+        gm = mask.to(torch.uint8).to(DEV)
+        y = gx.clone()
+        rt.check(lib.mdt_inpaint_merge(rt.ptr(y), rt.ptr(gxm), rt.ptr(gm), rt.ptr(gnz), 0.7, 0, 0, 0, B, C, L, st))
+        src_noisy = xm + torch.tensor(0.7) * nz
+        assert torch.equal(y.cpu(), src_noisy * mask + x * ~mask)
+
+
+def test_counter_based_noise_is_normal_and_sharding_independent():
+    lib = rt.load_library()
+    B, C, L = 64, 16, 64
+    with torch.cuda.device(DEV):
+        st = rt.current_stream()
+        full = torch.empty(B, C, L, device=DEV)
+        rt.check(lib.mdt_init_noise(rt.ptr(full), 0, 1.0, 1234, 3, 0, B, C, L, st))
+        lo, hi = torch.empty(B // 2, C, L, device=DEV), torch.empty(B // 2, C, L, device=DEV)
+        rt.check(lib.mdt_init_noise(rt.ptr(lo), 0, 1.0, 1234, 3, 0, B // 2, C, L, st))
+        rt.check(lib.mdt_init_noise(rt.ptr(hi), 0, 1.0, 1234, 3, B // 2, B // 2, C, L, st))
+        other = torch.empty(B, C, L, device=DEV)
+        rt.check(lib.mdt_init_noise(rt.ptr(other), 0, 1.0, 1234, 4, 0, B, C, L, st))
+        torch.cuda.synchronize()
+    assert torch.equal(torch.cat([lo, hi]), full)
+    assert not torch.equal(other, full)
+    f = full.cpu().double()
+    n = f.numel()
+    assert abs(f.mean()) < 4 / math.sqrt(n) and abs(f.var() - 1) < 0.02
+    assert abs((f ** 3).mean()) < 0.05 and abs((f ** 4).mean() - 3) < 0.1
+    assert abs((f[:, :, 1:] * f[:, :, :-1]).mean()) < 0.01

@@ -1,0 +1,126 @@
+"""CPU tests: host-side scalar logic, class surface, lowering (via the CPU program interpreter), C ABI export."""
+import ctypes
+import re
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+from helpers import CASES, oracle_cfg, synth_sd
+from moleculediffusiontransformer_amd import (ADPM2Sampler, KarrasSchedule, QMDiffusion, QMDiffusionForward,
+                                              runtime as rt)
+from moleculediffusiontransformer_amd.compiler import compile_unet
+from moleculediffusiontransformer_amd.diffusion import adpm2_plan, scale_weights
+from moleculediffusiontransformer_amd.netspec import forward_unet_config, inverse_unet_config
+from oracle import unet_oracle as O
+from oracle.program_interp import Buffers, run_program
+
+
+def test_c_abi_exports_every_declared_symbol():
+    lib = rt.load_library()
+    hdr = open(os.path.join(ROOT, "include", "mdt_hip.h")).read()
+    declared = set(re.findall(r"\b(mdt_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(rt.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.mdt_abi_version() == 1
+    assert ctypes.sizeof(rt.MdtOp) == 8 + 10 * 16 + 24 * 4 + 8 * 4
+    bad = rt.MdtOp()
+    bad.kind = 1   # GEMM with cin == 0
+    with pytest.raises(RuntimeError, match="cin must be"):
+        rt.Program([bad])
+
+
+def test_plan_matches_reference_scalars():
+    g = load_golden("scalars.npz")
+    for T in (64, 100, 12):
+        sig, steps = adpm2_plan(T, KarrasSchedule(0.001, 9.0, 3.0), ADPM2Sampler(rho=1), 0.1)
+        assert np.array_equal(sig.numpy(), g[f"sigmas_{T}"])
+        assert len(steps) == T - 1
+        for i, s in enumerate(steps):
+            assert np.float32(s.sigma_up) == np.float32(g[f"up_{T}"][i])
+            assert np.float32(s.sigma_mid) == g[f"mid_{T}"][i]
+            assert np.float32(s.dt_down) == np.float32(np.float32(g[f"down_{T}"][i]) - g[f"sigmas_{T}"][i])
+            assert np.float32(s.dt_mid) == np.float32(g[f"mid_{T}"][i] - g[f"sigmas_{T}"][i])
+    for row, s in zip(g["scale_weights"], (9.0, 1.0, 0.001)):
+        w = scale_weights(torch.tensor(s), 0.1)
+        assert np.array_equal(np.array([w.c_skip, w.c_out, w.c_in, w.c_noise], dtype=np.float32), row)
+    # batch size does not change the to_batch()-ed scalars
+    for s in (9.0, 0.37, 0.001):
+        big = O.scale_weights(torch.full((1000,), s))
+        w = scale_weights(torch.tensor(s), 0.1)
+        assert float(big[0].flatten()[-1]) == w.c_skip and float(big[3][-1]) == w.c_noise
+
+
+def test_class_surface_and_checkpoint_layout(capsys):
+    g = load_golden("state_dict_keys.npz")
+    m = QMDiffusion(max_length=64, pred_dim=16, channels=64, context_embedding_max_length=12,
+                    text_embed_dim=64, embed_dim_position=64)
+    assert "Using unet type:  cfg" in capsys.readouterr().out          # generative.py:740
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(g["cfg1_keys"]) and len(sd) == 2301
+    assert [v.numel() for v in sd.values()] == list(g["cfg1_numel"])
+    assert sum(p.numel() for p in m.parameters()) == int(g["cfg1_nparams"]) == 32630960
+    # the three aliases share storage
+    assert sd["unet.to_mapping.0.weight"].data_ptr() == sd["diffusion.diffusion.net.to_mapping.0.weight"].data_ptr()
+    for attr in ("unet", "diffusion", "fc1", "GELUact", "p_enc_1d", "max_length", "pred_dim", "unet_type"):
+        assert hasattr(m, attr)
+    assert m.diffusion.diffusion.alias == "k" and m.diffusion.net is m.unet
+    # a checkpoint holding only unet.* restores the model under strict=False
+    only_unet = {k: torch.zeros_like(v) for k, v in sd.items() if k.startswith("unet.")}
+    m.load_state_dict(only_unet, strict=False)
+    assert float(m.state_dict()["diffusion.net.to_mapping.0.weight"].abs().max()) == 0.0
+    mf = QMDiffusionForward(64, 64, 1, None, 64, text_embed_dim=64, embed_dim_position=64)
+    assert list(mf.state_dict().keys()) == list(g["cfg3_keys"])
+    assert sum(p.numel() for p in mf.parameters()) == 18322684          # Forward_Diffusion.ipynb:1336
+    big = QMDiffusion(max_length=32, pred_dim=22, channels=128, context_embedding_max_length=12,
+                      text_embed_dim=64, embed_dim_position=64)
+    assert sum(p.numel() for p in big.parameters()) == 90965554         # Inverse_Diffusion.ipynb:1580
+
+
+def test_no_cpu_fallback():
+    m = QMDiffusion(max_length=32, pred_dim=16, channels=16, context_embedding_max_length=12,
+                    text_embed_dim=64, embed_dim_position=64)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.sample(torch.randn(2, 12), "cpu", cond_scale=1.0, timesteps=4)
+    with pytest.raises(NotImplementedError):
+        m(torch.randn(2, 12), torch.randn(2, 16, 32))
+
+
+@pytest.mark.parametrize("case", ["tiny", "pd22", "cfg3", "cfg1"])
+def test_lowering_matches_reference_golden(case):
+    """compiler.py's op program, executed by the CPU interpreter, reproduces the reference U-Net output."""
+    kind, kw = CASES[case]
+    mk = inverse_unet_config if kind == "inverse" else forward_unet_config
+    ucfg = mk(kw["pred_dim"], kw["channels"], 128, kw["context_embedding_max_length"])
+    usd = {k[5:]: v for k, v in synth_sd(case).items() if k.startswith("unet.")}
+    cu = compile_unet(ucfg, kw["max_length"], kw["context_embedding_max_length"], usd, max_time_rows=4)
+    g = load_golden(f"{case}_unet.npz")
+    x, t, emb = (torch.from_numpy(g[k]) for k in ("x", "t", "emb"))
+    B, C, L = x.shape
+    for fixed in (False, True):
+        outs = []
+        for b in range(min(B, 2) if fixed else B):
+            act, shr = torch.zeros(cu.act_floats), torch.zeros(cu.shr_floats)
+            xin = torch.zeros(1, L, cu.in_pad)
+            xin[0, :, :C] = x[b].T
+            out = torch.zeros(1, L, cu.in_pad)
+            bufs = Buffers(cu.weights, act, shr, {0: xin.view(-1), 1: emb[b:b + 1].contiguous().view(-1), 2: out.view(-1)})
+            shr[cu.shr["c_noise"]] = t[b]
+            run_program(cu.programs["time"], bufs, 1, 1)
+            ss = cu.ss_total
+            shr[cu.shr["ss_cur"]: cu.shr["ss_cur"] + ss] = shr[cu.shr["ss_all"]: cu.shr["ss_all"] + ss].clone()
+            run_program(cu.programs["ctx_fixed" if fixed else "ctx"], bufs, 1)
+            run_program(cu.programs["eval_fixed" if fixed else "eval"], bufs, 1)
+            outs.append(out[0, :, :C].T.clone())
+            assert float(out[0, :, C:].abs().max()) == 0.0 if cu.in_pad > C else True
+        y = torch.stack(outs)
+        if not fixed:
+            assert (y - torch.from_numpy(g["y_scale1"])).abs().max() < 1e-5
+            y_cond = y
+        else:
+            mix = y + (y_cond[: y.shape[0]] - y) * 7.5
+            assert (mix - torch.from_numpy(g["y_scale7p5"])[: y.shape[0]]).abs().max() < 5e-5
+    assert abs(cu.flops_per_sample_eval - {"cfg1": 388.7e6}.get(case, cu.flops_per_sample_eval)) < 1e6
