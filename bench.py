@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Headline benchmark: molecules/sec at 64 diffusion steps (QM9-shaped inverse model) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A "step" is one full QMDiffusion.sample() call over one batch: BASELINE.json configs[1] = inverse model
+channels=64, pred_dim=16, max_len=64, cond_len=12, batch 1024 per GPU, 64 timesteps (126 U-Net
+evaluations + 63 ADPM2 updates), fp32, cond_scale=1.0, synthetic weights/conditioning, inputs resident in
+HBM, on-device counter-based noise.  For N > 1 the driver launches one rank per GPU through
+torch.distributed.run; every rank samples its own 1024 molecules (weak scaling, no collective in the
+loop) and the generated samples are all-gathered once per call over RCCL.
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  "roofline":     the dominant kernel class (k_gemm: fp32-MFMA implicit GEMM), HIP-event timed per launch
+  "cpu_baseline": the CPU oracle (PyTorch restatement pinned to the reference) on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HBM_PEAK_GBS = 8000.0
+REF_FLOPS_PER_SAMPLE_EVAL = 455.3e6   # reference op graph (incl. per-eval cross-attn K/V + time mapping)
+REF_OPGRAPH_BYTES_PER_SAMPLE_EVAL = 13.21e6
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=1024, help="molecules per GPU per step")
+    ap.add_argument("--timesteps", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-breakdown", action="store_true")
+    return ap.parse_args()
+
+
+def kernel_breakdown(model, eng, torch, rt, B):
+    """HIP-event time of every op of ONE U-Net evaluation (plain launches, one interval per launch),
+    grouped by kernel class.  Returns dict class -> (launches, total_ms)."""
+    prog = eng.programs["eval"]
+    ops = eng.c.programs["eval"]
+    bind = eng._bind(xin=eng.xin, out=eng.pred)
+    names = {rt.OP_GEMM: "k_gemm", rt.OP_GN_STATS: "k_gn_stats", rt.OP_ATTN: "k_attn", rt.OP_CONCAT: "k_concat",
+             rt.OP_PATCH: "k_patch"}
+    best = None
+    for rep in range(3):
+        timer = rt.EventTimer(len(ops))
+        for i in range(len(ops)):
+            timer.start()
+            prog.run(bind, B, 0, i, 1)
+            timer.stop()
+        ms = timer.collect()
+        if best is None or sum(ms) < sum(best):
+            best = ms
+    out = {}
+    for op, t in zip(ops, best):
+        k = names[op.kind]
+        n, tot = out.get(k, (0, 0.0))
+        out[k] = (n + 1, tot + t)
+    return out
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the sampling path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    from gpu_util import make_model
+    from moleculediffusiontransformer_amd import NoiseSource, runtime as rt
+    from moleculediffusiontransformer_amd.distributed import all_gather_samples
+    from moleculediffusiontransformer_amd.synth import synth_normal
+
+    import gpu_util
+    gpu_util.DEV = str(device)
+    model = make_model("cfg1")                       # inverse c=64, pred_dim=16, L=64, cond_len=12; synthetic weights
+    B, T = a.batch, a.timesteps
+    seq = synth_normal(f"bench/seq/rank{rank}", (B, 12)).to(device)
+    evals = 2 * (T - 1)
+    eval_timer = rt.EventTimer(evals * (a.steps + a.warmup) + 8)
+
+    def one_step(step_idx, timed):
+        out = model.sample(seq, device, cond_scale=1.0, timesteps=T, clamp=False,
+                           noise=NoiseSource(seed=1234 + step_idx, sample0=rank * B),
+                           timer=eval_timer if timed else None)
+        if world > 1:
+            out = all_gather_samples(out, world * B)
+        return out
+
+    for w in range(a.warmup):
+        one_step(w, False)
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    fence()
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        out = one_step(a.warmup + k, True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(out).all()
+
+    eval_ms = eval_timer.collect()
+    result = None
+    if rank == 0:
+        eng = model.engine(device, 12)
+        mols = world * B * a.steps
+        value = mols / elapsed
+        flops_exec = eng.c.flops_per_sample_eval           # executed per sample per eval (K/V + time mapping hoisted)
+        avg_eval_ms = sum(eval_ms) / len(eval_ms)
+        roof = {"bound": "mfma", "kernel": "k_gemm (fp32 MFMA implicit GEMM, all instantiations)", "unit": "TFLOP/s",
+                "peak": FP32_MFMA_PEAK_TFLOPS, "traffic": None}
+        extra = {}
+        if not a.no_breakdown:
+            bd = kernel_breakdown(model, eng, torch, rt, B)
+            n_gemm, ms_gemm = bd["k_gemm"]
+            gemm_flops = sum(2 * o.i[rt.G_R_OUT] * o.i[rt.G_N] * o.i[rt.G_TAPS] * o.i[rt.G_CIN]
+                             for o in eng.c.programs["eval"] if o.kind == rt.OP_GEMM) * B
+            ach = gemm_flops / (ms_gemm * 1e-3) / 1e12
+            roof.update({"achieved": round(ach, 2), "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                         "launches_per_eval": n_gemm, "avg_launch_us": round(1e3 * ms_gemm / n_gemm, 2),
+                         "flops_per_launch_avg": gemm_flops / n_gemm})
+            extra["eval_breakdown_ms"] = {k: {"launches": n, "ms": round(t, 4)} for k, (n, t) in sorted(bd.items())}
+        else:
+            ach = flops_exec * B / (avg_eval_ms * 1e-3) / 1e12
+            roof.update({"achieved": round(ach, 2), "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4)})
+        extra["unet_eval"] = {
+            "ms_avg_graph_replay": round(avg_eval_ms, 4), "evals_timed": len(eval_ms),
+            "flops_per_sample_executed": flops_exec,
+            "tflops_executed": round(flops_exec * B / (avg_eval_ms * 1e-3) / 1e12, 2),
+            "mfma_fraction_executed": round(flops_exec * B / (avg_eval_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+            "mfma_fraction_reference_opgraph": round(REF_FLOPS_PER_SAMPLE_EVAL * B / (avg_eval_ms * 1e-3) / 1e12
+                                                     / FP32_MFMA_PEAK_TFLOPS, 4),
+            "hbm_fraction_reference_opgraph": round(REF_OPGRAPH_BYTES_PER_SAMPLE_EVAL * B / (avg_eval_ms * 1e-3) / 1e9
+                                                    / HBM_PEAK_GBS, 4),
+        }
+        result = {
+            "metric": "molecules/sec @64 diffusion steps (QM9 max_len=64)", "value": round(value, 2),
+            "unit": "molecules/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(1e3 * elapsed / a.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"QMDiffusion inverse sample(): channels=64 pred_dim=16 max_len=64 cond_len=12, "
+                                   f"batch={B}/GPU, {T} timesteps ({evals} U-Net evals), cond_scale=1.0, fp32",
+                       "global_batch": world * B, "timesteps": T, "parallelism": f"batch-shard x{world}"},
+            "roofline": roof,
+        }
+        result.update(extra)
+
+        if not a.no_cpu_baseline and world == 1:
+            from helpers import oracle_cfg, synth_sd
+            from oracle import unet_oracle as O
+            cb, ct = 128, 8                                   # bounded sample: 128 molecules, 8 timesteps = 14 evals
+            sd, cfg = synth_sd("cfg1"), oracle_cfg("cfg1")
+            cseq = synth_normal("bench/cpu/seq", (cb, 12))
+            init = synth_normal("bench/cpu/init", (cb, 16, 64))
+            nz = [synth_normal(f"bench/cpu/step{i}", (cb, 16, 64)) for i in range(ct - 1)]
+            O.sample(sd, cfg, cseq[:4], init[:4], lambda i, x: nz[i][:4], 3, 1.0, False)   # warm-up
+            c0 = time.perf_counter()
+            O.sample(sd, cfg, cseq, init, lambda i, x: nz[i], ct, 1.0, False)
+            cdt = time.perf_counter() - c0
+            per_eval = cdt / (2 * (ct - 1))
+            result["cpu_baseline"] = {
+                "value": round(cb / (per_eval * evals), 3), "unit": "molecules/s", "cores": torch.get_num_threads(),
+                "kind": "port",
+                "sample": f"oracle/unet_oracle.py (PyTorch CPU fp32, bit-exact to the reference): batch {cb}, {ct} "
+                          f"timesteps = {2 * (ct - 1)} U-Net evals in {cdt:.2f} s, scaled to {evals} evals"}
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,52 @@
+"""Batch-sharded sampling over the GPUs of one node: one process per GPU, weights replicated, no
+collective inside the step loop, ONE all-gather of the generated samples per call (RCCL over xGMI;
+backend "nccl" is RCCL on ROCm).  No cross-sample op exists on the path, so sharding
+the batch axis is exact: with the counter-based noise keyed by the GLOBAL sample index an N-rank run
+returns the same samples as a 1-rank run.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+Tensor = torch.Tensor
+
+
+def shard_bounds(total: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous [start, stop) of `total` items owned by `rank` (first `total % world` ranks get one more)."""
+    q, r = divmod(total, world)
+    start = rank * q + min(rank, r)
+    return start, start + q + (1 if rank < r else 0)
+
+
+def all_gather_samples(local: Tensor, total: int, group=None) -> Tensor:
+    """All-gather per-rank (b_r, C, L) results into the global (total, C, L) tensor on every rank."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return local
+    rank = dist.get_rank(group)
+    sizes = [shard_bounds(total, world, r)[1] - shard_bounds(total, world, r)[0] for r in range(world)]
+    assert local.shape[0] == sizes[rank], (local.shape, sizes, rank)
+    mx = max(sizes)
+    pad = local
+    if local.shape[0] < mx:
+        pad = torch.cat([local, local.new_zeros((mx - local.shape[0],) + tuple(local.shape[1:]))])
+    out = local.new_empty((world * mx,) + tuple(local.shape[1:]))
+    dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
+    if all(s == mx for s in sizes):
+        return out
+    return torch.cat([out[r * mx: r * mx + s] for r, s in enumerate(sizes)])
+
+
+def sample_sharded(local_sample: Callable[[Tensor, int], Tensor], sequences: Tensor, group=None) -> Tensor:
+    """Every rank passes the same global `sequences` (B, n); rank r generates samples for its contiguous
+    slice via ``local_sample(seq_slice, first_global_index)`` and all ranks receive the full result."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    lo, hi = shard_bounds(sequences.shape[0], world, rank)
+    local = local_sample(sequences[lo:hi], lo)
+    if world == 1:
+        return local
+    return all_gather_samples(local, sequences.shape[0], group)
