@@ -121,7 +121,9 @@ typedef struct mdt_op {
   int32_t kind;
   int32_t reserved;
   mdt_ref a;    /* GEMM A / GN input / ATTN q / CONCAT a / PATCH in / TIME c_noise values        */
-  mdt_ref a2;   /* ATTN k (v = k + heads*64 floats) / CONCAT b                                   */
+  mdt_ref a2;   /* ATTN k (v = k + heads*64 floats) / CONCAT b / GEMM: bf16 lo plane of split weights:
+                   when set, w is the bf16 hi plane [N][K] and the product is formed as hi*hi + hi*lo + lo*hi
+                   on bf16 MFMAs with fp32 accumulation (needs cin % 32 == 0); unset = exact fp32 MFMA */
   mdt_ref w;    /* GEMM weights [N][K], K contiguous / TIME fourier weights                       */
   mdt_ref bias; /* GEMM bias [N]                                                                  */
   mdt_ref out;

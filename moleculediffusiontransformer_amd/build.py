@@ -19,6 +19,7 @@ STAMP = os.path.join(CSRC, ".build_stamp")
 # (source, extra flags).  k_elem keeps the reference's separate fp32 mul/add rounding.
 SOURCES = [
     ("k_gemm.hip", []),
+    ("k_gemm_bf16x3.hip", []),
     ("k_norm.hip", []),
     ("k_attn.hip", []),
     ("k_elem.hip", ["-ffp-contract=off"]),

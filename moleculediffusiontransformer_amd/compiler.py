@@ -120,12 +120,17 @@ class CompiledUNet:
     n_cross: int
     flops_per_sample_eval: int       # 2*MACs of one conditional U-Net evaluation (dense contractions + attention)
     flops_ctx_per_sample: int
+    gemm_mode: str = "bf16x3"
     weight_index: Dict[str, int] = field(default_factory=dict)
 
 
 class UNetCompiler:
     def __init__(self, cfg: UNetConfig, length: int, cond_len: int, sd: Dict[str, torch.Tensor],
-                 max_time_rows: int = 512):
+                 max_time_rows: int = 512, gemm_mode: str = "bf16x3"):
+        if gemm_mode not in ("f32", "bf16x3"):
+            raise ValueError("gemm_mode must be 'f32' (exact fp32 MFMA) or 'bf16x3' (split-bf16 MFMA)")
+        self.gemm_mode = gemm_mode
+        self._packed: Dict = {}
         if cfg.channels % 16:
             raise ValueError("channels must be a multiple of 16")
         if length % (cfg.patch_size * _prod(cfg.factors)):
@@ -168,24 +173,40 @@ class UNetCompiler:
         out[: v.numel()] = v
         return self.W.add(key, out)
 
-    def _lin_w(self, key: str, n_pad: Optional[int] = None, k_pad: Optional[int] = None) -> int:
+    def _lin_w(self, key: str, n_pad: Optional[int] = None, k_pad: Optional[int] = None):
         w = self.sd[key]                       # [N, K]
         n, k = w.shape
         out = torch.zeros(n_pad or pad16(n), k_pad or pad16(k))
         out[:n, :k] = w
-        return self.W.add(key, out)
+        return (key, out)
 
-    def _conv_w(self, key: str, cin_pad: int, n_pad: int) -> int:
+    def _conv_w(self, key: str, cin_pad: int, n_pad: int):
         w = self.sd[key]                       # [Cout, Cin, k] -> [Np][k][Cin_p]
         co, ci, k = w.shape
         out = torch.zeros(n_pad, k, cin_pad)
         out[:co, :, :ci] = w.permute(0, 2, 1)
-        return self.W.add(key, out)
+        return (key, out.reshape(n_pad, k * cin_pad))
+
+    def _pack_w(self, wt, cin: int):
+        """Packs a GEMM weight [N][K] once.  Returns (offset, lo_offset or None): exact fp32, or the two bf16
+        planes of the split-bf16 kernel (value rounded to nearest-even bf16, then its residual)."""
+        name, w = wt
+        split = self.gemm_mode == "bf16x3" and cin % 32 == 0
+        key = (name, split)
+        if key not in self._packed:
+            if split:
+                hi = w.to(torch.bfloat16)
+                lo = (w - hi.float()).to(torch.bfloat16)
+                self._packed[key] = (self.W.add(name + "/bf16_hi", hi.contiguous().view(-1).view(torch.float32)),
+                                     self.W.add(name + "/bf16_lo", lo.contiguous().view(-1).view(torch.float32)))
+            else:
+                self._packed[key] = (self.W.add(name, w), None)
+        return self._packed[key]
 
     def _emit(self, op: rt.MdtOp) -> None:
         self.ops.append(op)
 
-    def gemm(self, a: Ten, w_off: int, n: int, out: Ten, *, cin: int, bias_off: Optional[int] = None,
+    def gemm(self, a: Ten, wt, n: int, out: Ten, *, cin: int, bias_off: Optional[int] = None,
              taps: int = 1, t_stride: int = 1, t_dj: int = 0, t_off: int = 0, r_out: Optional[int] = None,
              o_stride: int = 1, o_off: int = 0, res: Optional[Ten] = None, pro: int = rt.PRO_NONE,
              gain: Optional[int] = None, nbias: Optional[int] = None, stats: Optional[Ten] = None,
@@ -194,7 +215,10 @@ class UNetCompiler:
              count_flops: bool = True) -> None:
         op = rt.MdtOp()
         op.kind = rt.OP_GEMM
+        w_off, wlo_off = self._pack_w(wt, cin)
         op.a, op.w, op.out = a.ref(), _ref(rt.SP_WEIGHT, w_off), out.ref()
+        if wlo_off is not None:
+            op.a2 = _ref(rt.SP_WEIGHT, wlo_off)
         if bias_off is not None:
             op.bias = _ref(rt.SP_WEIGHT, bias_off)
         if res is not None:
@@ -435,7 +459,7 @@ class UNetCompiler:
             for ph in range(f):
                 shift = 1 if ph < f // 2 else 0
                 wp = torch.stack((wt[:, :, ph], wt[:, :, ph + f]), dim=0).permute(2, 0, 1)   # [Cout][2][Cin]
-                self.gemm(x, self.W.add(f"{up}upsample.weight/phase{ph}", wp), co, y, cin=ci, bias_off=bias, taps=2,
+                self.gemm(x, (f"{up}upsample.weight/phase{ph}", wp.reshape(co, 2 * ci)), co, y, cin=ci, bias_off=bias, taps=2,
                           t_stride=1, t_dj=-1, t_off=shift, r_out=x.rows, o_stride=f, o_off=f * shift + ph - f // 2,
                           res=res)
             self._free(x)
@@ -528,7 +552,7 @@ class UNetCompiler:
             b_all[off: off + c] = b[:c]
             b_all[off + cp: off + cp + c] = b[c:]
         t_ss = Ten(rt.SP_SHR, ss_all, 1, self.ss_total)
-        self.gemm(t3, self.W.add("scale_shift_all.weight", w_all), self.ss_total, t_ss, cin=mapf,
+        self.gemm(t3, ("scale_shift_all.weight", w_all), self.ss_total, t_ss, cin=mapf,
                   bias_off=self.W.add("scale_shift_all.bias", b_all), pro=rt.PRO_SILU, m_mode=1)
         programs["time"] = self.ops
 
@@ -555,7 +579,7 @@ class UNetCompiler:
         return CompiledUNet(cfg=cfg, length=self.L, cond_len=self.n_ctx, in_pad=self.in_pad, weights=self.W.pack(),
                             programs=programs, act_floats=act_floats, shr_floats=self.shr_top,
                             max_time_rows=rows, shr=dict(self.shr), ss_total=self.ss_total, n_cross=n_cross,
-                            flops_per_sample_eval=flops_eval, flops_ctx_per_sample=flops_ctx,
+                            flops_per_sample_eval=flops_eval, flops_ctx_per_sample=flops_ctx, gemm_mode=self.gemm_mode,
                             weight_index=dict(self.W.index))
 
 
@@ -572,5 +596,5 @@ def _prod(xs) -> int:
 
 
 def compile_unet(cfg: UNetConfig, length: int, cond_len: int, sd: Dict[str, torch.Tensor],
-                 max_time_rows: int = 512) -> CompiledUNet:
-    return UNetCompiler(cfg, length, cond_len, sd, max_time_rows).build()
+                 max_time_rows: int = 512, gemm_mode: str = "bf16x3") -> CompiledUNet:
+    return UNetCompiler(cfg, length, cond_len, sd, max_time_rows, gemm_mode).build()

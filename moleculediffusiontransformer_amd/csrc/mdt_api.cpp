@@ -68,6 +68,7 @@ static const char* validate(const mdt_op& o, int idx, char* buf, size_t nbuf) {
       }
       if (i[MDT_G_M_MODE] < 0 || i[MDT_G_M_MODE] > 2) return bad("bad m_mode");
       if (o.res.space && i[MDT_G_LDR] <= 0) return bad("residual without ldr");
+      if (o.a2.space && i[MDT_G_CIN] % 32) return bad("split-bf16 weights need cin % 32 == 0");
       break;
     }
     case MDT_OP_GN_STATS:
@@ -152,7 +153,7 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
       case MDT_OP_GEMM: {
         const int32_t* i = o.i;
         mdt::GemmArgs g;
-        g.A = ptr(o.a); g.W = ptr(o.w); g.bias = ptr(o.bias); g.out = ptr(o.out); g.res = ptr(o.res);
+        g.A = ptr(o.a); g.W = ptr(o.w); g.W_lo = ptr(o.a2); g.bias = ptr(o.bias); g.out = ptr(o.out); g.res = ptr(o.res);
         g.p0 = ptr(o.p0); g.p1 = ptr(o.p1); g.p2 = ptr(o.p2); g.p3 = ptr(o.p3);
         const int batches = i[MDT_G_M_MODE] == 0 ? B : (i[MDT_G_M_MODE] == 1 ? n_shared_rows : 1);
         g.M = batches * i[MDT_G_R_OUT];
@@ -162,7 +163,7 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
         g.o_off = i[MDT_G_O_OFF]; g.ldr = i[MDT_G_LDR]; g.pro = i[MDT_G_PRO]; g.groups = i[MDT_G_GROUPS];
         g.gsize = i[MDT_G_GSIZE]; g.pro_silu = i[MDT_G_PRO_SILU]; g.act = i[MDT_G_ACT]; g.a_col = i[MDT_G_A_COL];
         g.o_col = i[MDT_G_O_COL]; g.eps = o.f[MDT_GF_EPS];
-        if (!missing) e = mdt::launch_gemm(g, stream);
+        if (!missing) e = g.W_lo ? mdt::launch_gemm_bf16x3(g, stream) : mdt::launch_gemm(g, stream);
         break;
       }
       case MDT_OP_GN_STATS: {

@@ -8,7 +8,8 @@ namespace mdt {
 
 struct GemmArgs {
   const float* A;
-  const float* W;
+  const float* W;     // fp32 [N][K], or the bf16 hi plane when W_lo != nullptr
+  const float* W_lo;  // bf16 lo plane [N][K] (split-bf16 GEMM) or nullptr (exact fp32 MFMA)
   const float* bias;
   float* out;
   const float* res;
@@ -21,7 +22,8 @@ struct GemmArgs {
   int pro, groups, gsize, pro_silu, act, a_col, o_col;
   float eps;
 };
-hipError_t launch_gemm(const GemmArgs& g, hipStream_t s);
+hipError_t launch_gemm(const GemmArgs& g, hipStream_t s);          // exact fp32 MFMA (k_gemm.hip)
+hipError_t launch_gemm_bf16x3(const GemmArgs& g, hipStream_t s);   // split-bf16 MFMA (k_gemm_bf16x3.hip)
 
 struct GnStatsArgs {
   const float* x;

@@ -7,6 +7,7 @@ path runs on an MI355X through libmdt_hip.so; there is no CPU implementation beh
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Optional
 
 import torch
@@ -108,13 +109,15 @@ class _QMBase(nn.Module):
                                       sigma_data=0.1, dynamic_threshold=0.0)
         object.__setattr__(self.diffusion.diffusion, "_owner", self)
         self.unet._evaluator = self._unet_call
+        # 'bf16x3': split-bf16 MFMA GEMMs (fp32-class accuracy, ~5x the fp32-MFMA rate); 'f32': exact fp32 MFMA
+        self.gemm_mode = os.environ.get("MDT_GEMM", "bf16x3")
         self._engine: Optional[UNetEngine] = None
         self._engine_key = None
         self.sampler_stats = {}
 
     # ------------------------------------------------------------------ engine management
     def _param_key(self, device, n_ctx):
-        return (str(device), n_ctx, tuple((p.data_ptr(), p._version) for p in self.unet.parameters()))
+        return (str(device), n_ctx, self.gemm_mode, tuple((p.data_ptr(), p._version) for p in self.unet.parameters()))
 
     def engine(self, device, n_ctx: Optional[int] = None) -> UNetEngine:
         """Compiled-program engine for the current parameter values on `device` (rebuilt after an
@@ -127,7 +130,7 @@ class _QMBase(nn.Module):
         key = self._param_key(device, n_ctx)
         if self._engine is None or self._engine_key != key:
             sd = {k: v.detach().float().cpu() for k, v in self.unet.state_dict().items()}
-            compiled = compile_unet(self.unet.config, self.max_length, n_ctx, sd)
+            compiled = compile_unet(self.unet.config, self.max_length, n_ctx, sd, gemm_mode=self.gemm_mode)
             self._engine = UNetEngine(compiled, device)
             self._engine_key = key
         return self._engine

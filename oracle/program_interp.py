@@ -67,7 +67,13 @@ def run_program(ops, bufs: Buffers, B: int, n_shared_rows: int = 0) -> None:
                     a = _silu(a)
             elif pro == rt.PRO_SILU:
                 a = _silu(a)
-            w = bufs.view(op.w, B, n * taps * cin).view(n, taps, cin)
+            if op.a2.space != rt.SP_NONE:      # split-bf16 weights: two bf16 planes stored as raw bits
+                half = n * taps * cin // 2
+                hi = bufs.view(op.w, B, half).view(torch.bfloat16).float()
+                lo = bufs.view(op.a2, B, half).view(torch.bfloat16).float()
+                w = (hi + lo).view(n, taps, cin)
+            else:
+                w = bufs.view(op.w, B, n * taps * cin).view(n, taps, cin)
             r = torch.arange(r_out)
             acc = torch.zeros(batches, r_out, n)
             for t in range(taps):

@@ -267,3 +267,51 @@ def test_counter_based_noise_is_normal_and_sharding_independent():
     assert abs(f.mean()) < 4 / math.sqrt(n) and abs(f.var() - 1) < 0.02
     assert abs((f ** 3).mean()) < 0.05 and abs((f ** 4).mean() - 3) < 0.1
     assert abs((f[:, :, 1:] * f[:, :, :-1]).mean()) < 0.01
+
+
+def _split_planes(w):
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    return hi.contiguous().view(-1).view(torch.float32), lo.contiguous().view(-1).view(torch.float32)
+
+
+@pytest.mark.parametrize("B,R,cin,N,taps,pro", [
+    (64, 16, 128, 512, 1, rt.PRO_LAYERNORM),      # 128x128 tiles
+    (1024, 16, 128, 128, 3, rt.PRO_GROUPNORM),    # 128x64 tiles, conv taps, GN+FiLM+SiLU
+    (3, 16, 128, 96, 3, rt.PRO_GROUPNORM),        # 64x64 tiles, ragged N and M
+    (40, 4, 512, 256, 1, rt.PRO_NONE),
+    (5, 64, 64, 64, 3, rt.PRO_NONE),
+    (33, 1, 256, 160, 1, rt.PRO_SILU),
+])
+def test_gemm_split_bf16(B, R, cin, N, taps, pro):
+    """k_gemm3 (bf16x3) against the interpreter (fp32 activations x reconstructed hi+lo weights)."""
+    K = taps * cin
+    w = rnd(N, K, seed=1, scale=K ** -0.5)
+    hi, lo = _split_planes(w)
+    G = 8
+    gs = cin // G
+    weights = torch.cat([hi, lo, rnd(N, seed=2), 1 + 0.1 * rnd(cin, seed=3), 0.1 * rnd(cin, seed=4)])
+    o_hi, o_lo, o_b, o_g, o_nb = 0, hi.numel(), 2 * hi.numel(), 2 * hi.numel() + N, 2 * hi.numel() + N + cin
+    xoff, stoff, ooff, roff = 0, R * cin, R * cin + 64, R * cin + 64 + R * N
+    act = torch.zeros(B * (roff + R * N))
+    act[: B * R * cin] = rnd(B * R * cin, seed=5) * 1.3 + 0.2
+    act[B * roff:] = rnd(B * R * N, seed=6)
+    shr = 0.3 * rnd(2 * cin, seed=7)
+    ops = []
+    if pro == rt.PRO_GROUPNORM:
+        st = rt.MdtOp()
+        st.kind = rt.OP_GN_STATS
+        st.a, st.out = ref(A, xoff), ref(A, stoff)
+        st.i[rt.N_ROWS], st.i[rt.N_LD], st.i[rt.N_GROUPS], st.i[rt.N_GSIZE] = R, cin, G, gs
+        st.f[0] = 1e-5
+        ops.append(st)
+    op = gemm_op(a=ref(A, xoff), w=ref(W, o_hi), bias=ref(W, o_b), out=ref(A, ooff), res=ref(A, roff),
+                 p0=ref(W, o_g), p1=ref(W, o_nb), p2=ref(A, stoff), p3=ref(S, 0), r_out=R, r_in=R, lda=cin, cin=cin,
+                 taps=taps, t_dj=1 if taps > 1 else 0, t_off=-(taps // 2), n=N, ldc=N, o_rows=R, ldr=N, pro=pro,
+                 groups=G, gsize=gs, pro_silu=1, act=0, eps=1e-5)
+    op.a2 = ref(W, o_lo)
+    ops.append(op)
+    (ga, _, _), (ca, _, _) = run_both(ops, weights, act, shr, {}, B)
+    out_g, out_c = ga[B * ooff: B * roff], ca[B * ooff: B * roff]
+    scale = out_c.abs().max().item()
+    assert (out_g - out_c).abs().max() < 4e-5 * max(scale, 1.0), ((out_g - out_c).abs().max().item(), scale)

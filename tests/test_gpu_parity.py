@@ -17,13 +17,15 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-@pytest.fixture(scope="module")
-def models():
+@pytest.fixture(scope="module", params=["bf16x3", "f32"])
+def models(request):
+    """Every parity test runs with both GEMM kernels: split-bf16 MFMA (default) and exact fp32 MFMA."""
     cache = {}
 
     def get(case):
         if case not in cache:
             cache[case] = make_model(case)
+            cache[case].gemm_mode = request.param
         return cache[case]
     return get
 

@@ -89,14 +89,17 @@ def test_no_cpu_fallback():
         m(torch.randn(2, 12), torch.randn(2, 16, 32))
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
 @pytest.mark.parametrize("case", ["tiny", "pd22", "cfg3", "cfg1"])
-def test_lowering_matches_reference_golden(case):
+def test_lowering_matches_reference_golden(case, mode):
     """compiler.py's op program, executed by the CPU interpreter, reproduces the reference U-Net output."""
     kind, kw = CASES[case]
     mk = inverse_unet_config if kind == "inverse" else forward_unet_config
     ucfg = mk(kw["pred_dim"], kw["channels"], 128, kw["context_embedding_max_length"])
     usd = {k[5:]: v for k, v in synth_sd(case).items() if k.startswith("unet.")}
-    cu = compile_unet(ucfg, kw["max_length"], kw["context_embedding_max_length"], usd, max_time_rows=4)
+    cu = compile_unet(ucfg, kw["max_length"], kw["context_embedding_max_length"], usd, max_time_rows=4,
+                      gemm_mode=mode)
+    tol = 1e-5 if mode == "f32" else 5e-5      # split weights carry ~2^-17 relative rounding
     g = load_golden(f"{case}_unet.npz")
     x, t, emb = (torch.from_numpy(g[k]) for k in ("x", "t", "emb"))
     B, C, L = x.shape
@@ -118,9 +121,9 @@ def test_lowering_matches_reference_golden(case):
             assert float(out[0, :, C:].abs().max()) == 0.0 if cu.in_pad > C else True
         y = torch.stack(outs)
         if not fixed:
-            assert (y - torch.from_numpy(g["y_scale1"])).abs().max() < 1e-5
+            assert (y - torch.from_numpy(g["y_scale1"])).abs().max() < tol
             y_cond = y
         else:
             mix = y + (y_cond[: y.shape[0]] - y) * 7.5
-            assert (mix - torch.from_numpy(g["y_scale7p5"])[: y.shape[0]]).abs().max() < 5e-5
+            assert (mix - torch.from_numpy(g["y_scale7p5"])[: y.shape[0]]).abs().max() < 10 * tol
     assert abs(cu.flops_per_sample_eval - {"cfg1": 388.7e6}.get(case, cu.flops_per_sample_eval)) < 1e6
