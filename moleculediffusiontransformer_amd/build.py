@@ -20,6 +20,7 @@ STAMP = os.path.join(CSRC, ".build_stamp")
 SOURCES = [
     ("k_gemm.hip", []),
     ("k_gemm_bf16x3.hip", []),
+    ("k_gemm_as.hip", []),
     ("k_norm.hip", []),
     ("k_attn.hip", []),
     ("k_elem.hip", ["-ffp-contract=off"]),

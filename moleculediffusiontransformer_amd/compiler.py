@@ -131,6 +131,7 @@ class UNetCompiler:
             raise ValueError("gemm_mode must be 'f32' (exact fp32 MFMA) or 'bf16x3' (split-bf16 MFMA)")
         self.gemm_mode = gemm_mode
         self._packed: Dict = {}
+        self._zeros_off, self._zeros_len = 0, 0
         if cfg.channels % 16:
             raise ValueError("channels must be a multiple of 16")
         if length % (cfg.patch_size * _prod(cfg.factors)):
@@ -166,6 +167,12 @@ class UNetCompiler:
     def _free(self, t: Ten) -> None:
         if t.space == rt.SP_ACT:
             self.arena.release(t.off, t.rows * t.ld)
+
+    def _zeros(self, n: int) -> int:
+        if n > self._zeros_len:
+            self._zeros_off = self.W.add(f"zeros{n}", torch.zeros(n))
+            self._zeros_len = n
+        return self._zeros_off
 
     def _vec(self, key: str, pad_to: int) -> int:
         v = self.sd[key]
@@ -233,6 +240,8 @@ class UNetCompiler:
             op._film = film
         elif film is not None:
             op.p3 = film
+        elif pro == rt.PRO_GROUPNORM:    # no FiLM: scale = shift = 0 (x * (0 + 1) + 0 is exact)
+            op.p3 = _ref(rt.SP_WEIGHT, self._zeros(2 * cin))
         r_out = a.rows if r_out is None else r_out
         i = op.i
         i[rt.G_R_OUT], i[rt.G_R_IN], i[rt.G_LDA], i[rt.G_CIN], i[rt.G_TAPS] = r_out, a.rows, a.ld, cin, taps

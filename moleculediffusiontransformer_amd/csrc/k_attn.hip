@@ -17,6 +17,7 @@ namespace mdt {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+template <int KTM>   // key tiles held in registers: 1 (Tk <= 16) or 4 (Tk <= 64)
 __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
   constexpr int D = 64;
   const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -42,25 +43,39 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
         qr[4 * c] = t.x; qr[4 * c + 1] = t.y; qr[4 * c + 2] = t.z; qr[4 * c + 3] = t.w;
       }
     }
-    f32x4 st[4];
-    float mx = -INFINITY;
+    // K rows (A operand of S^T) and V columns (A operand of O^T) of every key tile are fetched up-front so
+    // that all global loads of the head are in flight together.
+    float kr[KTM][16], vr[KTM][16];
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < KTM; ++kt) {
       if (kt < KT) {
         const int j = kt * 16 + lo;
-        float kr[16];
         const float4* p = reinterpret_cast<const float4*>(k + (int64_t)(j < a.Tk ? j : 0) * a.ldkv + 16 * g);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const float4 t = p[c];
-          kr[4 * c] = t.x; kr[4 * c + 1] = t.y; kr[4 * c + 2] = t.z; kr[4 * c + 3] = t.w;
+          kr[kt][4 * c] = t.x; kr[kt][4 * c + 1] = t.y; kr[kt][4 * c + 2] = t.z; kr[kt][4 * c + 3] = t.w;
         }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int jj = kt * 16 + 4 * g + s;           // key row this lane quarter feeds at PV step s
+          const float* vrow = v + (int64_t)(jj < a.Tk ? jj : 0) * a.ldkv + lo;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) vr[kt][4 * s + dt] = jj < a.Tk ? vrow[16 * dt] : 0.f;
+        }
+      }
+    }
+    f32x4 st[KTM];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < KTM; ++kt) {
+      st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (kt < KT) {
         f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0;
 #pragma unroll
         for (int s = 0; s < 16; s += 2) {
-          s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[s], qr[s], s0, 0, 0, 0);
-          s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[s + 1], qr[s + 1], s1, 0, 0, 0);
+          s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[kt][s], qr[s], s0, 0, 0, 0);
+          s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[kt][s + 1], qr[s + 1], s1, 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -75,7 +90,7 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     float sum = 0.f;
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
+    for (int kt = 0; kt < KTM; ++kt) {
       if (kt < KT) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -91,20 +106,14 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
+    for (int kt = 0; kt < KTM; ++kt) {
       if (kt < KT) {
-        float pr[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) pr[r] = st[kt][r] / sum;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          const int jj = kt * 16 + 4 * g + s;           // key row this lane quarter feeds at step s
-          const float* vrow = v + (int64_t)(jj < a.Tk ? jj : 0) * a.ldkv + lo;
+          const float pr = st[kt][s] / sum;
 #pragma unroll
-          for (int dt = 0; dt < 4; ++dt) {
-            const float vv = jj < a.Tk ? vrow[16 * dt] : 0.f;
-            acc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv, pr[s], acc[dt], 0, 0, 0);
-          }
+          for (int dt = 0; dt < 4; ++dt)
+            acc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[kt][4 * s + dt], pr, acc[dt], 0, 0, 0);
         }
       }
     }
@@ -121,7 +130,10 @@ hipError_t launch_attn(const AttnArgs& a, hipStream_t s) {
   if (a.batch <= 0) return hipSuccess;
   if (a.T > 64 || a.Tk > 64 || a.ldq % 4 || a.ldkv % 4 || a.ldo % 4) return hipErrorInvalidValue;
   const int waves = a.batch * a.heads;
-  hipLaunchKernelGGL(k_attn, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a);
+  if (a.Tk <= 16)
+    hipLaunchKernelGGL(k_attn<1>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL(k_attn<4>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 

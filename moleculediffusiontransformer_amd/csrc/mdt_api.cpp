@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -163,7 +164,12 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
         g.o_off = i[MDT_G_O_OFF]; g.ldr = i[MDT_G_LDR]; g.pro = i[MDT_G_PRO]; g.groups = i[MDT_G_GROUPS];
         g.gsize = i[MDT_G_GSIZE]; g.pro_silu = i[MDT_G_PRO_SILU]; g.act = i[MDT_G_ACT]; g.a_col = i[MDT_G_A_COL];
         g.o_col = i[MDT_G_O_COL]; g.eps = o.f[MDT_GF_EPS];
-        if (!missing) e = g.W_lo ? mdt::launch_gemm_bf16x3(g, stream) : mdt::launch_gemm(g, stream);
+        if (!missing) {
+          static const bool no_as = getenv("MDT_NO_AS") != nullptr;   // tuning aid: disable the A-stationary kernel
+          if (!g.W_lo) e = mdt::launch_gemm(g, stream);
+          else if (!no_as && mdt::gemm_as_eligible(g)) e = mdt::launch_gemm_as(g, stream);
+          else e = mdt::launch_gemm_bf16x3(g, stream);
+        }
         break;
       }
       case MDT_OP_GN_STATS: {

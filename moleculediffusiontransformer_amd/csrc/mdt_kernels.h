@@ -24,6 +24,8 @@ struct GemmArgs {
 };
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t s);          // exact fp32 MFMA (k_gemm.hip)
 hipError_t launch_gemm_bf16x3(const GemmArgs& g, hipStream_t s);   // split-bf16 MFMA (k_gemm_bf16x3.hip)
+bool gemm_as_eligible(const GemmArgs& g);                           // wide-N / small-K layers
+hipError_t launch_gemm_as(const GemmArgs& g, hipStream_t s);       // A-stationary split-bf16 (k_gemm_as.hip)
 
 struct GnStatsArgs {
   const float* x;
@@ -48,5 +50,42 @@ hipError_t launch_patch(const float* in, float* out, int batch, int rows_in, int
                         int patch, int inverse, hipStream_t s);
 hipError_t launch_time_embed(const float* cn, const float* w, float* out, int rows, int half, int ld,
                              hipStream_t s);
+
+
+#if defined(__HIPCC__)
+// Coalesced epilogue shared by the GEMM kernels.  The MFMA accumulator layout gives every lane ONE column
+// of 16 rows, i.e. 4-byte stores scattered over rows; measured on MI355X those stores cost more than the
+// whole rest of the kernel (M=16384 N=1024 K=128: 68.9 us with them, 28.8 us without).  So the accumulator
+// tile is first parked in LDS as fp32 [BM][BN+4] and then written by the whole workgroup as 16-byte stores,
+// 16 consecutive lanes per 256-byte row segment; bias, exact GELU and the residual are applied on the way
+// (bias/residual become float4 loads too).
+template <int BM, int BN>
+__device__ __forceinline__ void store_tile_coalesced(const float* Cs, const GemmArgs& g, int m0, int n0) {
+  constexpr int C4 = BN / 4, LDC = BN + 4;
+  for (int idx = threadIdx.x; idx < BM * C4; idx += 256) {
+    const int row = idx / C4, c4 = idx - row * C4;
+    const int m = m0 + row, n = n0 + c4 * 4;
+    if (m >= g.M || n >= g.N) continue;
+    const int bb = m / g.r_out;
+    const int64_t orow = (int64_t)bb * g.o_rows + (int64_t)(m - bb * g.r_out) * g.o_stride + g.o_off;
+    float4 v = *reinterpret_cast<const float4*>(Cs + row * LDC + c4 * 4);
+    if (g.bias) {
+      const float4 b = *reinterpret_cast<const float4*>(g.bias + n);
+      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    }
+    if (g.act == 1) {
+      v.x = 0.5f * v.x * (1.0f + erff(v.x * 0.70710678118654752440f));
+      v.y = 0.5f * v.y * (1.0f + erff(v.y * 0.70710678118654752440f));
+      v.z = 0.5f * v.z * (1.0f + erff(v.z * 0.70710678118654752440f));
+      v.w = 0.5f * v.w * (1.0f + erff(v.w * 0.70710678118654752440f));
+    }
+    if (g.res) {
+      const float4 r = *reinterpret_cast<const float4*>(g.res + orow * g.ldr + n);
+      v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    *reinterpret_cast<float4*>(g.out + orow * g.ldc + g.o_col + n) = v;
+  }
+}
+#endif
 
 }  // namespace mdt

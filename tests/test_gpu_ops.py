@@ -282,6 +282,9 @@ def _split_planes(w):
     (40, 4, 512, 256, 1, rt.PRO_NONE),
     (5, 64, 64, 64, 3, rt.PRO_NONE),
     (33, 1, 256, 160, 1, rt.PRO_SILU),
+    (40, 4, 256, 256, 1, rt.PRO_GROUPNORM),       # A-stationary kernel, GN prologue
+    (1024, 4, 256, 1024, 1, rt.PRO_LAYERNORM),    # A-stationary, column range split over workgroups
+    (700, 16, 128, 384, 1, rt.PRO_NONE),
 ])
 def test_gemm_split_bf16(B, R, cin, N, taps, pro):
     """k_gemm3 (bf16x3) against the interpreter (fp32 activations x reconstructed hi+lo weights)."""
