@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA (not the 2:1-sparse headline)
 HBM_PEAK_GBS = 8000.0
 REF_FLOPS_PER_SAMPLE_EVAL = 455.3e6   # reference op graph (incl. per-eval cross-attn K/V + time mapping)
 REF_OPGRAPH_BYTES_PER_SAMPLE_EVAL = 13.21e6
@@ -42,14 +43,32 @@ def parse():
     return ap.parse_args()
 
 
+def op_flops(op, rt, B):
+    """Algorithmic FLOPs (2*MAC, fp32-equivalent) of one op of the eval program for batch B."""
+    i = op.i
+    if op.kind == rt.OP_GEMM:
+        return 2.0 * B * i[rt.G_R_OUT] * i[rt.G_N] * i[rt.G_TAPS] * i[rt.G_CIN]
+    if op.kind == rt.OP_ATTN:
+        return 4.0 * B * i[rt.A_T] * i[rt.A_TK] * 64 * i[rt.A_HEADS]
+    if op.kind == rt.OP_TBLOCK:
+        c, t, nch, tk = i[rt.B_C], i[rt.B_T], i[rt.B_NCHUNK], i[rt.B_TK]
+        mid = 64 * nch
+        if i[rt.B_MODE] == rt.TB_FF:
+            return 4.0 * B * t * c * mid
+        if i[rt.B_MODE] == rt.TB_SELF:
+            return B * (2.0 * t * c * 3 * mid + 4.0 * t * t * mid + 2.0 * t * mid * c)
+        return B * (2.0 * t * c * mid + 4.0 * t * tk * mid + 2.0 * t * mid * c)
+    return 0.0
+
+
 def kernel_breakdown(model, eng, torch, rt, B):
     """HIP-event time of every op of ONE U-Net evaluation (plain launches, one interval per launch),
-    grouped by kernel class.  Returns dict class -> (launches, total_ms)."""
+    grouped by kernel class.  Returns dict class -> (launches, total_ms, flops)."""
     prog = eng.programs["eval"]
     ops = eng.c.programs["eval"]
     bind = eng._bind(xin=eng.xin, out=eng.pred)
     names = {rt.OP_GEMM: "k_gemm", rt.OP_GN_STATS: "k_gn_stats", rt.OP_ATTN: "k_attn", rt.OP_CONCAT: "k_concat",
-             rt.OP_PATCH: "k_patch"}
+             rt.OP_PATCH: "k_patch", rt.OP_TBLOCK: "k_tblock"}
     best = None
     for rep in range(3):
         timer = rt.EventTimer(len(ops))
@@ -63,8 +82,8 @@ def kernel_breakdown(model, eng, torch, rt, B):
     out = {}
     for op, t in zip(ops, best):
         k = names[op.kind]
-        n, tot = out.get(k, (0, 0.0))
-        out[k] = (n + 1, tot + t)
+        n, tot, fl = out.get(k, (0, 0.0, 0.0))
+        out[k] = (n + 1, tot + t, fl + op_flops(op, rt, B))
     return out
 
 
@@ -135,22 +154,30 @@ def main():
         value = mols / elapsed
         flops_exec = eng.c.flops_per_sample_eval           # executed per sample per eval (K/V + time mapping hoisted)
         avg_eval_ms = sum(eval_ms) / len(eval_ms)
-        roof = {"bound": "mfma", "kernel": "k_gemm (fp32 MFMA implicit GEMM, all instantiations)", "unit": "TFLOP/s",
-                "peak": FP32_MFMA_PEAK_TFLOPS, "traffic": None}
+        split = eng.c.gemm_mode == "bf16x3"
+        # split-bf16 path: every fp32 product is 3 bf16 MFMAs, so the executed matrix-core work is 3x the
+        # algorithmic FLOPs and the roof is the dense bf16 MFMA peak; exact path: fp32 MFMA peak.
+        peak = BF16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
+        mult = 3.0 if split else 1.0
+        roof = {"bound": "mfma", "unit": "TFLOP/s", "peak": peak, "traffic": None,
+                "mfma_dtype": "bf16 (3 MFMAs per fp32 product, fp32 accumulate)" if split else "f32"}
         extra = {}
         if not a.no_breakdown:
             bd = kernel_breakdown(model, eng, torch, rt, B)
-            n_gemm, ms_gemm = bd["k_gemm"]
-            gemm_flops = sum(2 * o.i[rt.G_R_OUT] * o.i[rt.G_N] * o.i[rt.G_TAPS] * o.i[rt.G_CIN]
-                             for o in eng.c.programs["eval"] if o.kind == rt.OP_GEMM) * B
-            ach = gemm_flops / (ms_gemm * 1e-3) / 1e12
-            roof.update({"achieved": round(ach, 2), "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-                         "launches_per_eval": n_gemm, "avg_launch_us": round(1e3 * ms_gemm / n_gemm, 2),
-                         "flops_per_launch_avg": gemm_flops / n_gemm})
-            extra["eval_breakdown_ms"] = {k: {"launches": n, "ms": round(t, 4)} for k, (n, t) in sorted(bd.items())}
+            dom = max((k for k in bd if bd[k][2] > 0), key=lambda k: bd[k][1])
+            n_dom, ms_dom, fl_dom = bd[dom]
+            alg = fl_dom / (ms_dom * 1e-3) / 1e12
+            roof.update({"kernel": dom + " (all instantiations of the dominant kernel class in one U-Net eval)",
+                         "achieved": round(alg * mult, 2), "frac": round(alg * mult / peak, 4),
+                         "algorithmic_tflops_fp32_equiv": round(alg, 2), "launches_per_eval": n_dom,
+                         "avg_launch_us": round(1e3 * ms_dom / n_dom, 2), "flops_per_launch_avg": fl_dom / n_dom})
+            extra["eval_breakdown_ms"] = {k: {"launches": n, "ms": round(t, 4),
+                                              "algorithmic_tflops": round(f / (t * 1e-3) / 1e12, 2) if f else None}
+                                          for k, (n, t, f) in sorted(bd.items())}
         else:
-            ach = flops_exec * B / (avg_eval_ms * 1e-3) / 1e12
-            roof.update({"achieved": round(ach, 2), "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4)})
+            alg = flops_exec * B / (avg_eval_ms * 1e-3) / 1e12
+            roof.update({"kernel": "whole U-Net eval", "achieved": round(alg * mult, 2),
+                         "frac": round(alg * mult / peak, 4)})
         extra["unet_eval"] = {
             "ms_avg_graph_replay": round(avg_eval_ms, 4), "evals_timed": len(eval_ms),
             "flops_per_sample_executed": flops_exec,
@@ -165,7 +192,9 @@ def main():
             "metric": "molecules/sec @64 diffusion steps (QM9 max_len=64)", "value": round(value, 2),
             "unit": "molecules/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(1e3 * elapsed / a.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": "f32 storage/accumulate; GEMM products as split-bf16 (bf16x3) MFMA" if split else "f32",
+            "data": "synthetic",
             "config": {"workload": f"QMDiffusion inverse sample(): channels=64 pred_dim=16 max_len=64 cond_len=12, "
                                    f"batch={B}/GPU, {T} timesteps ({evals} U-Net evals), cond_scale=1.0, fp32",
                        "global_batch": world * B, "timesteps": T, "parallelism": f"batch-shard x{world}"},

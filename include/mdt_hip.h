@@ -61,7 +61,10 @@ enum mdt_op_kind {
   MDT_OP_ATTN = 3,     /* AttentionBase.forward core: softmax(q k^T * scale) v (modules.py:350-363) */
   MDT_OP_CONCAT = 4,   /* UpsampleBlock1d.add_skip: cat([x, skip * s], channel) (modules.py:828-829) */
   MDT_OP_PATCH = 5,    /* Patcher / Unpatcher rearrange (modules.py:230, :255)                   */
-  MDT_OP_TIME_EMBED = 6 /* LearnedPositionalEmbedding.forward (modules.py:554-559)               */
+  MDT_OP_TIME_EMBED = 6, /* LearnedPositionalEmbedding.forward (modules.py:554-559)              */
+  MDT_OP_TBLOCK = 7    /* fused transformer sub-block, in place on x (TransformerBlock.forward, modules.py:456-461):
+                          x += Attention(x) | x += Attention(x, context) | x += FeedForward(x); LayerNorm affine
+                          folded into the projection weights, q/k/v/probabilities/hidden never leave registers */
 };
 
 /* prologue applied to the A operand of MDT_OP_GEMM while it is staged into LDS */
@@ -116,6 +119,16 @@ enum mdt_patch_i { MDT_P_ROWS_IN = 0, MDT_P_C_IN = 1, MDT_P_LD_IN = 2, MDT_P_LD_
                    MDT_P_INVERSE = 5 };
 
 enum mdt_time_i { MDT_T_HALF = 0, MDT_T_LD = 1 };
+
+/* MDT_OP_TBLOCK: a = x (in place), w = weight tile stream, bias = packed biases, a2 = hoisted K|V (cross) */
+enum mdt_tblock_mode { MDT_TB_SELF = 0, MDT_TB_CROSS = 1, MDT_TB_FF = 2 };
+enum mdt_tblock_i {
+  MDT_B_MODE = 0, MDT_B_C = 1,      /* features (128 or 256)                                             */
+  MDT_B_T = 2,                      /* tokens per sample (must divide 16)                                */
+  MDT_B_NCHUNK = 3,                 /* heads (attention) or hidden/64 (feed-forward)                     */
+  MDT_B_NBIAS = 4, MDT_B_TK = 5, MDT_B_KV_BSTRIDE = 6, MDT_B_LDKV = 7, MDT_B_HEADS = 8
+};
+enum mdt_tblock_f { MDT_BF_EPS = 0, MDT_BF_SCALE = 1 };
 
 typedef struct mdt_op {
   int32_t kind;

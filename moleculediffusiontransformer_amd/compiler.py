@@ -18,6 +18,7 @@ in one arena that is scaled by the batch size at run time, so a compiled model s
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
 
@@ -126,7 +127,9 @@ class CompiledUNet:
 
 class UNetCompiler:
     def __init__(self, cfg: UNetConfig, length: int, cond_len: int, sd: Dict[str, torch.Tensor],
-                 max_time_rows: int = 512, gemm_mode: str = "bf16x3"):
+                 max_time_rows: int = 512, gemm_mode: str = "bf16x3", fuse_blocks: bool = True):
+        self.fuse_blocks = fuse_blocks
+        self.fuse_c256 = os.environ.get("MDT_FUSE_C256", "0") == "1"
         if gemm_mode not in ("f32", "bf16x3"):
             raise ValueError("gemm_mode must be 'f32' (exact fp32 MFMA) or 'bf16x3' (split-bf16 MFMA)")
         self.gemm_mode = gemm_mode
@@ -320,6 +323,85 @@ class UNetCompiler:
             self._free(x)
         return y
 
+    # ------------------------------------------------------------------ fused transformer sub-blocks
+    # slot order of the output-projection K dimension: the kernel takes the B operand straight from the
+    # accumulator registers of the previous MFMA, which hold feature d = 32 sp + 16 (e >> 2) + 4 g + (e & 3)
+    # in k-slot sigma = 32 sp + 8 g + e (csrc/k_tblock.hip)
+    _SLOT_PERM = [32 * (s >> 5) + 16 * ((s & 7) >> 2) + 4 * ((s >> 3) & 3) + (s & 3) for s in range(64)]
+
+    def can_fuse_transformer(self, c: int, rows: int, cross: bool) -> bool:
+        if self.gemm_mode != "bf16x3" or not self.fuse_blocks:
+            return False
+        if c not in (128, 256) or rows > 16 or 16 % rows or self.cfg.head_features != 64:
+            return False
+        # Measured on MI355X at B = 1024 (tools/tblock_bench.py): a C = 256 level has only 4096 rows = 64
+        # workgroups, the fused kernel then leaves 3/4 of the CUs idle and merely ties the layer-by-layer
+        # path (self 69 vs 71 us) or loses (cross 102 vs 44 us, ff 40 vs 26 us); C = 128 levels win clearly
+        # (self 46 vs 120 us, ff 16 vs 32 us).  So only C = 128 is fused unless asked otherwise.
+        if c == 256 and not self.fuse_c256:
+            return False
+        if (c * self.cfg.ff_mult) % 64:
+            return False
+        return not cross or (16 // rows) * self.n_ctx <= 64
+
+    @staticmethod
+    def _tile(w: torch.Tensor) -> torch.Tensor:
+        """[rows][cols] fp32 -> bf16 hi plane then lo plane, as raw bits viewed as float32."""
+        hi = w.to(torch.bfloat16)
+        lo = (w - hi.float()).to(torch.bfloat16)
+        return torch.cat([hi.contiguous().view(-1), lo.contiguous().view(-1)]).view(torch.float32)
+
+    def tblock(self, t: Ten, mode: int, p: str, cross_index: Optional[int] = None) -> None:
+        """One fused sub-block, in place on t: MDT_OP_TBLOCK (self-attention / cross-attention / feed-forward)."""
+        cfg, sd = self.cfg, self.sd
+        c, rows = t.ld, t.rows
+        perm = torch.tensor(self._SLOT_PERM)
+        tiles: List[torch.Tensor] = []
+        if mode == rt.TB_FF:
+            w1, b1 = sd[p + "0.weight"], sd[p + "0.bias"]          # [2C, C]
+            w2, b2 = sd[p + "2.weight"], sd[p + "2.bias"]          # [C, 2C]
+            nchunk = w1.shape[0] // 64
+            for h in range(nchunk):
+                tiles += [self._tile(w1[64 * h: 64 * h + 64]), self._tile(w2[:, 64 * h: 64 * h + 64][:, perm])]
+            bias = torch.cat([b1, b2])
+            self.flops += 2 * 2 * rows * c * w1.shape[0]
+        else:
+            g_q, b_q = sd[p + "norm.weight"], sd[p + "norm.bias"]
+            wq = sd[p + "to_q.weight"]                              # [mid, C]
+            wo, bo = sd[p + "attention.to_out.weight"], sd[p + "attention.to_out.bias"]   # [C, mid]
+            nchunk = wq.shape[0] // 64
+            wq_f, bq_f = wq * g_q.unsqueeze(0), wq @ b_q           # LayerNorm affine folded: W (g*xn + b) = (W g) xn + W b
+            if mode == rt.TB_SELF:
+                g_c, b_c = sd[p + "norm_context.weight"], sd[p + "norm_context.bias"]
+                wkv = sd[p + "to_kv.weight"]                        # [2 mid, C]
+                wkv_f, bkv_f = wkv * g_c.unsqueeze(0), wkv @ b_c
+                mid = wq.shape[0]
+                for h in range(nchunk):
+                    tiles += [self._tile(wq_f[64 * h: 64 * h + 64]), self._tile(wkv_f[64 * h: 64 * h + 64]),
+                              self._tile(wkv_f[mid + 64 * h: mid + 64 * h + 64]),
+                              self._tile(wo[:, 64 * h: 64 * h + 64][:, perm])]
+                bias = torch.cat([bq_f, bkv_f, bo])
+                self.flops += 2 * rows * c * 3 * mid + 4 * rows * rows * mid + 2 * rows * mid * c
+            else:
+                for h in range(nchunk):
+                    tiles += [self._tile(wq_f[64 * h: 64 * h + 64]), self._tile(wo[:, 64 * h: 64 * h + 64][:, perm])]
+                bias = torch.cat([bq_f, bo])
+                mid = wq.shape[0]
+                self.flops += 2 * rows * c * mid + 4 * rows * self.n_ctx * mid + 2 * rows * mid * c
+        op = rt.MdtOp()
+        op.kind = rt.OP_TBLOCK
+        op.a = t.ref()
+        op.w = _ref(rt.SP_WEIGHT, self.W.add(p + "tblock.tiles", torch.cat(tiles)))
+        op.bias = _ref(rt.SP_WEIGHT, self.W.add(p + "tblock.bias", bias))
+        i = op.i
+        i[rt.B_MODE], i[rt.B_C], i[rt.B_T], i[rt.B_NCHUNK], i[rt.B_NBIAS] = mode, c, rows, nchunk, bias.numel()
+        i[rt.B_TK], i[rt.B_KV_BSTRIDE], i[rt.B_LDKV], i[rt.B_HEADS] = self.n_ctx, self.n_ctx, 2 * cfg.mid_features, cfg.heads
+        op.f[0], op.f[1] = 1e-5, float(cfg.head_features) ** -0.5
+        if mode == rt.TB_CROSS:
+            op._kv = ("kv", cross_index)
+            op.a2 = _ref(rt.SP_ACT, 0)
+        self._emit(op)
+
     def attention_layer(self, t: Ten, p: str, cross_index: Optional[int]) -> None:
         """x = Attention(x[, context]) + x, in place on t (modules.py:401-410, :457-459)."""
         cfg = self.cfg
@@ -354,8 +436,16 @@ class UNetCompiler:
         self._free(st)
         if free_input:
             self._free(x)
+        fused = self.can_fuse_transformer(c, t.rows, cross)
         for i in range(layers):
             bp = p + f"blocks.{i}."
+            if fused:
+                self.tblock(t, rt.TB_SELF, bp + "attention.")
+                if cross:
+                    self.cross_layers.append(bp + "cross_attention.")
+                    self.tblock(t, rt.TB_CROSS, bp + "cross_attention.", len(self.cross_layers) - 1)
+                self.tblock(t, rt.TB_FF, bp + "feed_forward.")
+                continue
             self.attention_layer(t, bp + "attention.", None)
             if cross:
                 self.cross_layers.append(bp + "cross_attention.")
@@ -520,11 +610,12 @@ class UNetCompiler:
                 C_memmove(o, op)
                 if op.kind == rt.OP_GEMM and isinstance(getattr(op, "_film", None), tuple):
                     o.p3 = _ref(rt.SP_SHR, ss_cur + op._film[1])
-                if op.kind == rt.OP_ATTN and isinstance(getattr(op, "_kv", None), tuple):
+                if op.kind in (rt.OP_ATTN, rt.OP_TBLOCK) and isinstance(getattr(op, "_kv", None), tuple):
                     idx = op._kv[1]
+                    slot = rt.A_KV_BSTRIDE if op.kind == rt.OP_ATTN else rt.B_KV_BSTRIDE
                     if fixed:
                         o.a2 = _ref(rt.SP_SHR, self.kv_fixed[idx])
-                        o.i[rt.A_KV_BSTRIDE] = 0
+                        o.i[slot] = 0
                     else:
                         o.a2 = _ref(rt.SP_ACT, self.kv_slots[idx])
                 out.append(o)
@@ -605,5 +696,5 @@ def _prod(xs) -> int:
 
 
 def compile_unet(cfg: UNetConfig, length: int, cond_len: int, sd: Dict[str, torch.Tensor],
-                 max_time_rows: int = 512, gemm_mode: str = "bf16x3") -> CompiledUNet:
-    return UNetCompiler(cfg, length, cond_len, sd, max_time_rows, gemm_mode).build()
+                 max_time_rows: int = 512, gemm_mode: str = "bf16x3", fuse_blocks: bool = True) -> CompiledUNet:
+    return UNetCompiler(cfg, length, cond_len, sd, max_time_rows, gemm_mode, fuse_blocks).build()

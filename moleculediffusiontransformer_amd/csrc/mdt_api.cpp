@@ -90,6 +90,16 @@ static const char* validate(const mdt_op& o, int idx, char* buf, size_t nbuf) {
     case MDT_OP_TIME_EMBED:
       if (o.i[MDT_T_LD] < 2 * o.i[MDT_T_HALF] + 1) return bad("ld too small");
       break;
+    case MDT_OP_TBLOCK: {
+      const int32_t* i = o.i;
+      if (i[MDT_B_C] != 128 && i[MDT_B_C] != 256) return bad("fused block needs C in {128, 256}");
+      if (i[MDT_B_T] <= 0 || 16 % i[MDT_B_T]) return bad("tokens per sample must divide 16");
+      if (i[MDT_B_MODE] < 0 || i[MDT_B_MODE] > 2 || i[MDT_B_NCHUNK] <= 0) return bad("bad mode / chunks");
+      if (i[MDT_B_MODE] == MDT_TB_CROSS && (!o.a2.space || (16 / i[MDT_B_T]) * i[MDT_B_TK] > 64 || i[MDT_B_TK] <= 0))
+        return bad("cross block needs K/V and at most 64 keys per 16 rows");
+      if (!o.a.space || !o.w.space || !o.bias.space) return bad("missing operand");
+      break;
+    }
     default:
       return bad("unknown op kind");
   }
@@ -199,6 +209,16 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
         if (!missing)
           e = mdt::launch_patch(in, out, B, o.i[MDT_P_ROWS_IN], o.i[MDT_P_C_IN], o.i[MDT_P_LD_IN], o.i[MDT_P_LD_OUT],
                                 o.i[MDT_P_PATCH], o.i[MDT_P_INVERSE], stream);
+        break;
+      }
+      case MDT_OP_TBLOCK: {
+        mdt::TBlockArgs a;
+        a.x = ptr(o.a); a.w = ptr(o.w); a.bias = ptr(o.bias); a.kv = ptr(o.a2); a.dbgbuf = ptr(o.p0);
+        a.mode = o.i[MDT_B_MODE]; a.C = o.i[MDT_B_C]; a.T = o.i[MDT_B_T]; a.M = B * a.T;
+        a.nchunk = o.i[MDT_B_NCHUNK]; a.nbias = o.i[MDT_B_NBIAS]; a.ldx = a.C; a.Tk = o.i[MDT_B_TK];
+        a.kv_bstride = o.i[MDT_B_KV_BSTRIDE]; a.ldkv = o.i[MDT_B_LDKV]; a.nheads = o.i[MDT_B_HEADS]; a.nsamples = B;
+        a.eps = o.f[MDT_BF_EPS]; a.scale = o.f[MDT_BF_SCALE];
+        if (!missing) e = mdt::launch_tblock(a, stream);
         break;
       }
       case MDT_OP_TIME_EMBED: {

@@ -44,6 +44,17 @@ struct AttnArgs {
 };
 hipError_t launch_attn(const AttnArgs& a, hipStream_t s);
 
+struct TBlockArgs {
+  float* x;            // [M][ldx] fp32, updated in place
+  const float* w;      // weight tile stream (bf16 hi/lo planes, 256*C bytes per tile)
+  const float* bias;   // SELF [bq|bk|bv|bo], CROSS [bq|bo], FF [b1|b2]
+  const float* kv;     // CROSS: hoisted K|V rows [sample][Tk][ldkv]
+  const float* dbgbuf; // diagnostic stamps (MDT_DBG & 8), normally nullptr
+  int mode, C, M, T, nchunk, nbias, ldx, Tk, kv_bstride, ldkv, nheads, nsamples;
+  float eps, scale;
+};
+hipError_t launch_tblock(const TBlockArgs& a, hipStream_t s);
+
 hipError_t launch_concat(const float* a, const float* b, float* out, int64_t rows, int ca, int cb, float scale_b,
                          hipStream_t s);
 hipError_t launch_patch(const float* in, float* out, int batch, int rows_in, int c_in, int ld_in, int ld_out,

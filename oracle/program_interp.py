@@ -145,5 +145,60 @@ def run_program(ops, bufs: Buffers, B: int, n_shared_rows: int = 0) -> None:
             out[:, 0:1] = t
             out[:, 1: 1 + half] = fr.sin()
             out[:, 1 + half: 1 + 2 * half] = fr.cos()
+        elif op.kind == rt.OP_TBLOCK:
+            _tblock(op, bufs, B)
         else:
             raise ValueError(f"unknown op kind {op.kind}")
+
+
+_SLOT_PERM = [32 * (s >> 5) + 16 * ((s & 7) >> 2) + 4 * ((s >> 3) & 3) + (s & 3) for s in range(64)]
+
+
+def _untile(stream: torch.Tensor, k: int, rows: int, cols: int) -> torch.Tensor:
+    """Tile k of the weight stream (bf16 hi plane then lo plane, 256*C bytes) -> fp32 [rows][cols]."""
+    n = rows * cols                       # bf16 elements per plane; tile = 2 n bf16 = n floats
+    raw = stream[k * n: (k + 1) * n].contiguous().view(torch.bfloat16)
+    return (raw[:n].float() + raw[n:].float()).view(rows, cols)
+
+
+def _tblock(op, bufs: Buffers, B: int) -> None:
+    """MDT_OP_TBLOCK semantics (include/mdt_hip.h) reconstructed from the packed tiles."""
+    i, f = op.i, op.f
+    mode, C, T, nchunk, nbias = i[rt.B_MODE], i[rt.B_C], i[rt.B_T], i[rt.B_NCHUNK], i[rt.B_NBIAS]
+    x = bufs.view(op.a, B, B * T * C).view(B, T, C)
+    tpc = 4 if mode == rt.TB_SELF else 2
+    stream = bufs.view(op.w, B, nchunk * tpc * 64 * C)
+    bias = bufs.view(op.bias, B, nbias)
+    inv = torch.empty(64, dtype=torch.long)
+    inv[torch.tensor(_SLOT_PERM)] = torch.arange(64)
+    mid = 64 * nchunk
+
+    def proj(k0):          # stack of P tiles k0, k0 + tpc, ... -> [mid, C]
+        return torch.cat([_untile(stream, h * tpc + k0, 64, C) for h in range(nchunk)])
+
+    def outw():            # O tiles -> [C, mid] with the slot permutation undone
+        return torch.cat([_untile(stream, h * tpc + tpc - 1, C, 64)[:, inv] for h in range(nchunk)], dim=1)
+
+    if mode == rt.TB_FF:
+        h = F.gelu(x @ proj(0).T + bias[:mid])
+        x += h @ outw().T + bias[mid:]
+        return
+    xn = F.layer_norm(x, (C,), None, None, eps=float(f[0]))
+    H, D = nchunk, 64
+    q = (xn @ proj(0).T + bias[:mid]).view(B, T, H, D).transpose(1, 2)
+    if mode == rt.TB_SELF:
+        k = (xn @ proj(1).T + bias[mid: 2 * mid]).view(B, T, H, D).transpose(1, 2)
+        v = (xn @ proj(2).T + bias[2 * mid: 3 * mid]).view(B, T, H, D).transpose(1, 2)
+        bo = bias[3 * mid:]
+    else:
+        Tk, bs, ldkv = i[rt.B_TK], i[rt.B_KV_BSTRIDE], i[rt.B_LDKV]
+        if bs == 0:
+            kv = bufs.view(op.a2, B, Tk * ldkv).view(1, Tk, ldkv).expand(B, -1, -1)
+        else:
+            kv = bufs.view(op.a2, B, B * Tk * ldkv).view(B, Tk, ldkv)
+        k = kv[:, :, : H * D].reshape(B, Tk, H, D).transpose(1, 2)
+        v = kv[:, :, H * D: 2 * H * D].reshape(B, Tk, H, D).transpose(1, 2)
+        bo = bias[mid:]
+    sim = (q @ k.transpose(-1, -2)) * float(f[1])
+    o = (sim.softmax(-1) @ v).transpose(1, 2).reshape(B, T, H * D)
+    x += o @ outw().T + bo

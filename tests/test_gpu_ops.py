@@ -318,3 +318,41 @@ def test_gemm_split_bf16(B, R, cin, N, taps, pro):
     out_g, out_c = ga[B * ooff: B * roff], ca[B * ooff: B * roff]
     scale = out_c.abs().max().item()
     assert (out_g - out_c).abs().max() < 4e-5 * max(scale, 1.0), ((out_g - out_c).abs().max().item(), scale)
+
+
+@pytest.mark.parametrize("mode", [rt.TB_FF, rt.TB_SELF, rt.TB_CROSS])
+@pytest.mark.parametrize("C,T,B", [(128, 16, 5), (256, 4, 37), (128, 4, 16), (256, 16, 3), (128, 1, 70)])
+def test_fused_transformer_sub_block(mode, C, T, B):
+    """k_tblock against the interpreter: LayerNorm folding, tile packing, DMA ring, MFMA operand chaining."""
+    from moleculediffusiontransformer_amd.compiler import Ten, UNetCompiler
+    from moleculediffusiontransformer_amd.netspec import inverse_unet_config
+    cfg = inverse_unet_config(16, 64, 128, 12)
+    n_ctx, mid = 12, 512
+    if mode == rt.TB_CROSS and (16 // T) * n_ctx > 64:
+        pytest.skip("more than 64 keys per 16 rows: the compiler keeps such layers unfused")
+    p = "blk."
+    sd = {p + "norm.weight": 1 + 0.2 * rnd(C, seed=1), p + "norm.bias": 0.2 * rnd(C, seed=2),
+          p + "norm_context.weight": 1 + 0.2 * rnd(C, seed=3), p + "norm_context.bias": 0.2 * rnd(C, seed=4),
+          p + "to_q.weight": rnd(mid, C, seed=5, scale=C ** -0.5), p + "to_kv.weight": rnd(2 * mid, C, seed=6, scale=C ** -0.5),
+          p + "attention.to_out.weight": rnd(C, mid, seed=7, scale=mid ** -0.5), p + "attention.to_out.bias": 0.1 * rnd(C, seed=8),
+          p + "0.weight": rnd(2 * C, C, seed=9, scale=C ** -0.5), p + "0.bias": 0.1 * rnd(2 * C, seed=10),
+          p + "2.weight": rnd(C, 2 * C, seed=11, scale=(2 * C) ** -0.5), p + "2.bias": 0.1 * rnd(C, seed=12)}
+    comp = UNetCompiler(cfg, 64, n_ctx, sd)
+    t = Ten(A, 0, T, C)
+    comp.tblock(t, mode, p, 0 if mode == rt.TB_CROSS else None)
+    op = comp.ops[0]
+    kv_off = T * C
+    if mode == rt.TB_CROSS:
+        op.a2 = ref(A, kv_off)
+    act = torch.cat([rnd(B * T * C, seed=13) * 1.5 + 0.3, rnd(B * n_ctx * 2 * mid, seed=14)])
+    (ga, _, _), (ca, _, _) = run_both([op], comp.W.pack(), act, torch.zeros(4), {}, B)
+    xg, xc = ga[: B * T * C], ca[: B * T * C]
+    assert torch.isfinite(xg).all()
+    assert (xg - xc).abs().max() < 1e-4 * max(1.0, xc.abs().max().item()), (xg - xc).abs().max().item()
+    assert torch.equal(ga[B * T * C:], ca[B * T * C:])      # K/V untouched
+    if mode == rt.TB_CROSS:                                  # batch-invariant context (guidance pass): stride 0
+        op.i[rt.B_KV_BSTRIDE] = 0
+        op.a2 = ref(S, 0)
+        shr = rnd(n_ctx * 2 * mid, seed=15)
+        (ga, _, _), (ca, _, _) = run_both([op], comp.W.pack(), act, shr, {}, B)
+        assert (ga[: B * T * C] - ca[: B * T * C]).abs().max() < 1e-4 * max(1.0, ca.abs().max().item())

@@ -1,0 +1,39 @@
+import sys
+sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+import torch
+from gpu_util import ref, rnd, run_both
+from moleculediffusiontransformer_amd import runtime as rt
+from moleculediffusiontransformer_amd.compiler import Ten, UNetCompiler
+from moleculediffusiontransformer_amd.netspec import inverse_unet_config
+A=rt.SP_ACT
+cfg = inverse_unet_config(16, 64, 128, 12)
+def case(mode, C, T, B):
+    n_ctx, mid = 12, 512
+    p="blk."
+    sd = {p + "norm.weight": 1 + 0.2 * rnd(C, seed=1), p + "norm.bias": 0.2 * rnd(C, seed=2),
+          p + "norm_context.weight": 1 + 0.2 * rnd(C, seed=3), p + "norm_context.bias": 0.2 * rnd(C, seed=4),
+          p + "to_q.weight": rnd(mid, C, seed=5, scale=C ** -0.5), p + "to_kv.weight": rnd(2 * mid, C, seed=6, scale=C ** -0.5),
+          p + "attention.to_out.weight": rnd(C, mid, seed=7, scale=mid ** -0.5), p + "attention.to_out.bias": 0.1 * rnd(C, seed=8),
+          p + "0.weight": rnd(2 * C, C, seed=9, scale=C ** -0.5), p + "0.bias": 0.1 * rnd(2 * C, seed=10),
+          p + "2.weight": rnd(C, 2 * C, seed=11, scale=(2 * C) ** -0.5), p + "2.bias": 0.1 * rnd(C, seed=12)}
+    comp = UNetCompiler(cfg, 64, n_ctx, sd)
+    t = Ten(A, 0, T, C)
+    comp.tblock(t, mode, p, 0 if mode == rt.TB_CROSS else None)
+    op = comp.ops[0]
+    if mode == rt.TB_CROSS: op.a2 = ref(A, T*C)
+    act = torch.cat([rnd(B * T * C, seed=13) * 1.5 + 0.3, rnd(B * n_ctx * 2 * mid, seed=14)])
+    W = comp.W.pack()
+    outs=[]
+    for rep in range(6):
+        (ga, _, _), (ca, _, _) = run_both([op], W, act, torch.zeros(4), {}, B)
+        xg, xc = ga[: B * T * C].view(B*T, C), ca[: B * T * C].view(B*T, C)
+        err = (xg-xc).abs()
+        bad = (err > 1e-4).nonzero()
+        outs.append(err.max().item())
+        if len(bad):
+            rows = sorted(set(bad[:,0].tolist())); cols = sorted(set(bad[:,1].tolist()))
+            print(f"  rep{rep}: max err {err.max().item():.3e}, bad rows {rows[:20]} ({len(rows)}), cols {cols[:8]}..{cols[-3:]} ({len(cols)})")
+    print(mode, C, T, B, ["%.1e" % e for e in outs])
+for mode in (2, 0, 1):
+    for (C,T,B) in [(128,16,5),(256,4,37),(128,4,16),(256,16,3),(128,16,64),(128,16,300)]:
+        case(mode,C,T,B)

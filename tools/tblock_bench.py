@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the fused transformer sub-block kernel (GPU box)."""
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+from gpu_util import ref, rnd
+from moleculediffusiontransformer_amd import runtime as rt
+from moleculediffusiontransformer_amd.compiler import Ten, UNetCompiler
+from moleculediffusiontransformer_amd.netspec import inverse_unet_config
+
+A = rt.SP_ACT
+cfg = inverse_unet_config(16, 64, 128, 12)
+dev = "cuda:0"
+for (C, T) in [(128, 16), (256, 4)]:
+    for mode, name in ((rt.TB_SELF, "SELF"), (rt.TB_CROSS, "CROSS"), (rt.TB_FF, "FF")):
+        for B in (64 * 16 // T // 16, 1024):
+            n_ctx, mid, p = 12, 512, "blk."
+            sd = {p + "norm.weight": torch.ones(C), p + "norm.bias": torch.zeros(C), p + "norm_context.weight": torch.ones(C),
+                  p + "norm_context.bias": torch.zeros(C), p + "to_q.weight": rnd(mid, C, scale=C ** -0.5),
+                  p + "to_kv.weight": rnd(2 * mid, C, scale=C ** -0.5), p + "attention.to_out.weight": rnd(C, mid, scale=mid ** -0.5),
+                  p + "attention.to_out.bias": torch.zeros(C), p + "0.weight": rnd(2 * C, C, scale=C ** -0.5), p + "0.bias": torch.zeros(2 * C),
+                  p + "2.weight": rnd(C, 2 * C, scale=(2 * C) ** -0.5), p + "2.bias": torch.zeros(C)}
+            comp = UNetCompiler(cfg, 64, n_ctx, sd)
+            comp.tblock(Ten(A, 0, T, C), mode, p, 0 if mode == rt.TB_CROSS else None)
+            op = comp.ops[0]
+            if mode == rt.TB_CROSS:
+                op.a2 = ref(A, T * C)
+            dbg = torch.zeros(256, device=dev)
+            if os.environ.get('MDT_DBG', '0') == '8':
+                op.p0 = ref(rt.SP_EXT0, 0)
+            W = comp.W.pack().to(dev)
+            act = torch.randn(B * (T * C + n_ctx * 2 * mid), device=dev) * 0.1
+            prog = rt.Program([op])
+            b = rt.MdtBindings(); b.weights, b.act = rt.ptr(W), rt.ptr(act); b.ext[0] = rt.ptr(dbg)
+            with torch.cuda.device(dev):
+                for _ in range(3): prog.run(b, B)
+                torch.cuda.synchronize()
+                t = rt.EventTimer(1); t.start()
+                for _ in range(20): prog.run(b, B)
+                t.stop(); ms = t.collect()[0] / 20
+            if os.environ.get('MDT_DBG', '0') == '8':
+                st = dbg.cpu().view(torch.int64)[:64].tolist()
+                d = [st[k + 1] - st[k] for k in range(40) if st[k + 1] > 0]
+                print("   stamps (cycles @100MHz*?):", d[:24])
+            print(f"C={C} T={T} {name:5s} B={B:5d} blocks={(B * T + 63) // 64:4d}: {ms * 1e3:7.1f} us  weights {W.numel() * 4 / 1e6:.2f} MB", flush=True)
