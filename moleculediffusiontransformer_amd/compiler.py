@@ -130,6 +130,7 @@ class UNetCompiler:
                  max_time_rows: int = 512, gemm_mode: str = "bf16x3", fuse_blocks: bool = True):
         self.fuse_blocks = fuse_blocks
         self.fuse_c256 = os.environ.get("MDT_FUSE_C256", "0") == "1"
+        self.fuse_cross = os.environ.get("MDT_FUSE_CROSS", "0") == "1"
         if gemm_mode not in ("f32", "bf16x3"):
             raise ValueError("gemm_mode must be 'f32' (exact fp32 MFMA) or 'bf16x3' (split-bf16 MFMA)")
         self.gemm_mode = gemm_mode
@@ -443,7 +444,12 @@ class UNetCompiler:
                 self.tblock(t, rt.TB_SELF, bp + "attention.")
                 if cross:
                     self.cross_layers.append(bp + "cross_attention.")
-                    self.tblock(t, rt.TB_CROSS, bp + "cross_attention.", len(self.cross_layers) - 1)
+                    if self.fuse_cross:
+                        self.tblock(t, rt.TB_CROSS, bp + "cross_attention.", len(self.cross_layers) - 1)
+                    else:
+                        # rocprofv3 (profiles/r1_kernel_stats.csv): the fused cross kernel averages 78 us against
+                        # ~62 us for q-GEMM + attention + out-GEMM: its per-head K/V loads are not pipelined yet
+                        self.attention_layer(t, bp + "cross_attention.", len(self.cross_layers) - 1)
                 self.tblock(t, rt.TB_FF, bp + "feed_forward.")
                 continue
             self.attention_layer(t, bp + "attention.", None)
