@@ -126,7 +126,9 @@ enum mdt_tblock_i {
   MDT_B_MODE = 0, MDT_B_C = 1,      /* features (128 or 256)                                             */
   MDT_B_T = 2,                      /* tokens per sample (must divide 16)                                */
   MDT_B_NCHUNK = 3,                 /* heads (attention) or hidden/64 (feed-forward)                     */
-  MDT_B_NBIAS = 4, MDT_B_TK = 5, MDT_B_KV_BSTRIDE = 6, MDT_B_LDKV = 7, MDT_B_HEADS = 8
+  MDT_B_NBIAS = 4, MDT_B_TK = 5, MDT_B_KV_BSTRIDE = 6, MDT_B_LDKV = 7, MDT_B_HEADS = 8,
+  MDT_B_VARIANT = 9                 /* 0: 64-row workgroups; 1: 16-row workgroups whose waves split the features
+                                       (levels with few rows)                                            */
 };
 enum mdt_tblock_f { MDT_BF_EPS = 0, MDT_BF_SCALE = 1 };
 

@@ -23,6 +23,7 @@ SOURCES = [
     ("k_gemm_as.hip", []),
     # VGPR-form MFMA: keeps the persistent accumulators out of the AGPR shuttle (v_accvgpr_write + s_nop per MFMA)
     ("k_tblock.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
+    ("k_tblock16.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("k_norm.hip", []),
     ("k_attn.hip", []),
     ("k_elem.hip", ["-ffp-contract=off"]),

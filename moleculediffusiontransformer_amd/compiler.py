@@ -129,7 +129,7 @@ class UNetCompiler:
     def __init__(self, cfg: UNetConfig, length: int, cond_len: int, sd: Dict[str, torch.Tensor],
                  max_time_rows: int = 512, gemm_mode: str = "bf16x3", fuse_blocks: bool = True):
         self.fuse_blocks = fuse_blocks
-        self.fuse_c256 = os.environ.get("MDT_FUSE_C256", "0") == "1"
+        self.fuse_c256 = os.environ.get("MDT_FUSE_C256", "1") == "1"
         self.fuse_cross = os.environ.get("MDT_FUSE_CROSS", "0") == "1"
         if gemm_mode not in ("f32", "bf16x3"):
             raise ValueError("gemm_mode must be 'f32' (exact fp32 MFMA) or 'bf16x3' (split-bf16 MFMA)")
@@ -335,10 +335,6 @@ class UNetCompiler:
             return False
         if c not in (128, 256) or rows > 16 or 16 % rows or self.cfg.head_features != 64:
             return False
-        # Measured on MI355X at B = 1024 (tools/tblock_bench.py): a C = 256 level has only 4096 rows = 64
-        # workgroups, the fused kernel then leaves 3/4 of the CUs idle and merely ties the layer-by-layer
-        # path (self 69 vs 71 us) or loses (cross 102 vs 44 us, ff 40 vs 26 us); C = 128 levels win clearly
-        # (self 46 vs 120 us, ff 16 vs 32 us).  So only C = 128 is fused unless asked otherwise.
         if c == 256 and not self.fuse_c256:
             return False
         if (c * self.cfg.ff_mult) % 64:
@@ -352,7 +348,7 @@ class UNetCompiler:
         lo = (w - hi.float()).to(torch.bfloat16)
         return torch.cat([hi.contiguous().view(-1), lo.contiguous().view(-1)]).view(torch.float32)
 
-    def tblock(self, t: Ten, mode: int, p: str, cross_index: Optional[int] = None) -> None:
+    def tblock(self, t: Ten, mode: int, p: str, cross_index: Optional[int] = None, variant: int = 0) -> None:
         """One fused sub-block, in place on t: MDT_OP_TBLOCK (self-attention / cross-attention / feed-forward)."""
         cfg, sd = self.cfg, self.sd
         c, rows = t.ld, t.rows
@@ -397,6 +393,7 @@ class UNetCompiler:
         i = op.i
         i[rt.B_MODE], i[rt.B_C], i[rt.B_T], i[rt.B_NCHUNK], i[rt.B_NBIAS] = mode, c, rows, nchunk, bias.numel()
         i[rt.B_TK], i[rt.B_KV_BSTRIDE], i[rt.B_LDKV], i[rt.B_HEADS] = self.n_ctx, self.n_ctx, 2 * cfg.mid_features, cfg.heads
+        i[rt.B_VARIANT] = variant
         op.f[0], op.f[1] = 1e-5, float(cfg.head_features) ** -0.5
         if mode == rt.TB_CROSS:
             op._kv = ("kv", cross_index)
@@ -438,19 +435,24 @@ class UNetCompiler:
         if free_input:
             self._free(x)
         fused = self.can_fuse_transformer(c, t.rows, cross)
+        # Kernel variant, from measurements at B = 1024 (tools/tblock_bench.py, MI355X):
+        #   C = 128 (16384 rows): 64-row workgroups          self 46 us (layer-by-layer 120), ff 16 (32)
+        #   C = 256 ( 4096 rows): 16-row feature-split ones  self 41 us (73), ff 22 (34); the 64-row kernel would
+        #                         fill only 64 CUs (self 70 us)
+        variant = 1 if c == 256 else 0
         for i in range(layers):
             bp = p + f"blocks.{i}."
             if fused:
-                self.tblock(t, rt.TB_SELF, bp + "attention.")
+                self.tblock(t, rt.TB_SELF, bp + "attention.", variant=variant)
                 if cross:
                     self.cross_layers.append(bp + "cross_attention.")
                     if self.fuse_cross:
-                        self.tblock(t, rt.TB_CROSS, bp + "cross_attention.", len(self.cross_layers) - 1)
+                        self.tblock(t, rt.TB_CROSS, bp + "cross_attention.", len(self.cross_layers) - 1, variant=variant)
                     else:
                         # rocprofv3 (profiles/r1_kernel_stats.csv): the fused cross kernel averages 78 us against
                         # ~62 us for q-GEMM + attention + out-GEMM: its per-head K/V loads are not pipelined yet
                         self.attention_layer(t, bp + "cross_attention.", len(self.cross_layers) - 1)
-                self.tblock(t, rt.TB_FF, bp + "feed_forward.")
+                self.tblock(t, rt.TB_FF, bp + "feed_forward.", variant=variant)
                 continue
             self.attention_layer(t, bp + "attention.", None)
             if cross:

@@ -218,7 +218,7 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
         a.nchunk = o.i[MDT_B_NCHUNK]; a.nbias = o.i[MDT_B_NBIAS]; a.ldx = a.C; a.Tk = o.i[MDT_B_TK];
         a.kv_bstride = o.i[MDT_B_KV_BSTRIDE]; a.ldkv = o.i[MDT_B_LDKV]; a.nheads = o.i[MDT_B_HEADS]; a.nsamples = B;
         a.eps = o.f[MDT_BF_EPS]; a.scale = o.f[MDT_BF_SCALE];
-        if (!missing) e = mdt::launch_tblock(a, stream);
+        if (!missing) e = o.i[MDT_B_VARIANT] == 1 ? mdt::launch_tblock16(a, stream) : mdt::launch_tblock(a, stream);
         break;
       }
       case MDT_OP_TIME_EMBED: {

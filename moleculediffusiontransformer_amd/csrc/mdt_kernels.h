@@ -53,7 +53,8 @@ struct TBlockArgs {
   int mode, C, M, T, nchunk, nbias, ldx, Tk, kv_bstride, ldkv, nheads, nsamples;
   float eps, scale;
 };
-hipError_t launch_tblock(const TBlockArgs& a, hipStream_t s);
+hipError_t launch_tblock(const TBlockArgs& a, hipStream_t s);     // 64-row workgroups (k_tblock.hip)
+hipError_t launch_tblock16(const TBlockArgs& a, hipStream_t s);   // 16-row workgroups, waves split the features (k_tblock16.hip)
 
 hipError_t launch_concat(const float* a, const float* b, float* out, int64_t rows, int ca, int cb, float scale_b,
                          hipStream_t s);

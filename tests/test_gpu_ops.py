@@ -320,9 +320,10 @@ def test_gemm_split_bf16(B, R, cin, N, taps, pro):
     assert (out_g - out_c).abs().max() < 4e-5 * max(scale, 1.0), ((out_g - out_c).abs().max().item(), scale)
 
 
+@pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("mode", [rt.TB_FF, rt.TB_SELF, rt.TB_CROSS])
 @pytest.mark.parametrize("C,T,B", [(128, 16, 5), (256, 4, 37), (128, 4, 16), (256, 16, 3), (128, 1, 70)])
-def test_fused_transformer_sub_block(mode, C, T, B):
+def test_fused_transformer_sub_block(mode, C, T, B, variant):
     """k_tblock against the interpreter: LayerNorm folding, tile packing, DMA ring, MFMA operand chaining."""
     from moleculediffusiontransformer_amd.compiler import Ten, UNetCompiler
     from moleculediffusiontransformer_amd.netspec import inverse_unet_config
@@ -339,7 +340,7 @@ def test_fused_transformer_sub_block(mode, C, T, B):
           p + "2.weight": rnd(C, 2 * C, seed=11, scale=(2 * C) ** -0.5), p + "2.bias": 0.1 * rnd(C, seed=12)}
     comp = UNetCompiler(cfg, 64, n_ctx, sd)
     t = Ten(A, 0, T, C)
-    comp.tblock(t, mode, p, 0 if mode == rt.TB_CROSS else None)
+    comp.tblock(t, mode, p, 0 if mode == rt.TB_CROSS else None, variant=variant)
     op = comp.ops[0]
     kv_off = T * C
     if mode == rt.TB_CROSS:

@@ -23,7 +23,7 @@ for (C, T) in [(128, 16), (256, 4)]:
                   p + "attention.to_out.bias": torch.zeros(C), p + "0.weight": rnd(2 * C, C, scale=C ** -0.5), p + "0.bias": torch.zeros(2 * C),
                   p + "2.weight": rnd(C, 2 * C, scale=(2 * C) ** -0.5), p + "2.bias": torch.zeros(C)}
             comp = UNetCompiler(cfg, 64, n_ctx, sd)
-            comp.tblock(Ten(A, 0, T, C), mode, p, 0 if mode == rt.TB_CROSS else None)
+            comp.tblock(Ten(A, 0, T, C), mode, p, 0 if mode == rt.TB_CROSS else None, variant=int(os.environ.get('VARIANT', '0')))
             op = comp.ops[0]
             if mode == rt.TB_CROSS:
                 op.a2 = ref(A, T * C)
