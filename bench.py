@@ -68,7 +68,7 @@ def kernel_breakdown(model, eng, torch, rt, B):
     ops = eng.c.programs["eval"]
     bind = eng._bind(xin=eng.xin, out=eng.pred)
     names = {rt.OP_GEMM: "k_gemm", rt.OP_GN_STATS: "k_gn_stats", rt.OP_ATTN: "k_attn", rt.OP_CONCAT: "k_concat",
-             rt.OP_PATCH: "k_patch", rt.OP_TBLOCK: "k_tblock"}
+             rt.OP_PATCH: "k_patch", rt.OP_TBLOCK: "k_tblock", rt.OP_GN_ACT: "k_gn_act"}
     best = None
     for rep in range(3):
         timer = rt.EventTimer(len(ops))

@@ -62,6 +62,9 @@ enum mdt_op_kind {
   MDT_OP_CONCAT = 4,   /* UpsampleBlock1d.add_skip: cat([x, skip * s], channel) (modules.py:828-829) */
   MDT_OP_PATCH = 5,    /* Patcher / Unpatcher rearrange (modules.py:230, :255)                   */
   MDT_OP_TIME_EMBED = 6, /* LearnedPositionalEmbedding.forward (modules.py:554-559)              */
+  MDT_OP_GN_ACT = 8,   /* nn.GroupNorm + FiLM + SiLU applied in one pass: out = silu(gn(a) * (scale + 1) + shift)
+                          (ConvBlock1d.forward before its convolution, modules.py:117-121); a -> out, p0 = gain,
+                          p1 = bias, p3 = [scale | shift] or none; ints as MDT_OP_GN_STATS plus MDT_N_SILU        */
   MDT_OP_TBLOCK = 7    /* fused transformer sub-block, in place on x (TransformerBlock.forward, modules.py:456-461):
                           x += Attention(x) | x += Attention(x, context) | x += FeedForward(x); LayerNorm affine
                           folded into the projection weights, q/k/v/probabilities/hidden never leave registers */
@@ -103,7 +106,7 @@ enum mdt_gemm_i {
 };
 enum mdt_gemm_f { MDT_GF_EPS = 0 };
 
-enum mdt_gn_i { MDT_N_ROWS = 0, MDT_N_LD = 1, MDT_N_GROUPS = 2, MDT_N_GSIZE = 3 };
+enum mdt_gn_i { MDT_N_ROWS = 0, MDT_N_LD = 1, MDT_N_GROUPS = 2, MDT_N_GSIZE = 3, MDT_N_SILU = 4 };
 enum mdt_gn_f { MDT_NF_EPS = 0 };
 
 enum mdt_attn_i {

@@ -131,6 +131,7 @@ class UNetCompiler:
         self.fuse_blocks = fuse_blocks
         self.fuse_c256 = os.environ.get("MDT_FUSE_C256", "1") == "1"
         self.fuse_cross = os.environ.get("MDT_FUSE_CROSS", "0") == "1"
+        self.use_gn_act = os.environ.get("MDT_GN_ACT", "1") == "1"
         if gemm_mode not in ("f32", "bf16x3"):
             raise ValueError("gemm_mode must be 'f32' (exact fp32 MFMA) or 'bf16x3' (split-bf16 MFMA)")
         self.gemm_mode = gemm_mode
@@ -269,6 +270,30 @@ class UNetCompiler:
         self._emit(op)
         return st
 
+    @staticmethod
+    def gn_act_ok(rows: int, ld: int, groups: int, gsize: int) -> bool:
+        """Mirror of gn_act_eligible (csrc/k_norm.hip)."""
+        if groups <= 0 or 256 % groups or gsize % 4 or groups * gsize != ld:
+            return False
+        tpg = 256 // groups
+        return (rows * (gsize // 4) + tpg - 1) // tpg <= 8
+
+    def gn_act(self, x: Ten, groups: int, gsize: int, eps: float, gain: int, nbias: int, silu: bool,
+               film=None) -> Ten:
+        """GroupNorm + FiLM + SiLU in one pass (MDT_OP_GN_ACT) -> new activated tensor."""
+        y = self._new(x.rows, x.ld, x.c)
+        op = rt.MdtOp()
+        op.kind = rt.OP_GN_ACT
+        op.a, op.out = x.ref(), y.ref()
+        op.p0, op.p1 = _ref(rt.SP_WEIGHT, gain), _ref(rt.SP_WEIGHT, nbias)
+        if isinstance(film, tuple):
+            op._film = film
+        i = op.i
+        i[rt.N_ROWS], i[rt.N_LD], i[rt.N_GROUPS], i[rt.N_GSIZE], i[rt.N_SILU] = x.rows, x.ld, groups, gsize, int(silu)
+        op.f[0] = eps
+        self._emit(op)
+        return y
+
     def attn(self, q: Ten, kv: rt.MdtRef, tk: int, kv_bstride: int, out: Ten) -> None:
         cfg = self.cfg
         op = rt.MdtOp()
@@ -291,15 +316,22 @@ class UNetCompiler:
         """ResnetBlock1d.forward (modules.py:193-205); x has `cin` real channels."""
         cin_p, cout_p = pad16(cin), pad16(cout)
         assert x.ld == cin_p, (p, x.ld, cin_p)
-        st1 = self.gn_stats(x, groups, cin // groups, 1e-5)
+        g1, b1 = self._vec(p + "block1.groupnorm.weight", cin_p), self._vec(p + "block1.groupnorm.bias", cin_p)
         h = self._new(x.rows, cout_p, cout)
-        self.gemm(x, self._conv_w(p + "block1.project.weight", cin_p, cout_p), cout_p, h, cin=cin_p,
-                  bias_off=self._vec(p + "block1.project.bias", cout_p), taps=3, t_dj=1, t_off=-1,
-                  pro=rt.PRO_GROUPNORM, gain=self._vec(p + "block1.groupnorm.weight", cin_p),
-                  nbias=self._vec(p + "block1.groupnorm.bias", cin_p), stats=st1, groups=groups,
-                  gsize=cin // groups, pro_silu=1)
-        self._free(st1)
-        st2 = self.gn_stats(h, groups, cout // groups, 1e-5)
+        w1 = self._conv_w(p + "block1.project.weight", cin_p, cout_p)
+        bias1 = self._vec(p + "block1.project.bias", cout_p)
+        if self.use_gn_act and self.gn_act_ok(x.rows, cin_p, groups, cin // groups):
+            # fused normalise + SiLU pass, then a plain conv GEMM (the prologue form recomputes the transform
+            # 3 taps x N/64 column tiles times per element and is VALU-bound)
+            a1 = self.gn_act(x, groups, cin // groups, 1e-5, g1, b1, True)
+            self.gemm(a1, w1, cout_p, h, cin=cin_p, bias_off=bias1, taps=3, t_dj=1, t_off=-1)
+            self._free(a1)
+        else:
+            st1 = self.gn_stats(x, groups, cin // groups, 1e-5)
+            self.gemm(x, w1, cout_p, h, cin=cin_p, bias_off=bias1, taps=3, t_dj=1, t_off=-1,
+                      pro=rt.PRO_GROUPNORM, gain=g1, nbias=b1, stats=st1, groups=groups, gsize=cin // groups,
+                      pro_silu=1)
+            self._free(st1)
         if (p + "to_out.weight") in self.sd:
             r = self._new(x.rows, cout_p, cout)
             self.gemm(x, self._conv_w(p + "to_out.weight", cin_p, cout_p), cout_p, r, cin=cin_p,
@@ -311,12 +343,19 @@ class UNetCompiler:
         self.ss_offsets[p] = ss_off
         self.ss_total += 2 * cout_p
         y = self._new(x.rows, cout_p, cout)
-        self.gemm(h, self._conv_w(p + "block2.project.weight", cout_p, cout_p), cout_p, y, cin=cout_p,
-                  bias_off=self._vec(p + "block2.project.bias", cout_p), taps=3, t_dj=1, t_off=-1,
-                  pro=rt.PRO_GROUPNORM, gain=self._vec(p + "block2.groupnorm.weight", cout_p),
-                  nbias=self._vec(p + "block2.groupnorm.bias", cout_p), stats=st2, groups=groups,
-                  gsize=cout // groups, pro_silu=1, film=("ss", ss_off), res=r)
-        self._free(st2)
+        g2, b2 = self._vec(p + "block2.groupnorm.weight", cout_p), self._vec(p + "block2.groupnorm.bias", cout_p)
+        w2 = self._conv_w(p + "block2.project.weight", cout_p, cout_p)
+        bias2 = self._vec(p + "block2.project.bias", cout_p)
+        if self.use_gn_act and self.gn_act_ok(h.rows, cout_p, groups, cout // groups):
+            a2 = self.gn_act(h, groups, cout // groups, 1e-5, g2, b2, True, film=("ss", ss_off))
+            self.gemm(a2, w2, cout_p, y, cin=cout_p, bias_off=bias2, taps=3, t_dj=1, t_off=-1, res=r)
+            self._free(a2)
+        else:
+            st2 = self.gn_stats(h, groups, cout // groups, 1e-5)
+            self.gemm(h, w2, cout_p, y, cin=cout_p, bias_off=bias2, taps=3, t_dj=1, t_off=-1,
+                      pro=rt.PRO_GROUPNORM, gain=g2, nbias=b2, stats=st2, groups=groups, gsize=cout // groups,
+                      pro_silu=1, film=("ss", ss_off), res=r)
+            self._free(st2)
         self._free(h)
         if r is not x:
             self._free(r)
@@ -426,12 +465,18 @@ class UNetCompiler:
         """Transformer1d.forward (modules.py:519-524)."""
         cfg = self.cfg
         assert x.ld == c and c % 32 == 0
-        st = self.gn_stats(x, 32, c // 32, 1e-6)
         t = self._new(x.rows, c)
-        self.gemm(x, self._conv_w(p + "to_in.1.weight", c, c), c, t, cin=c, bias_off=self._vec(p + "to_in.1.bias", c),
-                  pro=rt.PRO_GROUPNORM, gain=self._vec(p + "to_in.0.weight", c), nbias=self._vec(p + "to_in.0.bias", c),
-                  stats=st, groups=32, gsize=c // 32, pro_silu=0)
-        self._free(st)
+        gi, bi = self._vec(p + "to_in.0.weight", c), self._vec(p + "to_in.0.bias", c)
+        wi, bias_i = self._conv_w(p + "to_in.1.weight", c, c), self._vec(p + "to_in.1.bias", c)
+        if self.use_gn_act and self.gn_act_ok(x.rows, c, 32, c // 32):
+            xa = self.gn_act(x, 32, c // 32, 1e-6, gi, bi, False)
+            self.gemm(xa, wi, c, t, cin=c, bias_off=bias_i)
+            self._free(xa)
+        else:
+            st = self.gn_stats(x, 32, c // 32, 1e-6)
+            self.gemm(x, wi, c, t, cin=c, bias_off=bias_i, pro=rt.PRO_GROUPNORM, gain=gi, nbias=bi,
+                      stats=st, groups=32, gsize=c // 32, pro_silu=0)
+            self._free(st)
         if free_input:
             self._free(x)
         fused = self.can_fuse_transformer(c, t.rows, cross)
@@ -616,7 +661,7 @@ class UNetCompiler:
             for op in ops:
                 o = rt.MdtOp()
                 C_memmove(o, op)
-                if op.kind == rt.OP_GEMM and isinstance(getattr(op, "_film", None), tuple):
+                if op.kind in (rt.OP_GEMM, rt.OP_GN_ACT) and isinstance(getattr(op, "_film", None), tuple):
                     o.p3 = _ref(rt.SP_SHR, ss_cur + op._film[1])
                 if op.kind in (rt.OP_ATTN, rt.OP_TBLOCK) and isinstance(getattr(op, "_kv", None), tuple):
                     idx = op._kv[1]

@@ -51,6 +51,107 @@ __global__ __launch_bounds__(NT) void k_gn_stats(GnStatsArgs g) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused GroupNorm apply: statistics + normalise + affine + FiLM + SiLU in ONE pass over a sample
+// (ConvBlock1d.forward up to the convolution, modules.py:117-121).  As a GEMM prologue the same
+// transform is recomputed for every tap and every N-tile (12x per element for a k=3 conv with 4 column
+// tiles) and made those GEMMs VALU-bound; here each element is read once, transformed once and written
+// once, and the convolution becomes a plain GEMM on the activated tensor (zero padding is then exact).
+// One workgroup per sample; group g is owned by 256/G consecutive threads, which hold the group's
+// elements in registers (two-pass variance, shuffle reduction in a fixed order: deterministic).
+template <int NF4>
+__global__ __launch_bounds__(256) void k_gn_act(GnActArgs a) {
+  __shared__ float red[8];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int tpg = 256 / a.groups;                  // threads per group (power of two)
+  const int grp = tid / tpg, u = tid % tpg;
+  const int q4 = a.gsize / 4;                      // float4 per row of the group's channel span
+  const int nf4 = a.rows * q4;                     // float4 per group
+  const float* xb = a.x + (int64_t)b * a.rows * a.ld + grp * a.gsize;
+  float* yb = a.y + (int64_t)b * a.rows * a.ld + grp * a.gsize;
+  float4 v[NF4];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < NF4; ++k) {
+    const int e = u + k * tpg;
+    v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e < nf4) {
+      const int r = e / q4, q = e - r * q4;
+      v[k] = *reinterpret_cast<const float4*>(xb + (int64_t)r * a.ld + 4 * q);
+      s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    }
+  }
+  auto group_sum = [&](float val) -> float {
+    if (tpg <= 64) {
+      for (int off = tpg >> 1; off >= 1; off >>= 1) val += __shfl_xor(val, off, 64);
+      return val;
+    }
+    // one group = the whole workgroup (G = 1): wave shuffle + 4 partials through LDS
+    for (int off = 32; off >= 1; off >>= 1) val += __shfl_xor(val, off, 64);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = val;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+  };
+  const float n = (float)(a.rows * a.gsize);
+  const float mean = group_sum(s) / n;
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < NF4; ++k) {
+    const int e = u + k * tpg;
+    if (e < nf4) {
+      const float d0 = v[k].x - mean, d1 = v[k].y - mean, d2 = v[k].z - mean, d3 = v[k].w - mean;
+      ss += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(group_sum(ss) / n + a.eps);
+#pragma unroll
+  for (int k = 0; k < NF4; ++k) {
+    const int e = u + k * tpg;
+    if (e < nf4) {
+      const int r = e / q4, q = e - r * q4;
+      const int c = grp * a.gsize + 4 * q;
+      const float4 ga = *reinterpret_cast<const float4*>(a.gamma + c);
+      const float4 be = *reinterpret_cast<const float4*>(a.beta + c);
+      float x[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+      const float g4[4] = {ga.x, ga.y, ga.z, ga.w}, b4[4] = {be.x, be.y, be.z, be.w};
+      float f4[4] = {1.f, 1.f, 1.f, 1.f}, h4[4] = {0.f, 0.f, 0.f, 0.f};
+      if (a.film) {
+        const float4 fs = *reinterpret_cast<const float4*>(a.film + c);
+        const float4 fh = *reinterpret_cast<const float4*>(a.film + a.ld + c);
+        f4[0] = fs.x + 1.0f; f4[1] = fs.y + 1.0f; f4[2] = fs.z + 1.0f; f4[3] = fs.w + 1.0f;
+        h4[0] = fh.x; h4[1] = fh.y; h4[2] = fh.z; h4[3] = fh.w;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float sc = rstd * g4[j];
+        float t = x[j] * sc + (b4[j] - sc * mean);
+        t = t * f4[j] + h4[j];
+        if (a.silu) t = t / (1.0f + expf(-t));
+        x[j] = t;
+      }
+      *reinterpret_cast<float4*>(yb + (int64_t)r * a.ld + 4 * q) = make_float4(x[0], x[1], x[2], x[3]);
+    }
+  }
+}
+
+bool gn_act_eligible(int rows, int ld, int groups, int gsize) {
+  if (groups <= 0 || 256 % groups || gsize % 4 || groups * gsize != ld) return false;
+  const int tpg = 256 / groups, nf4 = rows * (gsize / 4);
+  return (nf4 + tpg - 1) / tpg <= 8;
+}
+
+hipError_t launch_gn_act(const GnActArgs& a, hipStream_t s) {
+  if (a.batch <= 0) return hipSuccess;
+  if (!gn_act_eligible(a.rows, a.ld, a.groups, a.gsize)) return hipErrorInvalidValue;
+  const int tpg = 256 / a.groups, per = (a.rows * (a.gsize / 4) + tpg - 1) / tpg;
+  if (per <= 1) hipLaunchKernelGGL((k_gn_act<1>), dim3(a.batch), dim3(256), 0, s, a);
+  else if (per <= 2) hipLaunchKernelGGL((k_gn_act<2>), dim3(a.batch), dim3(256), 0, s, a);
+  else if (per <= 4) hipLaunchKernelGGL((k_gn_act<4>), dim3(a.batch), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((k_gn_act<8>), dim3(a.batch), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_gn_stats(const GnStatsArgs& g, hipStream_t s) {
   if (g.batch <= 0) return hipSuccess;
   const unsigned nblk = (unsigned)(g.batch * g.groups);

@@ -76,6 +76,11 @@ static const char* validate(const mdt_op& o, int idx, char* buf, size_t nbuf) {
       if (o.i[MDT_N_ROWS] <= 0 || o.i[MDT_N_GROUPS] <= 0 || o.i[MDT_N_GSIZE] <= 0) return bad("bad dims");
       if (!o.a.space || !o.out.space) return bad("missing operand");
       break;
+    case MDT_OP_GN_ACT:
+      if (!mdt::gn_act_eligible(o.i[MDT_N_ROWS], o.i[MDT_N_LD], o.i[MDT_N_GROUPS], o.i[MDT_N_GSIZE]))
+        return bad("shape not supported by the fused GroupNorm-apply kernel");
+      if (!o.a.space || !o.out.space || !o.p0.space || !o.p1.space) return bad("missing operand");
+      break;
     case MDT_OP_ATTN:
       if (o.i[MDT_A_T] <= 0 || o.i[MDT_A_T] > 64 || o.i[MDT_A_TK] <= 0 || o.i[MDT_A_TK] > 64)
         return bad("attention supports 1..64 queries and keys per sample");
@@ -187,6 +192,14 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
         g.x = ptr(o.a); g.stats = ptr(o.out); g.batch = B; g.rows = o.i[MDT_N_ROWS]; g.ld = o.i[MDT_N_LD];
         g.groups = o.i[MDT_N_GROUPS]; g.gsize = o.i[MDT_N_GSIZE]; g.eps = o.f[MDT_NF_EPS];
         if (!missing) e = mdt::launch_gn_stats(g, stream);
+        break;
+      }
+      case MDT_OP_GN_ACT: {
+        mdt::GnActArgs a;
+        a.x = ptr(o.a); a.y = ptr(o.out); a.gamma = ptr(o.p0); a.beta = ptr(o.p1); a.film = ptr(o.p3);
+        a.batch = B; a.rows = o.i[MDT_N_ROWS]; a.ld = o.i[MDT_N_LD]; a.groups = o.i[MDT_N_GROUPS];
+        a.gsize = o.i[MDT_N_GSIZE]; a.silu = o.i[MDT_N_SILU]; a.eps = o.f[MDT_NF_EPS];
+        if (!missing) e = mdt::launch_gn_act(a, stream);
         break;
       }
       case MDT_OP_ATTN: {

@@ -35,6 +35,18 @@ struct GnStatsArgs {
 };
 hipError_t launch_gn_stats(const GnStatsArgs& g, hipStream_t s);
 
+struct GnActArgs {
+  const float* x;
+  float* y;
+  const float* gamma;
+  const float* beta;
+  const float* film;   // [scale(ld) | shift(ld)] or nullptr
+  int batch, rows, ld, groups, gsize, silu;
+  float eps;
+};
+bool gn_act_eligible(int rows, int ld, int groups, int gsize);
+hipError_t launch_gn_act(const GnActArgs& a, hipStream_t s);
+
 struct AttnArgs {
   const float* q;
   const float* k;  // v = k + heads*64

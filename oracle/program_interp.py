@@ -100,6 +100,16 @@ def run_program(ops, bufs: Buffers, B: int, n_shared_rows: int = 0) -> None:
             st = bufs.view(op.out, B, B * G * 2).view(B, G, 2)
             st[:, :, 0] = mean
             st[:, :, 1] = 1.0 / torch.sqrt(var + float(f[0]))
+        elif op.kind == rt.OP_GN_ACT:
+            rows, ld, G, gs = i[rt.N_ROWS], i[rt.N_LD], i[rt.N_GROUPS], i[rt.N_GSIZE]
+            x = bufs.view(op.a, B, B * rows * ld).view(B, rows, ld)
+            y = F.group_norm(x.transpose(1, 2), G, bufs.view(op.p0, B, ld), bufs.view(op.p1, B, ld), float(f[0])).transpose(1, 2)
+            if op.p3.space != rt.SP_NONE:
+                ss = bufs.view(op.p3, B, 2 * ld)
+                y = y * (ss[:ld] + 1.0) + ss[ld:]
+            if i[rt.N_SILU]:
+                y = _silu(y)
+            bufs.view(op.out, B, B * rows * ld).view(B, rows, ld)[:] = y
         elif op.kind == rt.OP_ATTN:
             T, Tk, H = i[rt.A_T], i[rt.A_TK], i[rt.A_HEADS]
             ldq, ldkv, ldo, bs = i[rt.A_LDQ], i[rt.A_LDKV], i[rt.A_LDO], i[rt.A_KV_BSTRIDE]

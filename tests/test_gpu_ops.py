@@ -357,3 +357,29 @@ def test_fused_transformer_sub_block(mode, C, T, B, variant):
         shr = rnd(n_ctx * 2 * mid, seed=15)
         (ga, _, _), (ca, _, _) = run_both([op], comp.W.pack(), act, shr, {}, B)
         assert (ga[: B * T * C] - ca[: B * T * C]).abs().max() < 1e-4 * max(1.0, ca.abs().max().item())
+
+
+@pytest.mark.parametrize("B,R,C,G,film,silu,eps", [(5, 64, 64, 1, False, True, 1e-5), (3, 16, 128, 8, True, True, 1e-5),
+                                                    (4, 4, 512, 8, True, True, 1e-5), (6, 16, 128, 32, False, False, 1e-6),
+                                                    (2, 4, 256, 32, False, False, 1e-6), (3, 64, 16, 1, False, True, 1e-5)])
+def test_gn_act(B, R, C, G, film, silu, eps):
+    """k_gn_act (statistics + normalise + FiLM + SiLU in one pass) against torch's GroupNorm."""
+    weights = torch.cat([1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)])
+    shr = 0.3 * rnd(2 * C, seed=9)
+    act = torch.cat([rnd(B * R * C, seed=4) * 1.5 + 0.3, torch.zeros(B * R * C)])
+    op = rt.MdtOp()
+    op.kind = rt.OP_GN_ACT
+    op.a, op.out, op.p0, op.p1 = ref(A, 0), ref(A, R * C), ref(W, 0), ref(W, C)
+    if film:
+        op.p3 = ref(S, 0)
+    op.i[rt.N_ROWS], op.i[rt.N_LD], op.i[rt.N_GROUPS], op.i[rt.N_GSIZE], op.i[rt.N_SILU] = R, C, G, C // G, int(silu)
+    op.f[0] = eps
+    (ga, _, _), (ca, _, _) = run_both([op], weights, act, shr, {}, B)
+    assert (ga - ca).abs().max() < 2e-5
+    x = act[: B * R * C].view(B, R, C).transpose(1, 2)
+    h = torch.nn.functional.group_norm(x, G, weights[:C], weights[C:], eps)
+    if film:
+        h = h * (shr[:C].view(1, C, 1) + 1) + shr[C:].view(1, C, 1)
+    if silu:
+        h = torch.nn.functional.silu(h)
+    assert (ga[B * R * C:].view(B, R, C) - h.transpose(1, 2)).abs().max() < 2e-5

@@ -54,6 +54,10 @@ def main():
             fl = 0
             desc = f"GNST  rows={i[rt.N_ROWS]} ld={i[rt.N_LD]} G={i[rt.N_GROUPS]}"
             key = desc
+        elif op.kind == rt.OP_GN_ACT:
+            fl = 0
+            desc = f"GNACT rows={i[rt.N_ROWS]} ld={i[rt.N_LD]} G={i[rt.N_GROUPS]}"
+            key = desc
         elif op.kind == rt.OP_TBLOCK:
             fl = 0
             desc = f"TBLK  mode={i[rt.B_MODE]} C={i[rt.B_C]} T={i[rt.B_T]}"
