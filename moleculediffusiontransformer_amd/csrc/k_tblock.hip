@@ -202,6 +202,20 @@ __global__ __launch_bounds__(256) void k_tblock(TBlockArgs a, int dbg) {
   }
 #pragma unroll
   for (int sp = 0; sp < 2; ++sp) aO[sp] = i * 128 + ((4 * sp + g) ^ ((i >> 1) & 7)) * 16;
+  // Fragment reads are issued as inline asm: hipcc's waitcnt pass only ever emits lgkmcnt(0) in this kernel
+  // (it then waits for the prefetch just issued and exposes one LDS latency per 12 MFMAs: 27 instead of 16.7
+  // cycles per MFMA).  Opaque asm reads + hand-counted s_waitcnt lgkmcnt(N) keep two units in flight.
+  auto lds_read = [&](bf16x8& dst, const unsigned char* p) {
+    // generic -> LDS address-space cast yields the 32-bit LDS byte address ds_read expects
+    const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)p;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr) : "memory");
+  };
+  auto lgkm_wait = [&](int pending) {                  // reads still allowed in flight
+    if (pending >= 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+    else if (pending >= 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
   auto fragP = [&](const unsigned char* slot, int tile16, int st, int plane) -> bf16x8 {
     return *reinterpret_cast<const bf16x8*>(slot + aP[st] + (tile16 * 16 * 4 * C + plane * 2 * C));
   };
@@ -223,8 +237,8 @@ __global__ __launch_bounds__(256) void k_tblock(TBlockArgs a, int dbg) {
     auto load = [&](int u, int set) {
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        fh[set][q] = fragP(slot, 2 * (u & 1) + q, u >> 1, 0);
-        fl[set][q] = fragP(slot, 2 * (u & 1) + q, u >> 1, 1);
+        lds_read(fh[set][q], slot + aP[u >> 1] + ((2 * (u & 1) + q) * 16 * 4 * C));
+        lds_read(fl[set][q], slot + aP[u >> 1] + ((2 * (u & 1) + q) * 16 * 4 * C + 2 * C));
       }
     };
     load(0, 0);
@@ -234,7 +248,7 @@ __global__ __launch_bounds__(256) void k_tblock(TBlockArgs a, int dbg) {
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
       if (u + 2 < NU) load(u + 2, (u + 2) % 3);
-      __builtin_amdgcn_sched_barrier(0);
+      lgkm_wait(4 * min(2, NU - 1 - u));
       const int st = u >> 1, f0 = 2 * (u & 1);
 #pragma unroll
       for (int q = 0; q < 2; ++q) out[f0 + q] = MDT_MFMA_BF16(fl[u % 3][q], xh[st], out[f0 + q], 0, 0, 0);
@@ -252,8 +266,8 @@ __global__ __launch_bounds__(256) void k_tblock(TBlockArgs a, int dbg) {
     auto load = [&](int u, int set) {
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        fh[set][q] = fragP(slot, 2 * (u & 1) + q, u >> 1, 0);
-        fl[set][q] = fragP(slot, 2 * (u & 1) + q, u >> 1, 1);
+        lds_read(fh[set][q], slot + aP[u >> 1] + ((2 * (u & 1) + q) * 16 * 4 * C));
+        lds_read(fl[set][q], slot + aP[u >> 1] + ((2 * (u & 1) + q) * 16 * 4 * C + 2 * C));
       }
     };
     load(0, 0);
@@ -266,7 +280,7 @@ __global__ __launch_bounds__(256) void k_tblock(TBlockArgs a, int dbg) {
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
       if (u + 2 < NU) load(u + 2, (u + 2) % 3);
-      __builtin_amdgcn_sched_barrier(0);
+      lgkm_wait(4 * min(2, NU - 1 - u));
       const int st = u >> 1, d0 = 2 * (u & 1);
 #pragma unroll
       for (int q = 0; q < 2; ++q) out[d0 + q] = MDT_MFMA_BF16(xl[st], fh[u % 3][q], out[d0 + q], 0, 0, 0);
@@ -293,12 +307,14 @@ __global__ __launch_bounds__(256) void k_tblock(TBlockArgs a, int dbg) {
   unsigned long long* stamps = reinterpret_cast<unsigned long long*>(const_cast<float*>(a.dbgbuf));
   int nstamp = 0;
   auto stamp = [&]() {
+#ifdef MDT_STAMPS
     if ((dbg & 8) && stamps && blockIdx.x == 0 && wave == 0 && nstamp < 64) {
       unsigned long long t;
       asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
       if (lane == 0) stamps[nstamp] = t;
       ++nstamp;
     }
+#endif
   };
 
   for (int h = 0; h < a.nchunk; ++h) {
@@ -459,8 +475,8 @@ __global__ __launch_bounds__(256) void k_tblock(TBlockArgs a, int dbg) {
         const int sp = u / CH, ct0 = 2 * (u % CH);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-          fh[set][q] = fragO(so, ct0 + q, sp, 0);
-          fl[set][q] = fragO(so, ct0 + q, sp, 1);
+          lds_read(fh[set][q], so + aO[sp] + ((ct0 + q) * 16 * 128));
+          lds_read(fl[set][q], so + aO[sp] + ((ct0 + q) * 16 * 128 + C * 128));
         }
       };
       load(0, 0);
@@ -469,7 +485,7 @@ __global__ __launch_bounds__(256) void k_tblock(TBlockArgs a, int dbg) {
       for (int u = 0; u < NU; ++u) {
         const int sp = u / CH, ct0 = 2 * (u % CH);
         if (u + 2 < NU) load(u + 2, (u + 2) % 3);
-        __builtin_amdgcn_sched_barrier(0);
+        lgkm_wait(4 * min(2, NU - 1 - u));
 #pragma unroll
         for (int q = 0; q < 2; ++q) accT[ct0 + q] = MDT_MFMA_BF16(fl[u % 3][q], oh[sp], accT[ct0 + q], 0, 0, 0);
 #pragma unroll

@@ -14,6 +14,8 @@ CASES = {
     "cfg3": ("forward", dict(max_length=64, pred_dim=1, channels=64, context_embedding_max_length=64)),
     "tiny": ("inverse", dict(max_length=32, pred_dim=16, channels=16, context_embedding_max_length=12)),
     "pd22": ("inverse", dict(max_length=32, pred_dim=22, channels=32, context_embedding_max_length=12)),
+    # BASELINE.json configs[4] architecture (deep U-Net): channels=256, pred_dim=32, max_len=128
+    "cfg5": ("inverse", dict(max_length=128, pred_dim=32, channels=256, context_embedding_max_length=12)),
 }
 
 
