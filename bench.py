@@ -15,6 +15,7 @@ Prints ONE JSON line (rank 0) with the contract fields plus
   "cpu_baseline": the CPU oracle (PyTorch restatement pinned to the reference) on a bounded sample
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -87,6 +88,28 @@ def kernel_breakdown(model, eng, torch, rt, B):
     return out
 
 
+def pmc_traffic(kernel_class):
+    """HBM bytes per launch of one kernel class, from the committed PMC summary of this same workload
+    (profiles/r*_pmc_hbm_traffic.csv: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                                          "r*_pmc_hbm_traffic.csv")))
+    if not files:
+        return None, None
+    n, mb = 0, 0.0
+    for line in open(files[-1]):
+        if line.startswith("#") or line.startswith("kernel,"):
+            continue
+        name, rest = line.rsplit(",", 5)[0], line.strip().rsplit(",", 5)[1:]
+        if name.startswith("mdt::" + kernel_class):
+            n += int(rest[0])
+            mb += int(rest[0]) * float(rest[4])
+    if n == 0:
+        return None, None
+    return round(mb / n * 1e6), ("bytes per launch; profiles/" + os.path.basename(files[-1]) +
+                                 " (rocprofv3 PMC passes of this workload, recorded earlier, not collected live)")
+
+
 def main():
     a = parse()
     import torch
@@ -111,7 +134,8 @@ def main():
 
     import gpu_util
     gpu_util.DEV = str(device)
-    model = make_model("cfg1")                       # inverse c=64, pred_dim=16, L=64, cond_len=12; synthetic weights
+    with contextlib.redirect_stdout(sys.stderr):     # the class prints "Using unet type" like the reference does
+        model = make_model("cfg1")                   # inverse c=64, pred_dim=16, L=64, cond_len=12; synthetic weights
     B, T = a.batch, a.timesteps
     seq = synth_normal(f"bench/seq/rank{rank}", (B, 12)).to(device)
     evals = 2 * (T - 1)
@@ -171,6 +195,7 @@ def main():
                          "achieved": round(alg * mult, 2), "frac": round(alg * mult / peak, 4),
                          "algorithmic_tflops_fp32_equiv": round(alg, 2), "launches_per_eval": n_dom,
                          "avg_launch_us": round(1e3 * ms_dom / n_dom, 2), "flops_per_launch_avg": fl_dom / n_dom})
+            roof["traffic"], roof["traffic_source"] = pmc_traffic(dom)
             extra["eval_breakdown_ms"] = {k: {"launches": n, "ms": round(t, 4),
                                               "algorithmic_tflops": round(f / (t * 1e-3) / 1e12, 2) if f else None}
                                           for k, (n, t, f) in sorted(bd.items())}

@@ -1,0 +1,65 @@
+"""Folds the rocprofv3 outputs of tools/profile_round.sh into the small csv summaries kept under profiles/.
+
+usage: python tools/pmc_summary.py gpurun_out/prof_r1 r1
+
+FETCH_SIZE is reported in KB and, on gfx950, counts exactly half of the bytes of wide coalesced reads
+(MI355X_MICROARCH.md, HBM section) -> corrected = 2 x raw.  WRITE_SIZE (KB) is exact.
+"""
+import collections
+import csv
+import glob
+import os
+import shutil
+import sys
+
+
+def short(name: str) -> str:
+    return name.split("(")[0].replace("void ", "").strip()
+
+
+def counters(d: str, counter: str):
+    tot, n = collections.Counter(), collections.Counter()
+    for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            k = short(r["Kernel_Name"])
+            tot[k] += float(r["Counter_Value"])
+            n[k] += 1
+    return tot, n
+
+
+def main():
+    src, tag = sys.argv[1], sys.argv[2]
+    dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    os.makedirs(dst, exist_ok=True)
+    for kind in ("kernel_stats", "domain_stats"):
+        fs = glob.glob(os.path.join(src, "trace", "**", f"*_{kind}.csv"), recursive=True)
+        if fs:
+            shutil.copy(fs[0], os.path.join(dst, f"{tag}_{kind}.csv"))
+    for a, b in (("bench.json", f"{tag}_bench.json"), ("bench_under_rocprof.json", f"{tag}_bench_under_rocprof.json")):
+        if os.path.exists(os.path.join(src, a)):
+            shutil.copy(os.path.join(src, a), os.path.join(dst, b))
+    fr, fn = counters(os.path.join(src, "pmc_fetch"), "FETCH_SIZE")
+    wr, wn = counters(os.path.join(src, "pmc_write"), "WRITE_SIZE")
+    with open(os.path.join(dst, f"{tag}_pmc_hbm_traffic.csv"), "w") as f:
+        f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), "
+                "bench.py --batch 1024 --timesteps 4\n")
+        f.write("# FETCH_SIZE is in KB and reads exactly 1/2 of the bytes of wide coalesced reads on gfx950 "
+                "(MI355X_MICROARCH.md, HBM): corrected = 2 x raw\n")
+        f.write("kernel,dispatches,fetch_raw_KB_per_dispatch,fetch_corrected_MB_per_dispatch,"
+                "write_MB_per_dispatch,hbm_MB_per_dispatch\n")
+        rows = []
+        for k in fr:
+            d = fn[k]
+            raw = fr[k] / d
+            w = (wr.get(k, 0.0) / max(wn.get(k, 1), 1)) / 1024.0
+            rows.append((k, d, raw, 2 * raw / 1024.0, w))
+        rows.sort(key=lambda r: -(r[3] + r[4]) * r[1])
+        for k, d, raw, fc, w in rows:
+            f.write(f"{k},{d},{raw:.1f},{fc:.2f},{w:.2f},{fc + w:.2f}\n")
+    print("profiles written for", tag)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Round profile recipe (run on the GPU box from the repo root):
+#   bash tools/profile_round.sh r1
+# 1. plain bench.py (with the CPU baseline leg)            -> gpurun_out/prof_<tag>/bench.json
+# 2. rocprofv3 --output-format csv --kernel-trace --stats of the same command   -> .../trace (kernel_stats.csv, domain_stats.csv)
+# 3. two PMC passes (FETCH_SIZE, WRITE_SIZE), kernel-trace only, on a 4-timestep run -> .../pmc_fetch, .../pmc_write
+# tools/pmc_summary.py then folds 2+3 into the csv files committed under profiles/.
+tag=${1:-r1}
+root=$(pwd)
+out=$root/gpurun_out/prof_$tag
+rm -rf "$out"; mkdir -p "$out"
+export TMPDIR=/tmp
+python3 bench.py > "$out/bench.json" 2> "$out/bench.err"
+cd /tmp
+rocprofv3 --output-format csv --kernel-trace --stats -d "$out/trace" -o runc -- python3 "$root/bench.py" --no-cpu-baseline \
+    > "$out/bench_under_rocprof.json" 2> "$out/trace.log"
+rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d "$out/pmc_fetch" -o runc -- python3 "$root/bench.py" \
+    --no-cpu-baseline --no-breakdown --timesteps 4 --steps 1 --warmup 1 > "$out/pmc_fetch.json" 2> "$out/pmc_fetch.log"
+rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d "$out/pmc_write" -o runc -- python3 "$root/bench.py" \
+    --no-cpu-baseline --no-breakdown --timesteps 4 --steps 1 --warmup 1 > "$out/pmc_write.json" 2> "$out/pmc_write.log"
+cd "$root"
+# then, where profiles/ is tracked:  python3 tools/pmc_summary.py gpurun_out/prof_$tag $tag
