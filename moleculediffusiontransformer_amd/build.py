@@ -24,6 +24,8 @@ SOURCES = [
     # VGPR-form MFMA: keeps the persistent accumulators out of the AGPR shuttle (v_accvgpr_write + s_nop per MFMA)
     ("k_tblock.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("k_tblock16.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
+    ("k_tblock_lw.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
+    ("k_tblock32.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("k_norm.hip", []),
     ("k_attn.hip", []),
     ("k_elem.hip", ["-ffp-contract=off"]),
@@ -47,7 +49,7 @@ def _digest() -> str:
             h.update(os.path.basename(p).encode())
             with open(p, "rb") as f:
                 h.update(f.read())
-    h.update(repr((SOURCES, COMMON)).encode())
+    h.update(repr((SOURCES, COMMON, os.environ.get('MDT_BUILD_DEFS', ''))).encode())
     return h.hexdigest()
 
 
@@ -71,7 +73,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     def compile_one(item):
         src, extra = item
         obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
-        cmd = [hipcc, *COMMON, *extra, "-I", INCLUDE, "-c", os.path.join(CSRC, src), "-o", obj]
+        defs = os.environ.get("MDT_BUILD_DEFS", "").split()       # tuning builds only, e.g. -DMDT_STAMPS
+        cmd = [hipcc, *COMMON, *extra, *defs, "-I", INCLUDE, "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")

@@ -130,6 +130,7 @@ class UNetCompiler:
                  max_time_rows: int = 512, gemm_mode: str = "bf16x3", fuse_blocks: bool = True):
         self.fuse_blocks = fuse_blocks
         self.fuse_c256 = os.environ.get("MDT_FUSE_C256", "1") == "1"
+        self.tb32 = os.environ.get("MDT_TB32", "1") == "1"           # C = 256 blocks on 32-row workgroups (k_tblock32)
         self.fuse_cross = os.environ.get("MDT_FUSE_CROSS", "0") == "1"
         self.use_gn_act = os.environ.get("MDT_GN_ACT", "1") == "1"
         if gemm_mode not in ("f32", "bf16x3"):
@@ -393,6 +394,8 @@ class UNetCompiler:
         c, rows = t.ld, t.rows
         perm = torch.tensor(self._SLOT_PERM)
         tiles: List[torch.Tensor] = []
+        if variant == 2:
+            assert c == 256 and mode != rt.TB_CROSS, "variant 2 (32-row workgroups) serves C = 256 self-attention / feed-forward"
         if mode == rt.TB_FF:
             w1, b1 = sd[p + "0.weight"], sd[p + "0.bias"]          # [2C, C]
             w2, b2 = sd[p + "2.weight"], sd[p + "2.bias"]          # [C, 2C]
@@ -424,6 +427,23 @@ class UNetCompiler:
                 bias = torch.cat([bq_f, bo])
                 mid = wq.shape[0]
                 self.flops += 2 * rows * c * mid + 4 * rows * self.n_ctx * mid + 2 * rows * mid * c
+        if variant == 2:
+            # k_tblock32 streams 32 KB sub-tiles in the C = 128 tile format: a [64][256] projection tile as its two
+            # K halves, a [256][64] output tile as its two row halves (tiles alternate P ... P O per chunk)
+            tpc = 4 if mode == rt.TB_SELF else 2
+            sub: List[torch.Tensor] = []
+            for k, tl in enumerate(tiles):
+                raw = tl.view(torch.bfloat16)
+                n = raw.numel() // 2
+                if k % tpc == tpc - 1:
+                    hi, lo = raw[:n].view(c, 64), raw[n:].view(c, 64)
+                    halves = [(hi[:128], lo[:128]), (hi[128:], lo[128:])]
+                else:
+                    hi, lo = raw[:n].view(64, c), raw[n:].view(64, c)
+                    halves = [(hi[:, :128], lo[:, :128]), (hi[:, 128:], lo[:, 128:])]
+                for hh, ll in halves:
+                    sub.append(torch.cat([hh.contiguous().view(-1), ll.contiguous().view(-1)]).view(torch.float32))
+            tiles = sub
         op = rt.MdtOp()
         op.kind = rt.OP_TBLOCK
         op.a = t.ref()
@@ -484,7 +504,9 @@ class UNetCompiler:
         #   C = 128 (16384 rows): 64-row workgroups          self 46 us (layer-by-layer 120), ff 16 (32)
         #   C = 256 ( 4096 rows): 16-row feature-split ones  self 41 us (73), ff 22 (34); the 64-row kernel would
         #                         fill only 64 CUs (self 70 us)
-        variant = 1 if c == 256 else 0
+        #   C = 256, 32-row workgroups + loader waves (k_tblock32, self-attention / feed-forward only): the 16-row form
+        #                         sits on the L2 -> LDS bandwidth roof (its weight stream is read by 256 workgroups)
+        variant = (2 if self.tb32 else 1) if c == 256 else 0
         for i in range(layers):
             bp = p + f"blocks.{i}."
             if fused:
@@ -492,7 +514,8 @@ class UNetCompiler:
                 if cross:
                     self.cross_layers.append(bp + "cross_attention.")
                     if self.fuse_cross:
-                        self.tblock(t, rt.TB_CROSS, bp + "cross_attention.", len(self.cross_layers) - 1, variant=variant)
+                        self.tblock(t, rt.TB_CROSS, bp + "cross_attention.", len(self.cross_layers) - 1,
+                                    variant=1 if variant == 2 else variant)
                     else:
                         # rocprofv3 (profiles/r1_kernel_stats.csv): the fused cross kernel averages 78 us against
                         # ~62 us for q-GEMM + attention + out-GEMM: its per-head K/V loads are not pipelined yet

@@ -1,0 +1,423 @@
+// Fused transformer sub-blocks for the C = 256 level (4 tokens per sample: 4096 rows at B = 1024), 32-row
+// workgroups.  Why 32: at 16 rows per workgroup (k_tblock16.hip) the weight stream is re-read by 256 workgroups
+// and the launch sits on the L2 -> LDS bandwidth roof (feed-forward: 512 MB per launch = 17.6 TB/s, measured);
+// 64 rows leave 192 CUs idle.  32 rows halve the stream and keep 128 CUs busy with loader waves beside them.
+//
+//   * compute wave w = (row tile rt = w >> 1, feature half fh = w & 1): 16 rows x 32 of each chunk's 64 features;
+//     the two waves of a row tile exchange the partial S^T = K Q^T (sum over features) through 4 KB of LDS and
+//     sum their output-projection accumulators once, at the end;
+//   * a wave's 32 features are exactly one k-step of the output projection (no zero padding as in k_tblock16);
+//   * weights arrive as 32 KB sub-tiles in the C = 128 tile format (host: compiler.py, variant 2), so the ring,
+//     the swizzle and the fragment addressing are those of k_tblock_lw.hip: 4 loader waves, 4 slots, issue
+//     distance 2, fragment reads interleaved with the MFMAs and pipelined across sub-tile boundaries.
+#include <cstdlib>
+#include <type_traits>
+
+#include "mdt_kernels.h"
+
+namespace mdt {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+enum { TB_SELF = 0, TB_CROSS = 1, TB_FF = 2 };
+enum { K_T = 0, K_N = 1, K_O = 2 };   // transposed projection, un-transposed projection, output projection
+
+#define MDT_MFMA_BF16 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define MDT_MFMA_F32 __builtin_amdgcn_mfma_f32_16x16x4f32
+
+__device__ __forceinline__ float gelu_32(float x) {   // exact-erf GELU, branch-free erf (A&S 7.1.26), see k_tblock.hip
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float erfa = 1.0f - poly * __expf(-z * z);
+  return 0.5f * x * (1.0f + copysignf(erfa, x));
+}
+
+__device__ __forceinline__ void split8_32(const float v[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const __bf16 h = (__bf16)v[e];
+    hi[e] = h;
+    lo[e] = (__bf16)(v[e] - (float)h);
+  }
+}
+
+__device__ __forceinline__ void lds_read16_32(bf16x8& dst, const unsigned char* p) {
+  const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)p;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr) : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void lgkm_wait() {   // at most N LDS/scalar operations still in flight
+  if constexpr (N >= 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+  else if constexpr (N >= 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+constexpr int C = 256;          // channels
+constexpr int CS = 128;         // sub-tile width: a [64][256] projection tile is streamed as two K halves, a
+                                // [256][64] output tile as two row halves, both in the C = 128 tile format
+constexpr int SLOT = 256 * CS;  // bytes per sub-tile (bf16 hi plane + lo plane)
+constexpr int NS = 4;           // ring slots
+constexpr int IPT = CS / 16;    // DMA pieces per sub-tile per loader wave
+constexpr int NST = C / 32;     // k-steps of a full projection
+constexpr int NCT = C / 16;     // 16-row tiles of the output projection
+constexpr int NU = 4;           // units (4 fragment reads + 6 MFMAs) per sub-tile per wave
+
+}  // namespace
+
+
+template <int MODE>
+__global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
+  constexpr int SPC = (MODE == TB_SELF) ? 8 : 4;   // sub-tiles per chunk (head / hidden chunk)
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  f32x4* red = reinterpret_cast<f32x4*>(smem + NS * SLOT);   // [4 waves][64 lanes] partial S^T
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int NT = a.nchunk * SPC;
+  const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(a.w);
+
+  if (wave >= 4) {
+    // ================= loader waves (see k_tblock_lw.hip) =================
+    const int iw = wave - 4;
+    __builtin_amdgcn_s_setprio(3);   // few instructions, all on the critical path of the stream: issue ahead of the MFMA waves
+    const int lpP = lane >> 5;
+    const int xP = (lane & 15) ^ lpP;
+    const int baseP = ((lane >> 4) & 1) * (128 * CS) + lpP * (2 * CS);
+    const int xO = (lane & 7) ^ (lane >> 4);
+    const int baseO = (lane >> 3) * 128;
+    // Per-lane source offsets of this wave's pieces inside a tile, computed ONCE: under MFMA load every VALU
+    // instruction of a loader wave waits for an issue slot, and address arithmetic per piece is what made a piece
+    // cost ~140 cycles instead of ~60.  Per piece there is now one scalar base + one 32-bit VGPR offset.
+    unsigned voffP[IPT], voffO[IPT];
+#pragma unroll
+    for (int q = 0; q < IPT; ++q) {
+      const int inst = iw + 4 * q;
+      const int U = 2 * inst;
+      voffP[q] = (unsigned)(U * (2 * CS) + ((xP ^ (U & 15)) << 4) + baseP);
+      voffO[q] = (unsigned)(((inst * 8) / CS) * (128 * CS) + ((inst * 8) % CS) * 128 + ((xO ^ (4 * (inst & 1))) << 4) + baseO);
+    }
+    auto issue_tile = [&](int tau) {
+      const unsigned char* tile = wsrc + (int64_t)tau * SLOT;       // wave-uniform
+      unsigned char* slot = smem + (tau % NS) * SLOT + iw * 1024;
+      if (!((tau % SPC) >= SPC - 2)) {
+#pragma unroll
+        for (int q = 0; q < IPT; ++q)
+          __builtin_amdgcn_global_load_lds(tile + voffP[q], (__attribute__((address_space(3))) void*)(slot + q * 4096), 16, 0, 0);
+      } else {
+#pragma unroll
+        for (int q = 0; q < IPT; ++q)
+          __builtin_amdgcn_global_load_lds(tile + voffO[q], (__attribute__((address_space(3))) void*)(slot + q * 4096), 16, 0, 0);
+      }
+    };
+    issue_tile(0);
+    if (NT > 1) issue_tile(1);
+    for (int k = 0; k < NT; ++k) {
+      if (k + 1 < NT) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                                      // B(k)
+      if (k + 2 < NT) issue_tile(k + 2);
+    }
+    return;
+  }
+
+  // ================= compute waves =================
+  const int i = lane & 15, g = lane >> 4;
+  const int rt = wave >> 1, fh = wave & 1;
+  const int row0 = blockIdx.x * 32 + rt * 16;
+  const int m = row0 + i;
+  const bool mvalid = m < a.M;
+  const int mc = mvalid ? m : a.M - 1;
+
+  bf16x8 xh[NST], xl[NST];
+  {
+    float xr[NST][8];
+    const float* xp = a.x + (int64_t)mc * a.ldx + 8 * g;
+    float s = 0.f;
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+      const float4 u = *reinterpret_cast<const float4*>(xp + 32 * st);
+      const float4 w = *reinterpret_cast<const float4*>(xp + 32 * st + 4);
+      xr[st][0] = u.x; xr[st][1] = u.y; xr[st][2] = u.z; xr[st][3] = u.w;
+      xr[st][4] = w.x; xr[st][5] = w.y; xr[st][6] = w.z; xr[st][7] = w.w;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += xr[st][e];
+    }
+    float mean = 0.f, rstd = 1.f;
+    if constexpr (MODE != TB_FF) {
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      mean = s / (float)C;
+      float ss = 0.f;
+#pragma unroll
+      for (int st = 0; st < NST; ++st)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = xr[st][e] - mean;
+          ss += d * d;
+        }
+      ss += __shfl_xor(ss, 16, 64);
+      ss += __shfl_xor(ss, 32, 64);
+      rstd = 1.0f / sqrtf(ss / (float)C + a.eps);
+    }
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = mvalid ? (xr[st][e] - mean) * rstd : 0.f;
+      split8_32(v, xh[st], xl[st]);
+    }
+  }
+
+  // fragment addressing inside a sub-tile (C = 128 tile format), this wave's feature half folded in:
+  //   projection sub-tile: row = 32 fh + 16 q + i, chunk = 4 st + g ; output sub-tile: row = 16 ct + i, chunk = 4 fh + g
+  int aP[4];
+#pragma unroll
+  for (int st = 0; st < 4; ++st) {
+    const int lc = 4 * st + g;
+    aP[st] = fh * (2 * 16 * 4 * CS) + i * (4 * CS) + ((lc & ~15) | ((lc & 15) ^ i)) * 16;
+  }
+  const int aO = i * 128 + ((4 * fh + g) ^ ((i >> 1) & 7)) * 16;
+
+  bf16x8 frh[3][2], frl[3][2];
+  auto frag_read = [&](auto kind, const unsigned char* slot, int u, int set, int j) {
+    constexpr int KIND = decltype(kind)::value;
+    const int q = j >> 1, lo = j & 1;
+    const unsigned char* p;
+    if constexpr (KIND == K_O) p = slot + aO + ((2 * u + q) * 16 * 128 + lo * (CS * 128));
+    else p = slot + aP[u] + (q * 16 * 4 * CS + lo * (2 * CS));
+    lds_read16_32(lo ? frl[set][q] : frh[set][q], p);
+  };
+  auto prefetch2 = [&](auto kind, const unsigned char* slot, int off) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) frag_read(kind, slot, u, (off + u) % 3, j);
+  };
+
+#ifdef MDT_STAMPS   // tuning build: wave 0 of workgroup 0 records the shader clock at phase boundaries into dbgbuf
+  unsigned long long* stamps = reinterpret_cast<unsigned long long*>(const_cast<float*>(a.dbgbuf));
+  int nstamp = 0;
+#define MDT_STAMP()                                                                   \
+  do {                                                                                \
+    if (stamps && blockIdx.x == 0 && wave == 0 && nstamp < 120) {                     \
+      unsigned long long t_;                                                          \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");      \
+      if (lane == 0) stamps[nstamp] = t_;                                             \
+      ++nstamp;                                                                       \
+    }                                                                                 \
+  } while (0)
+#else
+#define MDT_STAMP() do {} while (0)
+#endif
+  int tau = 0;
+  auto slot_of = [&](int t) -> const unsigned char* { return smem + (t % NS) * SLOT; };
+
+  // One MFMA phase over a sub-tile: 4 units of 4 fragment reads + 6 MFMAs.  Projection kinds: unit = k-step u of the
+  // K half, accumulators acc[0..1] = the wave's two feature tiles, operands bh[u]/bl[u].  Output kind: unit = row
+  // tiles 2u, 2u+1 of the row half, accumulators acc[2u..2u+1], the single operand bh[0]/bl[0].
+  auto phase = [&](auto kind, auto offc, auto nkind, bool has_next, f32x4* acc, const bf16x8* bh, const bf16x8* bl) {
+    constexpr int KIND = decltype(kind)::value, OFF = decltype(offc)::value;
+    const unsigned char* cur = slot_of(tau);
+    const unsigned char* nxt = slot_of(tau + 1);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      if (u == NU - 2 && has_next) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                // B(tau + 1)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const int s0 = (OFF + u) % 3, s2 = (OFF + u + 2) % 3;
+      const bool in_phase = u + 2 < NU;
+      const bool pre = in_phase || has_next;
+      const bool later = (u + 1 < NU) || has_next;
+      if (later) lgkm_wait<4>(); else lgkm_wait<0>();
+      const int ia = (KIND == K_O) ? 2 * u : 0, ib = (KIND == K_O) ? 0 : u;
+      auto rd = [&](int j) {
+        if (!pre) return;
+        __builtin_amdgcn_sched_barrier(0);
+        if (in_phase) frag_read(kind, cur, u + 2, s2, j);
+        else frag_read(nkind, nxt, u + 2 - NU, s2, j);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      auto mm = [&](const bf16x8& w, const bf16x8& x, int q) {
+        if constexpr (KIND == K_N) acc[ia + q] = MDT_MFMA_BF16(x, w, acc[ia + q], 0, 0, 0);
+        else acc[ia + q] = MDT_MFMA_BF16(w, x, acc[ia + q], 0, 0, 0);
+      };
+      mm(frl[s0][0], bh[ib], 0); rd(0);
+      mm(frl[s0][1], bh[ib], 1); rd(1);
+      mm(frh[s0][0], bl[ib], 0); rd(2);
+      mm(frh[s0][1], bl[ib], 1); rd(3);
+      mm(frh[s0][0], bh[ib], 0);
+      mm(frh[s0][1], bh[ib], 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    ++tau;
+    MDT_STAMP();
+  };
+  using IC0 = std::integral_constant<int, 0>;
+  using IC1 = std::integral_constant<int, 1>;
+  using IC2 = std::integral_constant<int, 2>;
+  const IC0 kT{};
+  const IC1 kN{};
+  const IC2 kO{};
+
+  f32x4 accT[NCT];
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) accT[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const float* bias = a.bias;
+  const int bo_off = (MODE == TB_SELF) ? 3 * 64 * a.nchunk : 64 * a.nchunk;
+  const int samp_q = i / a.T;                        // loop-invariant softmax pieces, see k_tblock_lw.hip
+  float kmask[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) kmask[r] = ((4 * g + r) / a.T == samp_q) ? 0.f : -INFINITY;
+  const float scale2 = a.scale * 1.44269504088896340736f;
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  __builtin_amdgcn_s_barrier();                      // B(0)
+  prefetch2(kT, slot_of(0), 0);
+
+  MDT_STAMP();
+  for (int h = 0; h < a.nchunk; ++h) {
+    const bool more = h + 1 < a.nchunk;
+    f32x4 oT[2];      // this wave's 32 features of the chunk: [feature 32 fh + 16 q + 4 g + r][token i]
+    if constexpr (MODE == TB_FF) {
+      f32x4 b1[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        b1[q] = *reinterpret_cast<const f32x4*>(bias + 64 * h + 32 * fh + 16 * q + 4 * g);
+        oT[q] = zero4;
+      }
+      phase(kT, IC0{}, kT, true, oT, xh, xl);               // K half 0
+      phase(kT, IC1{}, kT, false, oT, xh + 4, xl + 4);      // K half 1
+      __builtin_amdgcn_s_barrier();                         // B(first W2 sub-tile)
+      prefetch2(kO, slot_of(tau), 1);
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) oT[q][r] = gelu_32(oT[q][r] + b1[q][r]);
+    } else {
+      f32x4 qT[2], kTt[2], vT[2];
+      f32x4 bq[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {     // k / v biases initialise their accumulators (needed two phases from now)
+        bq[q] = *reinterpret_cast<const f32x4*>(bias + 64 * h + 32 * fh + 16 * q + 4 * g);
+        kTt[q] = *reinterpret_cast<const f32x4*>(bias + 64 * (a.nchunk + h) + 32 * fh + 16 * q + 4 * g);
+        const float bv = bias[64 * (2 * a.nchunk + h) + 32 * fh + 16 * q + i];
+        vT[q] = f32x4{bv, bv, bv, bv};
+        qT[q] = zero4;
+      }
+      phase(kT, IC0{}, kT, true, qT, xh, xl);
+      phase(kT, IC1{}, kT, true, qT, xh + 4, xl + 4);
+      phase(kT, IC2{}, kT, true, kTt, xh, xl);
+      phase(kT, IC0{}, kN, true, kTt, xh + 4, xl + 4);
+      phase(kN, IC1{}, kN, true, vT, xh, xl);
+      phase(kN, IC2{}, kN, false, vT, xh + 4, xl + 4);
+      qT[0] += bq[0];
+      qT[1] += bq[1];
+      // partial S^T over this wave's 32 features; the partner wave (other feature half) holds the rest
+      f32x4 sp0 = zero4, sp1 = zero4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        sp0 = MDT_MFMA_F32(kTt[0][r], qT[0][r], sp0, 0, 0, 0);
+        sp1 = MDT_MFMA_F32(kTt[1][r], qT[1][r], sp1, 0, 0, 0);
+      }
+      const f32x4 mine = sp0 + sp1;
+      red[wave * 64 + lane] = mine;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                         // B(first output sub-tile) + partial exchange
+      const f32x4 other = red[(wave ^ 1) * 64 + lane];
+      prefetch2(kO, slot_of(tau), 1);
+      // both waves of a row tile must form the SAME sum: add in feature-half order
+      const f32x4 s01 = fh ? (other + mine) : (mine + other);
+      f32x4 st;
+      float mx = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float sv = s01[r] * scale2 + kmask[r];
+        st[r] = sv;
+        mx = fmaxf(mx, sv);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __builtin_amdgcn_exp2f(st[r] - mx);
+        st[r] = e;
+        sum += e;
+      }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float inv = __builtin_amdgcn_rcpf(sum);
+      oT[0] = zero4; oT[1] = zero4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = st[r] * inv;
+        oT[0] = MDT_MFMA_F32(vT[0][r], p, oT[0], 0, 0, 0);
+        oT[1] = MDT_MFMA_F32(vT[1][r], p, oT[1], 0, 0, 0);
+      }
+    }
+    MDT_STAMP();
+    // ---- output projection: k-step = this wave's 32 features of the chunk ----
+    bf16x8 oh[1], ol[1];
+    {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = oT[e >> 2][e & 3];
+      split8_32(v, oh[0], ol[0]);
+    }
+    phase(kO, IC1{}, kO, true, accT, oh, ol);               // output rows 0..127
+    phase(kO, IC2{}, kT, more, accT + 8, oh, ol);           // output rows 128..255
+  }
+
+  // ---- sum the two feature halves' accumulators through LDS (the ring is idle now), add bias + residual ----
+  // wave (rt, fh) finalises row tiles 8 fh .. 8 fh + 7 (read back from LDS: a register array cannot be indexed by fh)
+  __builtin_amdgcn_s_barrier();                       // every wave is done with the last weight slot
+  f32x4* part = reinterpret_cast<f32x4*>(smem);       // [4 waves][16][64 lanes] = 64 KB
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) part[(wave * NCT + ct) * 64 + lane] = accT[ct];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (mvalid) {
+    float* xo = a.x + (int64_t)m * a.ldx + 4 * g;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int ct = 8 * fh + c;
+      const f32x4 p0 = part[((2 * rt) * NCT + ct) * 64 + lane], p1 = part[((2 * rt + 1) * NCT + ct) * 64 + lane];
+      const f32x4 sum = p0 + p1;                            // feature half 0 first
+      const float4 xr = *reinterpret_cast<const float4*>(xo + 16 * ct);
+      const float4 bo = *reinterpret_cast<const float4*>(bias + bo_off + 16 * ct + 4 * g);
+      *reinterpret_cast<float4*>(xo + 16 * ct) =
+          make_float4(sum[0] + bo.x + xr.x, sum[1] + bo.y + xr.y, sum[2] + bo.z + xr.z, sum[3] + bo.w + xr.w);
+    }
+  }
+}
+
+template <int MODE>
+static hipError_t launch_32(const TBlockArgs& a, hipStream_t s) {
+  const size_t smem = (size_t)NS * SLOT + 4 * 64 * 16;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tblock32<MODE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_tblock32<MODE>), dim3((unsigned)((a.M + 31) / 32)), dim3(512), smem, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_tblock32(const TBlockArgs& a, hipStream_t s) {
+  if (a.M <= 0) return hipSuccess;
+  if (a.C != 256 || (a.mode != TB_SELF && a.mode != TB_FF) || a.T <= 0 || 16 % a.T || a.nchunk <= 0)
+    return hipErrorInvalidValue;
+  return a.mode == TB_SELF ? launch_32<TB_SELF>(a, s) : launch_32<TB_FF>(a, s);
+}
+
+}  // namespace mdt

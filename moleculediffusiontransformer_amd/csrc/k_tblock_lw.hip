@@ -1,0 +1,447 @@
+// Fused transformer sub-blocks (see k_tblock.hip for the maths and the register-chained layout), C = 128,
+// 64-row workgroups, restructured around two measurements on gfx950 (tools/ubench/proj_phase.hip):
+//
+//   * with one wave per SIMD, an LDS-DMA instruction costs its issuing wave ~60 cycles, so the 8 pieces per tile
+//     per wave that the compute waves used to issue cost ~500 cycles per tile, none of it overlapped.  Here FOUR
+//     LOADER WAVES (waves 4..7, one per SIMD, next to the compute waves) own the whole weight stream; the compute
+//     waves issue no vector-memory instruction between their prologue and epilogue except bias loads.
+//   * fragment reads issued as a burst of 4 ds_read_b128 in front of 6 MFMAs stall the in-order issue while the LDS
+//     pipe (shared by 4 waves) takes them: 27 cycles per MFMA.  Issued one at a time BETWEEN the MFMAs they hide in
+//     the MFMA shadow, and when the read pipeline also runs across tile boundaries (the next tile is published two
+//     units before the current one ends) the phase runs at ~22-24 cycles per MFMA (17.5 = bare issue rate).
+//
+// Ring protocol (4 slots of 32 KB, issue distance 2 tiles).  Barrier B(k) publishes tile k:
+//   loader : wait until its own pieces of tile k have landed (vmcnt), s_barrier, issue tile k+2 into the slot of
+//            tile k-2 (every compute wave is past unit 5 of tile k-1 at least, hence done with tile k-2);
+//   compute: s_barrier at the point where it first wants to prefetch fragments of tile k.
+// Every barrier is executed by all 8 waves, NT + 0 times in total.
+#include <cstdlib>
+#include <type_traits>
+
+#include "mdt_kernels.h"
+
+namespace mdt {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+enum { TB_SELF = 0, TB_CROSS = 1, TB_FF = 2 };
+enum { K_T = 0, K_N = 1, K_O = 2 };   // transposed projection, un-transposed projection, output projection
+
+#define MDT_MFMA_BF16 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define MDT_MFMA_F32 __builtin_amdgcn_mfma_f32_16x16x4f32
+
+__device__ __forceinline__ float gelu_lw(float x) {   // exact-erf GELU, branch-free erf (A&S 7.1.26), see k_tblock.hip
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float erfa = 1.0f - poly * __expf(-z * z);
+  return 0.5f * x * (1.0f + copysignf(erfa, x));
+}
+
+__device__ __forceinline__ void split8_lw(const float v[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const __bf16 h = (__bf16)v[e];
+    hi[e] = h;
+    lo[e] = (__bf16)(v[e] - (float)h);
+  }
+}
+
+__device__ __forceinline__ void lds_read16(bf16x8& dst, const unsigned char* p) {
+  const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)p;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr) : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void lgkm_wait() {   // at most N LDS/scalar operations still in flight
+  if constexpr (N >= 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+  else if constexpr (N >= 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+constexpr int C = 128;
+constexpr int SLOT = 256 * C;   // bytes per weight tile (bf16 hi plane + lo plane)
+constexpr int NS = 4;           // ring slots
+constexpr int IPT = C / 16;     // DMA pieces per tile per loader wave
+constexpr int NST = C / 32;     // k-steps of a projection
+constexpr int NCT = C / 16;     // 16-row tiles of the output projection
+constexpr int NU = 8;           // units (4 fragment reads + 6 MFMAs) per tile, all three kinds
+
+}  // namespace
+
+template <int MODE>
+__global__ __launch_bounds__(512) void k_tblock_lw(TBlockArgs a) {
+  constexpr int TPC = (MODE == TB_SELF) ? 4 : 2;   // tiles per chunk (head / hidden chunk)
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int NT = a.nchunk * TPC;
+  const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(a.w);
+
+  if (wave >= 4) {
+    // ================= loader waves: the weight stream =================
+    // Piece `inst` (= iw + 4 q) fills slot bytes [inst*1024, +1024), lane l supplies bytes inst*1024 + 16 l.  The
+    // XOR swizzle that makes the fragment reads conflict-free is applied through the SOURCE address
+    // (k_tblock.hip spells out the factorisation into a lane-only and a wave-uniform part).
+    const int iw = wave - 4;
+    __builtin_amdgcn_s_setprio(3);   // few instructions, all on the critical path of the stream: issue ahead of the MFMA waves
+    const int lpP = lane >> 5;
+    const int xP = (lane & 15) ^ lpP;
+    const int baseP = ((lane >> 4) & 1) * (128 * C) + lpP * (2 * C);
+    const int xO = (lane & 7) ^ (lane >> 4);
+    const int baseO = (lane >> 3) * 128;
+    // Per-lane source offsets of this wave's pieces inside a tile, computed ONCE: under MFMA load every VALU
+    // instruction of a loader wave waits for an issue slot, and address arithmetic per piece is what made a piece
+    // cost ~140 cycles instead of ~60.  Per piece there is now one scalar base + one 32-bit VGPR offset.
+    unsigned voffP[IPT], voffO[IPT];
+#pragma unroll
+    for (int q = 0; q < IPT; ++q) {
+      const int inst = iw + 4 * q;
+      const int U = 2 * inst;
+      voffP[q] = (unsigned)(U * (2 * C) + ((xP ^ (U & 15)) << 4) + baseP);
+      voffO[q] = (unsigned)(((inst * 8) / C) * (128 * C) + ((inst * 8) % C) * 128 + ((xO ^ (4 * (inst & 1))) << 4) + baseO);
+    }
+    auto issue_tile = [&](int tau) {
+      const unsigned char* tile = wsrc + (int64_t)tau * SLOT;       // wave-uniform
+      unsigned char* slot = smem + (tau % NS) * SLOT + iw * 1024;
+      if (!((tau % TPC) == TPC - 1)) {
+#pragma unroll
+        for (int q = 0; q < IPT; ++q)
+          __builtin_amdgcn_global_load_lds(tile + voffP[q], (__attribute__((address_space(3))) void*)(slot + q * 4096), 16, 0, 0);
+      } else {
+#pragma unroll
+        for (int q = 0; q < IPT; ++q)
+          __builtin_amdgcn_global_load_lds(tile + voffO[q], (__attribute__((address_space(3))) void*)(slot + q * 4096), 16, 0, 0);
+      }
+    };
+    issue_tile(0);
+    if (NT > 1) issue_tile(1);
+#ifdef MDT_STAMPS
+    unsigned long long* lst = reinterpret_cast<unsigned long long*>(const_cast<float*>(a.dbgbuf)) + 128;
+    int nl = 0;
+#define MDT_LSTAMP()                                                                  \
+  do {                                                                                \
+    if (a.dbgbuf && blockIdx.x == 0 && wave == 4 && nl < 120) {                       \
+      unsigned long long t_;                                                          \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");      \
+      if (lane == 0) lst[nl] = t_;                                                    \
+      ++nl;                                                                           \
+    }                                                                                 \
+  } while (0)
+#else
+#define MDT_LSTAMP() do {} while (0)
+#endif
+    for (int k = 0; k < NT; ++k) {
+      MDT_LSTAMP();
+      if (k + 1 < NT) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile k landed; tile k+1 may be in flight
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      MDT_LSTAMP();
+      __builtin_amdgcn_s_barrier();                                      // B(k)
+      MDT_LSTAMP();
+      if (k + 2 < NT) issue_tile(k + 2);
+    }
+    return;
+  }
+
+  // ================= compute waves =================
+  const int i = lane & 15, g = lane >> 4;
+  const int row0 = blockIdx.x * 64 + wave * 16;
+  const int m = row0 + i;
+  const bool mvalid = m < a.M;
+  const int mc = mvalid ? m : a.M - 1;
+
+  // this wave's 16 rows in MFMA operand layout: lane (i, g) holds x[i][32 st + 8 g + e]
+  bf16x8 xh[NST], xl[NST];
+  {
+    float xr[NST][8];
+    const float* xp = a.x + (int64_t)mc * a.ldx + 8 * g;
+    float s = 0.f;
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+      const float4 u = *reinterpret_cast<const float4*>(xp + 32 * st);
+      const float4 w = *reinterpret_cast<const float4*>(xp + 32 * st + 4);
+      xr[st][0] = u.x; xr[st][1] = u.y; xr[st][2] = u.z; xr[st][3] = u.w;
+      xr[st][4] = w.x; xr[st][5] = w.y; xr[st][6] = w.z; xr[st][7] = w.w;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += xr[st][e];
+    }
+    float mean = 0.f, rstd = 1.f;
+    if constexpr (MODE != TB_FF) {       // nn.LayerNorm statistics (two-pass; gain/bias folded into the weights)
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      mean = s / (float)C;
+      float ss = 0.f;
+#pragma unroll
+      for (int st = 0; st < NST; ++st)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = xr[st][e] - mean;
+          ss += d * d;
+        }
+      ss += __shfl_xor(ss, 16, 64);
+      ss += __shfl_xor(ss, 32, 64);
+      rstd = 1.0f / sqrtf(ss / (float)C + a.eps);
+    }
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = mvalid ? (xr[st][e] - mean) * rstd : 0.f;
+      split8_lw(v, xh[st], xl[st]);
+    }
+  }
+
+  // Fragment addressing: lane-dependent swizzled part per k-step (projection tiles) / per k-half (output tiles);
+  // the 16-row tile and the hi/lo plane are compile-time immediates of the ds_read_b128.
+  //   projection tile: row = 16 t + i, chunk = 4 st + g :  row*4C + plane*2C + ((chunk&~15) | ((chunk&15)^(row&15)))*16
+  //   output tile:     row = 16 t + i, chunk = 4 sp + g :  plane*C*128 + row*128 + (chunk ^ ((row>>1)&7))*16
+  int aP[NST], aO[2];
+#pragma unroll
+  for (int st = 0; st < NST; ++st) {
+    const int lc = 4 * st + g;
+    aP[st] = i * (4 * C) + ((lc & ~15) | ((lc & 15) ^ i)) * 16;
+  }
+#pragma unroll
+  for (int sp = 0; sp < 2; ++sp) aO[sp] = i * 128 + ((4 * sp + g) ^ ((i >> 1) & 7)) * 16;
+
+  bf16x8 fh[3][2], fl[3][2];   // three fragment sets: unit u of a phase with set offset OFF lives in set (OFF + u) % 3
+  // the four reads of one unit, individually addressable so that they can be dropped between MFMAs
+  auto frag_read = [&](auto kind, const unsigned char* slot, int u, int set, int j) {
+    constexpr int KIND = decltype(kind)::value;
+    const int q = j >> 1, lo = j & 1;
+    const unsigned char* p;
+    if constexpr (KIND == K_O) {
+      const int sp = u / (NCT / 2), ct0 = 2 * (u % (NCT / 2));
+      p = slot + aO[sp] + ((ct0 + q) * 16 * 128 + lo * (C * 128));
+    } else {
+      p = slot + aP[u >> 1] + ((2 * (u & 1) + q) * 16 * 4 * C + lo * (2 * C));
+    }
+    lds_read16(lo ? fl[set][q] : fh[set][q], p);
+  };
+  auto prefetch2 = [&](auto kind, const unsigned char* slot, int off) {   // units 0 and 1 of a phase, as a burst
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) frag_read(kind, slot, u, (off + u) % 3, j);
+  };
+
+#ifdef MDT_STAMPS   // tuning build: wave 0 of workgroup 0 records the shader clock at phase boundaries into dbgbuf
+  unsigned long long* stamps = reinterpret_cast<unsigned long long*>(const_cast<float*>(a.dbgbuf));
+  int nstamp = 0;
+#define MDT_STAMP()                                                                   \
+  do {                                                                                \
+    if (stamps && blockIdx.x == 0 && wave == 0 && nstamp < 120) {                     \
+      unsigned long long t_;                                                          \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");      \
+      if (lane == 0) stamps[nstamp] = t_;                                             \
+      ++nstamp;                                                                       \
+    }                                                                                 \
+  } while (0)
+#else
+#define MDT_STAMP() do {} while (0)
+#endif
+  int tau = 0;                                       // tile being consumed
+  auto slot_of = [&](int t) -> const unsigned char* { return smem + (t % NS) * SLOT; };
+
+  // One MFMA phase over the tile in `cur`: 8 units.  acc[] are the phase's accumulators, bh/bl the register-resident
+  // operand (activations) per k-step.  The reads of unit u+2 ride between the MFMAs of unit u; for u+2 >= NU they
+  // belong to units 0/1 of the NEXT phase (kind NK, in tile tau+1), published by the barrier before unit NU-2.
+  auto phase = [&](auto kind, auto offc, auto nkind, bool has_next, f32x4* acc, const bf16x8* bh, const bf16x8* bl) {
+    constexpr int KIND = decltype(kind)::value, OFF = decltype(offc)::value;
+    const unsigned char* cur = slot_of(tau);
+    const unsigned char* nxt = slot_of(tau + 1);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      if (u == NU - 2 && has_next) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                // B(tau + 1)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const int s0 = (OFF + u) % 3, s2 = (OFF + u + 2) % 3;
+      const bool in_phase = u + 2 < NU;
+      const bool pre = in_phase || has_next;
+      const bool later = (u + 1 < NU) || has_next;   // unit u+1's reads are in flight behind unit u's
+      if (later) lgkm_wait<4>(); else lgkm_wait<0>();
+      int ia, ib;                                    // accumulator index, operand index
+      if constexpr (KIND == K_O) { ia = 2 * (u % (NCT / 2)); ib = u / (NCT / 2); }
+      else { ia = 2 * (u & 1); ib = u >> 1; }
+      auto rd = [&](int j) {
+        if (!pre) return;
+        __builtin_amdgcn_sched_barrier(0);
+        if (in_phase) frag_read(kind, cur, u + 2, s2, j);
+        else frag_read(nkind, nxt, u + 2 - NU, s2, j);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      auto mm = [&](const bf16x8& w, const bf16x8& x, int q) {
+        if constexpr (KIND == K_N) acc[ia + q] = MDT_MFMA_BF16(x, w, acc[ia + q], 0, 0, 0);
+        else acc[ia + q] = MDT_MFMA_BF16(w, x, acc[ia + q], 0, 0, 0);
+      };
+      mm(fl[s0][0], bh[ib], 0); rd(0);
+      mm(fl[s0][1], bh[ib], 1); rd(1);
+      mm(fh[s0][0], bl[ib], 0); rd(2);
+      mm(fh[s0][1], bl[ib], 1); rd(3);
+      mm(fh[s0][0], bh[ib], 0);
+      mm(fh[s0][1], bh[ib], 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    ++tau;
+    MDT_STAMP();
+  };
+  using IC0 = std::integral_constant<int, 0>;
+  using IC1 = std::integral_constant<int, 1>;
+  using IC2 = std::integral_constant<int, 2>;
+  const IC0 kT{};   // K_T
+  const IC1 kN{};   // K_N
+  const IC2 kO{};   // K_O
+
+  f32x4 accT[NCT];
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) accT[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const float* bias = a.bias;                        // [bq | bk | bv | bo] / [b1 | b2], global (L2-resident)
+  const int bo_off = (MODE == TB_SELF) ? 3 * 64 * a.nchunk : 64 * a.nchunk;
+  // Loop-invariant softmax pieces: additive mask of key j = 4 g + r against query column i (other samples of the
+  // wave's 16 rows -> -inf), and the logit scale folded with log2(e) so that the exponential is one v_exp_f32.
+  const int samp_q = i / a.T;                        // sample (within the wave's 16 rows) of query column i
+  float kmask[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) kmask[r] = ((4 * g + r) / a.T == samp_q) ? 0.f : -INFINITY;
+  const float scale2 = a.scale * 1.44269504088896340736f;
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  __builtin_amdgcn_s_barrier();                      // B(0)
+  prefetch2(kT, slot_of(0), 0);
+
+  MDT_STAMP();
+  for (int h = 0; h < a.nchunk; ++h) {
+    const bool more = h + 1 < a.nchunk;
+    f32x4 oT[4];
+    if constexpr (MODE == TB_FF) {
+      f32x4 b1[4];
+#pragma unroll
+      for (int ft = 0; ft < 4; ++ft) {
+        b1[ft] = *reinterpret_cast<const f32x4*>(bias + 64 * h + 16 * ft + 4 * g);
+        oT[ft] = zero4;
+      }
+      phase(kT, IC0{}, kT, false, oT, xh, xl);       // hidden chunk^T = W1 x^T
+      __builtin_amdgcn_s_barrier();                  // B(w2 tile)
+      prefetch2(kO, slot_of(tau), 1);
+#pragma unroll
+      for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) oT[ft][r] = gelu_lw(oT[ft][r] + b1[ft][r]);
+    } else {
+      f32x4 qT[4], kTt[4], vT[4];
+      f32x4 bq[4], bk[4];
+      float bv[4];
+#pragma unroll
+      for (int ft = 0; ft < 4; ++ft) {
+        bq[ft] = *reinterpret_cast<const f32x4*>(bias + 64 * h + 16 * ft + 4 * g);
+        bk[ft] = *reinterpret_cast<const f32x4*>(bias + 64 * (a.nchunk + h) + 16 * ft + 4 * g);
+        bv[ft] = bias[64 * (2 * a.nchunk + h) + 16 * ft + i];
+        qT[ft] = zero4; kTt[ft] = zero4; vT[ft] = zero4;
+      }
+      phase(kT, IC0{}, kT, true, qT, xh, xl);        // q^T
+      phase(kT, IC2{}, kN, true, kTt, xh, xl);       // k^T
+      phase(kN, IC1{}, kN, false, vT, xh, xl);       // v (un-transposed)
+      __builtin_amdgcn_s_barrier();                  // B(output tile)
+      prefetch2(kO, slot_of(tau), 1);
+#pragma unroll
+      for (int ft = 0; ft < 4; ++ft) {
+        qT[ft] += bq[ft];
+        kTt[ft] += bk[ft];
+        vT[ft] += f32x4{bv[ft], bv[ft], bv[ft], bv[ft]};
+      }
+      f32x4 s0 = zero4, s1 = zero4;
+#pragma unroll
+      for (int ft = 0; ft < 4; ++ft) {
+        s0 = MDT_MFMA_F32(kTt[ft][0], qT[ft][0], s0, 0, 0, 0);
+        s1 = MDT_MFMA_F32(kTt[ft][1], qT[ft][1], s1, 0, 0, 0);
+        s0 = MDT_MFMA_F32(kTt[ft][2], qT[ft][2], s0, 0, 0, 0);
+        s1 = MDT_MFMA_F32(kTt[ft][3], qT[ft][3], s1, 0, 0, 0);
+      }
+      f32x4 st;
+      float mx = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {                  // key token 4 g + r (within the wave's 16 rows)
+        const float sv = (s0[r] + s1[r]) * scale2 + kmask[r];
+        st[r] = sv;
+        mx = fmaxf(mx, sv);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __builtin_amdgcn_exp2f(st[r] - mx);
+        st[r] = e;
+        sum += e;
+      }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float inv = __builtin_amdgcn_rcpf(sum);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) oT[dt] = zero4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = st[r] * inv;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) oT[dt] = MDT_MFMA_F32(vT[dt][r], p, oT[dt], 0, 0, 0);
+      }
+    }
+    MDT_STAMP();
+    // ---- output projection of this chunk: accT[c][i] += sum_d Wo[c][64 h + d] * o[d][i] ----
+    bf16x8 oh[2], ol[2];
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = oT[2 * sp + (e >> 2)][e & 3];
+      split8_lw(v, oh[sp], ol[sp]);
+    }
+    phase(kO, IC1{}, kT, more, accT, oh, ol);
+  }
+
+  // ---- residual + output bias: x[m][16 ct + 4 g + r] += accT[ct][r] + bo[..] ----
+  if (mvalid) {
+    float* xo = a.x + (int64_t)m * a.ldx + 4 * g;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      const float4 xr = *reinterpret_cast<const float4*>(xo + 16 * ct);
+      const float4 bo = *reinterpret_cast<const float4*>(bias + bo_off + 16 * ct + 4 * g);
+      *reinterpret_cast<float4*>(xo + 16 * ct) =
+          make_float4(accT[ct][0] + bo.x + xr.x, accT[ct][1] + bo.y + xr.y, accT[ct][2] + bo.z + xr.z,
+                      accT[ct][3] + bo.w + xr.w);
+    }
+  }
+}
+
+template <int MODE>
+static hipError_t launch_lw(const TBlockArgs& a, hipStream_t s) {
+  const size_t smem = (size_t)NS * SLOT;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tblock_lw<MODE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_tblock_lw<MODE>), dim3((unsigned)((a.M + 63) / 64)), dim3(512), smem, s, a);
+  return hipGetLastError();
+}
+
+bool tblock_lw_supported(const TBlockArgs& a) {
+  return a.C == 128 && (a.mode == TB_SELF || a.mode == TB_FF) && a.T > 0 && 16 % a.T == 0 && a.nchunk > 0;
+}
+
+hipError_t launch_tblock_lw(const TBlockArgs& a, hipStream_t s) {
+  if (a.M <= 0) return hipSuccess;
+  if (!tblock_lw_supported(a)) return hipErrorInvalidValue;
+  return a.mode == TB_SELF ? launch_lw<TB_SELF>(a, s) : launch_lw<TB_FF>(a, s);
+}
+
+}  // namespace mdt

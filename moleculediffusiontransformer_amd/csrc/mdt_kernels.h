@@ -66,6 +66,9 @@ struct TBlockArgs {
   float eps, scale;
 };
 hipError_t launch_tblock(const TBlockArgs& a, hipStream_t s);     // 64-row workgroups (k_tblock.hip)
+bool tblock_lw_supported(const TBlockArgs& a);                  // k_tblock_lw.hip: C = 128 self-attention / feed-forward
+hipError_t launch_tblock_lw(const TBlockArgs& a, hipStream_t s);
+hipError_t launch_tblock32(const TBlockArgs& a, hipStream_t s);   // 32-row workgroups, C = 256, sub-tile stream (k_tblock32.hip)
 hipError_t launch_tblock16(const TBlockArgs& a, hipStream_t s);   // 16-row workgroups, waves split the features (k_tblock16.hip)
 
 hipError_t launch_concat(const float* a, const float* b, float* out, int64_t rows, int ca, int cb, float scale_b,

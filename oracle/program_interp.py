@@ -183,11 +183,19 @@ def _tblock(op, bufs: Buffers, B: int) -> None:
     inv[torch.tensor(_SLOT_PERM)] = torch.arange(64)
     mid = 64 * nchunk
 
+    def tile(k, rows, cols):
+        if i[rt.B_VARIANT] != 2:
+            return _untile(stream, k, rows, cols)
+        # variant 2 (k_tblock32): every tile is stored as two 128-wide sub-tiles (K halves / output-row halves)
+        if rows == 64:
+            return torch.cat([_untile(stream, 2 * k, 64, 128), _untile(stream, 2 * k + 1, 64, 128)], dim=1)
+        return torch.cat([_untile(stream, 2 * k, 128, 64), _untile(stream, 2 * k + 1, 128, 64)], dim=0)
+
     def proj(k0):          # stack of P tiles k0, k0 + tpc, ... -> [mid, C]
-        return torch.cat([_untile(stream, h * tpc + k0, 64, C) for h in range(nchunk)])
+        return torch.cat([tile(h * tpc + k0, 64, C) for h in range(nchunk)])
 
     def outw():            # O tiles -> [C, mid] with the slot permutation undone
-        return torch.cat([_untile(stream, h * tpc + tpc - 1, C, 64)[:, inv] for h in range(nchunk)], dim=1)
+        return torch.cat([tile(h * tpc + tpc - 1, C, 64)[:, inv] for h in range(nchunk)], dim=1)
 
     if mode == rt.TB_FF:
         h = F.gelu(x @ proj(0).T + bias[:mid])

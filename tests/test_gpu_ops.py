@@ -320,7 +320,7 @@ def test_gemm_split_bf16(B, R, cin, N, taps, pro):
     assert (out_g - out_c).abs().max() < 4e-5 * max(scale, 1.0), ((out_g - out_c).abs().max().item(), scale)
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("mode", [rt.TB_FF, rt.TB_SELF, rt.TB_CROSS])
 @pytest.mark.parametrize("C,T,B", [(128, 16, 5), (256, 4, 37), (128, 4, 16), (256, 16, 3), (128, 1, 70)])
 def test_fused_transformer_sub_block(mode, C, T, B, variant):
@@ -331,6 +331,8 @@ def test_fused_transformer_sub_block(mode, C, T, B, variant):
     n_ctx, mid = 12, 512
     if mode == rt.TB_CROSS and (16 // T) * n_ctx > 64:
         pytest.skip("more than 64 keys per 16 rows: the compiler keeps such layers unfused")
+    if variant == 2 and (C != 256 or mode == rt.TB_CROSS):
+        pytest.skip("variant 2 (32-row workgroups) serves C = 256 self-attention / feed-forward")
     p = "blk."
     sd = {p + "norm.weight": 1 + 0.2 * rnd(C, seed=1), p + "norm.bias": 0.2 * rnd(C, seed=2),
           p + "norm_context.weight": 1 + 0.2 * rnd(C, seed=3), p + "norm_context.bias": 0.2 * rnd(C, seed=4),

@@ -15,19 +15,22 @@ cfg = inverse_unet_config(16, 64, 128, 12)
 dev = "cuda:0"
 for (C, T) in [(128, 16), (256, 4)]:
     for mode, name in ((rt.TB_SELF, "SELF"), (rt.TB_CROSS, "CROSS"), (rt.TB_FF, "FF")):
+        variant = int(os.environ.get('VARIANT', '0'))
+        if variant == 2 and (C != 256 or mode == rt.TB_CROSS):
+            continue
         for B in (64 * 16 // T // 16, 1024):
             n_ctx, mid, p = 12, 512, "blk."
             sd = {p + "norm.weight": torch.ones(C), p + "norm.bias": torch.zeros(C), p + "norm_context.weight": torch.ones(C),
                   p + "norm_context.bias": torch.zeros(C), p + "to_q.weight": rnd(mid, C, scale=C ** -0.5),
                   p + "to_kv.weight": rnd(2 * mid, C, scale=C ** -0.5), p + "attention.to_out.weight": rnd(C, mid, scale=mid ** -0.5),
-                  p + "attention.to_out.bias": torch.zeros(C), p + "0.weight": rnd(2 * C, C, scale=C ** -0.5), p + "0.bias": torch.zeros(2 * C),
-                  p + "2.weight": rnd(C, 2 * C, scale=(2 * C) ** -0.5), p + "2.bias": torch.zeros(C)}
+                  p + "attention.to_out.bias": torch.zeros(C), p + "0.weight": rnd(4 * C, C, scale=C ** -0.5), p + "0.bias": torch.zeros(4 * C),
+                  p + "2.weight": rnd(C, 4 * C, scale=(4 * C) ** -0.5), p + "2.bias": torch.zeros(C)}
             comp = UNetCompiler(cfg, 64, n_ctx, sd)
-            comp.tblock(Ten(A, 0, T, C), mode, p, 0 if mode == rt.TB_CROSS else None, variant=int(os.environ.get('VARIANT', '0')))
+            comp.tblock(Ten(A, 0, T, C), mode, p, 0 if mode == rt.TB_CROSS else None, variant=variant)
             op = comp.ops[0]
             if mode == rt.TB_CROSS:
                 op.a2 = ref(A, T * C)
-            dbg = torch.zeros(256, device=dev)
+            dbg = torch.zeros(1024, device=dev)
             if os.environ.get('MDT_DBG', '0') == '8':
                 op.p0 = ref(rt.SP_EXT0, 0)
             W = comp.W.pack().to(dev)
@@ -41,7 +44,10 @@ for (C, T) in [(128, 16), (256, 4)]:
                 for _ in range(20): prog.run(b, B)
                 t.stop(); ms = t.collect()[0] / 20
             if os.environ.get('MDT_DBG', '0') == '8':
-                st = dbg.cpu().view(torch.int64)[:64].tolist()
-                d = [st[k + 1] - st[k] for k in range(40) if st[k + 1] > 0]
-                print("   stamps (cycles @100MHz*?):", d[:24])
+                st = dbg.cpu().view(torch.int64)[:120].tolist()
+                d = [st[k + 1] - st[k] for k in range(119) if st[k + 1] > 0]
+                print("   stamp deltas (s_memtime ticks):", d[:44], " total", st[max(k for k in range(120) if st[k] > 0)] - st[0])
+                ls = dbg.cpu().view(torch.int64)[128:248].tolist()
+                if ls[0] > 0:
+                    print("   loader (wait-landed, barrier, issue+loop) x tiles:", [(ls[3*k+1]-ls[3*k], ls[3*k+2]-ls[3*k+1], ls[3*k+3]-ls[3*k+2]) for k in range(12) if ls[3*k+3] > 0])
             print(f"C={C} T={T} {name:5s} B={B:5d} blocks={(B * T + 63) // 64:4d}: {ms * 1e3:7.1f} us  weights {W.numel() * 4 / 1e6:.2f} MB", flush=True)
