@@ -131,7 +131,9 @@ class UNetCompiler:
         self.fuse_blocks = fuse_blocks
         self.fuse_c256 = os.environ.get("MDT_FUSE_C256", "1") == "1"
         self.tb32 = os.environ.get("MDT_TB32", "1") == "1"           # C = 256 blocks on 32-row workgroups (k_tblock32)
-        self.fuse_cross = os.environ.get("MDT_FUSE_CROSS", "0") == "1"
+        # cross-attention sub-blocks: "1" fuses the shapes whose K/V rows stream through the loader-wave ring
+        # (k_tblock_lw: C = 128, at most 16 context rows per 16 token rows), "all" also the older kernels' shapes
+        self.fuse_cross = os.environ.get("MDT_FUSE_CROSS", "1")
         self.use_gn_act = os.environ.get("MDT_GN_ACT", "1") == "1"
         if gemm_mode not in ("f32", "bf16x3"):
             raise ValueError("gemm_mode must be 'f32' (exact fp32 MFMA) or 'bf16x3' (split-bf16 MFMA)")
@@ -513,12 +515,13 @@ class UNetCompiler:
                 self.tblock(t, rt.TB_SELF, bp + "attention.", variant=variant)
                 if cross:
                     self.cross_layers.append(bp + "cross_attention.")
-                    if self.fuse_cross:
+                    ring_ok = c == 128 and (16 // t.rows) * self.n_ctx <= 16
+                    if self.fuse_cross == "all" or (self.fuse_cross == "1" and ring_ok):
                         self.tblock(t, rt.TB_CROSS, bp + "cross_attention.", len(self.cross_layers) - 1,
                                     variant=1 if variant == 2 else variant)
                     else:
-                        # rocprofv3 (profiles/r1_kernel_stats.csv): the fused cross kernel averages 78 us against
-                        # ~62 us for q-GEMM + attention + out-GEMM: its per-head K/V loads are not pipelined yet
+                        # q-GEMM + attention + out-GEMM (the pre-ring fused cross kernels measured slower than this:
+                        # 78 us against ~62 us, their per-head K/V loads were not pipelined)
                         self.attention_layer(t, bp + "cross_attention.", len(self.cross_layers) - 1)
                 self.tblock(t, rt.TB_FF, bp + "feed_forward.", variant=variant)
                 continue

@@ -73,9 +73,10 @@ constexpr int NU = 8;           // units (4 fragment reads + 6 MFMAs) per tile, 
 
 }  // namespace
 
-template <int MODE>
+// NPW (MODE_CROSS only): LDS-DMA pieces per loader wave per K / V tile = ceil(context rows of the workgroup / 16)
+template <int MODE, int NPW>
 __global__ __launch_bounds__(512) void k_tblock_lw(TBlockArgs a) {
-  constexpr int TPC = (MODE == TB_SELF) ? 4 : 2;   // tiles per chunk (head / hidden chunk)
+  constexpr int TPC = (MODE == TB_FF) ? 2 : 4;     // tiles per chunk: q k v o | q K V o (K, V = hoisted context rows) | w1 w2
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -106,10 +107,44 @@ __global__ __launch_bounds__(512) void k_tblock_lw(TBlockArgs a) {
       voffP[q] = (unsigned)(U * (2 * C) + ((xP ^ (U & 15)) << 4) + baseP);
       voffO[q] = (unsigned)(((inst * 8) / C) * (128 * C) + ((inst * 8) % C) * 128 + ((xO ^ (4 * (inst & 1))) << 4) + baseO);
     }
-    auto issue_tile = [&](int tau) {
-      const unsigned char* tile = wsrc + (int64_t)tau * SLOT;       // wave-uniform
+    // MODE_CROSS: tiles 1 and 2 of a head are the K and V rows of the workgroup's samples, head h: row R = (sample,
+    // key) concatenated, 256 B (64 fp32) per row, 16-byte chunks XOR-swizzled with R & 15 (conflict-free
+    // ds_read_b128 over 16 keys, ds_read_b32 over 16 features x 4 keys).  A piece = 4 rows.
+    const int kv_rows = (MODE == TB_CROSS) ? (64 / a.T) * a.Tk : 0;
+    constexpr int npw = NPW;                         // rows are padded to 16 NPW with clamped (valid, unused) rows
+    unsigned voffKV[4];                              // NPW <= 4 used (a fixed bound: hipcc's host pass silently drops the
+                                                     // kernel stub when a lambda captures an array of dependent size)
+    if constexpr (MODE == TB_CROSS) {
+      const int sample0 = blockIdx.x * (64 / a.T);
+#pragma unroll
+      for (int q = 0; q < NPW; ++q) {
+        const int R = 4 * (iw + 4 * q) + (lane >> 4);
+        const int Rc = min(R, kv_rows - 1);
+        const int sm = min(Rc / a.Tk, a.nsamples - 1 - sample0), key = Rc % a.Tk;
+        voffKV[q] = (unsigned)(((sm * a.kv_bstride + key) * a.ldkv + 4 * ((lane & 15) ^ (R & 15))) * 4);
+      }
+    }
+    auto pieces_of = [&](int tau) -> int {           // vector-memory operations this wave issues for tile tau
+      if constexpr (MODE == TB_CROSS) return ((tau & 3) == 1 || (tau & 3) == 2) ? npw : IPT;
+      return IPT;
+    };
+    auto issue_kv = [&](int tau) {
+      if constexpr (MODE == TB_CROSS) {
+        unsigned char* slot = smem + (tau % NS) * SLOT + iw * 1024;
+        const int sample0 = blockIdx.x * (64 / a.T);
+        const unsigned char* base = reinterpret_cast<const unsigned char*>(
+            a.kv + (int64_t)sample0 * a.kv_bstride * a.ldkv + 64 * (tau >> 2) + ((tau & 3) == 2 ? 64 * a.nheads : 0));
+#pragma unroll
+        for (int q = 0; q < NPW; ++q)
+          __builtin_amdgcn_global_load_lds(base + voffKV[q], (__attribute__((address_space(3))) void*)(slot + q * 4096), 16, 0, 0);
+      }
+    };
+    auto issue_w = [&](int tau) {
       unsigned char* slot = smem + (tau % NS) * SLOT + iw * 1024;
-      if (!((tau % TPC) == TPC - 1)) {
+      const int j = tau % TPC;
+      const int wt = (MODE == TB_CROSS) ? 2 * (tau >> 2) + (j == 3) : tau;      // index into the weight-tile stream
+      const unsigned char* tile = wsrc + (int64_t)wt * SLOT;       // wave-uniform
+      if (j != TPC - 1) {
 #pragma unroll
         for (int q = 0; q < IPT; ++q)
           __builtin_amdgcn_global_load_lds(tile + voffP[q], (__attribute__((address_space(3))) void*)(slot + q * 4096), 16, 0, 0);
@@ -117,6 +152,24 @@ __global__ __launch_bounds__(512) void k_tblock_lw(TBlockArgs a) {
 #pragma unroll
         for (int q = 0; q < IPT; ++q)
           __builtin_amdgcn_global_load_lds(tile + voffO[q], (__attribute__((address_space(3))) void*)(slot + q * 4096), 16, 0, 0);
+      }
+    };
+    auto issue_tile = [&](int tau) {
+      const bool kv = (MODE == TB_CROSS) && ((tau & 3) == 1 || (tau & 3) == 2);
+      if (kv) issue_kv(tau);
+      else issue_w(tau);
+    };
+    auto wait_vm = [&](int allow) {                  // at most `allow` of this wave's vector-memory operations in flight
+      switch (allow) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
       }
     };
     issue_tile(0);
@@ -138,8 +191,7 @@ __global__ __launch_bounds__(512) void k_tblock_lw(TBlockArgs a) {
 #endif
     for (int k = 0; k < NT; ++k) {
       MDT_LSTAMP();
-      if (k + 1 < NT) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile k landed; tile k+1 may be in flight
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      wait_vm(k + 1 < NT ? pieces_of(k + 1) : 0);                        // tile k landed; tile k+1 may be in flight
       MDT_LSTAMP();
       __builtin_amdgcn_s_barrier();                                      // B(k)
       MDT_LSTAMP();
@@ -304,7 +356,7 @@ __global__ __launch_bounds__(512) void k_tblock_lw(TBlockArgs a) {
   for (int ct = 0; ct < NCT; ++ct) accT[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const float* bias = a.bias;                        // [bq | bk | bv | bo] / [b1 | b2], global (L2-resident)
-  const int bo_off = (MODE == TB_SELF) ? 3 * 64 * a.nchunk : 64 * a.nchunk;
+  const int bo_off = (MODE == TB_SELF) ? 3 * 64 * a.nchunk : 64 * a.nchunk;   // [bq | bk | bv | bo] / [bq | bo] / [b1 | b2]
   // Loop-invariant softmax pieces: additive mask of key j = 4 g + r against query column i (other samples of the
   // wave's 16 rows -> -inf), and the logit scale folded with log2(e) so that the exponential is one v_exp_f32.
   const int samp_q = i / a.T;                        // sample (within the wave's 16 rows) of query column i
@@ -312,6 +364,26 @@ __global__ __launch_bounds__(512) void k_tblock_lw(TBlockArgs a) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) kmask[r] = ((4 * g + r) / a.T == samp_q) ? 0.f : -INFINITY;
   const float scale2 = a.scale * 1.44269504088896340736f;
+  // MODE_CROSS (one key tile: at most 16 context rows per wave): LDS addresses of this wave's K / V rows inside a
+  // K or V tile and the validity of key column 4 g + r for query column i.  Rows past the wave's keys are clamped to
+  // a real row (finite data): their scores are masked by select, their probabilities are exactly 0.
+  int aK = 0, xK = 0, aV[4] = {0, 0, 0, 0}, xV[4] = {0, 0, 0, 0};
+  bool kok[4] = {false, false, false, false};
+  if constexpr (MODE == TB_CROSS) {
+    const int nkeys = (16 / a.T) * a.Tk;             // this wave's context rows
+    const int Rw = wave * nkeys;
+    const int Rk = Rw + min(i, nkeys - 1);
+    aK = Rk * 256;
+    xK = Rk & 15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int jj = 4 * g + r;
+      const int Rv = Rw + min(jj, nkeys - 1);
+      aV[r] = Rv * 256 + (i & 3) * 4;
+      xV[r] = Rv & 15;
+      kok[r] = jj < nkeys && (jj / a.Tk) == samp_q;
+    }
+  }
   const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
 
   __builtin_amdgcn_s_barrier();                      // B(0)
@@ -335,6 +407,71 @@ __global__ __launch_bounds__(512) void k_tblock_lw(TBlockArgs a) {
       for (int ft = 0; ft < 4; ++ft)
 #pragma unroll
         for (int r = 0; r < 4; ++r) oT[ft][r] = gelu_lw(oT[ft][r] + b1[ft][r]);
+    } else if constexpr (MODE == TB_CROSS) {
+      f32x4 qT[4], bq[4];
+#pragma unroll
+      for (int ft = 0; ft < 4; ++ft) {
+        bq[ft] = *reinterpret_cast<const f32x4*>(bias + 64 * h + 16 * ft + 4 * g);
+        qT[ft] = zero4;
+      }
+      phase(kT, IC0{}, kT, false, qT, xh, xl);       // q^T
+      __builtin_amdgcn_s_barrier();                  // B(K tile)
+      const unsigned char* sk = slot_of(tau);
+      float4 kk[4];                                  // A operand of S^T: K[key i][64 h + 16 ft + 4 g + s]
+#pragma unroll
+      for (int ft = 0; ft < 4; ++ft)
+        kk[ft] = *reinterpret_cast<const float4*>(sk + aK + (((4 * ft + g) ^ xK) << 4));
+#pragma unroll
+      for (int ft = 0; ft < 4; ++ft) qT[ft] += bq[ft];
+      f32x4 s0 = zero4, s1 = zero4;
+#pragma unroll
+      for (int ft = 0; ft < 4; ++ft) {
+        s0 = MDT_MFMA_F32(kk[ft].x, qT[ft][0], s0, 0, 0, 0);
+        s1 = MDT_MFMA_F32(kk[ft].y, qT[ft][1], s1, 0, 0, 0);
+        s0 = MDT_MFMA_F32(kk[ft].z, qT[ft][2], s0, 0, 0, 0);
+        s1 = MDT_MFMA_F32(kk[ft].w, qT[ft][3], s1, 0, 0, 0);
+      }
+      ++tau;
+      __builtin_amdgcn_s_barrier();                  // B(V tile)
+      const unsigned char* sv = slot_of(tau);
+      f32x4 vT[4];                                   // A operand of O^T: V[key 4 g + r][64 h + 16 dt + i]
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          vT[dt][r] = *reinterpret_cast<const float*>(sv + aV[r] + (((4 * dt + (i >> 2)) ^ xV[r]) << 4));
+      f32x4 st;
+      float mx = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float sv2 = kok[r] ? (s0[r] + s1[r]) * scale2 : -INFINITY;
+        st[r] = sv2;
+        mx = fmaxf(mx, sv2);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __builtin_amdgcn_exp2f(st[r] - mx);
+        st[r] = e;
+        sum += e;
+      }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float inv = __builtin_amdgcn_rcpf(sum);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) oT[dt] = zero4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = st[r] * inv;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) oT[dt] = MDT_MFMA_F32(vT[dt][r], p, oT[dt], 0, 0, 0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the V reads above are complete before the slot can be refilled
+      ++tau;
+      __builtin_amdgcn_s_barrier();                  // B(output tile)
+      prefetch2(kO, slot_of(tau), 1);
     } else {
       f32x4 qT[4], kTt[4], vT[4];
       f32x4 bq[4], bk[4];
@@ -421,26 +558,37 @@ __global__ __launch_bounds__(512) void k_tblock_lw(TBlockArgs a) {
   }
 }
 
-template <int MODE>
+template <int MODE, int NPW = 0>
 static hipError_t launch_lw(const TBlockArgs& a, hipStream_t s) {
   const size_t smem = (size_t)NS * SLOT;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tblock_lw<MODE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tblock_lw<MODE, NPW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_tblock_lw<MODE>), dim3((unsigned)((a.M + 63) / 64)), dim3(512), smem, s, a);
+  hipLaunchKernelGGL((k_tblock_lw<MODE, NPW>), dim3((unsigned)((a.M + 63) / 64)), dim3(512), smem, s, a);
   return hipGetLastError();
 }
 
 bool tblock_lw_supported(const TBlockArgs& a) {
-  return a.C == 128 && (a.mode == TB_SELF || a.mode == TB_FF) && a.T > 0 && 16 % a.T == 0 && a.nchunk > 0;
+  if (a.C != 128 || a.T <= 0 || 16 % a.T || a.nchunk <= 0) return false;
+  if (a.mode == TB_CROSS) return a.Tk > 0 && (16 / a.T) * a.Tk <= 16;   // one key tile per wave, K / V tile <= 64 rows
+  return a.mode == TB_SELF || a.mode == TB_FF;
 }
 
 hipError_t launch_tblock_lw(const TBlockArgs& a, hipStream_t s) {
   if (a.M <= 0) return hipSuccess;
   if (!tblock_lw_supported(a)) return hipErrorInvalidValue;
+  if (a.mode == TB_CROSS) {
+    switch (((64 / a.T) * a.Tk + 15) / 16) {
+      case 1: return launch_lw<TB_CROSS, 1>(a, s);
+      case 2: return launch_lw<TB_CROSS, 2>(a, s);
+      case 3: return launch_lw<TB_CROSS, 3>(a, s);
+      case 4: return launch_lw<TB_CROSS, 4>(a, s);
+      default: return hipErrorInvalidValue;          // unreachable: at most 16 context rows per wave = 64 per workgroup
+    }
+  }
   return a.mode == TB_SELF ? launch_lw<TB_SELF>(a, s) : launch_lw<TB_FF>(a, s);
 }
 
