@@ -131,8 +131,10 @@ enum mdt_tblock_i {
   MDT_B_NCHUNK = 3,                 /* heads (attention) or hidden/64 (feed-forward)                     */
   MDT_B_NBIAS = 4, MDT_B_TK = 5, MDT_B_KV_BSTRIDE = 6, MDT_B_LDKV = 7, MDT_B_HEADS = 8,
   MDT_B_VARIANT = 9                 /* 0: 64-row workgroups; 1: 16-row workgroups whose waves split the features
-                                       (levels with few rows); 2: 32-row workgroups, C = 256, self/ff only, weight
-                                       stream packed as 128-wide sub-tiles (K halves / output-row halves)  */
+                                       (levels with few rows); 2: 32-row workgroups, C = 256 (cross: <= 48 keys per 16 rows), weight
+                                       stream packed as 128-wide sub-tiles (K halves / output-row halves);
+                                       3: as 2, with the heads / hidden chunks of a row block split over two
+                                       workgroups: out = scratch [2][B T][C] for their partial sums         */
 };
 enum mdt_tblock_f { MDT_BF_EPS = 0, MDT_BF_SCALE = 1 };
 

@@ -131,8 +131,10 @@ class UNetCompiler:
         self.fuse_blocks = fuse_blocks
         self.fuse_c256 = os.environ.get("MDT_FUSE_C256", "1") == "1"
         self.tb32 = os.environ.get("MDT_TB32", "1") == "1"           # C = 256 blocks on 32-row workgroups (k_tblock32)
+        self.tb_split = os.environ.get("MDT_TB_SPLIT", "1") == "1"   # ... their heads split over two workgroups
         # cross-attention sub-blocks: "1" fuses the shapes whose K/V rows stream through the loader-wave ring
-        # (k_tblock_lw: C = 128, at most 16 context rows per 16 token rows), "all" also the older kernels' shapes
+        # (k_tblock_lw: C = 128, at most 16 context rows per 16 token rows; k_tblock32: C = 256, at most 48),
+        # "all" also the older kernels' shapes
         self.fuse_cross = os.environ.get("MDT_FUSE_CROSS", "1")
         self.use_gn_act = os.environ.get("MDT_GN_ACT", "1") == "1"
         if gemm_mode not in ("f32", "bf16x3"):
@@ -396,8 +398,9 @@ class UNetCompiler:
         c, rows = t.ld, t.rows
         perm = torch.tensor(self._SLOT_PERM)
         tiles: List[torch.Tensor] = []
-        if variant == 2:
-            assert c == 256 and mode != rt.TB_CROSS, "variant 2 (32-row workgroups) serves C = 256 self-attention / feed-forward"
+        if variant in (2, 3):
+            assert c == 256, "variants 2 / 3 (32-row workgroups, sub-tile stream) serve C = 256"
+            assert mode != rt.TB_CROSS or (16 // rows) * self.n_ctx <= 48, "at most 48 context rows per 16 token rows"
         if mode == rt.TB_FF:
             w1, b1 = sd[p + "0.weight"], sd[p + "0.bias"]          # [2C, C]
             w2, b2 = sd[p + "2.weight"], sd[p + "2.bias"]          # [C, 2C]
@@ -429,7 +432,7 @@ class UNetCompiler:
                 bias = torch.cat([bq_f, bo])
                 mid = wq.shape[0]
                 self.flops += 2 * rows * c * mid + 4 * rows * self.n_ctx * mid + 2 * rows * mid * c
-        if variant == 2:
+        if variant in (2, 3):
             # k_tblock32 streams 32 KB sub-tiles in the C = 128 tile format: a [64][256] projection tile as its two
             # K halves, a [256][64] output tile as its two row halves (tiles alternate P ... P O per chunk)
             tpc = 4 if mode == rt.TB_SELF else 2
@@ -459,7 +462,14 @@ class UNetCompiler:
         if mode == rt.TB_CROSS:
             op._kv = ("kv", cross_index)
             op.a2 = _ref(rt.SP_ACT, 0)
+        part = None
+        if variant == 3:                         # scratch for the two head groups' partial sums: [2][B rows][c]
+            assert nchunk % 2 == 0
+            part = self._new(rows, 2 * c)
+            op.out = part.ref()
         self._emit(op)
+        if part is not None:
+            self._free(part)
 
     def attention_layer(self, t: Ten, p: str, cross_index: Optional[int]) -> None:
         """x = Attention(x[, context]) + x, in place on t (modules.py:401-410, :457-459)."""
@@ -509,16 +519,19 @@ class UNetCompiler:
         #   C = 256, 32-row workgroups + loader waves (k_tblock32, self-attention / feed-forward only): the 16-row form
         #                         sits on the L2 -> LDS bandwidth roof (its weight stream is read by 256 workgroups)
         variant = (2 if self.tb32 else 1) if c == 256 else 0
+        split = 3 if (variant == 2 and self.tb_split) else variant     # self / cross: two workgroups per row block
         for i in range(layers):
             bp = p + f"blocks.{i}."
             if fused:
-                self.tblock(t, rt.TB_SELF, bp + "attention.", variant=variant)
+                self.tblock(t, rt.TB_SELF, bp + "attention.", variant=split)
                 if cross:
                     self.cross_layers.append(bp + "cross_attention.")
-                    ring_ok = c == 128 and (16 // t.rows) * self.n_ctx <= 16
+                    keys16 = (16 // t.rows) * self.n_ctx            # context rows per 16 token rows
+                    ring_ok = (c == 128 and keys16 <= 16) or (variant == 2 and keys16 <= 48)
+                    xv = split if ring_ok else (1 if variant == 2 else variant)
                     if self.fuse_cross == "all" or (self.fuse_cross == "1" and ring_ok):
                         self.tblock(t, rt.TB_CROSS, bp + "cross_attention.", len(self.cross_layers) - 1,
-                                    variant=1 if variant == 2 else variant)
+                                    variant=xv)
                     else:
                         # q-GEMM + attention + out-GEMM (the pre-ring fused cross kernels measured slower than this:
                         # 78 us against ~62 us, their per-head K/V loads were not pipelined)

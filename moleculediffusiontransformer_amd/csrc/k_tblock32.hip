@@ -71,15 +71,36 @@ constexpr int NU = 4;           // units (4 fragment reads + 6 MFMAs) per sub-ti
 }  // namespace
 
 
-template <int MODE>
+// x[m][c] += bias[c] + sum_k part[k][m][c]  (fixed order: the result does not depend on which workgroup finished first)
+__global__ __launch_bounds__(256) void k_tb_reduce(float* x, const float* part, const float* bo, int M, int nsplit) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (int64_t)M * (C / 4)) return;
+  const int c4 = (int)(t % (C / 4));
+  float4 v = reinterpret_cast<const float4*>(part)[t];
+  for (int k = 1; k < nsplit; ++k) {
+    const float4 p = reinterpret_cast<const float4*>(part)[(int64_t)k * M * (C / 4) + t];
+    v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+  }
+  const float4 b = reinterpret_cast<const float4*>(bo)[c4];
+  float4 xr = reinterpret_cast<float4*>(x)[t];
+  xr.x = v.x + b.x + xr.x; xr.y = v.y + b.y + xr.y; xr.z = v.z + b.z + xr.z; xr.w = v.w + b.w + xr.w;
+  reinterpret_cast<float4*>(x)[t] = xr;
+}
+
+// NPW (MODE_CROSS only): LDS-DMA pieces per loader wave per K / V tile = ceil(context rows of the workgroup / 16)
+template <int MODE, int NPW>
 __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
-  constexpr int SPC = (MODE == TB_SELF) ? 8 : 4;   // sub-tiles per chunk (head / hidden chunk)
+  // sub-tiles per chunk: q0 q1 k0 k1 v0 v1 o0 o1 | q0 q1 K V o0 o1 (K, V = hoisted context rows) | w1a w1b w2a w2b
+  constexpr int SPC = (MODE == TB_SELF) ? 8 : (MODE == TB_CROSS) ? 6 : 4;
+  constexpr int KTM = 3;                           // key tiles per wave (MODE_CROSS): at most 48 context rows per 16 token rows
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-  f32x4* red = reinterpret_cast<f32x4*>(smem + NS * SLOT);   // [4 waves][64 lanes] partial S^T
+  f32x4* red = reinterpret_cast<f32x4*>(smem + NS * SLOT);   // [key tile][4 waves][64 lanes] partial S^T
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int NT = a.nchunk * SPC;
+  // head / hidden-chunk range of this workgroup: blockIdx.y of gridDim.y workgroups share the row block (nsplit)
+  const int h0 = (int)blockIdx.y * (a.nchunk / (int)gridDim.y), h1 = h0 + a.nchunk / (int)gridDim.y;
+  const int NT = (h1 - h0) * SPC;                  // tau counts this workgroup's sub-tiles; the stream index is tau + h0 SPC
   const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(a.w);
 
   if (wave >= 4) {
@@ -102,10 +123,38 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
       voffP[q] = (unsigned)(U * (2 * CS) + ((xP ^ (U & 15)) << 4) + baseP);
       voffO[q] = (unsigned)(((inst * 8) / CS) * (128 * CS) + ((inst * 8) % CS) * 128 + ((xO ^ (4 * (inst & 1))) << 4) + baseO);
     }
-    auto issue_tile = [&](int tau) {
-      const unsigned char* tile = wsrc + (int64_t)tau * SLOT;       // wave-uniform
+    // MODE_CROSS: sub-tiles 2 and 3 of a head are the K and V rows (row = (sample, key), 256 B, chunks swizzled with
+    // the row index) of the workgroup's samples -- layout and padding as in k_tblock_lw.hip
+    const int kv_rows = (MODE == TB_CROSS) ? (32 / a.T) * a.Tk : 0;
+    unsigned voffKV[8];                              // NPW <= 8 used (fixed bound, see k_tblock_lw.hip)
+    if constexpr (MODE == TB_CROSS) {
+      const int sample0 = blockIdx.x * (32 / a.T);
+#pragma unroll
+      for (int q = 0; q < NPW; ++q) {
+        const int R = 4 * (iw + 4 * q) + (lane >> 4);
+        const int Rc = min(R, kv_rows - 1);
+        const int sm = min(Rc / a.Tk, a.nsamples - 1 - sample0), key = Rc % a.Tk;
+        voffKV[q] = (unsigned)(((sm * a.kv_bstride + key) * a.ldkv + 4 * ((lane & 15) ^ (R & 15))) * 4);
+      }
+    }
+    auto is_kv = [&](int tau) -> bool { return (MODE == TB_CROSS) && ((tau % SPC) == 2 || (tau % SPC) == 3); };
+    auto issue_kv = [&](int tau) {
+      if constexpr (MODE == TB_CROSS) {
+        unsigned char* slot = smem + (tau % NS) * SLOT + iw * 1024;
+        const int sample0 = blockIdx.x * (32 / a.T);
+        const unsigned char* base = reinterpret_cast<const unsigned char*>(
+            a.kv + (int64_t)sample0 * a.kv_bstride * a.ldkv + 64 * (h0 + tau / SPC) + ((tau % SPC) == 3 ? 64 * a.nheads : 0));
+#pragma unroll
+        for (int q = 0; q < NPW; ++q)
+          __builtin_amdgcn_global_load_lds(base + voffKV[q], (__attribute__((address_space(3))) void*)(slot + q * 4096), 16, 0, 0);
+      }
+    };
+    auto issue_w = [&](int tau) {
+      const int j = tau % SPC;
+      const int wt = (MODE == TB_CROSS) ? 4 * (h0 + tau / SPC) + (j < 2 ? j : j - 2) : tau + h0 * SPC;   // index into the weight stream
+      const unsigned char* tile = wsrc + (int64_t)wt * SLOT;       // wave-uniform
       unsigned char* slot = smem + (tau % NS) * SLOT + iw * 1024;
-      if (!((tau % SPC) >= SPC - 2)) {
+      if (j < SPC - 2) {
 #pragma unroll
         for (int q = 0; q < IPT; ++q)
           __builtin_amdgcn_global_load_lds(tile + voffP[q], (__attribute__((address_space(3))) void*)(slot + q * 4096), 16, 0, 0);
@@ -115,11 +164,27 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
           __builtin_amdgcn_global_load_lds(tile + voffO[q], (__attribute__((address_space(3))) void*)(slot + q * 4096), 16, 0, 0);
       }
     };
+    auto issue_tile = [&](int tau) {
+      if (is_kv(tau)) issue_kv(tau);
+      else issue_w(tau);
+    };
+    auto wait_vm = [&](int allow) {                  // at most `allow` of this wave's vector-memory operations in flight
+      switch (allow) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      }
+    };
     issue_tile(0);
     if (NT > 1) issue_tile(1);
     for (int k = 0; k < NT; ++k) {
-      if (k + 1 < NT) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      wait_vm(k + 1 < NT ? (is_kv(k + 1) ? NPW : IPT) : 0);              // tile k landed; tile k+1 may be in flight
       __builtin_amdgcn_s_barrier();                                      // B(k)
       if (k + 2 < NT) issue_tile(k + 2);
     }
@@ -272,20 +337,36 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
   for (int ct = 0; ct < NCT; ++ct) accT[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const float* bias = a.bias;
-  const int bo_off = (MODE == TB_SELF) ? 3 * 64 * a.nchunk : 64 * a.nchunk;
+  const int bo_off = (MODE == TB_SELF) ? 3 * 64 * a.nchunk : 64 * a.nchunk;   // [bq | bk | bv | bo] / [bq | bo] / [b1 | b2]
   const int samp_q = i / a.T;                        // loop-invariant softmax pieces, see k_tblock_lw.hip
   float kmask[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) kmask[r] = ((4 * g + r) / a.T == samp_q) ? 0.f : -INFINITY;
   const float scale2 = a.scale * 1.44269504088896340736f;
+  // MODE_CROSS: this row tile's context rows inside a K / V tile start at row rt * nkeys; lane (i, g) reads K row
+  // 16 kt + i and V rows 16 kt + 4 g + r (clamped to a real row past the end: masked scores, zero probabilities).
+  // Validity of key column 16 kt + 4 g + r for query column i is bit 4 kt + r of okbits.
+  int nkeys = 0, Rw = 0;
+  unsigned okbits = 0;
+  if constexpr (MODE == TB_CROSS) {
+    nkeys = (16 / a.T) * a.Tk;
+    Rw = rt * nkeys;
+#pragma unroll
+    for (int kt = 0; kt < KTM; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int jj = 16 * kt + 4 * g + r;
+        if (jj < nkeys && (jj / a.Tk) == samp_q) okbits |= 1u << (4 * kt + r);
+      }
+  }
   const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
 
   __builtin_amdgcn_s_barrier();                      // B(0)
   prefetch2(kT, slot_of(0), 0);
 
   MDT_STAMP();
-  for (int h = 0; h < a.nchunk; ++h) {
-    const bool more = h + 1 < a.nchunk;
+  for (int h = h0; h < h1; ++h) {
+    const bool more = h + 1 < h1;
     f32x4 oT[2];      // this wave's 32 features of the chunk: [feature 32 fh + 16 q + 4 g + r][token i]
     if constexpr (MODE == TB_FF) {
       f32x4 b1[2];
@@ -302,6 +383,105 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
       for (int q = 0; q < 2; ++q)
 #pragma unroll
         for (int r = 0; r < 4; ++r) oT[q][r] = gelu_32(oT[q][r] + b1[q][r]);
+    } else if constexpr (MODE == TB_CROSS) {
+      f32x4 qT[2], bq[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        bq[q] = *reinterpret_cast<const f32x4*>(bias + 64 * h + 32 * fh + 16 * q + 4 * g);
+        qT[q] = zero4;
+      }
+      phase(kT, IC0{}, kT, true, qT, xh, xl);
+      phase(kT, IC1{}, kT, false, qT, xh + 4, xl + 4);
+      __builtin_amdgcn_s_barrier();                         // B(K tile)
+      MDT_STAMP();
+      const unsigned char* sk = slot_of(tau);
+      qT[0] += bq[0];
+      qT[1] += bq[1];
+      f32x4 st[KTM];
+#pragma unroll
+      for (int kt = 0; kt < KTM; ++kt) {                    // partial S^T over this wave's 32 features, key tile kt
+        st[kt] = zero4;
+        if (16 * kt < nkeys) {
+          const int R = Rw + min(16 * kt + i, nkeys - 1);
+          const unsigned char* kp = sk + R * 256;
+          const float4 k0 = *reinterpret_cast<const float4*>(kp + (((8 * fh + g) ^ (R & 15)) << 4));
+          const float4 k1 = *reinterpret_cast<const float4*>(kp + (((8 * fh + 4 + g) ^ (R & 15)) << 4));
+          f32x4 sp0 = zero4, sp1 = zero4;
+          sp0 = MDT_MFMA_F32(k0.x, qT[0][0], sp0, 0, 0, 0);
+          sp1 = MDT_MFMA_F32(k1.x, qT[1][0], sp1, 0, 0, 0);
+          sp0 = MDT_MFMA_F32(k0.y, qT[0][1], sp0, 0, 0, 0);
+          sp1 = MDT_MFMA_F32(k1.y, qT[1][1], sp1, 0, 0, 0);
+          sp0 = MDT_MFMA_F32(k0.z, qT[0][2], sp0, 0, 0, 0);
+          sp1 = MDT_MFMA_F32(k1.z, qT[1][2], sp1, 0, 0, 0);
+          sp0 = MDT_MFMA_F32(k0.w, qT[0][3], sp0, 0, 0, 0);
+          sp1 = MDT_MFMA_F32(k1.w, qT[1][3], sp1, 0, 0, 0);
+          st[kt] = sp0 + sp1;
+          red[(kt * 4 + wave) * 64 + lane] = st[kt];
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      ++tau;
+      MDT_STAMP();
+      __builtin_amdgcn_s_barrier();                         // B(V tile) + partial exchange
+      MDT_STAMP();
+      const unsigned char* sv = slot_of(tau);
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < KTM; ++kt) {
+        if (16 * kt < nkeys) {
+          const f32x4 other = red[(kt * 4 + (wave ^ 1)) * 64 + lane];
+          const f32x4 s01 = fh ? (other + st[kt]) : (st[kt] + other);   // same sum in both waves of the row tile
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float sv2 = ((okbits >> (4 * kt + r)) & 1u) ? s01[r] * scale2 : -INFINITY;
+            st[kt][r] = sv2;
+            mx = fmaxf(mx, sv2);
+          }
+        } else {
+          st[kt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < KTM; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = __builtin_amdgcn_exp2f(st[kt][r] - mx);
+          st[kt][r] = e;
+          sum += e;
+        }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float inv = __builtin_amdgcn_rcpf(sum);
+      MDT_STAMP();
+      oT[0] = zero4; oT[1] = zero4;
+#pragma unroll
+      for (int kt = 0; kt < KTM; ++kt) {
+        if (16 * kt < nkeys) {
+          f32x4 v0, v1;                                     // V[key 16 kt + 4 g + r][32 fh + 16 dt + i], dt = 0, 1
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int R = Rw + min(16 * kt + 4 * g + r, nkeys - 1);
+            const unsigned char* vp = sv + R * 256 + (i & 3) * 4;
+            v0[r] = *reinterpret_cast<const float*>(vp + (((8 * fh + (i >> 2)) ^ (R & 15)) << 4));
+            v1[r] = *reinterpret_cast<const float*>(vp + (((8 * fh + 4 + (i >> 2)) ^ (R & 15)) << 4));
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = st[kt][r] * inv;
+            oT[0] = MDT_MFMA_F32(v0[r], p, oT[0], 0, 0, 0);
+            oT[1] = MDT_MFMA_F32(v1[r], p, oT[1], 0, 0, 0);
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // V reads complete before the slot can be refilled
+      ++tau;
+      MDT_STAMP();
+      __builtin_amdgcn_s_barrier();                         // B(first output sub-tile)
+      MDT_STAMP();
+      prefetch2(kO, slot_of(tau), 1);
     } else {
       f32x4 qT[2], kTt[2], vT[2];
       f32x4 bq[2];
@@ -392,6 +572,11 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
       const int ct = 8 * fh + c;
       const f32x4 p0 = part[((2 * rt) * NCT + ct) * 64 + lane], p1 = part[((2 * rt + 1) * NCT + ct) * 64 + lane];
       const f32x4 sum = p0 + p1;                            // feature half 0 first
+      if (gridDim.y > 1) {                                  // partial over this workgroup's heads: k_tb_reduce adds the rest
+        *reinterpret_cast<float4*>(a.part + ((int64_t)blockIdx.y * a.M + m) * C + 16 * ct + 4 * g) =
+            make_float4(sum[0], sum[1], sum[2], sum[3]);
+        continue;
+      }
       const float4 xr = *reinterpret_cast<const float4*>(xo + 16 * ct);
       const float4 bo = *reinterpret_cast<const float4*>(bias + bo_off + 16 * ct + 4 * g);
       *reinterpret_cast<float4*>(xo + 16 * ct) =
@@ -400,23 +585,42 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
   }
 }
 
-template <int MODE>
+template <int MODE, int NPW = 0>
 static hipError_t launch_32(const TBlockArgs& a, hipStream_t s) {
-  const size_t smem = (size_t)NS * SLOT + 4 * 64 * 16;
+  const size_t smem = (size_t)NS * SLOT + (MODE == TB_CROSS ? 3 : 1) * 4 * 64 * 16;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tblock32<MODE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tblock32<MODE, NPW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_tblock32<MODE>), dim3((unsigned)((a.M + 31) / 32)), dim3(512), smem, s, a);
+  const int nsplit = a.nsplit > 1 ? a.nsplit : 1;
+  hipLaunchKernelGGL((k_tblock32<MODE, NPW>), dim3((unsigned)((a.M + 31) / 32), (unsigned)nsplit), dim3(512), smem, s, a);
+  if (nsplit > 1) {
+    const int bo_off = (MODE == TB_SELF) ? 3 * 64 * a.nchunk : 64 * a.nchunk;
+    const int64_t n4 = (int64_t)a.M * (C / 4);
+    hipLaunchKernelGGL(k_tb_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, a.x, a.part, a.bias + bo_off, a.M, nsplit);
+  }
   return hipGetLastError();
 }
 
 hipError_t launch_tblock32(const TBlockArgs& a, hipStream_t s) {
   if (a.M <= 0) return hipSuccess;
-  if (a.C != 256 || (a.mode != TB_SELF && a.mode != TB_FF) || a.T <= 0 || 16 % a.T || a.nchunk <= 0)
-    return hipErrorInvalidValue;
+  if (a.C != 256 || a.T <= 0 || 16 % a.T || a.nchunk <= 0) return hipErrorInvalidValue;
+  if (a.nsplit > 1 && (a.nchunk % a.nsplit || !a.part)) return hipErrorInvalidValue;
+  if (a.mode == TB_CROSS) {
+    if (a.Tk <= 0 || (16 / a.T) * a.Tk > 48) return hipErrorInvalidValue;   // three key tiles per wave at most
+    switch (((32 / a.T) * a.Tk + 15) / 16) {
+      case 1: return launch_32<TB_CROSS, 1>(a, s);
+      case 2: return launch_32<TB_CROSS, 2>(a, s);
+      case 3: return launch_32<TB_CROSS, 3>(a, s);
+      case 4: return launch_32<TB_CROSS, 4>(a, s);
+      case 5: return launch_32<TB_CROSS, 5>(a, s);
+      case 6: return launch_32<TB_CROSS, 6>(a, s);
+      default: return hipErrorInvalidValue;
+    }
+  }
+  if (a.mode != TB_SELF && a.mode != TB_FF) return hipErrorInvalidValue;
   return a.mode == TB_SELF ? launch_32<TB_SELF>(a, s) : launch_32<TB_FF>(a, s);
 }
 

@@ -62,6 +62,8 @@ struct TBlockArgs {
   const float* bias;   // SELF [bq|bk|bv|bo], CROSS [bq|bo], FF [b1|b2]
   const float* kv;     // CROSS: hoisted K|V rows [sample][Tk][ldkv]
   const float* dbgbuf; // diagnostic stamps (MDT_DBG & 8), normally nullptr
+  float* part;         // k_tblock32 with nsplit > 1: partial outputs [nsplit][M][C] (no bias / residual), summed by k_tb_reduce
+  int nsplit;          // workgroups sharing a row block, each taking nchunk / nsplit heads or hidden chunks
   int mode, C, M, T, nchunk, nbias, ldx, Tk, kv_bstride, ldkv, nheads, nsamples;
   float eps, scale;
 };

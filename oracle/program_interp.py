@@ -184,7 +184,7 @@ def _tblock(op, bufs: Buffers, B: int) -> None:
     mid = 64 * nchunk
 
     def tile(k, rows, cols):
-        if i[rt.B_VARIANT] != 2:
+        if i[rt.B_VARIANT] not in (2, 3):
             return _untile(stream, k, rows, cols)
         # variant 2 (k_tblock32): every tile is stored as two 128-wide sub-tiles (K halves / output-row halves)
         if rows == 64:

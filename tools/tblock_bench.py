@@ -16,7 +16,7 @@ dev = "cuda:0"
 for (C, T) in [(128, 16), (256, 4)]:
     for mode, name in ((rt.TB_SELF, "SELF"), (rt.TB_CROSS, "CROSS"), (rt.TB_FF, "FF")):
         variant = int(os.environ.get('VARIANT', '0'))
-        if variant == 2 and (C != 256 or mode == rt.TB_CROSS):
+        if variant >= 2 and C != 256:
             continue
         for B in (64 * 16 // T // 16, 1024):
             n_ctx, mid, p = 12, 512, "blk."
@@ -34,7 +34,9 @@ for (C, T) in [(128, 16), (256, 4)]:
             if os.environ.get('MDT_DBG', '0') == '8':
                 op.p0 = ref(rt.SP_EXT0, 0)
             W = comp.W.pack().to(dev)
-            act = torch.randn(B * (T * C + n_ctx * 2 * mid), device=dev) * 0.1
+            if variant == 3:
+                op.out = ref(A, T * C + n_ctx * 2 * mid)
+            act = torch.randn(B * (T * C + n_ctx * 2 * mid + 2 * T * C), device=dev) * 0.1
             prog = rt.Program([op])
             b = rt.MdtBindings(); b.weights, b.act = rt.ptr(W), rt.ptr(act); b.ext[0] = rt.ptr(dbg)
             with torch.cuda.device(dev):
