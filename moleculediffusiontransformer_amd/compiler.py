@@ -132,6 +132,7 @@ class UNetCompiler:
         self.fuse_c256 = os.environ.get("MDT_FUSE_C256", "1") == "1"
         self.tb32 = os.environ.get("MDT_TB32", "1") == "1"           # C = 256 blocks on 32-row workgroups (k_tblock32)
         self.tb_split = os.environ.get("MDT_TB_SPLIT", "1") == "1"   # ... their heads split over two workgroups
+        self.use_rconv = os.environ.get("MDT_RCONV", "1") == "1"     # row-stationary convs (k_rconv) at C = 128 / 256
         # cross-attention sub-blocks: "1" fuses the shapes whose K/V rows stream through the loader-wave ring
         # (k_tblock_lw: C = 128, at most 16 context rows per 16 token rows; k_tblock32: C = 256, at most 48),
         # "all" also the older kernels' shapes
@@ -316,11 +317,101 @@ class UNetCompiler:
         self._emit(op)
         self.flops += 2 * 2 * q.rows * tk * cfg.mid_features
 
+    # ------------------------------------------------------------------ row-stationary convolution (MDT_OP_RCONV)
+    def rconv_ok(self, rows: int, c: int, taps: int, gsize: int) -> bool:
+        """Mirror of rconv_supported (csrc/k_rconv.hip) plus the policy switches."""
+        if not (self.use_rconv and self.gemm_mode == "bf16x3" and self.fuse_blocks):
+            return False
+        return c in (128, 256) and 0 < rows <= 16 and 16 % rows == 0 and taps in (1, 3) and gsize in (0, 4, 8, 16, 32, 64)
+
+    def rconv(self, x: Ten, w: torch.Tensor, name: str, out: Ten, *, taps: int, bias_off: Optional[int] = None,
+              res: Optional[Ten] = None, gn=None, film=None, in_scale: float = 1.0) -> None:
+        """out = bias + conv_k(silu(gn(in_scale * x) * (scale + 1) + shift)) (+ res); w is [C][C][taps] (a slice of
+        the reference Conv1d weight), gn = (gain offset, bias offset, gsize, eps, silu) in the packed weights."""
+        c = x.ld
+        assert w.shape == (c, c, taps) and out.ld == c and out.rows == x.rows, (name, tuple(w.shape), c, taps)
+        tiles = [self._tile(w[64 * ch: 64 * ch + 64, 128 * kh: 128 * kh + 128, tap])
+                 for tap in range(taps) for kh in range(c // 128) for ch in range(c // 64)]
+        op = rt.MdtOp()
+        op.kind = rt.OP_RCONV
+        op.a, op.out = x.ref(), out.ref()
+        op.w = _ref(rt.SP_WEIGHT, self.W.add(name + "/rconv.tiles", torch.cat(tiles)))
+        if bias_off is not None:
+            op.bias = _ref(rt.SP_WEIGHT, bias_off)
+        if res is not None:
+            op.res = res.ref()
+        i = op.i
+        i[rt.R_T], i[rt.R_C], i[rt.R_LDA], i[rt.R_LDC], i[rt.R_TAPS] = x.rows, c, x.ld, out.ld, taps
+        i[rt.R_LDR] = res.ld if res is not None else 0
+        i[rt.R_FILM_LD] = c
+        op.f[0], op.f[1] = 1e-5, in_scale
+        if gn is not None:
+            gain, nbias, gsize, eps, silu = gn
+            op.p0, op.p1 = _ref(rt.SP_WEIGHT, gain), _ref(rt.SP_WEIGHT, nbias)
+            i[rt.R_GSIZE], i[rt.R_SILU] = gsize, int(silu)
+            op.f[0] = eps
+        if isinstance(film, tuple):
+            op._film = film
+        self._emit(op)
+        self.flops += 2 * x.rows * c * c * taps
+
+    def _resnet_rconv(self, xa: Ten, xb: Optional[Ten], scale_b: float, p: str, c: int, groups: int,
+                      free_input: bool) -> Ten:
+        """ResnetBlock1d.forward (modules.py:193-205) on row-stationary convolutions; with xb the block input is
+        cat([xa, scale_b * xb]) (UpsampleBlock1d.add_skip, modules.py:828-829) and is never materialised: every
+        2C-channel convolution is two C-channel launches, the second accumulating into the first's output."""
+        sd = self.sd
+        cin = 2 * c if xb is not None else c
+        gsize = cin // groups
+        g1, b1 = self._vec(p + "block1.groupnorm.weight", cin), self._vec(p + "block1.groupnorm.bias", cin)
+        w1 = sd[p + "block1.project.weight"]                          # [c, cin, 3]
+        h = self._new(xa.rows, c)
+        self.rconv(xa, w1[:, :c], p + "block1.project.weight/a", h, taps=3, bias_off=self._vec(p + "block1.project.bias", c),
+                   gn=(g1, b1, gsize, 1e-5, True))
+        if xb is not None:
+            self.rconv(xb, w1[:, c:], p + "block1.project.weight/b", h, taps=3, res=h,
+                       gn=(g1 + c, b1 + c, gsize, 1e-5, True), in_scale=scale_b)
+            wr = sd[p + "to_out.weight"]                              # [c, 2c, 1]
+            r = self._new(xa.rows, c)
+            self.rconv(xa, wr[:, :c], p + "to_out.weight/a", r, taps=1, bias_off=self._vec(p + "to_out.bias", c))
+            self.rconv(xb, wr[:, c:], p + "to_out.weight/b", r, taps=1, res=r, in_scale=scale_b)
+        else:
+            assert (p + "to_out.weight") not in sd
+            r = xa
+        ss_off = self.ss_total                                        # FiLM vectors inside the shared (scale | shift) row
+        self.ss_offsets[p] = ss_off
+        self.ss_total += 2 * c
+        y = self._new(xa.rows, c)
+        g2, b2 = self._vec(p + "block2.groupnorm.weight", c), self._vec(p + "block2.groupnorm.bias", c)
+        self.rconv(h, sd[p + "block2.project.weight"], p + "block2.project.weight", y, taps=3,
+                   bias_off=self._vec(p + "block2.project.bias", c), res=r, gn=(g2, b2, c // groups, 1e-5, True),
+                   film=("ss", ss_off))
+        self._free(h)
+        if r is not xa:
+            self._free(r)
+        if free_input:
+            self._free(xa)
+            if xb is not None:
+                self._free(xb)
+        return y
+
+    def resnet_cat(self, xa: Ten, xb: Ten, scale_b: float, p: str, c: int, groups: int) -> Ten:
+        """ResnetBlock1d on cat([xa, scale_b * xb]) (2c -> c channels); frees both inputs."""
+        if xa.ld == c and xb.ld == c and groups % 2 == 0 and self.rconv_ok(xa.rows, c, 3, 2 * c // groups):
+            return self._resnet_rconv(xa, xb, scale_b, p, c, groups, True)
+        cat = self.concat(xa, xb, scale_b)
+        self._free(xa)
+        self._free(xb)
+        return self.resnet(cat, p, 2 * c, c, groups)
+
     # ------------------------------------------------------------------ blocks
     def resnet(self, x: Ten, p: str, cin: int, cout: int, groups: int, free_input: bool = True) -> Ten:
         """ResnetBlock1d.forward (modules.py:193-205); x has `cin` real channels."""
         cin_p, cout_p = pad16(cin), pad16(cout)
         assert x.ld == cin_p, (p, x.ld, cin_p)
+        if cin == cout and x.ld == cin and (p + "to_out.weight") not in self.sd and groups > 0 and cin % groups == 0 \
+                and self.rconv_ok(x.rows, cin, 3, cin // groups):
+            return self._resnet_rconv(x, None, 1.0, p, cin, groups, free_input)
         g1, b1 = self._vec(p + "block1.groupnorm.weight", cin_p), self._vec(p + "block1.groupnorm.bias", cin_p)
         h = self._new(x.rows, cout_p, cout)
         w1 = self._conv_w(p + "block1.project.weight", cin_p, cout_p)
@@ -500,7 +591,10 @@ class UNetCompiler:
         t = self._new(x.rows, c)
         gi, bi = self._vec(p + "to_in.0.weight", c), self._vec(p + "to_in.0.bias", c)
         wi, bias_i = self._conv_w(p + "to_in.1.weight", c, c), self._vec(p + "to_in.1.bias", c)
-        if self.use_gn_act and self.gn_act_ok(x.rows, c, 32, c // 32):
+        if self.rconv_ok(x.rows, c, 1, c // 32):
+            self.rconv(x, self.sd[p + "to_in.1.weight"], p + "to_in.1.weight", t, taps=1, bias_off=bias_i,
+                       gn=(gi, bi, c // 32, 1e-6, False))
+        elif self.use_gn_act and self.gn_act_ok(x.rows, c, 32, c // 32):
             xa = self.gn_act(x, 32, c // 32, 1e-6, gi, bi, False)
             self.gemm(xa, wi, c, t, cin=c, bias_off=bias_i)
             self._free(xa)
@@ -549,7 +643,11 @@ class UNetCompiler:
                       bias_off=self._vec(bp + "feed_forward.2.bias", c), res=t)
             self._free(h)
         y = self._new(t.rows, c)
-        self.gemm(t, self._conv_w(p + "to_out.1.weight", c, c), c, y, cin=c, bias_off=self._vec(p + "to_out.1.bias", c))
+        if self.rconv_ok(t.rows, c, 1, 0):
+            self.rconv(t, self.sd[p + "to_out.1.weight"], p + "to_out.1.weight", y, taps=1,
+                       bias_off=self._vec(p + "to_out.1.bias", c))
+        else:
+            self.gemm(t, self._conv_w(p + "to_out.1.weight", c, c), c, y, cin=c, bias_off=self._vec(p + "to_out.1.bias", c))
         self._free(t)
         return y
 
@@ -629,10 +727,7 @@ class UNetCompiler:
             n_res = cfg.num_blocks[i] + (1 if cfg.attentions[i] else 0)
             for j in range(n_res):
                 s = skips.pop()
-                cat = self.concat(x, s, 2 ** -0.5)
-                self._free(x)
-                self._free(s)
-                x = self.resnet(cat, up + f"blocks.{j}.", 2 * ci, ci, g)
+                x = self.resnet_cat(x, s, 2 ** -0.5, up + f"blocks.{j}.", ci, g)
             for s in skips:               # DownsampleBlock1d emits one more skip than is consumed (:702, :843-845)
                 self._free(s)
             if cfg.pre_transformer > 0:
@@ -700,7 +795,7 @@ class UNetCompiler:
             for op in ops:
                 o = rt.MdtOp()
                 C_memmove(o, op)
-                if op.kind in (rt.OP_GEMM, rt.OP_GN_ACT) and isinstance(getattr(op, "_film", None), tuple):
+                if op.kind in (rt.OP_GEMM, rt.OP_GN_ACT, rt.OP_RCONV) and isinstance(getattr(op, "_film", None), tuple):
                     o.p3 = _ref(rt.SP_SHR, ss_cur + op._film[1])
                 if op.kind in (rt.OP_ATTN, rt.OP_TBLOCK) and isinstance(getattr(op, "_kv", None), tuple):
                     idx = op._kv[1]

@@ -1,0 +1,421 @@
+// Row-stationary convolution for the C = 128 / C = 256 levels of the U-Net (MDT_OP_RCONV):
+//
+//   xn  = in_scale * x                                              (skip scaling of UpsampleBlock1d.add_skip)
+//   xn  = silu( GroupNorm(xn) * (scale + 1) + shift )               (ConvBlock1d.forward, modules.py:117-121; optional)
+//   out = bias + sum_tap W[:, tap, :] xn[t + tap - taps/2]  (+ res)  (Conv1d k = 1 | 3, zero padding inside the sample)
+//
+// with C input and C output channels per launch (a 2C-channel concatenated input is two launches, the second
+// accumulating through `res`; GroupNorm groups never straddle the two halves).
+//
+// Why not the tiled GEMM (k_gemm_bf16x3.hip): at B = 1024 these layers are 4096..16384 rows x 128..256 columns,
+// one 64x64 tile per CU, and the tiled kernel spends ~1800 cycles per 32-deep k-step on load -> LDS -> MFMA
+// latency (17.6 us for K = 768, 9x its MFMA time), after a separate GroupNorm launch.  Here the structure of the
+// fused transformer blocks (k_tblock_lw.hip / k_tblock32.hip) is reused:
+//   * a wave keeps its 16 token rows, normalised, as bf16 hi/lo MFMA operands in registers for the whole launch;
+//     the GroupNorm statistics are wave-local (a wave owns whole samples and all C channels);
+//   * the +-1 taps are the same registers shifted by one lane inside the 16-lane row (DPP row_shr / row_shl, zero
+//     fill at the row ends, one select at sample boundaries inside the row);
+//   * weights arrive as 32 KB tiles [64 features][128 k] (C = 128 tile format) through the 4-slot LDS ring filled
+//     by four loader waves; fragment reads are interleaved with the MFMAs and pipelined across tiles.
+// Tile order: tap, K half, 64-feature chunk (the shifted operands of a (tap, K half) serve all chunks).
+//   RTW = 4: 64-row workgroups, wave = row tile, 4 feature tiles per chunk per wave   (16384-row level)
+//   RTW = 2: 32-row workgroups, wave = (row tile, feature half)                       ( 4096-row level)
+#include <cstdlib>
+#include <type_traits>
+
+#include "mdt_kernels.h"
+
+namespace mdt {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+#define MDT_MFMA_BF16 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+
+constexpr int CS = 128;         // k-width of a weight tile
+constexpr int SLOT = 256 * CS;  // bytes per tile (bf16 hi plane + lo plane)
+constexpr int NS = 4;           // ring slots
+constexpr int IPT = CS / 16;    // DMA pieces per tile per loader wave
+
+__device__ __forceinline__ void split8_rc(const float v[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const __bf16 h = (__bf16)v[e];
+    hi[e] = h;
+    lo[e] = (__bf16)(v[e] - (float)h);
+  }
+}
+
+__device__ __forceinline__ void lds_read16_rc(bf16x8& dst, const unsigned char* p) {
+  const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)p;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr) : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void lgkm_wait_rc() {
+  if constexpr (N >= 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// operand of the neighbouring token row: lane i takes lane i - 1 (SHR) or i + 1 inside its 16-lane row, 0 at the ends
+template <bool SHR>
+__device__ __forceinline__ bf16x8 row_shift(const bf16x8& v, bool keep) {
+  const i32x4 s = __builtin_bit_cast(i32x4, v);
+  i32x4 r;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int t = __builtin_amdgcn_update_dpp(0, s[k], SHR ? 0x111 : 0x101, 0xf, 0xf, true);
+    r[k] = keep ? t : 0;
+  }
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+}  // namespace
+
+// NSPLIT workgroups (blockIdx.y) share a row block, each producing C / NSPLIT of the output channels: no reduction,
+// half the weight stream per workgroup, twice the workgroups (the 4096-row level has only 128 row blocks).
+template <int RTW, int C, int TAPS, int NSPLIT>
+__global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
+  constexpr int NST = C / 32;               // k-steps of the input channels
+  constexpr int NKH = C / CS;               // K halves (tiles per tap per chunk)
+  constexpr int NCHT = C / 64;              // 64-feature output chunks in total
+  constexpr int NCH = NCHT / NSPLIT;        // ... of this workgroup
+  constexpr int NFT = (RTW == 4) ? 4 : 2;   // feature tiles per chunk per wave
+  constexpr int NU = 2 * NFT;               // units (4 fragment reads + 6 MFMAs) per tile per wave
+  constexpr int NT = TAPS * NKH * NCH;      // tiles of this workgroup
+  constexpr int NSTW = (RTW == 2) ? NST / 2 : NST;   // k-steps normalised by this wave (RTW = 2: the wave pair splits them)
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(a.w);
+
+  if (wave >= 4) {
+    // ================= loader waves: the weight stream (k_tblock_lw.hip) =================
+    const int iw = wave - 4;
+    __builtin_amdgcn_s_setprio(3);
+    const int lpP = lane >> 5;
+    const int xP = (lane & 15) ^ lpP;
+    const int baseP = ((lane >> 4) & 1) * (128 * CS) + lpP * (2 * CS);
+    unsigned voffP[IPT];
+#pragma unroll
+    for (int q = 0; q < IPT; ++q) {
+      const int U = 2 * (iw + 4 * q);
+      voffP[q] = (unsigned)(U * (2 * CS) + ((xP ^ (U & 15)) << 4) + baseP);
+    }
+    auto issue_tile = [&](int tau) {
+      // stream order (tap, K half, chunk): this workgroup's chunks are NCH consecutive ones of every (tap, K half)
+      const int ts = (tau / NCH) * NCHT + (int)blockIdx.y * NCH + tau % NCH;
+      const unsigned char* tile = wsrc + (int64_t)ts * SLOT;
+      unsigned char* slot = smem + (tau % NS) * SLOT + iw * 1024;
+#pragma unroll
+      for (int q = 0; q < IPT; ++q)
+        __builtin_amdgcn_global_load_lds(tile + voffP[q], (__attribute__((address_space(3))) void*)(slot + q * 4096), 16, 0, 0);
+    };
+    issue_tile(0);
+    if (NT > 1) issue_tile(1);
+    if (RTW == 2) __builtin_amdgcn_s_barrier();                          // X: operand exchange of the compute waves
+    for (int k = 0; k < NT; ++k) {
+      if (k + 1 < NT) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile k landed; tile k+1 may be in flight
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                                      // B(k)
+      if (k + 2 < NT) issue_tile(k + 2);
+    }
+    return;
+  }
+
+  // ================= compute waves =================
+#ifdef MDT_STAMPS   // tuning build: wave 0 of workgroup 0 records the shader clock into the film buffer's tail (never in a real run)
+  unsigned long long* stamps = reinterpret_cast<unsigned long long*>(const_cast<float*>(a.dbgbuf));
+  int nstamp = 0;
+#define MDT_STAMP()                                                                   \
+  do {                                                                                \
+    if (stamps && blockIdx.x == 0 && wave == 0 && nstamp < 60) {                      \
+      unsigned long long t_;                                                          \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");      \
+      if (lane == 0) stamps[nstamp] = t_;                                             \
+      ++nstamp;                                                                       \
+    }                                                                                 \
+  } while (0)
+#else
+#define MDT_STAMP() do {} while (0)
+#endif
+  MDT_STAMP();
+  const int i = lane & 15, g = lane >> 4;
+  const int rt = (RTW == 4) ? wave : (wave >> 1), fh = (RTW == 4) ? 0 : (wave & 1);
+  const int row0 = blockIdx.x * (16 * RTW) + rt * 16;
+  const int m = row0 + i;
+  const bool mvalid = m < a.M;
+  const int mc = mvalid ? m : a.M - 1;
+
+  // ---- the wave's 16 rows: load, (GroupNorm + FiLM + SiLU), split into bf16 hi/lo MFMA operands ----
+  // lane (i, g) holds x[i][32 st + 8 g + e].  RTW = 2: the two waves of a row tile normalise half of the k-steps each
+  // (GroupNorm groups are at most 64 channels wide, a half is 128) and exchange the operands through the LDS of ring
+  // slot 3, which the loaders first touch after barrier B(1).
+  bf16x8 xh[NST], xl[NST];
+  {
+    const int st0 = (RTW == 2) ? fh * NSTW : 0;
+    float xr[NSTW][8];
+    const float* xp = a.x + (int64_t)mc * a.lda + 32 * st0 + 8 * g;
+#pragma unroll
+    for (int st = 0; st < NSTW; ++st) {
+      const float4 u = *reinterpret_cast<const float4*>(xp + 32 * st);
+      const float4 w = *reinterpret_cast<const float4*>(xp + 32 * st + 4);
+      const float sc = mvalid ? a.in_scale : 0.f;
+      xr[st][0] = u.x * sc; xr[st][1] = u.y * sc; xr[st][2] = u.z * sc; xr[st][3] = u.w * sc;
+      xr[st][4] = w.x * sc; xr[st][5] = w.y * sc; xr[st][6] = w.z * sc; xr[st][7] = w.w * sc;
+    }
+    if (a.gsize > 0) {
+      // group statistics over (tokens of the sample) x (gsize channels): the lane's 4-value halves, the lane groups g,
+      // the paired k-steps, then the sample's token lanes.  Stage-major: every stage is one batch of independent
+      // shuffles with a compile-time distance (a dependent chain per value, value after value, cost 30k cycles).
+      const int gs = a.gsize;
+      auto group_sum = [&](float (&s)[NSTW][2]) {
+        if (gs >= 8) {
+#pragma unroll
+          for (int st = 0; st < NSTW; ++st) { const float t = s[st][0] + s[st][1]; s[st][0] = t; s[st][1] = t; }
+        }
+        auto all_lanes = [&](auto fn) {
+#pragma unroll
+          for (int st = 0; st < NSTW; ++st) {
+            s[st][0] = fn(s[st][0]);
+            if (gs >= 8) s[st][1] = s[st][0];          // halves already merged: one shuffle serves both
+            else s[st][1] = fn(s[st][1]);
+          }
+        };
+        if (gs >= 16) all_lanes([](float v) { return v + __shfl_xor(v, 16, 64); });
+        if (gs >= 32) all_lanes([](float v) { return v + __shfl_xor(v, 32, 64); });
+        if (gs >= 64) {
+#pragma unroll
+          for (int st = 0; st + 1 < NSTW; st += 2)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) { const float t = s[st][hf] + s[st + 1][hf]; s[st][hf] = t; s[st + 1][hf] = t; }
+        }
+        if (a.T > 1) all_lanes([](float v) { return v + __shfl_xor(v, 1, 64); });
+        if (a.T > 2) all_lanes([](float v) { return v + __shfl_xor(v, 2, 64); });
+        if (a.T > 4) all_lanes([](float v) { return v + __shfl_xor(v, 4, 64); });
+        if (a.T > 8) all_lanes([](float v) { return v + __shfl_xor(v, 8, 64); });
+      };
+      const float inv_n = 1.0f / (float)(a.T * gs);
+      float mean[NSTW][2], rstd[NSTW][2];
+#pragma unroll
+      for (int st = 0; st < NSTW; ++st) {
+        mean[st][0] = (xr[st][0] + xr[st][1]) + (xr[st][2] + xr[st][3]);
+        mean[st][1] = (xr[st][4] + xr[st][5]) + (xr[st][6] + xr[st][7]);
+      }
+      group_sum(mean);
+#pragma unroll
+      for (int st = 0; st < NSTW; ++st)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          mean[st][hf] *= inv_n;
+          float ss = 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float d = xr[st][4 * hf + e] - mean[st][hf];
+            ss += d * d;
+          }
+          rstd[st][hf] = ss;
+        }
+      group_sum(rstd);
+#pragma unroll
+      for (int st = 0; st < NSTW; ++st)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) rstd[st][hf] = 1.0f / sqrtf(rstd[st][hf] * inv_n + a.eps);
+#pragma unroll
+      for (int st = 0; st < NSTW; ++st)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const int c = 32 * (st0 + st) + 8 * g + 4 * hf;
+          const float4 ga = *reinterpret_cast<const float4*>(a.gamma + c);
+          const float4 be = *reinterpret_cast<const float4*>(a.beta + c);
+          const float g4[4] = {ga.x, ga.y, ga.z, ga.w}, b4[4] = {be.x, be.y, be.z, be.w};
+          float f4[4] = {1.f, 1.f, 1.f, 1.f}, h4[4] = {0.f, 0.f, 0.f, 0.f};
+          if (a.film) {
+            const float4 fs = *reinterpret_cast<const float4*>(a.film + c);
+            const float4 fsh = *reinterpret_cast<const float4*>(a.film + a.film_ld + c);
+            f4[0] = fs.x + 1.0f; f4[1] = fs.y + 1.0f; f4[2] = fs.z + 1.0f; f4[3] = fs.w + 1.0f;
+            h4[0] = fsh.x; h4[1] = fsh.y; h4[2] = fsh.z; h4[3] = fsh.w;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float sc = rstd[st][hf] * g4[e];
+            float t = xr[st][4 * hf + e] * sc + (b4[e] - sc * mean[st][hf]);
+            t = t * f4[e] + h4[e];
+            if (a.silu) t = t * __builtin_amdgcn_rcpf(1.0f + __expf(-t));
+            xr[st][4 * hf + e] = mvalid ? t : 0.f;
+          }
+        }
+    }
+    if constexpr (RTW == 2) {
+      // exchange: [wave][k-step][hi | lo][lane] 16-byte entries; every wave reads back all NST k-steps of its row tile
+      unsigned char* ex = smem + 3 * SLOT;
+#pragma unroll
+      for (int st = 0; st < NSTW; ++st) {
+        bf16x8 h, l;
+        split8_rc(xr[st], h, l);
+        *reinterpret_cast<bf16x8*>(ex + (((wave * NSTW + st) * 2 + 0) * 64 + lane) * 16) = h;
+        *reinterpret_cast<bf16x8*>(ex + (((wave * NSTW + st) * 2 + 1) * 64 + lane) * 16) = l;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                    // X
+#pragma unroll
+      for (int st = 0; st < NST; ++st) {
+        const int src = (2 * rt + st / NSTW) * NSTW + st % NSTW;
+        xh[st] = *reinterpret_cast<const bf16x8*>(ex + ((src * 2 + 0) * 64 + lane) * 16);
+        xl[st] = *reinterpret_cast<const bf16x8*>(ex + ((src * 2 + 1) * 64 + lane) * 16);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // before the loaders may refill slot 3 (after B(1))
+    } else {
+#pragma unroll
+      for (int st = 0; st < NST; ++st) split8_rc(xr[st], xh[st], xl[st]);
+    }
+  }
+  // neighbours inside the sample: row i - 1 exists unless i starts a sample, row i + 1 unless i ends one
+  const bool has_prev = (i % a.T) != 0, has_next_row = (i % a.T) != a.T - 1;
+
+  // fragment addressing inside a tile: row = 16 ft + i, chunk = 4 st + g (C = 128 tile format, k_tblock_lw.hip)
+  int aP[4];
+#pragma unroll
+  for (int st = 0; st < 4; ++st) {
+    const int lc = 4 * st + g;
+    aP[st] = fh * (2 * 16 * 4 * CS) + i * (4 * CS) + ((lc & ~15) | ((lc & 15) ^ i)) * 16;
+  }
+  bf16x8 frh[3][2], frl[3][2];
+  auto frag_read = [&](const unsigned char* slot, int u, int set, int j) {
+    const int q = j >> 1, lo = j & 1;
+    const unsigned char* p = (RTW == 4) ? slot + aP[u >> 1] + ((2 * (u & 1) + q) * 16 * 4 * CS + lo * (2 * CS))
+                                        : slot + aP[u] + (q * 16 * 4 * CS + lo * (2 * CS));
+    lds_read16_rc(lo ? frl[set][q] : frh[set][q], p);
+  };
+  auto slot_of = [&](int t) -> const unsigned char* { return smem + (t % NS) * SLOT; };
+
+  f32x4 acc[NCH][NFT];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int q = 0; q < NFT; ++q) acc[c][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  MDT_STAMP();
+  __builtin_amdgcn_s_barrier();                      // B(0)
+  MDT_STAMP();
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) frag_read(slot_of(0), u, u, j);
+
+  // tiles in stream order; everything below is fully unrolled, so tile index, fragment-set rotation (tau NU mod 3)
+  // and accumulator indices are compile-time
+#pragma unroll
+  for (int tap = 0; tap < TAPS; ++tap) {
+#pragma unroll
+    for (int kh = 0; kh < NKH; ++kh) {
+      MDT_STAMP();
+      bf16x8 oph[4], opl[4];                         // the 4 k-steps of this K half as seen by this tap
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int st = 4 * kh + k;
+        if (TAPS == 1 || tap == 1) { oph[k] = xh[st]; opl[k] = xl[st]; }
+        else if (tap == 0) { oph[k] = row_shift<true>(xh[st], has_prev); opl[k] = row_shift<true>(xl[st], has_prev); }
+        else { oph[k] = row_shift<false>(xh[st], has_next_row); opl[k] = row_shift<false>(xl[st], has_next_row); }
+      }
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int tau = (tap * NKH + kh) * NCH + c;
+        const int off = (tau * NU) % 3;
+        const bool more = tau + 1 < NT;
+        const unsigned char* cur = slot_of(tau);
+        const unsigned char* nxt = slot_of(tau + 1);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          if (u == NU - 2 && more) {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();            // B(tau + 1)
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          const int s0 = (off + u) % 3, s2 = (off + u + 2) % 3;
+          const bool in_tile = u + 2 < NU;
+          const bool pre = in_tile || more;
+          const bool later = (u + 1 < NU) || more;
+          if (later) lgkm_wait_rc<4>(); else lgkm_wait_rc<0>();
+          const int ia = (RTW == 4) ? 2 * (u & 1) : 0, ib = (RTW == 4) ? (u >> 1) : u;
+          auto rd = [&](int j) {
+            if (!pre) return;
+            __builtin_amdgcn_sched_barrier(0);
+            if (in_tile) frag_read(cur, u + 2, s2, j);
+            else frag_read(nxt, u + 2 - NU, s2, j);
+            __builtin_amdgcn_sched_barrier(0);
+          };
+          auto mm = [&](const bf16x8& w, const bf16x8& x, int q) {
+            acc[c][ia + q] = MDT_MFMA_BF16(w, x, acc[c][ia + q], 0, 0, 0);
+          };
+          mm(frl[s0][0], oph[ib], 0); rd(0);
+          mm(frl[s0][1], oph[ib], 1); rd(1);
+          mm(frh[s0][0], opl[ib], 0); rd(2);
+          mm(frh[s0][1], opl[ib], 1); rd(3);
+          mm(frh[s0][0], oph[ib], 0);
+          mm(frh[s0][1], oph[ib], 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  }
+
+  MDT_STAMP();
+  // ---- out[m][64 c + 16 ft + 4 g + r] = acc + bias (+ res) ----
+  if (mvalid) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int q = 0; q < NFT; ++q) {
+        const int f = 64 * ((int)blockIdx.y * NCH + c) + 16 * (NFT * fh + q) + 4 * g;
+        float4 y = make_float4(acc[c][q][0], acc[c][q][1], acc[c][q][2], acc[c][q][3]);
+        if (a.bias) {
+          const float4 b = *reinterpret_cast<const float4*>(a.bias + f);
+          y.x += b.x; y.y += b.y; y.z += b.z; y.w += b.w;
+        }
+        if (a.res) {
+          const float4 r = *reinterpret_cast<const float4*>(a.res + (int64_t)m * a.ldr + f);
+          y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w;
+        }
+        *reinterpret_cast<float4*>(a.out + (int64_t)m * a.ldc + f) = y;
+      }
+  }
+}
+
+template <int RTW, int C, int TAPS, int NSPLIT>
+static hipError_t launch_rc(const RConvArgs& a, hipStream_t s) {
+  const size_t smem = (size_t)NS * SLOT;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rconv<RTW, C, TAPS, NSPLIT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+    attr_set = true;
+  }
+  const int rows = 16 * RTW;
+  hipLaunchKernelGGL((k_rconv<RTW, C, TAPS, NSPLIT>), dim3((unsigned)((a.M + rows - 1) / rows), NSPLIT), dim3(512), smem, s, a);
+  return hipGetLastError();
+}
+
+bool rconv_supported(int C, int T, int taps, int gsize) {
+  if (C != 128 && C != 256) return false;
+  if (T <= 0 || 16 % T || (taps != 1 && taps != 3)) return false;
+  return gsize == 0 || gsize == 4 || gsize == 8 || gsize == 16 || gsize == 32 || gsize == 64;
+}
+
+hipError_t launch_rconv(const RConvArgs& a, hipStream_t s) {
+  if (a.M <= 0) return hipSuccess;
+  if (!rconv_supported(a.C, a.T, a.taps, a.gsize) || (a.gsize > 0 && (!a.gamma || !a.beta))) return hipErrorInvalidValue;
+  // C = 128: 64-row workgroups (wave = row tile); C = 256: 32-row workgroups, features split over wave pairs (the
+  // 64-row form needs 64 operand + 64 accumulator + 32 shifted-operand registers per lane and spills)
+  if (a.C == 128) return a.taps == 3 ? launch_rc<4, 128, 3, 1>(a, s) : launch_rc<4, 128, 1, 1>(a, s);
+  // two workgroups per row block (each half of the output channels) while that still fits one wave of workgroups
+  if ((a.M + 31) / 32 <= 128) return a.taps == 3 ? launch_rc<2, 256, 3, 2>(a, s) : launch_rc<2, 256, 1, 2>(a, s);
+  return a.taps == 3 ? launch_rc<2, 256, 3, 1>(a, s) : launch_rc<2, 256, 1, 1>(a, s);
+}
+
+}  // namespace mdt

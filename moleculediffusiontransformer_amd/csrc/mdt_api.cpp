@@ -81,6 +81,12 @@ static const char* validate(const mdt_op& o, int idx, char* buf, size_t nbuf) {
         return bad("shape not supported by the fused GroupNorm-apply kernel");
       if (!o.a.space || !o.out.space || !o.p0.space || !o.p1.space) return bad("missing operand");
       break;
+    case MDT_OP_RCONV:
+      if (!mdt::rconv_supported(o.i[MDT_R_C], o.i[MDT_R_T], o.i[MDT_R_TAPS], o.i[MDT_R_GSIZE]))
+        return bad("shape not supported by the row-stationary convolution");
+      if (!o.a.space || !o.w.space || !o.out.space) return bad("missing operand");
+      if (o.i[MDT_R_GSIZE] > 0 && (!o.p0.space || !o.p1.space)) return bad("GroupNorm prologue needs gain and bias");
+      break;
     case MDT_OP_ATTN:
       if (o.i[MDT_A_T] <= 0 || o.i[MDT_A_T] > 64 || o.i[MDT_A_TK] <= 0 || o.i[MDT_A_TK] > 64)
         return bad("attention supports 1..64 queries and keys per sample");
@@ -204,6 +210,16 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
         a.batch = B; a.rows = o.i[MDT_N_ROWS]; a.ld = o.i[MDT_N_LD]; a.groups = o.i[MDT_N_GROUPS];
         a.gsize = o.i[MDT_N_GSIZE]; a.silu = o.i[MDT_N_SILU]; a.eps = o.f[MDT_NF_EPS];
         if (!missing) e = mdt::launch_gn_act(a, stream);
+        break;
+      }
+      case MDT_OP_RCONV: {
+        mdt::RConvArgs a;
+        a.x = ptr(o.a); a.w = ptr(o.w); a.bias = ptr(o.bias); a.res = ptr(o.res); a.out = ptr(o.out);
+        a.gamma = ptr(o.p0); a.beta = ptr(o.p1); a.film = ptr(o.p3); a.dbgbuf = ptr(o.p2);
+        a.T = o.i[MDT_R_T]; a.M = B * a.T; a.C = o.i[MDT_R_C]; a.lda = o.i[MDT_R_LDA]; a.ldc = o.i[MDT_R_LDC];
+        a.ldr = o.i[MDT_R_LDR]; a.taps = o.i[MDT_R_TAPS]; a.gsize = o.i[MDT_R_GSIZE]; a.silu = o.i[MDT_R_SILU];
+        a.film_ld = o.i[MDT_R_FILM_LD]; a.eps = o.f[MDT_RF_EPS]; a.in_scale = o.f[MDT_RF_IN_SCALE];
+        if (!missing) e = mdt::launch_rconv(a, stream);
         break;
       }
       case MDT_OP_ATTN: {

@@ -47,6 +47,23 @@ struct GnActArgs {
 bool gn_act_eligible(int rows, int ld, int groups, int gsize);
 hipError_t launch_gn_act(const GnActArgs& a, hipStream_t s);
 
+// MDT_OP_RCONV (k_rconv.hip): GroupNorm + FiLM + SiLU + Conv1d(k = 1 | 3) with C input and C output channels
+struct RConvArgs {
+  const float* x;      // [M][lda]
+  const float* w;      // weight tiles [64 features][128 k], order (tap, K half, feature chunk)
+  const float* bias;   // [C] or nullptr
+  const float* res;    // [M][ldr] added to the result, or nullptr (may alias out)
+  float* out;          // [M][ldc]
+  const float* gamma;  // GroupNorm gain / bias of the C input channels (gsize > 0)
+  const float* beta;
+  const float* film;   // [scale | shift] rows film_ld apart, or nullptr
+  const float* dbgbuf; // diagnostic stamps (tuning builds), normally nullptr
+  int M, T, C, lda, ldc, ldr, taps, gsize, silu, film_ld;
+  float eps, in_scale;
+};
+bool rconv_supported(int C, int T, int taps, int gsize);
+hipError_t launch_rconv(const RConvArgs& a, hipStream_t s);
+
 struct AttnArgs {
   const float* q;
   const float* k;  // v = k + heads*64

@@ -110,6 +110,8 @@ def run_program(ops, bufs: Buffers, B: int, n_shared_rows: int = 0) -> None:
             if i[rt.N_SILU]:
                 y = _silu(y)
             bufs.view(op.out, B, B * rows * ld).view(B, rows, ld)[:] = y
+        elif op.kind == rt.OP_RCONV:
+            _rconv(op, bufs, B)
         elif op.kind == rt.OP_ATTN:
             T, Tk, H = i[rt.A_T], i[rt.A_TK], i[rt.A_HEADS]
             ldq, ldkv, ldo, bs = i[rt.A_LDQ], i[rt.A_LDKV], i[rt.A_LDO], i[rt.A_KV_BSTRIDE]
@@ -169,6 +171,38 @@ def _untile(stream: torch.Tensor, k: int, rows: int, cols: int) -> torch.Tensor:
     n = rows * cols                       # bf16 elements per plane; tile = 2 n bf16 = n floats
     raw = stream[k * n: (k + 1) * n].contiguous().view(torch.bfloat16)
     return (raw[:n].float() + raw[n:].float()).view(rows, cols)
+
+
+def _rconv(op, bufs: Buffers, B: int) -> None:
+    """MDT_OP_RCONV semantics (include/mdt_hip.h): GroupNorm + FiLM + SiLU + Conv1d(k = 1 | 3), C -> C channels,
+    weights reconstructed from the packed tiles ([64 features][128 k], order tap / K half / feature chunk)."""
+    i, f = op.i, op.f
+    T, C, lda, ldc, ldr, taps, gs = (i[rt.R_T], i[rt.R_C], i[rt.R_LDA], i[rt.R_LDC], i[rt.R_LDR], i[rt.R_TAPS],
+                                     i[rt.R_GSIZE])
+    x = bufs.view(op.a, B, B * T * lda).view(B, T, lda)[:, :, :C] * float(f[1])
+    if gs > 0:
+        y = F.group_norm(x.transpose(1, 2), C // gs, bufs.view(op.p0, B, C), bufs.view(op.p1, B, C), float(f[0])).transpose(1, 2)
+        if op.p3.space != rt.SP_NONE:
+            ss = bufs.view(op.p3, B, i[rt.R_FILM_LD] + C)
+            y = y * (ss[:C] + 1.0) + ss[i[rt.R_FILM_LD]: i[rt.R_FILM_LD] + C]
+        if i[rt.R_SILU]:
+            y = _silu(y)
+    else:
+        y = x
+    nkh, nch = C // 128, C // 64
+    stream = bufs.view(op.w, B, taps * C * C)
+    w = torch.empty(C, C, taps)
+    k = 0
+    for tap in range(taps):
+        for kh in range(nkh):
+            for ch in range(nch):
+                w[64 * ch: 64 * ch + 64, 128 * kh: 128 * kh + 128, tap] = _untile(stream, k, 64, 128)
+                k += 1
+    bias = bufs.view(op.bias, B, C) if op.bias.space != rt.SP_NONE else None
+    o = F.conv1d(y.transpose(1, 2), w, bias, padding=taps // 2).transpose(1, 2)
+    if op.res.space != rt.SP_NONE:
+        o = o + bufs.view(op.res, B, B * T * ldr).view(B, T, ldr)[:, :, :C]
+    bufs.view(op.out, B, B * T * ldc).view(B, T, ldc)[:, :, :C] = o
 
 
 def _tblock(op, bufs: Buffers, B: int) -> None:

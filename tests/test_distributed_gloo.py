@@ -28,7 +28,8 @@ def _worker(rank, world, port, total, q):
         out = sample_sharded(_fake_local_sample, seq)
         lo, hi = shard_bounds(total, world, rank)
         again = all_gather_samples(_fake_local_sample(seq[lo:hi], lo), total)
-        q.put((rank, out, again))
+        q.put((rank, out.numpy(), again.numpy()))    # by value: a tensor would travel as a shared-memory handle that
+                                                      # dies with this process if the parent is slow to open it
     finally:
         dist.destroy_process_group()
 
@@ -50,7 +51,7 @@ def test_two_rank_result_equals_single_rank(total):
     seq = torch.arange(total * 4, dtype=torch.float32).view(total, 4) * 0.01
     want = _fake_local_sample(seq, 0)
     for rank, out, again in results:
-        assert torch.equal(out, want) and torch.equal(again, want), rank
+        assert torch.equal(torch.from_numpy(out), want) and torch.equal(torch.from_numpy(again), want), rank
 
 
 def test_shard_bounds_cover_the_batch():

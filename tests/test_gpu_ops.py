@@ -389,3 +389,53 @@ def test_gn_act(B, R, C, G, film, silu, eps):
     if silu:
         h = torch.nn.functional.silu(h)
     assert (ga[B * R * C:].view(B, R, C) - h.transpose(1, 2)).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("C,T,B,taps,gsize,film,silu,res,in_scale", [
+    (128, 16, 5, 3, 16, True, True, "other", 1.0),     # ResnetBlock1d block2 at the 128-channel level (FiLM, residual)
+    (128, 16, 70, 3, 32, False, True, None, 0.7071),   # half of a concatenated block1 input (skip scaling)
+    (256, 4, 37, 3, 32, True, True, "other", 1.0),
+    (256, 4, 9, 3, 64, False, True, "accumulate", 0.7071),   # second half: accumulates into the first half's output
+    (256, 4, 16, 1, 8, False, False, None, 1.0),       # Transformer1d to_in: GroupNorm(32 groups, eps 1e-6) + 1x1 conv
+    (128, 16, 3, 1, 4, False, False, None, 1.0),
+    (128, 8, 6, 1, 0, False, False, "accumulate", 1.0),      # plain 1x1 conv (to_out), 8 tokens per sample
+    (256, 1, 33, 3, 32, False, True, None, 1.0),       # one token per sample: both neighbours are padding
+])
+def test_row_stationary_conv(C, T, B, taps, gsize, film, silu, res, in_scale):
+    """k_rconv (GroupNorm + FiLM + SiLU prologue, DPP-shifted taps, loader-wave weight ring) against the interpreter
+    and against torch's group_norm / conv1d."""
+    from moleculediffusiontransformer_amd.compiler import Ten, UNetCompiler
+    from moleculediffusiontransformer_amd.netspec import inverse_unet_config
+    comp = UNetCompiler(inverse_unet_config(16, 64, 128, 12), 64, 12, {})
+    w = rnd(C, C, taps, seed=1, scale=(C * taps) ** -0.5)
+    gb = torch.cat([1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3), 0.1 * rnd(C, seed=5)])   # gain | beta | conv bias
+    g_off = comp.W.add("gb", gb)
+    x, out, other = Ten(A, 0, T, C), Ten(A, T * C, T, C), Ten(A, 2 * T * C, T, C)
+    eps = 1e-6 if taps == 1 else 1e-5
+    comp.rconv(x, w, "w", out, taps=taps, bias_off=None if res == "accumulate" else g_off + 2 * C,
+               res={"other": other, "accumulate": out, None: None}[res],
+               gn=(g_off, g_off + C, gsize, eps, silu) if gsize else None, in_scale=in_scale)
+    op = comp.ops[0]
+    if film:
+        op.p3 = ref(S, 0)
+    shr = 0.3 * rnd(2 * C, seed=9)
+    act = torch.cat([rnd(B * T * C, seed=4) * 1.5 + 0.3, rnd(B * T * C, seed=6), rnd(B * T * C, seed=7)])
+    (ga, _, _), (ca, _, _) = run_both([op], comp.W.pack(), act, shr, {}, B)
+    og, oc = ga[B * T * C: 2 * B * T * C], ca[B * T * C: 2 * B * T * C]
+    scale = max(1.0, oc.abs().max().item())
+    assert torch.isfinite(og).all() and (og - oc).abs().max() < 1e-4 * scale, (og - oc).abs().max().item()
+    assert torch.equal(ga[: B * T * C], ca[: B * T * C]) and torch.equal(ga[2 * B * T * C:], ca[2 * B * T * C:])
+    # independent closed form
+    h = (act[: B * T * C].view(B, T, C) * in_scale).transpose(1, 2)
+    if gsize:
+        h = torch.nn.functional.group_norm(h, C // gsize, gb[:C], gb[C: 2 * C], eps)
+        if film:
+            h = h * (shr[:C].view(1, C, 1) + 1) + shr[C:].view(1, C, 1)
+        if silu:
+            h = torch.nn.functional.silu(h)
+    y = torch.nn.functional.conv1d(h, w, None if res == "accumulate" else gb[2 * C:], padding=taps // 2).transpose(1, 2)
+    if res == "other":
+        y = y + act[2 * B * T * C:].view(B, T, C)
+    elif res == "accumulate":
+        y = y + act[B * T * C: 2 * B * T * C].view(B, T, C)
+    assert (og.view(B, T, C) - y).abs().max() < 1e-4 * scale

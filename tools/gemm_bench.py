@@ -14,6 +14,7 @@ SHAPES_ALL = [  # (rows/sample R, B, cin, taps, N, pro)
     (4, 1024, 512, 1, 256, 0), (4, 1024, 256, 1, 512, 1), (4, 1024, 256, 1, 1024, 1), (16, 1024, 128, 1, 1024, 1),
     (16, 1024, 128, 1, 512, 1), (16, 1024, 512, 1, 128, 0), (4, 1024, 256, 3, 256, 2), (16, 1024, 128, 3, 128, 2),
     (16, 1024, 256, 1, 128, 0), (4, 1024, 256, 1, 512, 0),
+    (4, 1024, 256, 3, 256, 0), (16, 1024, 128, 3, 128, 0), (4, 1024, 512, 3, 256, 0), (16, 1024, 256, 3, 128, 0),   # 10-13: resnet convs
 ]
 SHAPES = [SHAPES_ALL[int(i)] for i in os.environ["SHAPES"].split(",")] if os.environ.get("SHAPES") else SHAPES_ALL
 

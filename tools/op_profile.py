@@ -58,6 +58,10 @@ def main():
             fl = 0
             desc = f"GNACT rows={i[rt.N_ROWS]} ld={i[rt.N_LD]} G={i[rt.N_GROUPS]}"
             key = desc
+        elif op.kind == rt.OP_RCONV:
+            fl = 2.0 * B * i[rt.R_T] * i[rt.R_C] * i[rt.R_C] * i[rt.R_TAPS]
+            desc = f"RCONV T={i[rt.R_T]} C={i[rt.R_C]} taps={i[rt.R_TAPS]} gsize={i[rt.R_GSIZE]} res={int(op.res.space != 0)}"
+            key = desc
         elif op.kind == rt.OP_TBLOCK:
             fl = 0
             desc = f"TBLK  mode={i[rt.B_MODE]} C={i[rt.B_C]} T={i[rt.B_T]}"
