@@ -239,8 +239,13 @@ def main():
             nz = [synth_normal(f"bench/cpu/step{i}", (cb, 16, 64)) for i in range(ct - 1)]
             O.sample(sd, cfg, cseq[:4], init[:4], lambda i, x: nz[i][:4], 3, 1.0, False)   # warm-up
             c0 = time.perf_counter()
-            O.sample(sd, cfg, cseq, init, lambda i, x: nz[i], ct, 1.0, False)
+            cpu_out = O.sample(sd, cfg, cseq, init, lambda i, x: nz[i], ct, 1.0, False)
             cdt = time.perf_counter() - c0
+            # the same bounded sample through the HIP path on the identical noise: the checker of this run
+            hip_out = model.sample(cseq, device, cond_scale=1.0, timesteps=ct, clamp=False,
+                                   noise=NoiseSource(init=init, steps=lambda i: nz[i])).cpu()
+            result["parity"] = {"max_abs_vs_cpu_reference_path": float((hip_out - cpu_out).abs().max()),
+                                "tolerance": 1e-4, "sample": f"batch {cb}, {ct} timesteps, identical noise"}
             per_eval = cdt / (2 * (ct - 1))
             result["cpu_baseline"] = {
                 "value": round(cb / (per_eval * evals), 3), "unit": "molecules/s", "cores": torch.get_num_threads(),
