@@ -67,6 +67,8 @@ enum mdt_op_kind {
                           p1 = bias, p3 = [scale | shift] or none; ints as MDT_OP_GN_STATS plus MDT_N_SILU        */
   MDT_OP_RCONV = 9,    /* row-stationary Conv1d (k = 1 | 3, C -> C channels, C in {128, 256}) with the ConvBlock1d prologue
                           computed in the kernel: out = bias + conv(silu(gn(s * a) * (scale + 1) + shift)) (+ res);
+                          with a2 the input is cat([s * a, s2 * a2]) (2C channels, GroupNorm groups inside a half; the second
+                          half's gain / bias / weight tiles follow the first's);
                           a, w = weight tiles, bias | none, out, res | none, p0 = gain, p1 = bias of the GroupNorm | none,
                           p3 = [scale | shift] | none (modules.py:117-121, :193-205)                             */
   MDT_OP_TBLOCK = 7    /* fused transformer sub-block, in place on x (TransformerBlock.forward, modules.py:456-461):
@@ -115,8 +117,9 @@ enum mdt_gn_f { MDT_NF_EPS = 0 };
 
 enum mdt_rconv_i { MDT_R_T = 0, MDT_R_C = 1, MDT_R_LDA = 2, MDT_R_LDC = 3, MDT_R_LDR = 4, MDT_R_TAPS = 5,
                    MDT_R_GSIZE = 6 /* channels per GroupNorm group, 0 = no normalisation */, MDT_R_SILU = 7,
-                   MDT_R_FILM_LD = 8 /* floats between the scale and the shift row */ };
-enum mdt_rconv_f { MDT_RF_EPS = 0, MDT_RF_IN_SCALE = 1 };
+                   MDT_R_FILM_LD = 8 /* floats between the scale and the shift row */,
+                   MDT_R_LDA2 = 9 /* floats per row of the second source (a2), if any */ };
+enum mdt_rconv_f { MDT_RF_EPS = 0, MDT_RF_IN_SCALE = 1, MDT_RF_IN_SCALE2 = 2 };
 
 enum mdt_attn_i {
   MDT_A_T = 0, MDT_A_TK = 1, MDT_A_HEADS = 2, MDT_A_LDQ = 3, MDT_A_LDKV = 4, MDT_A_LDO = 5,

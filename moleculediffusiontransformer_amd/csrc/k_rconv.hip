@@ -4,8 +4,9 @@
 //   xn  = silu( GroupNorm(xn) * (scale + 1) + shift )               (ConvBlock1d.forward, modules.py:117-121; optional)
 //   out = bias + sum_tap W[:, tap, :] xn[t + tap - taps/2]  (+ res)  (Conv1d k = 1 | 3, zero padding inside the sample)
 //
-// with C input and C output channels per launch (a 2C-channel concatenated input is two launches, the second
-// accumulating through `res`; GroupNorm groups never straddle the two halves).
+// with C output channels and one or two C-channel input sources per launch: the 2C-channel input cat([x, s * skip])
+// of the up path is never materialised, the launch runs prologue + taps for source a, then for source b, into the
+// same accumulators (GroupNorm groups never straddle the two halves; b's gain/bias/weight tiles follow a's).
 //
 // Why not the tiled GEMM (k_gemm_bf16x3.hip): at B = 1024 these layers are 4096..16384 rows x 128..256 columns,
 // one 64x64 tile per CU, and the tiled kernel spends ~1800 cycles per 32-deep k-step on load -> LDS -> MFMA
@@ -78,7 +79,7 @@ __device__ __forceinline__ bf16x8 row_shift(const bf16x8& v, bool keep) {
 
 // NSPLIT workgroups (blockIdx.y) share a row block, each producing C / NSPLIT of the output channels: no reduction,
 // half the weight stream per workgroup, twice the workgroups (the 4096-row level has only 128 row blocks).
-template <int RTW, int C, int TAPS, int NSPLIT>
+template <int RTW, int C, int TAPS, int NSPLIT, int NSRC>
 __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
   constexpr int NST = C / 32;               // k-steps of the input channels
   constexpr int NKH = C / CS;               // K halves (tiles per tap per chunk)
@@ -88,6 +89,9 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
   constexpr int NU = 2 * NFT;               // units (4 fragment reads + 6 MFMAs) per tile per wave
   constexpr int NT = TAPS * NKH * NCH;      // tiles of this workgroup
   constexpr int NSTW = (RTW == 2) ? NST / 2 : NST;   // k-steps normalised by this wave (RTW = 2: the wave pair splits them)
+  constexpr int NTF = TAPS * NKH * NCHT;    // tiles per source in the stream (all workgroups)
+  constexpr int nsrc = NSRC;                // input sources (2: a concatenated input, never materialised)
+  constexpr int TT = nsrc * NT;             // tiles this workgroup consumes
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -109,7 +113,8 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
     }
     auto issue_tile = [&](int tau) {
       // stream order (tap, K half, chunk): this workgroup's chunks are NCH consecutive ones of every (tap, K half)
-      const int ts = (tau / NCH) * NCHT + (int)blockIdx.y * NCH + tau % NCH;
+      const int tl = tau % NT;
+      const int ts = (tau / NT) * NTF + (tl / NCH) * NCHT + (int)blockIdx.y * NCH + tl % NCH;
       const unsigned char* tile = wsrc + (int64_t)ts * SLOT;
       unsigned char* slot = smem + (tau % NS) * SLOT + iw * 1024;
 #pragma unroll
@@ -117,13 +122,14 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
         __builtin_amdgcn_global_load_lds(tile + voffP[q], (__attribute__((address_space(3))) void*)(slot + q * 4096), 16, 0, 0);
     };
     issue_tile(0);
-    if (NT > 1) issue_tile(1);
+    if (TT > 1) issue_tile(1);
     if (RTW == 2) __builtin_amdgcn_s_barrier();                          // X: operand exchange of the compute waves
-    for (int k = 0; k < NT; ++k) {
-      if (k + 1 < NT) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile k landed; tile k+1 may be in flight
+    for (int k = 0; k < TT; ++k) {
+      if (k + 1 < TT) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile k landed; tile k+1 may be in flight
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                                      // B(k)
-      if (k + 2 < NT) issue_tile(k + 2);
+      if (k + 2 < TT) issue_tile(k + 2);
+      if (RTW == 2 && k == NT && nsrc == 2) __builtin_amdgcn_s_barrier();   // X of the second source (follows B(NT))
     }
     return;
   }
@@ -152,20 +158,52 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
   const bool mvalid = m < a.M;
   const int mc = mvalid ? m : a.M - 1;
 
+  // neighbours inside the sample: row i - 1 exists unless i starts a sample, row i + 1 unless i ends one
+  const bool has_prev = (i % a.T) != 0, has_next_row = (i % a.T) != a.T - 1;
+
+  // fragment addressing inside a tile: row = 16 ft + i, chunk = 4 st + g (C = 128 tile format, k_tblock_lw.hip)
+  int aP[4];
+#pragma unroll
+  for (int st = 0; st < 4; ++st) {
+    const int lc = 4 * st + g;
+    aP[st] = fh * (2 * 16 * 4 * CS) + i * (4 * CS) + ((lc & ~15) | ((lc & 15) ^ i)) * 16;
+  }
+  bf16x8 frh[3][2], frl[3][2];
+  auto frag_read = [&](const unsigned char* slot, int u, int set, int j) {
+    const int q = j >> 1, lo = j & 1;
+    const unsigned char* p = (RTW == 4) ? slot + aP[u >> 1] + ((2 * (u & 1) + q) * 16 * 4 * CS + lo * (2 * CS))
+                                        : slot + aP[u] + (q * 16 * 4 * CS + lo * (2 * CS));
+    lds_read16_rc(lo ? frl[set][q] : frh[set][q], p);
+  };
+  auto slot_of = [&](int t) -> const unsigned char* { return smem + (t % NS) * SLOT; };
+
+  f32x4 acc[NCH][NFT];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int q = 0; q < NFT; ++q) acc[c][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+  for (int src = 0; src < nsrc; ++src) {
+  const float* xsrc = src ? a.x2 : a.x;
+  const int lda = src ? a.lda2 : a.lda;
+  const float in_scale = src ? a.in_scale2 : a.in_scale;
+  const float* gamma = a.gamma + src * C;            // source b's gain / bias follow source a's
+  const float* beta = a.beta + src * C;
   // ---- the wave's 16 rows: load, (GroupNorm + FiLM + SiLU), split into bf16 hi/lo MFMA operands ----
   // lane (i, g) holds x[i][32 st + 8 g + e].  RTW = 2: the two waves of a row tile normalise half of the k-steps each
-  // (GroupNorm groups are at most 64 channels wide, a half is 128) and exchange the operands through the LDS of ring
-  // slot 3, which the loaders first touch after barrier B(1).
+  // (GroupNorm groups are at most 64 channels wide, a half is 128) and exchange the operands through 32 KB of LDS
+  // behind the ring.
   bf16x8 xh[NST], xl[NST];
   {
     const int st0 = (RTW == 2) ? fh * NSTW : 0;
     float xr[NSTW][8];
-    const float* xp = a.x + (int64_t)mc * a.lda + 32 * st0 + 8 * g;
+    const float* xp = xsrc + (int64_t)mc * lda + 32 * st0 + 8 * g;
 #pragma unroll
     for (int st = 0; st < NSTW; ++st) {
       const float4 u = *reinterpret_cast<const float4*>(xp + 32 * st);
       const float4 w = *reinterpret_cast<const float4*>(xp + 32 * st + 4);
-      const float sc = mvalid ? a.in_scale : 0.f;
+      const float sc = mvalid ? in_scale : 0.f;
       xr[st][0] = u.x * sc; xr[st][1] = u.y * sc; xr[st][2] = u.z * sc; xr[st][3] = u.w * sc;
       xr[st][4] = w.x * sc; xr[st][5] = w.y * sc; xr[st][6] = w.z * sc; xr[st][7] = w.w * sc;
     }
@@ -231,8 +269,8 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
           const int c = 32 * (st0 + st) + 8 * g + 4 * hf;
-          const float4 ga = *reinterpret_cast<const float4*>(a.gamma + c);
-          const float4 be = *reinterpret_cast<const float4*>(a.beta + c);
+          const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
+          const float4 be = *reinterpret_cast<const float4*>(beta + c);
           const float g4[4] = {ga.x, ga.y, ga.z, ga.w}, b4[4] = {be.x, be.y, be.z, be.w};
           float f4[4] = {1.f, 1.f, 1.f, 1.f}, h4[4] = {0.f, 0.f, 0.f, 0.f};
           if (a.film) {
@@ -253,7 +291,7 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
     }
     if constexpr (RTW == 2) {
       // exchange: [wave][k-step][hi | lo][lane] 16-byte entries; every wave reads back all NST k-steps of its row tile
-      unsigned char* ex = smem + 3 * SLOT;
+      unsigned char* ex = smem + NS * SLOT;            // 32 KB behind the ring
 #pragma unroll
       for (int st = 0; st < NSTW; ++st) {
         bf16x8 h, l;
@@ -269,44 +307,21 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
         xh[st] = *reinterpret_cast<const bf16x8*>(ex + ((src * 2 + 0) * 64 + lane) * 16);
         xl[st] = *reinterpret_cast<const bf16x8*>(ex + ((src * 2 + 1) * 64 + lane) * 16);
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // before the loaders may refill slot 3 (after B(1))
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     } else {
 #pragma unroll
       for (int st = 0; st < NST; ++st) split8_rc(xr[st], xh[st], xl[st]);
     }
   }
-  // neighbours inside the sample: row i - 1 exists unless i starts a sample, row i + 1 unless i ends one
-  const bool has_prev = (i % a.T) != 0, has_next_row = (i % a.T) != a.T - 1;
-
-  // fragment addressing inside a tile: row = 16 ft + i, chunk = 4 st + g (C = 128 tile format, k_tblock_lw.hip)
-  int aP[4];
+  MDT_STAMP();
+  if (src == 0) {
+    __builtin_amdgcn_s_barrier();                    // B(0)
 #pragma unroll
-  for (int st = 0; st < 4; ++st) {
-    const int lc = 4 * st + g;
-    aP[st] = fh * (2 * 16 * 4 * CS) + i * (4 * CS) + ((lc & ~15) | ((lc & 15) ^ i)) * 16;
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) frag_read(slot_of(0), u, u, j);
   }
-  bf16x8 frh[3][2], frl[3][2];
-  auto frag_read = [&](const unsigned char* slot, int u, int set, int j) {
-    const int q = j >> 1, lo = j & 1;
-    const unsigned char* p = (RTW == 4) ? slot + aP[u >> 1] + ((2 * (u & 1) + q) * 16 * 4 * CS + lo * (2 * CS))
-                                        : slot + aP[u] + (q * 16 * 4 * CS + lo * (2 * CS));
-    lds_read16_rc(lo ? frl[set][q] : frh[set][q], p);
-  };
-  auto slot_of = [&](int t) -> const unsigned char* { return smem + (t % NS) * SLOT; };
-
-  f32x4 acc[NCH][NFT];
-#pragma unroll
-  for (int c = 0; c < NCH; ++c)
-#pragma unroll
-    for (int q = 0; q < NFT; ++q) acc[c][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-
   MDT_STAMP();
-  __builtin_amdgcn_s_barrier();                      // B(0)
-  MDT_STAMP();
-#pragma unroll
-  for (int u = 0; u < 2; ++u)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) frag_read(slot_of(0), u, u, j);
 
   // tiles in stream order; everything below is fully unrolled, so tile index, fragment-set rotation (tau NU mod 3)
   // and accumulator indices are compile-time
@@ -325,16 +340,16 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
       }
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
-        const int tau = (tap * NKH + kh) * NCH + c;
+        const int tau = (tap * NKH + kh) * NCH + c;       // tile within this source (compile-time)
         const int off = (tau * NU) % 3;
-        const bool more = tau + 1 < NT;
-        const unsigned char* cur = slot_of(tau);
-        const unsigned char* nxt = slot_of(tau + 1);
+        const bool more = (tau + 1 < NT) || (src + 1 < nsrc);
+        const unsigned char* cur = slot_of(src * NT + tau);
+        const unsigned char* nxt = slot_of(src * NT + tau + 1);
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
           if (u == NU - 2 && more) {
             __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();            // B(tau + 1)
+            __builtin_amdgcn_s_barrier();            // B(src NT + tau + 1)
             __builtin_amdgcn_sched_barrier(0);
           }
           const int s0 = (off + u) % 3, s2 = (off + u + 2) % 3;
@@ -365,6 +380,22 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
     }
   }
 
+  if (src + 1 < nsrc && (NT * NU) % 3 != 0) {
+    // the next source's code expects units 0 / 1 of its first tile in fragment sets 0 / 1
+    constexpr int R = (NT * NU) % 3;
+    bf16x8 th[3][2], tl[3][2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) { th[j][q] = frh[(j + R) % 3][q]; tl[j][q] = frl[(j + R) % 3][q]; }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the in-flight prefetch writes the old sets
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) { frh[j][q] = th[j][q]; frl[j][q] = tl[j][q]; }
+  }
+  }   // sources
+
   MDT_STAMP();
   // ---- out[m][64 c + 16 ft + 4 g + r] = acc + bias (+ res) ----
   if (mvalid) {
@@ -387,18 +418,23 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
   }
 }
 
-template <int RTW, int C, int TAPS, int NSPLIT>
-static hipError_t launch_rc(const RConvArgs& a, hipStream_t s) {
-  const size_t smem = (size_t)NS * SLOT;
+template <int RTW, int C, int TAPS, int NSPLIT, int NSRC>
+static hipError_t launch_rc2(const RConvArgs& a, hipStream_t s) {
+  const size_t smem = (size_t)NS * SLOT + (RTW == 2 ? SLOT : 0);      // ring (+ operand exchange area)
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rconv<RTW, C, TAPS, NSPLIT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rconv<RTW, C, TAPS, NSPLIT, NSRC>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
     attr_set = true;
   }
   const int rows = 16 * RTW;
-  hipLaunchKernelGGL((k_rconv<RTW, C, TAPS, NSPLIT>), dim3((unsigned)((a.M + rows - 1) / rows), NSPLIT), dim3(512), smem, s, a);
+  hipLaunchKernelGGL((k_rconv<RTW, C, TAPS, NSPLIT, NSRC>), dim3((unsigned)((a.M + rows - 1) / rows), NSPLIT), dim3(512), smem, s, a);
   return hipGetLastError();
+}
+
+template <int RTW, int C, int TAPS, int NSPLIT>
+static hipError_t launch_rc(const RConvArgs& a, hipStream_t s) {
+  return a.x2 ? launch_rc2<RTW, C, TAPS, NSPLIT, 2>(a, s) : launch_rc2<RTW, C, TAPS, NSPLIT, 1>(a, s);
 }
 
 bool rconv_supported(int C, int T, int taps, int gsize) {
@@ -410,6 +446,7 @@ bool rconv_supported(int C, int T, int taps, int gsize) {
 hipError_t launch_rconv(const RConvArgs& a, hipStream_t s) {
   if (a.M <= 0) return hipSuccess;
   if (!rconv_supported(a.C, a.T, a.taps, a.gsize) || (a.gsize > 0 && (!a.gamma || !a.beta))) return hipErrorInvalidValue;
+  if (a.x2 && a.film) return hipErrorInvalidValue;   // FiLM only ever precedes a single-source convolution
   // C = 128: 64-row workgroups (wave = row tile); C = 256: 32-row workgroups, features split over wave pairs (the
   // 64-row form needs 64 operand + 64 accumulator + 32 shifted-operand registers per lane and spills)
   if (a.C == 128) return a.taps == 3 ? launch_rc<4, 128, 3, 1>(a, s) : launch_rc<4, 128, 1, 1>(a, s);

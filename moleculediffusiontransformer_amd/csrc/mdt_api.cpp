@@ -214,11 +214,12 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
       }
       case MDT_OP_RCONV: {
         mdt::RConvArgs a;
-        a.x = ptr(o.a); a.w = ptr(o.w); a.bias = ptr(o.bias); a.res = ptr(o.res); a.out = ptr(o.out);
+        a.x = ptr(o.a); a.x2 = ptr(o.a2); a.w = ptr(o.w); a.bias = ptr(o.bias); a.res = ptr(o.res); a.out = ptr(o.out);
         a.gamma = ptr(o.p0); a.beta = ptr(o.p1); a.film = ptr(o.p3); a.dbgbuf = ptr(o.p2);
         a.T = o.i[MDT_R_T]; a.M = B * a.T; a.C = o.i[MDT_R_C]; a.lda = o.i[MDT_R_LDA]; a.ldc = o.i[MDT_R_LDC];
         a.ldr = o.i[MDT_R_LDR]; a.taps = o.i[MDT_R_TAPS]; a.gsize = o.i[MDT_R_GSIZE]; a.silu = o.i[MDT_R_SILU];
         a.film_ld = o.i[MDT_R_FILM_LD]; a.eps = o.f[MDT_RF_EPS]; a.in_scale = o.f[MDT_RF_IN_SCALE];
+        a.lda2 = o.i[MDT_R_LDA2]; a.in_scale2 = o.f[MDT_RF_IN_SCALE2];
         if (!missing) e = mdt::launch_rconv(a, stream);
         break;
       }

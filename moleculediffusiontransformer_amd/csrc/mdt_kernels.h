@@ -50,7 +50,8 @@ hipError_t launch_gn_act(const GnActArgs& a, hipStream_t s);
 // MDT_OP_RCONV (k_rconv.hip): GroupNorm + FiLM + SiLU + Conv1d(k = 1 | 3) with C input and C output channels
 struct RConvArgs {
   const float* x;      // [M][lda]
-  const float* w;      // weight tiles [64 features][128 k], order (tap, K half, feature chunk)
+  const float* x2;     // second input source [M][lda2] or nullptr (its tiles / gain / bias follow the first source's)
+  const float* w;      // weight tiles [64 features][128 k], order (source, tap, K half, feature chunk)
   const float* bias;   // [C] or nullptr
   const float* res;    // [M][ldr] added to the result, or nullptr (may alias out)
   float* out;          // [M][ldc]
@@ -58,8 +59,8 @@ struct RConvArgs {
   const float* beta;
   const float* film;   // [scale | shift] rows film_ld apart, or nullptr
   const float* dbgbuf; // diagnostic stamps (tuning builds), normally nullptr
-  int M, T, C, lda, ldc, ldr, taps, gsize, silu, film_ld;
-  float eps, in_scale;
+  int M, T, C, lda, lda2, ldc, ldr, taps, gsize, silu, film_ld;
+  float eps, in_scale, in_scale2;
 };
 bool rconv_supported(int C, int T, int taps, int gsize);
 hipError_t launch_rconv(const RConvArgs& a, hipStream_t s);

@@ -179,25 +179,36 @@ def _rconv(op, bufs: Buffers, B: int) -> None:
     i, f = op.i, op.f
     T, C, lda, ldc, ldr, taps, gs = (i[rt.R_T], i[rt.R_C], i[rt.R_LDA], i[rt.R_LDC], i[rt.R_LDR], i[rt.R_TAPS],
                                      i[rt.R_GSIZE])
-    x = bufs.view(op.a, B, B * T * lda).view(B, T, lda)[:, :, :C] * float(f[1])
-    if gs > 0:
-        y = F.group_norm(x.transpose(1, 2), C // gs, bufs.view(op.p0, B, C), bufs.view(op.p1, B, C), float(f[0])).transpose(1, 2)
-        if op.p3.space != rt.SP_NONE:
-            ss = bufs.view(op.p3, B, i[rt.R_FILM_LD] + C)
-            y = y * (ss[:C] + 1.0) + ss[i[rt.R_FILM_LD]: i[rt.R_FILM_LD] + C]
-        if i[rt.R_SILU]:
-            y = _silu(y)
-    else:
-        y = x
+    srcs = [(bufs.view(op.a, B, B * T * lda).view(B, T, lda)[:, :, :C] * float(f[1]))]
+    if op.a2.space != rt.SP_NONE:                       # second half of a concatenated input
+        lda2 = i[rt.R_LDA2]
+        srcs.append(bufs.view(op.a2, B, B * T * lda2).view(B, T, lda2)[:, :, :C] * float(f[2]))
+    nsrc = len(srcs)
+    ys = []
+    for s_, x in enumerate(srcs):
+        if gs > 0:
+            gain = bufs.view(op.p0, B, nsrc * C)[s_ * C: (s_ + 1) * C]
+            beta = bufs.view(op.p1, B, nsrc * C)[s_ * C: (s_ + 1) * C]
+            y = F.group_norm(x.transpose(1, 2), C // gs, gain, beta, float(f[0])).transpose(1, 2)
+            if op.p3.space != rt.SP_NONE:
+                ss = bufs.view(op.p3, B, i[rt.R_FILM_LD] + C)
+                y = y * (ss[:C] + 1.0) + ss[i[rt.R_FILM_LD]: i[rt.R_FILM_LD] + C]
+            if i[rt.R_SILU]:
+                y = _silu(y)
+        else:
+            y = x
+        ys.append(y)
+    y = torch.cat(ys, dim=2)
     nkh, nch = C // 128, C // 64
-    stream = bufs.view(op.w, B, taps * C * C)
-    w = torch.empty(C, C, taps)
+    stream = bufs.view(op.w, B, nsrc * taps * C * C)
+    w = torch.empty(C, nsrc * C, taps)
     k = 0
-    for tap in range(taps):
-        for kh in range(nkh):
-            for ch in range(nch):
-                w[64 * ch: 64 * ch + 64, 128 * kh: 128 * kh + 128, tap] = _untile(stream, k, 64, 128)
-                k += 1
+    for s_ in range(nsrc):
+        for tap in range(taps):
+            for kh in range(nkh):
+                for ch in range(nch):
+                    w[64 * ch: 64 * ch + 64, s_ * C + 128 * kh: s_ * C + 128 * kh + 128, tap] = _untile(stream, k, 64, 128)
+                    k += 1
     bias = bufs.view(op.bias, B, C) if op.bias.space != rt.SP_NONE else None
     o = F.conv1d(y.transpose(1, 2), w, bias, padding=taps // 2).transpose(1, 2)
     if op.res.space != rt.SP_NONE:

@@ -391,6 +391,39 @@ def test_gn_act(B, R, C, G, film, silu, eps):
     assert (ga[B * R * C:].view(B, R, C) - h.transpose(1, 2)).abs().max() < 2e-5
 
 
+@pytest.mark.parametrize("C,T,B,taps,gsize,silu,in_scale2", [
+    (128, 16, 70, 3, 32, True, 0.7071),    # ResnetBlock1d block1 on cat([x, skip / sqrt 2]) at the 128-channel level
+    (256, 4, 37, 3, 64, True, 0.7071),
+    (256, 4, 9, 1, 0, False, 0.7071),      # its 1x1 residual convolution on the raw concatenation
+    (128, 16, 5, 1, 0, False, 0.5),
+])
+def test_row_stationary_conv_two_sources(C, T, B, taps, gsize, silu, in_scale2):
+    """k_rconv on a concatenated input that is never materialised: prologue + taps for source a, then for source b,
+    into the same accumulators (second exchange barrier, fragment-set rotation between the sources)."""
+    from moleculediffusiontransformer_amd.compiler import Ten, UNetCompiler
+    from moleculediffusiontransformer_amd.netspec import inverse_unet_config
+    comp = UNetCompiler(inverse_unet_config(16, 64, 128, 12), 64, 12, {})
+    w = rnd(C, 2 * C, taps, seed=1, scale=(2 * C * taps) ** -0.5)
+    gb = torch.cat([1 + 0.1 * rnd(2 * C, seed=2), 0.1 * rnd(2 * C, seed=3), 0.1 * rnd(C, seed=5)])   # gain | beta | conv bias
+    g_off = comp.W.add("gb", gb)
+    xa, out, xb = Ten(A, 0, T, C), Ten(A, T * C, T, C), Ten(A, 2 * T * C, T, C)
+    comp.rconv(xa, w, "w", out, taps=taps, bias_off=g_off + 4 * C,
+               gn=(g_off, g_off + 2 * C, gsize, 1e-5, silu) if gsize else None, x2=xb, in_scale2=in_scale2)
+    op = comp.ops[0]
+    act = torch.cat([rnd(B * T * C, seed=4) * 1.5 + 0.3, rnd(B * T * C, seed=6), rnd(B * T * C, seed=7) * 0.8 - 0.2])
+    (ga, _, _), (ca, _, _) = run_both([op], comp.W.pack(), act, torch.zeros(4), {}, B)
+    og, oc = ga[B * T * C: 2 * B * T * C], ca[B * T * C: 2 * B * T * C]
+    scale = max(1.0, oc.abs().max().item())
+    assert torch.isfinite(og).all() and (og - oc).abs().max() < 1e-4 * scale, (og - oc).abs().max().item()
+    h = torch.cat([act[: B * T * C].view(B, T, C), in_scale2 * act[2 * B * T * C:].view(B, T, C)], dim=2).transpose(1, 2)
+    if gsize:
+        h = torch.nn.functional.group_norm(h, 2 * C // gsize, gb[: 2 * C], gb[2 * C: 4 * C], 1e-5)
+        if silu:
+            h = torch.nn.functional.silu(h)
+    y = torch.nn.functional.conv1d(h, w, gb[4 * C:], padding=taps // 2).transpose(1, 2)
+    assert (og.view(B, T, C) - y).abs().max() < 1e-4 * scale
+
+
 @pytest.mark.parametrize("C,T,B,taps,gsize,film,silu,res,in_scale", [
     (128, 16, 5, 3, 16, True, True, "other", 1.0),     # ResnetBlock1d block2 at the 128-channel level (FiLM, residual)
     (128, 16, 70, 3, 32, False, True, None, 0.7071),   # half of a concatenated block1 input (skip scaling)
