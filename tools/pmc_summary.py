@@ -58,6 +58,43 @@ def main():
         rows.sort(key=lambda r: -(r[3] + r[4]) * r[1])
         for k, d, raw, fc, w in rows:
             f.write(f"{k},{d},{raw:.1f},{fc:.2f},{w:.2f},{fc + w:.2f}\n")
+    # SQ pass: where the waves spend their cycles, MFMA pipe occupancy, LDS bank conflicts (per kernel, per dispatch)
+    names = ["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_VALU_MFMA_BUSY_CYCLES",
+             "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "GRBM_GUI_ACTIVE"]
+    vals = {n: counters(os.path.join(src, "pmc_sq"), n) for n in names}
+    if vals["SQ_WAVE_CYCLES"][0]:
+        with open(os.path.join(dst, f"{tag}_pmc_sq.csv"), "w") as f:
+            f.write("# rocprofv3 --pmc " + " ".join(names) + " (one pass, --kernel-trace only), bench.py --timesteps 4\n")
+            f.write("# SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are quad-cycles summed over waves; WAIT_ANY = parked on "
+                    "s_waitcnt / s_barrier, WAIT_INST_ANY = issue stall, ACTIVE_INST_ANY = issuing; MFMA busy in cycles; "
+                    "GRBM_GUI_ACTIVE summed over the 8 XCDs (per-launch cycles = value / 8)\n")
+            f.write("# mfma_util = MFMA_BUSY_CYCLES / (kernel duration of the same pass x 2.4 GHz nominal x 256 CUs x 4 SIMDs); "
+                    "fractions are over ALL waves of a workgroup: the ring kernels' 4 loader waves (of 8) are parked by design\n")
+            f.write("kernel,dispatches,parked_frac,issue_stall_frac,issuing_frac,mfma_busy_cycles_per_dispatch,"
+                    "avg_duration_us,mfma_util,lds_conflict_frac\n")
+            dur, dn = collections.Counter(), collections.Counter()
+            for tf in glob.glob(os.path.join(src, "pmc_sq", "**", "*_kernel_trace.csv"), recursive=True):
+                for r in csv.DictReader(open(tf)):
+                    k = short(r["Kernel_Name"])
+                    dur[k] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+                    dn[k] += 1
+            tot, n = vals["SQ_WAVE_CYCLES"]
+            rows = []
+            for k in tot:
+                wc = tot[k]
+                if wc <= 0:
+                    continue
+                d = n[k]
+                g = lambda name: vals[name][0].get(k, 0.0)
+                us = dur[k] / max(dn[k], 1) / 1e3
+                gui = us * 2400.0                          # cycles at the nominal clock
+                mf = g("SQ_VALU_MFMA_BUSY_CYCLES") / d
+                lds = g("SQ_LDS_IDX_ACTIVE")
+                rows.append((wc, f"{k},{d},{g('SQ_WAIT_ANY') / wc:.3f},{g('SQ_WAIT_INST_ANY') / wc:.3f},"
+                                 f"{g('SQ_ACTIVE_INST_ANY') / wc:.3f},{mf:.0f},{us:.1f},"
+                                 f"{mf / (gui * 1024) if gui else 0:.4f},{g('SQ_LDS_BANK_CONFLICT') / lds if lds else 0:.4f}\n"))
+            for _, line in sorted(rows, key=lambda r: -r[0]):
+                f.write(line)
     print("profiles written for", tag)
 
 

@@ -3,7 +3,8 @@
 #   bash tools/profile_round.sh r1
 # 1. plain bench.py (with the CPU baseline leg)            -> gpurun_out/prof_<tag>/bench.json
 # 2. rocprofv3 --output-format csv --kernel-trace --stats of the same command   -> .../trace (kernel_stats.csv, domain_stats.csv)
-# 3. two PMC passes (FETCH_SIZE, WRITE_SIZE), kernel-trace only, on a 4-timestep run -> .../pmc_fetch, .../pmc_write
+# 3. PMC passes, kernel-trace only, on a 4-timestep run: FETCH_SIZE, WRITE_SIZE (HBM traffic), SQ wave-state /
+#    MFMA-busy / LDS-conflict counters -> .../pmc_fetch, .../pmc_write, .../pmc_sq
 # tools/pmc_summary.py then folds 2+3 into the csv files committed under profiles/.
 tag=${1:-r1}
 root=$(pwd)
@@ -18,5 +19,7 @@ rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d "$out/pmc_fetch
     --no-cpu-baseline --no-breakdown --timesteps 4 --steps 1 --warmup 1 > "$out/pmc_fetch.json" 2> "$out/pmc_fetch.log"
 rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d "$out/pmc_write" -o runc -- python3 "$root/bench.py" \
     --no-cpu-baseline --no-breakdown --timesteps 4 --steps 1 --warmup 1 > "$out/pmc_write.json" 2> "$out/pmc_write.log"
+rocprofv3 --output-format csv --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d "$out/pmc_sq" -o runc -- python3 "$root/bench.py" \
+    --no-cpu-baseline --no-breakdown --timesteps 4 --steps 1 --warmup 1 > "$out/pmc_sq.json" 2> "$out/pmc_sq.log"
 cd "$root"
 # then, where profiles/ is tracked:  python3 tools/pmc_summary.py gpurun_out/prof_$tag $tag

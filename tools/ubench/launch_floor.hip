@@ -26,8 +26,28 @@ __global__ __launch_bounds__(512) void k_regs(float* p) {   // forces a 256-VGPR
   if (threadIdx.x == 0 && blockIdx.x == 0) p[0] += sm[0] * 1e-30f;
 }
 
+// one dependent global load -> store per thread (what every prologue / epilogue does at least once)
+__global__ __launch_bounds__(512) void k_ldst(float* p) {
+  extern __shared__ float sm[];
+  const int t = blockIdx.x * 512 + threadIdx.x;
+  const float4 v = reinterpret_cast<const float4*>(p)[t];
+  reinterpret_cast<float4*>(p)[t + 262144] = make_float4(v.x + 1.f, v.y, v.z, v.w);
+}
+
+// the same plus a chain of 3 dependent loads (pointer-chase-like: x rows -> params -> weights)
+__global__ __launch_bounds__(512) void k_chain(float* p) {
+  extern __shared__ float sm[];
+  const int t = blockIdx.x * 512 + threadIdx.x;
+  float4 v = reinterpret_cast<const float4*>(p)[t];
+  int j = ((int)v.x & 1023);
+  v = reinterpret_cast<const float4*>(p)[t + 131072 + j];
+  j = ((int)v.y & 1023);
+  v = reinterpret_cast<const float4*>(p)[t + 65536 + j];
+  reinterpret_cast<float4*>(p)[t + 262144] = v;
+}
+
 int main() {
-  float* p; hipMalloc(&p, 1 << 20); hipMemset(p, 0, 1 << 20);
+  float* p; hipMalloc(&p, 1 << 24); hipMemset(p, 0, 1 << 24);
   hipStream_t st; hipStreamCreate(&st);
   const int N = 200;
   auto run = [&](const char* name, auto launch) {
@@ -59,6 +79,11 @@ int main() {
   run("512 thr x 256 WG, 4 KB LDS", [&] { hipLaunchKernelGGL(k_lds, dim3(256), dim3(512), 4096, st, p); });
   run("512 thr x 256 WG, 128 KB LDS", [&] { hipLaunchKernelGGL(k_lds, dim3(256), dim3(512), 131072, st, p); });
   run("512 thr x 128 WG, 128 KB LDS", [&] { hipLaunchKernelGGL(k_lds, dim3(128), dim3(512), 131072, st, p); });
+  hipFuncSetAttribute((const void*)k_ldst, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipFuncSetAttribute((const void*)k_chain, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  run("512 thr x 256 WG, 128 KB LDS, load -> store", [&] { hipLaunchKernelGGL(k_ldst, dim3(256), dim3(512), 131072, st, p); });
+  run("512 thr x 2 WG, 128 KB LDS, load -> store", [&] { hipLaunchKernelGGL(k_ldst, dim3(2), dim3(512), 131072, st, p); });
+  run("512 thr x 256 WG, 128 KB LDS, 3 dependent loads -> store", [&] { hipLaunchKernelGGL(k_chain, dim3(256), dim3(512), 131072, st, p); });
   run("512 thr x 256 WG, 128 KB LDS, 256 VGPRs", [&] { hipLaunchKernelGGL(k_regs, dim3(256), dim3(512), 131072, st, p); });
   return 0;
 }
