@@ -39,6 +39,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=1024, help="molecules per GPU per step")
     ap.add_argument("--timesteps", type=int, default=64)
+    ap.add_argument("--workload", default="cfg1", choices=["cfg1", "cfg3", "cfg5"],
+                    help="cfg1 = BASELINE configs[1] (the headline metric, default); cfg3 = QMDiffusionForward "
+                         "(configs[2]: --batch 4096 --timesteps 100); cfg5 = deep U-Net architecture of configs[4] "
+                         "(channels 256, max_len 128).  Other workloads are informational: no CPU baseline / parity leg")
+    ap.add_argument("--cond-scale", type=float, default=1.0, help="classifier-free guidance scale (2 U-Net passes if != 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
     return ap.parse_args()
@@ -137,14 +142,17 @@ def main():
     import gpu_util
     gpu_util.DEV = str(device)
     with contextlib.redirect_stdout(sys.stderr):     # the class prints "Using unet type" like the reference does
-        model = make_model("cfg1")                   # inverse c=64, pred_dim=16, L=64, cond_len=12; synthetic weights
+        model = make_model(a.workload)               # cfg1: inverse c=64, pred_dim=16, L=64, cond_len=12; synthetic weights
     B, T = a.batch, a.timesteps
-    seq = synth_normal(f"bench/seq/rank{rank}", (B, 12)).to(device)
+    n_cond = model.unet.config.ctx_max_length
+    seq = synth_normal(f"bench/seq/rank{rank}", (B, n_cond)).to(device)
+    if a.workload != "cfg1" or a.cond_scale != 1.0:
+        a.no_cpu_baseline = True
     evals = 2 * (T - 1)
     eval_timer = rt.EventTimer(evals * (a.steps + a.warmup) + 8)
 
     def one_step(step_idx, timed):
-        out = model.sample(seq, device, cond_scale=1.0, timesteps=T, clamp=False,
+        out = model.sample(seq, device, cond_scale=a.cond_scale, timesteps=T, clamp=False,
                            noise=NoiseSource(seed=1234 + step_idx, sample0=rank * B),
                            timer=eval_timer if timed else None)
         if world > 1:
@@ -175,7 +183,7 @@ def main():
     eval_ms = eval_timer.collect()
     result = None
     if rank == 0:
-        eng = model.engine(device, 12)
+        eng = model.engine(device, n_cond)
         mols = world * B * a.steps
         value = mols / elapsed
         flops_exec = eng.c.flops_per_sample_eval           # executed per sample per eval (K/V + time mapping hoisted)
@@ -197,7 +205,8 @@ def main():
                          "achieved": round(alg * mult, 2), "frac": round(alg * mult / peak, 4),
                          "algorithmic_tflops_fp32_equiv": round(alg, 2), "launches_per_eval": n_dom,
                          "avg_launch_us": round(1e3 * ms_dom / n_dom, 2), "flops_per_launch_avg": fl_dom / n_dom})
-            roof["traffic"], roof["traffic_source"] = pmc_traffic(dom)
+            if a.workload == "cfg1" and B == 1024:     # the committed PMC summary is of exactly this workload
+                roof["traffic"], roof["traffic_source"] = pmc_traffic(dom)
             extra["eval_breakdown_ms"] = {k: {"launches": n, "ms": round(t, 4),
                                               "algorithmic_tflops": round(f / (t * 1e-3) / 1e12, 2) if f else None}
                                           for k, (n, t, f) in sorted(bd.items())}
@@ -215,15 +224,21 @@ def main():
             "hbm_fraction_reference_opgraph": round(REF_OPGRAPH_BYTES_PER_SAMPLE_EVAL * B / (avg_eval_ms * 1e-3) / 1e9
                                                     / HBM_PEAK_GBS, 4),
         }
+        if a.workload != "cfg1":
+            for k in ("mfma_fraction_reference_opgraph", "hbm_fraction_reference_opgraph"):
+                extra["unet_eval"].pop(k, None)
         result = {
-            "metric": "molecules/sec @64 diffusion steps (QM9 max_len=64)", "value": round(value, 2),
+            "metric": "molecules/sec @64 diffusion steps (QM9 max_len=64)" if a.workload == "cfg1"
+                      else f"molecules/sec @{T} diffusion steps ({a.workload})", "value": round(value, 2),
             "unit": "molecules/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(1e3 * elapsed / a.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32 storage/accumulate; GEMM products as split-bf16 (bf16x3) MFMA" if split else "f32",
             "data": "synthetic",
-            "config": {"workload": f"QMDiffusion inverse sample(): channels=64 pred_dim=16 max_len=64 cond_len=12, "
-                                   f"batch={B}/GPU, {T} timesteps ({evals} U-Net evals), cond_scale=1.0, fp32",
+            "config": {"workload": {"cfg1": "QMDiffusion inverse sample(): channels=64 pred_dim=16 max_len=64 cond_len=12, ",
+                                    "cfg3": "QMDiffusionForward sample(): channels=64 pred_dim=1 max_len=64 cond_len=64, ",
+                                    "cfg5": "QMDiffusion inverse sample(): channels=256 pred_dim=32 max_len=128 cond_len=12, "}[a.workload]
+                                   + f"batch={B}/GPU, {T} timesteps ({evals} U-Net evals), cond_scale={a.cond_scale}, fp32",
                        "global_batch": world * B, "timesteps": T, "parallelism": f"batch-shard x{world}"},
             "roofline": roof,
         }
