@@ -55,6 +55,16 @@ __device__ __forceinline__ void lds_read16_rc(bf16x8& dst, const unsigned char* 
   asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr) : "memory");
 }
 
+template <int OFF>      // fragment read with the (tile, plane) part of the address as immediate offset (k_tblock_lw.hip)
+__device__ __forceinline__ void lds_read16_off_rc(bf16x8& dst, unsigned addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read_b128 offset field");
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+
+__device__ __forceinline__ unsigned lds_addr_rc(const unsigned char* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)p;
+}
+
 template <int N>
 __device__ __forceinline__ void lgkm_wait_rc() {
   if constexpr (N >= 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
@@ -169,12 +179,18 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
     aP[st] = fh * (2 * 16 * 4 * CS) + i * (4 * CS) + ((lc & ~15) | ((lc & 15) ^ i)) * 16;
   }
   bf16x8 frh[3][2], frl[3][2];
-  auto frag_read = [&](const unsigned char* slot, int u, int set, int j) {
-    const int q = j >> 1, lo = j & 1;
-    const unsigned char* p = (RTW == 4) ? slot + aP[u >> 1] + ((2 * (u & 1) + q) * 16 * 4 * CS + lo * (2 * CS))
-                                        : slot + aP[u] + (q * 16 * 4 * CS + lo * (2 * CS));
-    lds_read16_rc(lo ? frl[set][q] : frh[set][q], p);
+  // read j (= 2 q + plane) of unit u; `base` = LDS address of the slot + the lane's swizzled part for the unit's
+  // k-step (RTW = 4: aP[u >> 1], RTW = 2: aP[u]); the (feature tile, plane) part is the instruction's immediate offset
+  auto frag_read = [&](unsigned base, auto uc, int set, auto jc) {
+    constexpr int u = decltype(uc)::value, j = decltype(jc)::value;
+    constexpr int q = j >> 1, lo = j & 1;
+    constexpr int off = (RTW == 4) ? ((2 * (u & 1) + q) * 16 * 4 * CS + lo * (2 * CS)) : (q * 16 * 4 * CS + lo * (2 * CS));
+    lds_read16_off_rc<off>(lo ? frl[set][q] : frh[set][q], base);
   };
+  using J0 = std::integral_constant<int, 0>;
+  using J1 = std::integral_constant<int, 1>;
+  using J2 = std::integral_constant<int, 2>;
+  using J3 = std::integral_constant<int, 3>;
   auto slot_of = [&](int t) -> const unsigned char* { return smem + (t % NS) * SLOT; };
 
   f32x4 acc[NCH][NFT];
@@ -316,10 +332,10 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
   MDT_STAMP();
   if (src == 0) {
     __builtin_amdgcn_s_barrier();                    // B(0)
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) frag_read(slot_of(0), u, u, j);
+    const unsigned l0 = lds_addr_rc(slot_of(0));
+    const unsigned p0 = l0 + aP[0], p1 = l0 + aP[(RTW == 4) ? 0 : 1];
+    frag_read(p0, J0{}, 0, J0{}); frag_read(p0, J0{}, 0, J1{}); frag_read(p0, J0{}, 0, J2{}); frag_read(p0, J0{}, 0, J3{});
+    frag_read(p1, J1{}, 1, J0{}); frag_read(p1, J1{}, 1, J1{}); frag_read(p1, J1{}, 1, J2{}); frag_read(p1, J1{}, 1, J3{});
   }
   MDT_STAMP();
 
@@ -343,38 +359,52 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
         const int tau = (tap * NKH + kh) * NCH + c;       // tile within this source (compile-time)
         const int off = (tau * NU) % 3;
         const bool more = (tau + 1 < NT) || (src + 1 < nsrc);
-        const unsigned char* cur = slot_of(src * NT + tau);
-        const unsigned char* nxt = slot_of(src * NT + tau + 1);
+        const unsigned lc = lds_addr_rc(slot_of(src * NT + tau)), ln = lds_addr_rc(slot_of(src * NT + tau + 1));
+        unsigned bc[4], bn[2];
 #pragma unroll
-        for (int u = 0; u < NU; ++u) {
+        for (int k = 0; k < 4; ++k) bc[k] = lc + aP[k];
+        bn[0] = ln + aP[0];
+        bn[1] = ln + aP[(RTW == 4) ? 0 : 1];
+        auto unit = [&](auto uc) {
+          constexpr int u = decltype(uc)::value;
           if (u == NU - 2 && more) {
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();            // B(src NT + tau + 1)
             __builtin_amdgcn_sched_barrier(0);
           }
           const int s0 = (off + u) % 3, s2 = (off + u + 2) % 3;
-          const bool in_tile = u + 2 < NU;
+          constexpr bool in_tile = u + 2 < NU;
           const bool pre = in_tile || more;
           const bool later = (u + 1 < NU) || more;
           if (later) lgkm_wait_rc<4>(); else lgkm_wait_rc<0>();
-          const int ia = (RTW == 4) ? 2 * (u & 1) : 0, ib = (RTW == 4) ? (u >> 1) : u;
-          auto rd = [&](int j) {
+          constexpr int ia = (RTW == 4) ? 2 * (u & 1) : 0, ib = (RTW == 4) ? (u >> 1) : u;
+          auto rd = [&](auto jc) {
             if (!pre) return;
             __builtin_amdgcn_sched_barrier(0);
-            if (in_tile) frag_read(cur, u + 2, s2, j);
-            else frag_read(nxt, u + 2 - NU, s2, j);
+            if constexpr (in_tile) {
+              constexpr int u2 = u + 2;
+              frag_read(bc[(RTW == 4) ? (u2 >> 1) : u2], std::integral_constant<int, u2>{}, s2, jc);
+            } else {
+              frag_read(bn[u + 2 - NU], std::integral_constant<int, u + 2 - NU>{}, s2, jc);
+            }
             __builtin_amdgcn_sched_barrier(0);
           };
           auto mm = [&](const bf16x8& w, const bf16x8& x, int q) {
             acc[c][ia + q] = MDT_MFMA_BF16(w, x, acc[c][ia + q], 0, 0, 0);
           };
-          mm(frl[s0][0], oph[ib], 0); rd(0);
-          mm(frl[s0][1], oph[ib], 1); rd(1);
-          mm(frh[s0][0], opl[ib], 0); rd(2);
-          mm(frh[s0][1], opl[ib], 1); rd(3);
+          mm(frl[s0][0], oph[ib], 0); rd(J0{});
+          mm(frl[s0][1], oph[ib], 1); rd(J1{});
+          mm(frh[s0][0], opl[ib], 0); rd(J2{});
+          mm(frh[s0][1], opl[ib], 1); rd(J3{});
           mm(frh[s0][0], oph[ib], 0);
           mm(frh[s0][1], oph[ib], 1);
           __builtin_amdgcn_sched_barrier(0);
+        };
+        unit(std::integral_constant<int, 0>{}); unit(std::integral_constant<int, 1>{});
+        unit(std::integral_constant<int, 2>{}); unit(std::integral_constant<int, 3>{});
+        if constexpr (NU == 8) {
+          unit(std::integral_constant<int, 4>{}); unit(std::integral_constant<int, 5>{});
+          unit(std::integral_constant<int, 6>{}); unit(std::integral_constant<int, 7>{});
         }
       }
     }

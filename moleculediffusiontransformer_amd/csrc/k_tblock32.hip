@@ -50,6 +50,16 @@ __device__ __forceinline__ void lds_read16_32(bf16x8& dst, const unsigned char* 
   asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr) : "memory");
 }
 
+template <int OFF>      // fragment read with the (tile, plane) part of the address as immediate offset (k_tblock_lw.hip)
+__device__ __forceinline__ void lds_read16_off(bf16x8& dst, unsigned addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read_b128 offset field");
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+
+__device__ __forceinline__ unsigned lds_addr(const unsigned char* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)p;
+}
+
 template <int N>
 __device__ __forceinline__ void lgkm_wait() {   // at most N LDS/scalar operations still in flight
   if constexpr (N >= 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
@@ -250,19 +260,26 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
   const int aO = i * 128 + ((4 * fh + g) ^ ((i >> 1) & 7)) * 16;
 
   bf16x8 frh[3][2], frl[3][2];
-  auto frag_read = [&](auto kind, const unsigned char* slot, int u, int set, int j) {
-    constexpr int KIND = decltype(kind)::value;
-    const int q = j >> 1, lo = j & 1;
-    const unsigned char* p;
-    if constexpr (KIND == K_O) p = slot + aO + ((2 * u + q) * 16 * 128 + lo * (CS * 128));
-    else p = slot + aP[u] + (q * 16 * 4 * CS + lo * (2 * CS));
-    lds_read16_32(lo ? frl[set][q] : frh[set][q], p);
+  // read j (= 2 q + plane) of unit u; `base` = LDS address of the slot + the lane's swizzled part (projection
+  // sub-tiles: aP[u], output sub-tiles: aO), the rest is the instruction's immediate offset
+  auto frag_read = [&](auto kind, unsigned base, auto uc, int set, auto jc) {
+    constexpr int KIND = decltype(kind)::value, u = decltype(uc)::value, j = decltype(jc)::value;
+    constexpr int q = j >> 1, lo = j & 1;
+    constexpr int off = (KIND == K_O) ? ((2 * u + q) * 16 * 128 + lo * (CS * 128)) : (q * 16 * 4 * CS + lo * (2 * CS));
+    lds_read16_off<off>(lo ? frl[set][q] : frh[set][q], base);
   };
+  using J0 = std::integral_constant<int, 0>;
+  using J1 = std::integral_constant<int, 1>;
+  using J2 = std::integral_constant<int, 2>;
+  using J3 = std::integral_constant<int, 3>;
   auto prefetch2 = [&](auto kind, const unsigned char* slot, int off) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) frag_read(kind, slot, u, (off + u) % 3, j);
+    constexpr int KIND = decltype(kind)::value;
+    const unsigned l = lds_addr(slot);
+    const unsigned b0 = l + (KIND == K_O ? aO : aP[0]), b1 = l + (KIND == K_O ? aO : aP[1]);
+    frag_read(kind, b0, J0{}, off % 3, J0{}); frag_read(kind, b0, J0{}, off % 3, J1{});
+    frag_read(kind, b0, J0{}, off % 3, J2{}); frag_read(kind, b0, J0{}, off % 3, J3{});
+    frag_read(kind, b1, J1{}, (off + 1) % 3, J0{}); frag_read(kind, b1, J1{}, (off + 1) % 3, J1{});
+    frag_read(kind, b1, J1{}, (off + 1) % 3, J2{}); frag_read(kind, b1, J1{}, (off + 1) % 3, J3{});
   };
 
 #ifdef MDT_STAMPS   // tuning build: wave 0 of workgroup 0 records the shader clock at phase boundaries into dbgbuf
@@ -287,41 +304,47 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
   // K half, accumulators acc[0..1] = the wave's two feature tiles, operands bh[u]/bl[u].  Output kind: unit = row
   // tiles 2u, 2u+1 of the row half, accumulators acc[2u..2u+1], the single operand bh[0]/bl[0].
   auto phase = [&](auto kind, auto offc, auto nkind, bool has_next, f32x4* acc, const bf16x8* bh, const bf16x8* bl) {
-    constexpr int KIND = decltype(kind)::value, OFF = decltype(offc)::value;
-    const unsigned char* cur = slot_of(tau);
-    const unsigned char* nxt = slot_of(tau + 1);
+    constexpr int KIND = decltype(kind)::value, OFF = decltype(offc)::value, NK = decltype(nkind)::value;
+    const unsigned lc = lds_addr(slot_of(tau)), ln = lds_addr(slot_of(tau + 1));
+    unsigned bc[4], bn[2];                           // per unit of this sub-tile / of the first two units of the next
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
+    for (int k = 0; k < 4; ++k) bc[k] = lc + (KIND == K_O ? aO : aP[k]);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) bn[k] = ln + (NK == K_O ? aO : aP[k]);
+    auto unit = [&](auto uc) {
+      constexpr int u = decltype(uc)::value;
       if (u == NU - 2 && has_next) {
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();                // B(tau + 1)
         __builtin_amdgcn_sched_barrier(0);
       }
-      const int s0 = (OFF + u) % 3, s2 = (OFF + u + 2) % 3;
-      const bool in_phase = u + 2 < NU;
+      constexpr int s0 = (OFF + u) % 3, s2 = (OFF + u + 2) % 3;
+      constexpr bool in_phase = u + 2 < NU;
       const bool pre = in_phase || has_next;
       const bool later = (u + 1 < NU) || has_next;
       if (later) lgkm_wait<4>(); else lgkm_wait<0>();
-      const int ia = (KIND == K_O) ? 2 * u : 0, ib = (KIND == K_O) ? 0 : u;
-      auto rd = [&](int j) {
+      constexpr int ia = (KIND == K_O) ? 2 * u : 0, ib = (KIND == K_O) ? 0 : u;
+      auto rd = [&](auto jc) {
         if (!pre) return;
         __builtin_amdgcn_sched_barrier(0);
-        if (in_phase) frag_read(kind, cur, u + 2, s2, j);
-        else frag_read(nkind, nxt, u + 2 - NU, s2, j);
+        if constexpr (in_phase) frag_read(kind, bc[u + 2], std::integral_constant<int, u + 2>{}, s2, jc);
+        else frag_read(nkind, bn[u + 2 - NU], std::integral_constant<int, u + 2 - NU>{}, s2, jc);
         __builtin_amdgcn_sched_barrier(0);
       };
       auto mm = [&](const bf16x8& w, const bf16x8& x, int q) {
         if constexpr (KIND == K_N) acc[ia + q] = MDT_MFMA_BF16(x, w, acc[ia + q], 0, 0, 0);
         else acc[ia + q] = MDT_MFMA_BF16(w, x, acc[ia + q], 0, 0, 0);
       };
-      mm(frl[s0][0], bh[ib], 0); rd(0);
-      mm(frl[s0][1], bh[ib], 1); rd(1);
-      mm(frh[s0][0], bl[ib], 0); rd(2);
-      mm(frh[s0][1], bl[ib], 1); rd(3);
+      mm(frl[s0][0], bh[ib], 0); rd(J0{});
+      mm(frl[s0][1], bh[ib], 1); rd(J1{});
+      mm(frh[s0][0], bl[ib], 0); rd(J2{});
+      mm(frh[s0][1], bl[ib], 1); rd(J3{});
       mm(frh[s0][0], bh[ib], 0);
       mm(frh[s0][1], bh[ib], 1);
       __builtin_amdgcn_sched_barrier(0);
-    }
+    };
+    unit(std::integral_constant<int, 0>{}); unit(std::integral_constant<int, 1>{});
+    unit(std::integral_constant<int, 2>{}); unit(std::integral_constant<int, 3>{});
     ++tau;
     MDT_STAMP();
   };

@@ -55,6 +55,19 @@ __device__ __forceinline__ void lds_read16(bf16x8& dst, const unsigned char* p) 
   asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr) : "memory");
 }
 
+// fragment read with the (tile, plane) part of the address in the instruction's immediate offset: per read there is no
+// address arithmetic left (one v_add_u32 per ds_read_b128 was 127 of the 679 instructions of a self-attention head,
+// in a kernel whose compute waves are issue-bound)
+template <int OFF>
+__device__ __forceinline__ void lds_read16_off(bf16x8& dst, unsigned addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read_b128 offset field");
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+
+__device__ __forceinline__ unsigned lds_addr(const unsigned char* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)p;
+}
+
 template <int N>
 __device__ __forceinline__ void lgkm_wait() {   // at most N LDS/scalar operations still in flight
   if constexpr (N >= 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
@@ -262,24 +275,26 @@ __global__ __launch_bounds__(512) void k_tblock_lw(TBlockArgs a) {
   for (int sp = 0; sp < 2; ++sp) aO[sp] = i * 128 + ((4 * sp + g) ^ ((i >> 1) & 7)) * 16;
 
   bf16x8 fh[3][2], fl[3][2];   // three fragment sets: unit u of a phase with set offset OFF lives in set (OFF + u) % 3
-  // the four reads of one unit, individually addressable so that they can be dropped between MFMAs
-  auto frag_read = [&](auto kind, const unsigned char* slot, int u, int set, int j) {
-    constexpr int KIND = decltype(kind)::value;
-    const int q = j >> 1, lo = j & 1;
-    const unsigned char* p;
-    if constexpr (KIND == K_O) {
-      const int sp = u / (NCT / 2), ct0 = 2 * (u % (NCT / 2));
-      p = slot + aO[sp] + ((ct0 + q) * 16 * 128 + lo * (C * 128));
-    } else {
-      p = slot + aP[u >> 1] + ((2 * (u & 1) + q) * 16 * 4 * C + lo * (2 * C));
-    }
-    lds_read16(lo ? fl[set][q] : fh[set][q], p);
+  // Read j (= 2 q + plane) of unit u of a tile of kind KIND; `base` = LDS address of the slot + the lane's swizzled part
+  // for the unit's k-step (projection tiles: aP[u >> 1]) or k-half (output tiles: aO[u / 4]); the rest is immediate.
+  auto frag_read = [&](auto kind, unsigned base, auto uc, int set, auto jc) {
+    constexpr int KIND = decltype(kind)::value, u = decltype(uc)::value, j = decltype(jc)::value;
+    constexpr int q = j >> 1, lo = j & 1;
+    constexpr int off = (KIND == K_O) ? ((2 * (u % (NCT / 2)) + q) * 16 * 128 + lo * (C * 128))
+                                      : ((2 * (u & 1) + q) * 16 * 4 * C + lo * (2 * C));
+    lds_read16_off<off>(lo ? fl[set][q] : fh[set][q], base);
   };
+  using J0 = std::integral_constant<int, 0>;
+  using J1 = std::integral_constant<int, 1>;
+  using J2 = std::integral_constant<int, 2>;
+  using J3 = std::integral_constant<int, 3>;
   auto prefetch2 = [&](auto kind, const unsigned char* slot, int off) {   // units 0 and 1 of a phase, as a burst
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) frag_read(kind, slot, u, (off + u) % 3, j);
+    constexpr int KIND = decltype(kind)::value;
+    const unsigned base = lds_addr(slot) + (KIND == K_O ? aO[0] : aP[0]);
+    frag_read(kind, base, J0{}, off % 3, J0{}); frag_read(kind, base, J0{}, off % 3, J1{});
+    frag_read(kind, base, J0{}, off % 3, J2{}); frag_read(kind, base, J0{}, off % 3, J3{});
+    frag_read(kind, base, J1{}, (off + 1) % 3, J0{}); frag_read(kind, base, J1{}, (off + 1) % 3, J1{});
+    frag_read(kind, base, J1{}, (off + 1) % 3, J2{}); frag_read(kind, base, J1{}, (off + 1) % 3, J3{});
   };
 
 #ifdef MDT_STAMPS   // tuning build: wave 0 of workgroup 0 records the shader clock at phase boundaries into dbgbuf
@@ -304,43 +319,53 @@ __global__ __launch_bounds__(512) void k_tblock_lw(TBlockArgs a) {
   // operand (activations) per k-step.  The reads of unit u+2 ride between the MFMAs of unit u; for u+2 >= NU they
   // belong to units 0/1 of the NEXT phase (kind NK, in tile tau+1), published by the barrier before unit NU-2.
   auto phase = [&](auto kind, auto offc, auto nkind, bool has_next, f32x4* acc, const bf16x8* bh, const bf16x8* bl) {
-    constexpr int KIND = decltype(kind)::value, OFF = decltype(offc)::value;
-    const unsigned char* cur = slot_of(tau);
-    const unsigned char* nxt = slot_of(tau + 1);
+    constexpr int KIND = decltype(kind)::value, OFF = decltype(offc)::value, NK = decltype(nkind)::value;
+    const unsigned lc = lds_addr(slot_of(tau)), ln = lds_addr(slot_of(tau + 1));
+    unsigned bc[4];                                  // per k-step (projection) / k-half (output: two used)
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
+    for (int k = 0; k < 4; ++k) bc[k] = lc + (KIND == K_O ? aO[k & 1] : aP[k]);
+    const unsigned bn = ln + (NK == K_O ? aO[0] : aP[0]);
+    auto unit = [&](auto uc) {
+      constexpr int u = decltype(uc)::value;
       if (u == NU - 2 && has_next) {
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();                // B(tau + 1)
         __builtin_amdgcn_sched_barrier(0);
       }
-      const int s0 = (OFF + u) % 3, s2 = (OFF + u + 2) % 3;
-      const bool in_phase = u + 2 < NU;
+      constexpr int s0 = (OFF + u) % 3, s2 = (OFF + u + 2) % 3;
+      constexpr bool in_phase = u + 2 < NU;
       const bool pre = in_phase || has_next;
       const bool later = (u + 1 < NU) || has_next;   // unit u+1's reads are in flight behind unit u's
       if (later) lgkm_wait<4>(); else lgkm_wait<0>();
-      int ia, ib;                                    // accumulator index, operand index
-      if constexpr (KIND == K_O) { ia = 2 * (u % (NCT / 2)); ib = u / (NCT / 2); }
-      else { ia = 2 * (u & 1); ib = u >> 1; }
-      auto rd = [&](int j) {
+      constexpr int ia = (KIND == K_O) ? 2 * (u % (NCT / 2)) : 2 * (u & 1);   // accumulator index
+      constexpr int ib = (KIND == K_O) ? u / (NCT / 2) : (u >> 1);             // operand index
+      auto rd = [&](auto jc) {
         if (!pre) return;
         __builtin_amdgcn_sched_barrier(0);
-        if (in_phase) frag_read(kind, cur, u + 2, s2, j);
-        else frag_read(nkind, nxt, u + 2 - NU, s2, j);
+        if constexpr (in_phase) {
+          constexpr int u2 = u + 2;
+          frag_read(kind, bc[KIND == K_O ? u2 / (NCT / 2) : (u2 >> 1)], std::integral_constant<int, u2>{}, s2, jc);
+        } else {
+          frag_read(nkind, bn, std::integral_constant<int, u + 2 - NU>{}, s2, jc);
+        }
         __builtin_amdgcn_sched_barrier(0);
       };
       auto mm = [&](const bf16x8& w, const bf16x8& x, int q) {
         if constexpr (KIND == K_N) acc[ia + q] = MDT_MFMA_BF16(x, w, acc[ia + q], 0, 0, 0);
         else acc[ia + q] = MDT_MFMA_BF16(w, x, acc[ia + q], 0, 0, 0);
       };
-      mm(fl[s0][0], bh[ib], 0); rd(0);
-      mm(fl[s0][1], bh[ib], 1); rd(1);
-      mm(fh[s0][0], bl[ib], 0); rd(2);
-      mm(fh[s0][1], bl[ib], 1); rd(3);
+      mm(fl[s0][0], bh[ib], 0); rd(J0{});
+      mm(fl[s0][1], bh[ib], 1); rd(J1{});
+      mm(fh[s0][0], bl[ib], 0); rd(J2{});
+      mm(fh[s0][1], bl[ib], 1); rd(J3{});
       mm(fh[s0][0], bh[ib], 0);
       mm(fh[s0][1], bh[ib], 1);
       __builtin_amdgcn_sched_barrier(0);
-    }
+    };
+    unit(std::integral_constant<int, 0>{}); unit(std::integral_constant<int, 1>{});
+    unit(std::integral_constant<int, 2>{}); unit(std::integral_constant<int, 3>{});
+    unit(std::integral_constant<int, 4>{}); unit(std::integral_constant<int, 5>{});
+    unit(std::integral_constant<int, 6>{}); unit(std::integral_constant<int, 7>{});
     ++tau;
     MDT_STAMP();
   };
