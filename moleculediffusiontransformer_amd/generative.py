@@ -144,6 +144,8 @@ class _QMBase(nn.Module):
         seq = sequences.detach().float().to(device).contiguous()
         B, n = seq.shape
         out = torch.empty(B, n, self._text_dim + self._pos_dim, device=device)
+        if B == 0:
+            return out
         w = self.fc1.weight.detach().float().to(device).contiguous().view(-1)
         b = self.fc1.bias.detach().float().to(device).contiguous()
         inv = self.p_enc_1d.inv_freq.detach().float().to(device).contiguous() if self._pos_dim else w
@@ -169,6 +171,8 @@ class _QMBase(nn.Module):
         if not isinstance(sampler, ADPM2Sampler) or not isinstance(sigma_schedule, KarrasSchedule):
             raise NotImplementedError("the MI355X path implements ADPM2Sampler with KarrasSchedule")
         device = embedding.device
+        if embedding.shape[0] == 0:                 # nothing to generate (the reference returns an empty tensor too)
+            return torch.empty(0, self.pred_dim, self.max_length, device=device)
         eng = self.engine(device, embedding.shape[1])
         ns = self._noise_source(noise, embedding.shape[0], device)
         with torch.no_grad():

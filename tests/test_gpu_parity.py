@@ -148,3 +148,20 @@ def test_cfg5_architecture_against_oracle():
         y_ref = O.unet_forward(sd, cfg, x, torch.full((B,), 0.2), emb)
     y = m.unet(x.to(DEV), torch.full((B,), 0.2), embedding=emb.to(DEV), embedding_scale=1.0).cpu()
     assert (y - y_ref).abs().max() < 1e-4 * max(1.0, y_ref.abs().max().item())
+
+
+def test_edge_batches_single_and_empty():
+    """B = 1 (a lone sample in a 32 / 64-row workgroup: every other row is padding) equals row 0 of a B = 3 run with
+    the same per-sample noise; B = 0 returns an empty tensor of the right shape without launching anything."""
+    m = make_model("cfg1")
+    seq = synth_normal("edge/seq", (3, 12))
+    init = synth_normal("edge/init", (3, 16, 64))
+    steps = [synth_normal(f"edge/step{i}", (3, 16, 64)) for i in range(5)]
+    full = m.sample(seq, DEV, cond_scale=1.0, timesteps=6, clamp=False,
+                    noise=NoiseSource(init=init, steps=lambda i: steps[i])).cpu()
+    one = m.sample(seq[:1], DEV, cond_scale=1.0, timesteps=6, clamp=False,
+                   noise=NoiseSource(init=init[:1], steps=lambda i: steps[i][:1])).cpu()
+    assert one.shape == (1, 16, 64) and torch.isfinite(one).all()
+    assert torch.equal(one[0], full[0])                 # per-sample arithmetic does not depend on the batch around it
+    empty = m.sample(seq[:0], DEV, cond_scale=1.0, timesteps=6, clamp=False, noise=NoiseSource(seed=3))
+    assert empty.shape == (0, 16, 64)
