@@ -146,7 +146,10 @@ enum mdt_tblock_i {
                                        (levels with few rows); 2: 32-row workgroups, C = 256 (cross: <= 48 keys per 16 rows), weight
                                        stream packed as 128-wide sub-tiles (K halves / output-row halves);
                                        3: as 2, with the heads / hidden chunks of a row block split over two
-                                       workgroups: out = scratch [2][B T][C] for their partial sums         */
+                                       workgroups: out = scratch [2][B T][C] for their partial sums;
+                                       4: chained form of 3 without the reduce launch: block input = a + res (res = the
+                                       previous block's second partial | none), out = block output written by head group 0
+                                       (never aliasing a), p2 = second head group's partial | none (one workgroup)   */
 };
 enum mdt_tblock_f { MDT_BF_EPS = 0, MDT_BF_SCALE = 1 };
 

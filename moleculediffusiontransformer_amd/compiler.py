@@ -132,6 +132,11 @@ class UNetCompiler:
         self.fuse_c256 = os.environ.get("MDT_FUSE_C256", "1") == "1"
         self.tb32 = os.environ.get("MDT_TB32", "1") == "1"           # C = 256 blocks on 32-row workgroups (k_tblock32)
         self.tb_split = os.environ.get("MDT_TB_SPLIT", "1") == "1"   # ... their heads split over two workgroups
+        self.ff_split = os.environ.get("MDT_FF_SPLIT", "0") == "1"   # ... also the feed-forward's hidden chunks
+        # ... partial sums handed to the next sub-block instead of a reduce launch.  Measured: 2511 molecules/s against
+        # 2578 with the 28 reduce launches (the extra dependent loads in every prologue / epilogue and the ping-pong
+        # buffers cost more than 5.4 us per block), so this is not the default.
+        self.tb_chain = os.environ.get("MDT_TB_CHAIN", "0") == "1"
         self.use_rconv = os.environ.get("MDT_RCONV", "1") == "1"     # row-stationary convs (k_rconv) at C = 128 / 256
         self.rconv_two = os.environ.get("MDT_RCONV2", "0") == "1"    # concatenated inputs as ONE two-source launch
         # cross-attention sub-blocks: "1" fuses the shapes whose K/V rows stream through the loader-wave ring
@@ -504,14 +509,16 @@ class UNetCompiler:
         lo = (w - hi.float()).to(torch.bfloat16)
         return torch.cat([hi.contiguous().view(-1), lo.contiguous().view(-1)]).view(torch.float32)
 
-    def tblock(self, t: Ten, mode: int, p: str, cross_index: Optional[int] = None, variant: int = 0) -> None:
-        """One fused sub-block, in place on t: MDT_OP_TBLOCK (self-attention / cross-attention / feed-forward)."""
+    def tblock(self, t: Ten, mode: int, p: str, cross_index: Optional[int] = None, variant: int = 0,
+               x_out: Optional[Ten] = None, p_in: Optional[Ten] = None, p_out: Optional[Ten] = None) -> None:
+        """One fused sub-block: MDT_OP_TBLOCK (self-attention / cross-attention / feed-forward), in place on t, or
+        (variant 4) from t + p_in into x_out with the second head group's partial sum left in p_out."""
         cfg, sd = self.cfg, self.sd
         c, rows = t.ld, t.rows
         perm = torch.tensor(self._SLOT_PERM)
         tiles: List[torch.Tensor] = []
-        if variant in (2, 3):
-            assert c == 256, "variants 2 / 3 (32-row workgroups, sub-tile stream) serve C = 256"
+        if variant in (2, 3, 4):
+            assert c == 256, "variants 2 / 3 / 4 (32-row workgroups, sub-tile stream) serve C = 256"
             assert mode != rt.TB_CROSS or (16 // rows) * self.n_ctx <= 48, "at most 48 context rows per 16 token rows"
         if mode == rt.TB_FF:
             w1, b1 = sd[p + "0.weight"], sd[p + "0.bias"]          # [2C, C]
@@ -544,7 +551,7 @@ class UNetCompiler:
                 bias = torch.cat([bq_f, bo])
                 mid = wq.shape[0]
                 self.flops += 2 * rows * c * mid + 4 * rows * self.n_ctx * mid + 2 * rows * mid * c
-        if variant in (2, 3):
+        if variant in (2, 3, 4):
             # k_tblock32 streams 32 KB sub-tiles in the C = 128 tile format: a [64][256] projection tile as its two
             # K halves, a [256][64] output tile as its two row halves (tiles alternate P ... P O per chunk)
             tpc = 4 if mode == rt.TB_SELF else 2
@@ -575,6 +582,13 @@ class UNetCompiler:
             op._kv = ("kv", cross_index)
             op.a2 = _ref(rt.SP_ACT, 0)
         part = None
+        if variant == 4:
+            assert x_out is not None and x_out is not t and (p_out is None or nchunk % 2 == 0)
+            op.out = x_out.ref()
+            if p_in is not None:
+                op.res = p_in.ref()
+            if p_out is not None:
+                op.p2 = p_out.ref()
         if variant == 3:                         # scratch for the two head groups' partial sums: [2][B rows][c]
             assert nchunk % 2 == 0
             part = self._new(rows, 2 * c)
@@ -635,23 +649,42 @@ class UNetCompiler:
         #                         sits on the L2 -> LDS bandwidth roof (its weight stream is read by 256 workgroups)
         variant = (2 if self.tb32 else 1) if c == 256 else 0
         split = 3 if (variant == 2 and self.tb_split) else variant     # self / cross: two workgroups per row block
+        keys16 = (16 // t.rows) * self.n_ctx                        # context rows per 16 token rows
+        ring_x = (c == 128 and keys16 <= 16) or (variant == 2 and keys16 <= 48)
+        # C = 256: the sub-blocks of a transformer hand the residual stream on as (x, second head group's partial)
+        # through ping-pong buffers, so the head split needs no reduce launch (every sub-block must be a ring kernel)
+        chain = fused and split == 3 and self.tb_chain and (not cross or (self.fuse_cross in ("1", "all") and ring_x))
+        pend: Optional[Ten] = None
         for i in range(layers):
             bp = p + f"blocks.{i}."
+            if chain:
+                steps = [(rt.TB_SELF, bp + "attention.", None, True)]
+                if cross:
+                    self.cross_layers.append(bp + "cross_attention.")
+                    steps.append((rt.TB_CROSS, bp + "cross_attention.", len(self.cross_layers) - 1, True))
+                steps.append((rt.TB_FF, bp + "feed_forward.", None, False))
+                for mode, name, ci, two in steps:
+                    nxt = self._new(t.rows, c)
+                    po = self._new(t.rows, c) if two else None
+                    self.tblock(t, mode, name, ci, variant=4, x_out=nxt, p_in=pend, p_out=po)
+                    self._free(t)
+                    if pend is not None:
+                        self._free(pend)
+                    t, pend = nxt, po
+                continue
             if fused:
                 self.tblock(t, rt.TB_SELF, bp + "attention.", variant=split)
                 if cross:
                     self.cross_layers.append(bp + "cross_attention.")
-                    keys16 = (16 // t.rows) * self.n_ctx            # context rows per 16 token rows
-                    ring_ok = (c == 128 and keys16 <= 16) or (variant == 2 and keys16 <= 48)
-                    xv = split if ring_ok else (1 if variant == 2 else variant)
-                    if self.fuse_cross == "all" or (self.fuse_cross == "1" and ring_ok):
+                    xv = split if ring_x else (1 if variant == 2 else variant)
+                    if self.fuse_cross == "all" or (self.fuse_cross == "1" and ring_x):
                         self.tblock(t, rt.TB_CROSS, bp + "cross_attention.", len(self.cross_layers) - 1,
                                     variant=xv)
                     else:
                         # q-GEMM + attention + out-GEMM (the pre-ring fused cross kernels measured slower than this:
                         # 78 us against ~62 us, their per-head K/V loads were not pipelined)
                         self.attention_layer(t, bp + "cross_attention.", len(self.cross_layers) - 1)
-                self.tblock(t, rt.TB_FF, bp + "feed_forward.", variant=variant)
+                self.tblock(t, rt.TB_FF, bp + "feed_forward.", variant=split if self.ff_split else variant)
                 continue
             self.attention_layer(t, bp + "attention.", None)
             if cross:

@@ -213,11 +213,18 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
   {
     float xr[NST][8];
     const float* xp = a.x + (int64_t)mc * a.ldx + 8 * g;
+    const float* pp = a.pin ? a.pin + (int64_t)mc * C + 8 * g : nullptr;   // chained form: block input = x + pin
     float s = 0.f;
 #pragma unroll
     for (int st = 0; st < NST; ++st) {
-      const float4 u = *reinterpret_cast<const float4*>(xp + 32 * st);
-      const float4 w = *reinterpret_cast<const float4*>(xp + 32 * st + 4);
+      float4 u = *reinterpret_cast<const float4*>(xp + 32 * st);
+      float4 w = *reinterpret_cast<const float4*>(xp + 32 * st + 4);
+      if (pp) {
+        const float4 pu = *reinterpret_cast<const float4*>(pp + 32 * st);
+        const float4 pw = *reinterpret_cast<const float4*>(pp + 32 * st + 4);
+        u.x += pu.x; u.y += pu.y; u.z += pu.z; u.w += pu.w;
+        w.x += pw.x; w.y += pw.y; w.z += pw.z; w.w += pw.w;
+      }
       xr[st][0] = u.x; xr[st][1] = u.y; xr[st][2] = u.z; xr[st][3] = u.w;
       xr[st][4] = w.x; xr[st][5] = w.y; xr[st][6] = w.z; xr[st][7] = w.w;
 #pragma unroll
@@ -589,18 +596,27 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (mvalid) {
-    float* xo = a.x + (int64_t)m * a.ldx + 4 * g;
+    const float* xi = a.x + (int64_t)m * a.ldx + 4 * g;
+    const float* pi = a.pin ? a.pin + (int64_t)m * C + 4 * g : nullptr;
+    float* xo = (a.xout ? a.xout : a.x) + (int64_t)m * a.ldx + 4 * g;
+    // who writes what: in-place / chained head group 0 -> block output (partial + bias + input); every other head
+    // group -> its bare partial (variant 3: slot blockIdx.y of `part` for k_tb_reduce; chained: pout)
+    const bool bare = gridDim.y > 1 && !(a.xout && blockIdx.y == 0);
+    float* po = a.xout ? a.pout + (int64_t)m * C + 4 * g : a.part + ((int64_t)blockIdx.y * a.M + m) * C + 4 * g;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const int ct = 8 * fh + c;
       const f32x4 p0 = part[((2 * rt) * NCT + ct) * 64 + lane], p1 = part[((2 * rt + 1) * NCT + ct) * 64 + lane];
       const f32x4 sum = p0 + p1;                            // feature half 0 first
-      if (gridDim.y > 1) {                                  // partial over this workgroup's heads: k_tb_reduce adds the rest
-        *reinterpret_cast<float4*>(a.part + ((int64_t)blockIdx.y * a.M + m) * C + 16 * ct + 4 * g) =
-            make_float4(sum[0], sum[1], sum[2], sum[3]);
+      if (bare) {
+        *reinterpret_cast<float4*>(po + 16 * ct) = make_float4(sum[0], sum[1], sum[2], sum[3]);
         continue;
       }
-      const float4 xr = *reinterpret_cast<const float4*>(xo + 16 * ct);
+      float4 xr = *reinterpret_cast<const float4*>(xi + 16 * ct);
+      if (pi) {
+        const float4 pr = *reinterpret_cast<const float4*>(pi + 16 * ct);
+        xr.x += pr.x; xr.y += pr.y; xr.z += pr.z; xr.w += pr.w;
+      }
       const float4 bo = *reinterpret_cast<const float4*>(bias + bo_off + 16 * ct + 4 * g);
       *reinterpret_cast<float4*>(xo + 16 * ct) =
           make_float4(sum[0] + bo.x + xr.x, sum[1] + bo.y + xr.y, sum[2] + bo.z + xr.z, sum[3] + bo.w + xr.w);
@@ -619,7 +635,7 @@ static hipError_t launch_32(const TBlockArgs& a, hipStream_t s) {
   }
   const int nsplit = a.nsplit > 1 ? a.nsplit : 1;
   hipLaunchKernelGGL((k_tblock32<MODE, NPW>), dim3((unsigned)((a.M + 31) / 32), (unsigned)nsplit), dim3(512), smem, s, a);
-  if (nsplit > 1) {
+  if (nsplit > 1 && !a.xout) {                        // variant 3: separate fixed-order reduce (the chained form needs none)
     const int bo_off = (MODE == TB_SELF) ? 3 * 64 * a.nchunk : 64 * a.nchunk;
     const int64_t n4 = (int64_t)a.M * (C / 4);
     hipLaunchKernelGGL(k_tb_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, a.x, a.part, a.bias + bo_off, a.M, nsplit);
@@ -630,7 +646,8 @@ static hipError_t launch_32(const TBlockArgs& a, hipStream_t s) {
 hipError_t launch_tblock32(const TBlockArgs& a, hipStream_t s) {
   if (a.M <= 0) return hipSuccess;
   if (a.C != 256 || a.T <= 0 || 16 % a.T || a.nchunk <= 0) return hipErrorInvalidValue;
-  if (a.nsplit > 1 && (a.nchunk % a.nsplit || !a.part)) return hipErrorInvalidValue;
+  if (a.nsplit > 1 && (a.nchunk % a.nsplit || !(a.xout ? (void*)a.pout : (void*)a.part))) return hipErrorInvalidValue;
+  if (a.xout && (a.nsplit > 2 || a.xout == a.x)) return hipErrorInvalidValue;
   if (a.mode == TB_CROSS) {
     if (a.Tk <= 0 || (16 / a.T) * a.Tk > 48) return hipErrorInvalidValue;   // three key tiles per wave at most
     switch (((32 / a.T) * a.Tk + 15) / 16) {

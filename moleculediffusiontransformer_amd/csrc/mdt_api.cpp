@@ -109,7 +109,9 @@ static const char* validate(const mdt_op& o, int idx, char* buf, size_t nbuf) {
       if (i[MDT_B_MODE] == MDT_TB_CROSS && (!o.a2.space || (16 / i[MDT_B_T]) * i[MDT_B_TK] > 64 || i[MDT_B_TK] <= 0))
         return bad("cross block needs K/V and at most 64 keys per 16 rows");
       if (!o.a.space || !o.w.space || !o.bias.space) return bad("missing operand");
-      if (i[MDT_B_VARIANT] < 0 || i[MDT_B_VARIANT] > 3) return bad("unknown fused-block variant");
+      if (i[MDT_B_VARIANT] < 0 || i[MDT_B_VARIANT] > 4) return bad("unknown fused-block variant");
+      if (i[MDT_B_VARIANT] == 4 && (!o.out.space || (o.p2.space && i[MDT_B_NCHUNK] % 2)))
+        return bad("variant 4 needs an output tensor (and an even chunk count when split)");
       if (i[MDT_B_VARIANT] == 3 && (!o.out.space || i[MDT_B_NCHUNK] % 2)) return bad("variant 3 needs a partial-sum buffer and an even chunk count");
       if (i[MDT_B_VARIANT] >= 2 && (i[MDT_B_C] != 256 || (i[MDT_B_MODE] == MDT_TB_CROSS && (16 / i[MDT_B_T]) * i[MDT_B_TK] > 48)))
         return bad("variant 2 (32-row workgroups) serves C = 256, cross blocks with at most 48 keys per 16 rows");
@@ -252,8 +254,12 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
         a.nchunk = o.i[MDT_B_NCHUNK]; a.nbias = o.i[MDT_B_NBIAS]; a.ldx = a.C; a.Tk = o.i[MDT_B_TK];
         a.kv_bstride = o.i[MDT_B_KV_BSTRIDE]; a.ldkv = o.i[MDT_B_LDKV]; a.nheads = o.i[MDT_B_HEADS]; a.nsamples = B;
         a.eps = o.f[MDT_BF_EPS]; a.scale = o.f[MDT_BF_SCALE];
-        a.part = nullptr; a.nsplit = 1;
+        a.part = nullptr; a.nsplit = 1; a.xout = nullptr; a.pin = nullptr; a.pout = nullptr;
         if (o.i[MDT_B_VARIANT] == 3) { a.part = ptr(o.out); a.nsplit = 2; }
+        if (o.i[MDT_B_VARIANT] == 4) {
+          a.xout = ptr(o.out); a.pin = ptr(o.res); a.pout = ptr(o.p2);
+          a.nsplit = o.p2.space ? 2 : 1;
+        }
         if (!missing)
           e = o.i[MDT_B_VARIANT] >= 2   ? mdt::launch_tblock32(a, stream)
               : o.i[MDT_B_VARIANT] == 1 ? mdt::launch_tblock16(a, stream)

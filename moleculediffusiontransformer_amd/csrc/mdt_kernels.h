@@ -82,6 +82,11 @@ struct TBlockArgs {
   const float* dbgbuf; // diagnostic stamps (MDT_DBG & 8), normally nullptr
   float* part;         // k_tblock32 with nsplit > 1: partial outputs [nsplit][M][C] (no bias / residual), summed by k_tb_reduce
   int nsplit;          // workgroups sharing a row block, each taking nchunk / nsplit heads or hidden chunks
+  // chained form (k_tblock32, no reduce launch): the block input is x + pin, head group 0 writes xout = input + its
+  // partial + bias, head group 1 writes its bare partial to pout; xout / pout never alias x / pin
+  float* xout;         // nullptr: in place on x (variants 2, 3)
+  const float* pin;    // partial of the previous block's second head group, or nullptr
+  float* pout;         // where this block's second head group leaves its partial (nsplit == 2)
   int mode, C, M, T, nchunk, nbias, ldx, Tk, kv_bstride, ldkv, nheads, nsamples;
   float eps, scale;
 };

@@ -221,6 +221,24 @@ def _tblock(op, bufs: Buffers, B: int) -> None:
     i, f = op.i, op.f
     mode, C, T, nchunk, nbias = i[rt.B_MODE], i[rt.B_C], i[rt.B_T], i[rt.B_NCHUNK], i[rt.B_NBIAS]
     x = bufs.view(op.a, B, B * T * C).view(B, T, C)
+    chained = i[rt.B_VARIANT] == 4     # block input = a + res; head group 0 -> out (+ bias + input), group 1 -> p2
+    if chained:
+        x_in = x if op.res.space == rt.SP_NONE else x + bufs.view(op.res, B, B * T * C).view(B, T, C)
+        x_out = bufs.view(op.out, B, B * T * C).view(B, T, C)
+        split = op.p2.space != rt.SP_NONE
+        x = x_in
+
+    def finish(hidden, w_out, b_out):
+        """hidden [B, T, mid] times w_out [C, mid]: in place, or split into the two head groups' partial sums."""
+        if not chained:
+            x.__iadd__(hidden @ w_out.T + b_out)
+            return
+        half = hidden.shape[-1] // 2
+        if split:
+            x_out[:] = x_in + hidden[..., :half] @ w_out[:, :half].T + b_out
+            bufs.view(op.p2, B, B * T * C).view(B, T, C)[:] = hidden[..., half:] @ w_out[:, half:].T
+        else:
+            x_out[:] = x_in + hidden @ w_out.T + b_out
     tpc = 4 if mode == rt.TB_SELF else 2
     stream = bufs.view(op.w, B, nchunk * tpc * 64 * C)
     bias = bufs.view(op.bias, B, nbias)
@@ -229,7 +247,7 @@ def _tblock(op, bufs: Buffers, B: int) -> None:
     mid = 64 * nchunk
 
     def tile(k, rows, cols):
-        if i[rt.B_VARIANT] not in (2, 3):
+        if i[rt.B_VARIANT] not in (2, 3, 4):
             return _untile(stream, k, rows, cols)
         # variant 2 (k_tblock32): every tile is stored as two 128-wide sub-tiles (K halves / output-row halves)
         if rows == 64:
@@ -244,7 +262,7 @@ def _tblock(op, bufs: Buffers, B: int) -> None:
 
     if mode == rt.TB_FF:
         h = F.gelu(x @ proj(0).T + bias[:mid])
-        x += h @ outw().T + bias[mid:]
+        finish(h, outw(), bias[mid:])
         return
     xn = F.layer_norm(x, (C,), None, None, eps=float(f[0]))
     H, D = nchunk, 64
@@ -264,4 +282,4 @@ def _tblock(op, bufs: Buffers, B: int) -> None:
         bo = bias[mid:]
     sim = (q @ k.transpose(-1, -2)) * float(f[1])
     o = (sim.softmax(-1) @ v).transpose(1, 2).reshape(B, T, H * D)
-    x += o @ outw().T + bo
+    finish(o, outw(), bo)

@@ -472,3 +472,43 @@ def test_row_stationary_conv(C, T, B, taps, gsize, film, silu, res, in_scale):
     elif res == "accumulate":
         y = y + act[B * T * C: 2 * B * T * C].view(B, T, C)
     assert (og.view(B, T, C) - y).abs().max() < 1e-4 * scale
+
+
+@pytest.mark.parametrize("mode,split,with_pin", [(rt.TB_SELF, True, False), (rt.TB_SELF, True, True), (rt.TB_CROSS, True, True),
+                                                 (rt.TB_FF, False, True), (rt.TB_FF, False, False)])
+@pytest.mark.parametrize("T,B", [(4, 37), (16, 3)])
+def test_chained_split_sub_block(mode, split, with_pin, T, B):
+    """MDT_OP_TBLOCK variant 4 (k_tblock32): block input = x + p_in, head group 0 writes x_out = input + its partial
+    + bias, head group 1 leaves its bare partial in p_out; no reduce launch, x itself is not touched."""
+    from moleculediffusiontransformer_amd.compiler import Ten, UNetCompiler
+    from moleculediffusiontransformer_amd.netspec import inverse_unet_config
+    C, n_ctx, mid = 256, 12, 512
+    if mode == rt.TB_CROSS and (16 // T) * n_ctx > 48:
+        pytest.skip("more than 48 keys per 16 rows")
+    p = "blk."
+    sd = {p + "norm.weight": 1 + 0.2 * rnd(C, seed=1), p + "norm.bias": 0.2 * rnd(C, seed=2),
+          p + "norm_context.weight": 1 + 0.2 * rnd(C, seed=3), p + "norm_context.bias": 0.2 * rnd(C, seed=4),
+          p + "to_q.weight": rnd(mid, C, seed=5, scale=C ** -0.5), p + "to_kv.weight": rnd(2 * mid, C, seed=6, scale=C ** -0.5),
+          p + "attention.to_out.weight": rnd(C, mid, seed=7, scale=mid ** -0.5), p + "attention.to_out.bias": 0.1 * rnd(C, seed=8),
+          p + "0.weight": rnd(2 * C, C, seed=9, scale=C ** -0.5), p + "0.bias": 0.1 * rnd(2 * C, seed=10),
+          p + "2.weight": rnd(C, 2 * C, seed=11, scale=(2 * C) ** -0.5), p + "2.bias": 0.1 * rnd(C, seed=12)}
+    comp = UNetCompiler(inverse_unet_config(16, 64, 128, 12), 64, n_ctx, sd)
+    n_x, n_kv = T * C, n_ctx * 2 * mid
+    x, x_out, p_in, p_out = Ten(A, 0, T, C), Ten(A, n_x + n_kv, T, C), Ten(A, 2 * n_x + n_kv, T, C), Ten(A, 3 * n_x + n_kv, T, C)
+    comp.tblock(x, mode, p, 0 if mode == rt.TB_CROSS else None, variant=4, x_out=x_out,
+                p_in=p_in if with_pin else None, p_out=p_out if split else None)
+    op = comp.ops[0]
+    if mode == rt.TB_CROSS:
+        op.a2 = ref(A, n_x)
+    act = torch.cat([rnd(B * n_x, seed=13) * 1.5 + 0.3, rnd(B * n_kv, seed=14), torch.zeros(B * n_x),
+                     0.5 * rnd(B * n_x, seed=15), torch.zeros(B * n_x)])
+    (ga, _, _), (ca, _, _) = run_both([op], comp.W.pack(), act, torch.zeros(4), {}, B)
+    lo = B * (n_x + n_kv)
+    og, oc = ga[lo: lo + B * n_x], ca[lo: lo + B * n_x]
+    assert torch.isfinite(og).all() and (og - oc).abs().max() < 1e-4 * max(1.0, oc.abs().max().item())
+    assert not torch.equal(oc, torch.zeros_like(oc))
+    if split:
+        pg, pc = ga[lo + 2 * B * n_x:], ca[lo + 2 * B * n_x:]
+        assert (pg - pc).abs().max() < 1e-4 * max(1.0, pc.abs().max().item()) and pc.abs().max() > 0
+    assert torch.equal(ga[: lo], ca[: lo])              # x and K/V untouched
+    assert torch.equal(ga[lo + B * n_x: lo + 2 * B * n_x], ca[lo + B * n_x: lo + 2 * B * n_x])   # p_in untouched
