@@ -98,7 +98,9 @@ __global__ __launch_bounds__(256) void k_tb_reduce(float* x, const float* part, 
 }
 
 // NPW (MODE_CROSS only): LDS-DMA pieces per loader wave per K / V tile = ceil(context rows of the workgroup / 16)
-template <int MODE, int NPW>
+// CHAIN: variant 4 (input = x + pin, outputs xout / pout); a separate instantiation so that the in-place kernels
+// keep their exact code (the chained form costs them 1.8 % when folded in as run-time branches)
+template <int MODE, int NPW, bool CHAIN>
 __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
   // sub-tiles per chunk: q0 q1 k0 k1 v0 v1 o0 o1 | q0 q1 K V o0 o1 (K, V = hoisted context rows) | w1a w1b w2a w2b
   constexpr int SPC = (MODE == TB_SELF) ? 8 : (MODE == TB_CROSS) ? 6 : 4;
@@ -213,23 +215,28 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
   {
     float xr[NST][8];
     const float* xp = a.x + (int64_t)mc * a.ldx + 8 * g;
-    const float* pp = a.pin ? a.pin + (int64_t)mc * C + 8 * g : nullptr;   // chained form: block input = x + pin
     float s = 0.f;
 #pragma unroll
     for (int st = 0; st < NST; ++st) {
-      float4 u = *reinterpret_cast<const float4*>(xp + 32 * st);
-      float4 w = *reinterpret_cast<const float4*>(xp + 32 * st + 4);
-      if (pp) {
-        const float4 pu = *reinterpret_cast<const float4*>(pp + 32 * st);
-        const float4 pw = *reinterpret_cast<const float4*>(pp + 32 * st + 4);
-        u.x += pu.x; u.y += pu.y; u.z += pu.z; u.w += pu.w;
-        w.x += pw.x; w.y += pw.y; w.z += pw.z; w.w += pw.w;
-      }
+      const float4 u = *reinterpret_cast<const float4*>(xp + 32 * st);
+      const float4 w = *reinterpret_cast<const float4*>(xp + 32 * st + 4);
       xr[st][0] = u.x; xr[st][1] = u.y; xr[st][2] = u.z; xr[st][3] = u.w;
       xr[st][4] = w.x; xr[st][5] = w.y; xr[st][6] = w.z; xr[st][7] = w.w;
+    }
+    if (CHAIN && a.pin) {                            // chained form (variant 4): block input = x + pin
+      const float* pp = a.pin + (int64_t)mc * C + 8 * g;
+#pragma unroll
+      for (int st = 0; st < NST; ++st) {
+        const float4 pu = *reinterpret_cast<const float4*>(pp + 32 * st);
+        const float4 pw = *reinterpret_cast<const float4*>(pp + 32 * st + 4);
+        xr[st][0] += pu.x; xr[st][1] += pu.y; xr[st][2] += pu.z; xr[st][3] += pu.w;
+        xr[st][4] += pw.x; xr[st][5] += pw.y; xr[st][6] += pw.z; xr[st][7] += pw.w;
+      }
+    }
+#pragma unroll
+    for (int st = 0; st < NST; ++st)
 #pragma unroll
       for (int e = 0; e < 8; ++e) s += xr[st][e];
-    }
     float mean = 0.f, rstd = 1.f;
     if constexpr (MODE != TB_FF) {
       s += __shfl_xor(s, 16, 64);
@@ -597,12 +604,12 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
   __builtin_amdgcn_s_barrier();
   if (mvalid) {
     const float* xi = a.x + (int64_t)m * a.ldx + 4 * g;
-    const float* pi = a.pin ? a.pin + (int64_t)m * C + 4 * g : nullptr;
-    float* xo = (a.xout ? a.xout : a.x) + (int64_t)m * a.ldx + 4 * g;
+    const float* pi = (CHAIN && a.pin) ? a.pin + (int64_t)m * C + 4 * g : nullptr;
+    float* xo = (CHAIN ? a.xout : a.x) + (int64_t)m * a.ldx + 4 * g;
     // who writes what: in-place / chained head group 0 -> block output (partial + bias + input); every other head
     // group -> its bare partial (variant 3: slot blockIdx.y of `part` for k_tb_reduce; chained: pout)
-    const bool bare = gridDim.y > 1 && !(a.xout && blockIdx.y == 0);
-    float* po = a.xout ? a.pout + (int64_t)m * C + 4 * g : a.part + ((int64_t)blockIdx.y * a.M + m) * C + 4 * g;
+    const bool bare = gridDim.y > 1 && !(CHAIN && blockIdx.y == 0);
+    float* po = CHAIN ? a.pout + (int64_t)m * C + 4 * g : a.part + ((int64_t)blockIdx.y * a.M + m) * C + 4 * g;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const int ct = 8 * fh + c;
@@ -613,7 +620,7 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
         continue;
       }
       float4 xr = *reinterpret_cast<const float4*>(xi + 16 * ct);
-      if (pi) {
+      if (CHAIN && pi) {
         const float4 pr = *reinterpret_cast<const float4*>(pi + 16 * ct);
         xr.x += pr.x; xr.y += pr.y; xr.z += pr.z; xr.w += pr.w;
       }
@@ -624,23 +631,28 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
   }
 }
 
-template <int MODE, int NPW = 0>
-static hipError_t launch_32(const TBlockArgs& a, hipStream_t s) {
+template <int MODE, int NPW, bool CHAIN>
+static hipError_t launch_32c(const TBlockArgs& a, hipStream_t s) {
   const size_t smem = (size_t)NS * SLOT + (MODE == TB_CROSS ? 3 : 1) * 4 * 64 * 16;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tblock32<MODE, NPW>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tblock32<MODE, NPW, CHAIN>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
     attr_set = true;
   }
   const int nsplit = a.nsplit > 1 ? a.nsplit : 1;
-  hipLaunchKernelGGL((k_tblock32<MODE, NPW>), dim3((unsigned)((a.M + 31) / 32), (unsigned)nsplit), dim3(512), smem, s, a);
+  hipLaunchKernelGGL((k_tblock32<MODE, NPW, CHAIN>), dim3((unsigned)((a.M + 31) / 32), (unsigned)nsplit), dim3(512), smem, s, a);
   if (nsplit > 1 && !a.xout) {                        // variant 3: separate fixed-order reduce (the chained form needs none)
     const int bo_off = (MODE == TB_SELF) ? 3 * 64 * a.nchunk : 64 * a.nchunk;
     const int64_t n4 = (int64_t)a.M * (C / 4);
     hipLaunchKernelGGL(k_tb_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, a.x, a.part, a.bias + bo_off, a.M, nsplit);
   }
   return hipGetLastError();
+}
+
+template <int MODE, int NPW = 0>
+static hipError_t launch_32(const TBlockArgs& a, hipStream_t s) {
+  return a.xout ? launch_32c<MODE, NPW, true>(a, s) : launch_32c<MODE, NPW, false>(a, s);
 }
 
 hipError_t launch_tblock32(const TBlockArgs& a, hipStream_t s) {
