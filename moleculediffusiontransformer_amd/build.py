@@ -69,6 +69,19 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     """Compile every translation unit for gfx950 and link libmdt_hip.so.  Returns its path."""
     if not force and is_fresh():
         return LIB
+    # one builder at a time: under torchrun every rank may find the library missing at the same moment
+    import fcntl
+    with open(os.path.join(CSRC, ".build_lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and is_fresh():          # another process built it while this one waited
+                return LIB
+            return _build_locked(verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(verbose: bool) -> str:
     hipcc = _hipcc()
 
     def compile_one(item):
