@@ -129,10 +129,16 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the sampling path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # test hook (one-GPU boxes): MDT_BENCH_SHARE_GPU=1 puts every rank on cuda:0 over gloo to exercise the N > 1 logic
+    share = os.environ.get("MDT_BENCH_SHARE_GPU", "0") == "1"
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     from gpu_util import make_model
     from moleculediffusiontransformer_amd import NoiseSource, runtime as rt

@@ -165,3 +165,23 @@ def test_edge_batches_single_and_empty():
     assert torch.equal(one[0], full[0])                 # per-sample arithmetic does not depend on the batch around it
     empty = m.sample(seq[:0], DEV, cond_scale=1.0, timesteps=6, clamp=False, noise=NoiseSource(seed=3))
     assert empty.shape == (0, 16, 64)
+
+
+def test_bench_two_rank_logic_on_one_gpu():
+    """bench.py's N > 1 path (barriers, one all-gather per call, max-over-ranks timing, ONE JSON line from rank 0):
+    two ranks share cuda:0 over gloo (test hook MDT_BENCH_SHARE_GPU; the real thing is one rank per GPU over RCCL)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MDT_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "64", "--timesteps", "4",
+                        "--no-breakdown"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["scaling"] == "weak" and d["value"] > 0
