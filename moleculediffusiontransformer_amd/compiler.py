@@ -543,7 +543,11 @@ class UNetCompiler:
                     tiles += [self._tile(wq_f[64 * h: 64 * h + 64]), self._tile(wkv_f[64 * h: 64 * h + 64]),
                               self._tile(wkv_f[mid + 64 * h: mid + 64 * h + 64]),
                               self._tile(wo[:, 64 * h: 64 * h + 64][:, perm])]
-                bias = torch.cat([bq_f, bkv_f, bo])
+                # k bias: softmax is invariant to a per-query constant (q . bk), drop it; v bias: sum_j p_j (v_j + bv)
+                # = sum_j p_j v_j + bv, so it moves into the output bias.  The kernels then load only bq per head
+                # (their own global loads queue behind the loader waves' DMA traffic: ~60 cycles of issue stall each).
+                bo_eff = bo + wo @ bkv_f[mid:]
+                bias = torch.cat([bq_f, torch.zeros(2 * mid), bo_eff])
                 self.flops += 2 * rows * c * 3 * mid + 4 * rows * rows * mid + 2 * rows * mid * c
             else:
                 for h in range(nchunk):

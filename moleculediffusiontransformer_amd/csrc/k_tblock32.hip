@@ -56,6 +56,11 @@ __device__ __forceinline__ void lds_read16_off(bf16x8& dst, unsigned addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
 }
 
+template <int OFF>      // per-chunk bias vector from LDS, read like a fragment (k_tblock_lw.hip)
+__device__ __forceinline__ void lds_read_f4_off(f32x4& dst, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+
 __device__ __forceinline__ unsigned lds_addr(const unsigned char* p) {
   return (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)p;
 }
@@ -398,8 +403,13 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
   }
   const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // this workgroup's per-chunk bias vectors (bq | b1 of chunks h0 .. h1-1) -> LDS behind the ring and the exchange area
+  float* bias_s = reinterpret_cast<float*>(smem + NS * SLOT + (MODE == TB_CROSS ? 3 : 1) * 4 * 64 * 16);
+  for (int t = tid; t < 64 * (h1 - h0); t += 256) bias_s[t] = bias[64 * h0 + t];
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                      // B(0)
   prefetch2(kT, slot_of(0), 0);
+  const unsigned bias_l = lds_addr(reinterpret_cast<const unsigned char*>(bias_s)) + 128 * fh + 16 * g;   // + 256 (h - h0)
 
   MDT_STAMP();
   for (int h = h0; h < h1; ++h) {
@@ -407,11 +417,8 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
     f32x4 oT[2];      // this wave's 32 features of the chunk: [feature 32 fh + 16 q + 4 g + r][token i]
     if constexpr (MODE == TB_FF) {
       f32x4 b1[2];
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        b1[q] = *reinterpret_cast<const f32x4*>(bias + 64 * h + 32 * fh + 16 * q + 4 * g);
-        oT[q] = zero4;
-      }
+      lds_read_f4_off<0>(b1[0], bias_l + 256 * (h - h0)); lds_read_f4_off<64>(b1[1], bias_l + 256 * (h - h0));
+      oT[0] = zero4; oT[1] = zero4;
       phase(kT, IC0{}, kT, true, oT, xh, xl);               // K half 0
       phase(kT, IC1{}, kT, false, oT, xh + 4, xl + 4);      // K half 1
       __builtin_amdgcn_s_barrier();                         // B(first W2 sub-tile)
@@ -422,11 +429,8 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
         for (int r = 0; r < 4; ++r) oT[q][r] = gelu_32(oT[q][r] + b1[q][r]);
     } else if constexpr (MODE == TB_CROSS) {
       f32x4 qT[2], bq[2];
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        bq[q] = *reinterpret_cast<const f32x4*>(bias + 64 * h + 32 * fh + 16 * q + 4 * g);
-        qT[q] = zero4;
-      }
+      lds_read_f4_off<0>(bq[0], bias_l + 256 * (h - h0)); lds_read_f4_off<64>(bq[1], bias_l + 256 * (h - h0));
+      qT[0] = zero4; qT[1] = zero4;
       phase(kT, IC0{}, kT, true, qT, xh, xl);
       phase(kT, IC1{}, kT, false, qT, xh + 4, xl + 4);
       __builtin_amdgcn_s_barrier();                         // B(K tile)
@@ -522,14 +526,10 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
     } else {
       f32x4 qT[2], kTt[2], vT[2];
       f32x4 bq[2];
+      // (the host folds the k bias away -- softmax-invariant -- and the v bias into the output bias)
+      lds_read_f4_off<0>(bq[0], bias_l + 256 * (h - h0)); lds_read_f4_off<64>(bq[1], bias_l + 256 * (h - h0));
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {     // k / v biases initialise their accumulators (needed two phases from now)
-        bq[q] = *reinterpret_cast<const f32x4*>(bias + 64 * h + 32 * fh + 16 * q + 4 * g);
-        kTt[q] = *reinterpret_cast<const f32x4*>(bias + 64 * (a.nchunk + h) + 32 * fh + 16 * q + 4 * g);
-        const float bv = bias[64 * (2 * a.nchunk + h) + 32 * fh + 16 * q + i];
-        vT[q] = f32x4{bv, bv, bv, bv};
-        qT[q] = zero4;
-      }
+      for (int q = 0; q < 2; ++q) { kTt[q] = zero4; vT[q] = zero4; qT[q] = zero4; }
       phase(kT, IC0{}, kT, true, qT, xh, xl);
       phase(kT, IC1{}, kT, true, qT, xh + 4, xl + 4);
       phase(kT, IC2{}, kT, true, kTt, xh, xl);
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
 
 template <int MODE, int NPW, bool CHAIN>
 static hipError_t launch_32c(const TBlockArgs& a, hipStream_t s) {
-  const size_t smem = (size_t)NS * SLOT + (MODE == TB_CROSS ? 3 : 1) * 4 * 64 * 16;
+  const size_t smem = (size_t)NS * SLOT + (MODE == TB_CROSS ? 3 : 1) * 4 * 64 * 16 + (size_t)64 * a.nchunk * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tblock32<MODE, NPW, CHAIN>),

@@ -64,6 +64,13 @@ __device__ __forceinline__ void lds_read16_off(bf16x8& dst, unsigned addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
 }
 
+// per-head bias vectors live in LDS behind the ring and are read like fragments (asm, counted in the lgkmcnt waits): a
+// global load issued by a compute wave queues behind the loader waves' DMA traffic and stalls its issue ~60 cycles
+template <int OFF>
+__device__ __forceinline__ void lds_read_f4_off(f32x4& dst, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+
 __device__ __forceinline__ unsigned lds_addr(const unsigned char* p) {
   return (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)p;
 }
@@ -361,6 +368,9 @@ __global__ __launch_bounds__(512) void k_tblock_lw(TBlockArgs a) {
       mm(fh[s0][0], bh[ib], 0);
       mm(fh[s0][1], bh[ib], 1);
       __builtin_amdgcn_sched_barrier(0);
+#ifdef MDT_STAMPS_UNITS
+      if constexpr (KIND == K_T && OFF == 0) MDT_STAMP();
+#endif
     };
     unit(std::integral_constant<int, 0>{}); unit(std::integral_constant<int, 1>{});
     unit(std::integral_constant<int, 2>{}); unit(std::integral_constant<int, 3>{});
@@ -411,8 +421,13 @@ __global__ __launch_bounds__(512) void k_tblock_lw(TBlockArgs a) {
   }
   const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // the first 64 * nchunk bias entries (bq | b1: the per-chunk vectors) -> LDS behind the ring
+  float* bias_s = reinterpret_cast<float*>(smem + NS * SLOT);
+  for (int t = tid; t < 64 * a.nchunk; t += 256) bias_s[t] = bias[t];
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                      // B(0)
   prefetch2(kT, slot_of(0), 0);
+  const unsigned bias_l = lds_addr(reinterpret_cast<const unsigned char*>(bias_s)) + 16 * g;   // + 256 h per chunk
 
   MDT_STAMP();
   for (int h = 0; h < a.nchunk; ++h) {
@@ -420,11 +435,10 @@ __global__ __launch_bounds__(512) void k_tblock_lw(TBlockArgs a) {
     f32x4 oT[4];
     if constexpr (MODE == TB_FF) {
       f32x4 b1[4];
+      lds_read_f4_off<0>(b1[0], bias_l + 256 * h); lds_read_f4_off<64>(b1[1], bias_l + 256 * h);
+      lds_read_f4_off<128>(b1[2], bias_l + 256 * h); lds_read_f4_off<192>(b1[3], bias_l + 256 * h);
 #pragma unroll
-      for (int ft = 0; ft < 4; ++ft) {
-        b1[ft] = *reinterpret_cast<const f32x4*>(bias + 64 * h + 16 * ft + 4 * g);
-        oT[ft] = zero4;
-      }
+      for (int ft = 0; ft < 4; ++ft) oT[ft] = zero4;
       phase(kT, IC0{}, kT, false, oT, xh, xl);       // hidden chunk^T = W1 x^T
       __builtin_amdgcn_s_barrier();                  // B(w2 tile)
       prefetch2(kO, slot_of(tau), 1);
@@ -434,11 +448,10 @@ __global__ __launch_bounds__(512) void k_tblock_lw(TBlockArgs a) {
         for (int r = 0; r < 4; ++r) oT[ft][r] = gelu_lw(oT[ft][r] + b1[ft][r]);
     } else if constexpr (MODE == TB_CROSS) {
       f32x4 qT[4], bq[4];
+      lds_read_f4_off<0>(bq[0], bias_l + 256 * h); lds_read_f4_off<64>(bq[1], bias_l + 256 * h);
+      lds_read_f4_off<128>(bq[2], bias_l + 256 * h); lds_read_f4_off<192>(bq[3], bias_l + 256 * h);
 #pragma unroll
-      for (int ft = 0; ft < 4; ++ft) {
-        bq[ft] = *reinterpret_cast<const f32x4*>(bias + 64 * h + 16 * ft + 4 * g);
-        qT[ft] = zero4;
-      }
+      for (int ft = 0; ft < 4; ++ft) qT[ft] = zero4;
       phase(kT, IC0{}, kT, false, qT, xh, xl);       // q^T
       __builtin_amdgcn_s_barrier();                  // B(K tile)
       const unsigned char* sk = slot_of(tau);
@@ -499,26 +512,18 @@ __global__ __launch_bounds__(512) void k_tblock_lw(TBlockArgs a) {
       prefetch2(kO, slot_of(tau), 1);
     } else {
       f32x4 qT[4], kTt[4], vT[4];
-      f32x4 bq[4], bk[4];
-      float bv[4];
+      f32x4 bq[4];       // the host folds the k bias away (softmax-invariant) and the v bias into the output bias
+      lds_read_f4_off<0>(bq[0], bias_l + 256 * h); lds_read_f4_off<64>(bq[1], bias_l + 256 * h);
+      lds_read_f4_off<128>(bq[2], bias_l + 256 * h); lds_read_f4_off<192>(bq[3], bias_l + 256 * h);
 #pragma unroll
-      for (int ft = 0; ft < 4; ++ft) {
-        bq[ft] = *reinterpret_cast<const f32x4*>(bias + 64 * h + 16 * ft + 4 * g);
-        bk[ft] = *reinterpret_cast<const f32x4*>(bias + 64 * (a.nchunk + h) + 16 * ft + 4 * g);
-        bv[ft] = bias[64 * (2 * a.nchunk + h) + 16 * ft + i];
-        qT[ft] = zero4; kTt[ft] = zero4; vT[ft] = zero4;
-      }
+      for (int ft = 0; ft < 4; ++ft) { qT[ft] = zero4; kTt[ft] = zero4; vT[ft] = zero4; }
       phase(kT, IC0{}, kT, true, qT, xh, xl);        // q^T
       phase(kT, IC2{}, kN, true, kTt, xh, xl);       // k^T
       phase(kN, IC1{}, kN, false, vT, xh, xl);       // v (un-transposed)
       __builtin_amdgcn_s_barrier();                  // B(output tile)
       prefetch2(kO, slot_of(tau), 1);
 #pragma unroll
-      for (int ft = 0; ft < 4; ++ft) {
-        qT[ft] += bq[ft];
-        kTt[ft] += bk[ft];
-        vT[ft] += f32x4{bv[ft], bv[ft], bv[ft], bv[ft]};
-      }
+      for (int ft = 0; ft < 4; ++ft) qT[ft] += bq[ft];
       f32x4 s0 = zero4, s1 = zero4;
 #pragma unroll
       for (int ft = 0; ft < 4; ++ft) {
@@ -585,7 +590,7 @@ __global__ __launch_bounds__(512) void k_tblock_lw(TBlockArgs a) {
 
 template <int MODE, int NPW = 0>
 static hipError_t launch_lw(const TBlockArgs& a, hipStream_t s) {
-  const size_t smem = (size_t)NS * SLOT;
+  const size_t smem = (size_t)NS * SLOT + (size_t)64 * a.nchunk * sizeof(float);   // ring + per-chunk bias vectors
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tblock_lw<MODE, NPW>),
