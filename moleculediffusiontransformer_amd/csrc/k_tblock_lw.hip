@@ -369,7 +369,7 @@ __global__ __launch_bounds__(512) void k_tblock_lw(TBlockArgs a) {
       mm(fh[s0][1], bh[ib], 1);
       __builtin_amdgcn_sched_barrier(0);
 #ifdef MDT_STAMPS_UNITS
-      if constexpr (KIND == K_T && OFF == 0) MDT_STAMP();
+      MDT_STAMP();
 #endif
     };
     unit(std::integral_constant<int, 0>{}); unit(std::integral_constant<int, 1>{});
