@@ -309,7 +309,7 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
     if (stamps && blockIdx.x == 0 && wave == 0 && nstamp < 120) {                     \
       unsigned long long t_;                                                          \
       asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");      \
-      if (lane == 0) stamps[nstamp] = t_;                                             \
+      if (lane == 0) stamps[nstamp] = (t_ & 0xffffffffffffull) | ((unsigned long long)__LINE__ << 48);  \
       ++nstamp;                                                                       \
     }                                                                                 \
   } while (0)
@@ -361,6 +361,9 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
       mm(frh[s0][0], bh[ib], 0);
       mm(frh[s0][1], bh[ib], 1);
       __builtin_amdgcn_sched_barrier(0);
+#ifdef MDT_STAMPS_UNITS
+      MDT_STAMP();
+#endif
     };
     unit(std::integral_constant<int, 0>{}); unit(std::integral_constant<int, 1>{});
     unit(std::integral_constant<int, 2>{}); unit(std::integral_constant<int, 3>{});

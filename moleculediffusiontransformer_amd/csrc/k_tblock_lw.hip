@@ -312,7 +312,7 @@ __global__ __launch_bounds__(512) void k_tblock_lw(TBlockArgs a) {
     if (stamps && blockIdx.x == 0 && wave == 0 && nstamp < 120) {                     \
       unsigned long long t_;                                                          \
       asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");      \
-      if (lane == 0) stamps[nstamp] = t_;                                             \
+      if (lane == 0) stamps[nstamp] = (t_ & 0xffffffffffffull) | ((unsigned long long)__LINE__ << 48);  \
       ++nstamp;                                                                       \
     }                                                                                 \
   } while (0)

@@ -46,9 +46,12 @@ for (C, T) in [(128, 16), (256, 4)]:
                 for _ in range(20): prog.run(b, B)
                 t.stop(); ms = t.collect()[0] / 20
             if os.environ.get('MDT_DBG', '0') == '8':
-                st = dbg.cpu().view(torch.int64)[:120].tolist()
-                d = [st[k + 1] - st[k] for k in range(119) if st[k + 1] > 0]
-                print("   stamp deltas (s_memtime ticks):", d[:44], " total", st[max(k for k in range(120) if st[k] > 0)] - st[0])
+                raw = dbg.cpu().view(torch.int64)[:120].tolist()
+                st = [v & 0xffffffffffff for v in raw]
+                tags = [(v >> 48) & 0xffff for v in raw]
+                d = [(tags[k + 1], st[k + 1] - st[k]) for k in range(119) if st[k + 1] > 0]
+                print("   stamps (source line of the stamp : cycles since the previous one):", " ".join(f"{t}:{c}" for t, c in d[:70]),
+                      " total", st[max(k for k in range(120) if st[k] > 0)] - st[0])
                 ls = dbg.cpu().view(torch.int64)[128:248].tolist()
                 if ls[0] > 0:
                     print("   loader (wait-landed, barrier, issue+loop) x tiles:", [(ls[3*k+1]-ls[3*k], ls[3*k+2]-ls[3*k+1], ls[3*k+3]-ls[3*k+2]) for k in range(12) if ls[3*k+3] > 0])
