@@ -441,27 +441,33 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
       const unsigned char* sk = slot_of(tau);
       qT[0] += bq[0];
       qT[1] += bq[1];
+      // Partial S^T over this wave's 32 features for all key tiles: branch-free (rows past the wave's keys are clamped
+      // to a real row, their scores are masked below), so that the six K reads go out together and the six
+      // independent MFMA chains interleave instead of read -> wait -> 8 dependent MFMAs -> write per key tile.
       f32x4 st[KTM];
+      float4 k0[KTM], k1[KTM];
 #pragma unroll
-      for (int kt = 0; kt < KTM; ++kt) {                    // partial S^T over this wave's 32 features, key tile kt
-        st[kt] = zero4;
-        if (16 * kt < nkeys) {
-          const int R = Rw + min(16 * kt + i, nkeys - 1);
-          const unsigned char* kp = sk + R * 256;
-          const float4 k0 = *reinterpret_cast<const float4*>(kp + (((8 * fh + g) ^ (R & 15)) << 4));
-          const float4 k1 = *reinterpret_cast<const float4*>(kp + (((8 * fh + 4 + g) ^ (R & 15)) << 4));
-          f32x4 sp0 = zero4, sp1 = zero4;
-          sp0 = MDT_MFMA_F32(k0.x, qT[0][0], sp0, 0, 0, 0);
-          sp1 = MDT_MFMA_F32(k1.x, qT[1][0], sp1, 0, 0, 0);
-          sp0 = MDT_MFMA_F32(k0.y, qT[0][1], sp0, 0, 0, 0);
-          sp1 = MDT_MFMA_F32(k1.y, qT[1][1], sp1, 0, 0, 0);
-          sp0 = MDT_MFMA_F32(k0.z, qT[0][2], sp0, 0, 0, 0);
-          sp1 = MDT_MFMA_F32(k1.z, qT[1][2], sp1, 0, 0, 0);
-          sp0 = MDT_MFMA_F32(k0.w, qT[0][3], sp0, 0, 0, 0);
-          sp1 = MDT_MFMA_F32(k1.w, qT[1][3], sp1, 0, 0, 0);
-          st[kt] = sp0 + sp1;
-          red[(kt * 4 + wave) * 64 + lane] = st[kt];
-        }
+      for (int kt = 0; kt < KTM; ++kt) {
+        const int R = Rw + min(16 * kt + i, nkeys - 1);
+        const unsigned char* kp = sk + R * 256;
+        k0[kt] = *reinterpret_cast<const float4*>(kp + (((8 * fh + g) ^ (R & 15)) << 4));
+        k1[kt] = *reinterpret_cast<const float4*>(kp + (((8 * fh + 4 + g) ^ (R & 15)) << 4));
+      }
+      f32x4 sp0[KTM], sp1[KTM];
+#pragma unroll
+      for (int kt = 0; kt < KTM; ++kt) { sp0[kt] = zero4; sp1[kt] = zero4; }
+#pragma unroll
+      for (int kt = 0; kt < KTM; ++kt) { sp0[kt] = MDT_MFMA_F32(k0[kt].x, qT[0][0], sp0[kt], 0, 0, 0); sp1[kt] = MDT_MFMA_F32(k1[kt].x, qT[1][0], sp1[kt], 0, 0, 0); }
+#pragma unroll
+      for (int kt = 0; kt < KTM; ++kt) { sp0[kt] = MDT_MFMA_F32(k0[kt].y, qT[0][1], sp0[kt], 0, 0, 0); sp1[kt] = MDT_MFMA_F32(k1[kt].y, qT[1][1], sp1[kt], 0, 0, 0); }
+#pragma unroll
+      for (int kt = 0; kt < KTM; ++kt) { sp0[kt] = MDT_MFMA_F32(k0[kt].z, qT[0][2], sp0[kt], 0, 0, 0); sp1[kt] = MDT_MFMA_F32(k1[kt].z, qT[1][2], sp1[kt], 0, 0, 0); }
+#pragma unroll
+      for (int kt = 0; kt < KTM; ++kt) { sp0[kt] = MDT_MFMA_F32(k0[kt].w, qT[0][3], sp0[kt], 0, 0, 0); sp1[kt] = MDT_MFMA_F32(k1[kt].w, qT[1][3], sp1[kt], 0, 0, 0); }
+#pragma unroll
+      for (int kt = 0; kt < KTM; ++kt) {
+        st[kt] = sp0[kt] + sp1[kt];
+        red[(kt * 4 + wave) * 64 + lane] = st[kt];
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       ++tau;
@@ -472,17 +478,13 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
       float mx = -INFINITY;
 #pragma unroll
       for (int kt = 0; kt < KTM; ++kt) {
-        if (16 * kt < nkeys) {
-          const f32x4 other = red[(kt * 4 + (wave ^ 1)) * 64 + lane];
-          const f32x4 s01 = fh ? (other + st[kt]) : (st[kt] + other);   // same sum in both waves of the row tile
+        const f32x4 other = red[(kt * 4 + (wave ^ 1)) * 64 + lane];
+        const f32x4 s01 = fh ? (other + st[kt]) : (st[kt] + other);   // same sum in both waves of the row tile
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float sv2 = ((okbits >> (4 * kt + r)) & 1u) ? s01[r] * scale2 : -INFINITY;
-            st[kt][r] = sv2;
-            mx = fmaxf(mx, sv2);
-          }
-        } else {
-          st[kt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        for (int r = 0; r < 4; ++r) {
+          const float sv2 = ((okbits >> (4 * kt + r)) & 1u) ? s01[r] * scale2 : -INFINITY;   // okbits: key exists, same sample
+          st[kt][r] = sv2;
+          mx = fmaxf(mx, sv2);
         }
       }
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
@@ -501,25 +503,24 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
       const float inv = __builtin_amdgcn_rcpf(sum);
       MDT_STAMP();
       oT[0] = zero4; oT[1] = zero4;
+      f32x4 v0[KTM], v1[KTM];                               // V[key 16 kt + 4 g + r][32 fh + 16 dt + i], dt = 0, 1
 #pragma unroll
-      for (int kt = 0; kt < KTM; ++kt) {
-        if (16 * kt < nkeys) {
-          f32x4 v0, v1;                                     // V[key 16 kt + 4 g + r][32 fh + 16 dt + i], dt = 0, 1
+      for (int kt = 0; kt < KTM; ++kt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int R = Rw + min(16 * kt + 4 * g + r, nkeys - 1);
-            const unsigned char* vp = sv + R * 256 + (i & 3) * 4;
-            v0[r] = *reinterpret_cast<const float*>(vp + (((8 * fh + (i >> 2)) ^ (R & 15)) << 4));
-            v1[r] = *reinterpret_cast<const float*>(vp + (((8 * fh + 4 + (i >> 2)) ^ (R & 15)) << 4));
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float p = st[kt][r] * inv;
-            oT[0] = MDT_MFMA_F32(v0[r], p, oT[0], 0, 0, 0);
-            oT[1] = MDT_MFMA_F32(v1[r], p, oT[1], 0, 0, 0);
-          }
+        for (int r = 0; r < 4; ++r) {
+          const int R = Rw + min(16 * kt + 4 * g + r, nkeys - 1);
+          const unsigned char* vp = sv + R * 256 + (i & 3) * 4;
+          v0[kt][r] = *reinterpret_cast<const float*>(vp + (((8 * fh + (i >> 2)) ^ (R & 15)) << 4));
+          v1[kt][r] = *reinterpret_cast<const float*>(vp + (((8 * fh + 4 + (i >> 2)) ^ (R & 15)) << 4));
         }
-      }
+#pragma unroll
+      for (int kt = 0; kt < KTM; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = st[kt][r] * inv;                  // exactly 0 for masked keys
+          oT[0] = MDT_MFMA_F32(v0[kt][r], p, oT[0], 0, 0, 0);
+          oT[1] = MDT_MFMA_F32(v1[kt][r], p, oT[1], 0, 0, 0);
+        }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // V reads complete before the slot can be refilled
       ++tau;
       MDT_STAMP();
