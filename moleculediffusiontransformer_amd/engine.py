@@ -117,7 +117,9 @@ class UNetEngine:
             self.programs[name].run(self._bind(xin=self.xin, out=out), self.B)
             torch.cuda.synchronize(self.device)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # thread_local: only this thread's launches are captured; other threads (e.g. the RCCL watchdog of a
+            # multi-GPU run) may keep issuing runtime calls without invalidating the capture
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self.programs[name].run(self._bind(xin=self.xin, out=out), self.B)
             self._graphs[name] = g
         g.replay()
