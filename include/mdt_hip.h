@@ -108,7 +108,10 @@ enum mdt_gemm_i {
   MDT_G_ACT = 18,    /* epilogue: 0 none, 1 exact-erf GELU                                         */
   MDT_G_M_MODE = 19, /* 0: M = B * R_OUT; 1: M = n_shared_rows * R_OUT; 2: M = R_OUT               */
   MDT_G_A_COL = 20,  /* first channel of the A row to consume                                     */
-  MDT_G_O_COL = 21   /* first column of the output row to write                                   */
+  MDT_G_O_COL = 21,  /* first column of the output row to write                                   */
+  MDT_G_PHASES = 22  /* f > 1: ConvTranspose1d(k = 2f, stride f, padding f/2) as f output phases of 2 taps in ONE
+                        launch (modules.py:74-81): phase ph uses weights [ph][N][K], T_OFF = (ph < f/2),
+                        O_OFF = f * T_OFF + ph - f/2, O_STRIDE = f; 0 / 1: a plain GEMM                 */
 };
 enum mdt_gemm_f { MDT_GF_EPS = 0 };
 

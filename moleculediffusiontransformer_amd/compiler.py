@@ -138,6 +138,7 @@ class UNetCompiler:
         # buffers cost more than 5.4 us per block), so this is not the default.
         self.tb_chain = os.environ.get("MDT_TB_CHAIN", "0") == "1"
         self.use_rconv = os.environ.get("MDT_RCONV", "1") == "1"     # row-stationary convs (k_rconv) at C = 128 / 256
+        self.convt_merge = os.environ.get("MDT_CONVT_MERGE", "1") == "1"   # ConvTranspose phases in one launch
         self.rconv_two = os.environ.get("MDT_RCONV2", "0") == "1"    # concatenated inputs as ONE two-source launch
         # cross-attention sub-blocks: "1" fuses the shapes whose K/V rows stream through the loader-wave ring
         # (k_tblock_lw: C = 128, at most 16 context rows per 16 token rows; k_tblock32: C = 256, at most 48),
@@ -236,7 +237,7 @@ class UNetCompiler:
              gain: Optional[int] = None, nbias: Optional[int] = None, stats: Optional[Ten] = None,
              film: Optional[rt.MdtRef] = None, groups: int = 0, gsize: int = 0, pro_silu: int = 0,
              act: int = 0, eps: float = 0.0, m_mode: int = 0, a_col: int = 0, o_col: int = 0,
-             count_flops: bool = True) -> None:
+             count_flops: bool = True, phases: int = 0) -> None:
         op = rt.MdtOp()
         op.kind = rt.OP_GEMM
         w_off, wlo_off = self._pack_w(wt, cin)
@@ -267,10 +268,11 @@ class UNetCompiler:
         i[rt.G_LDR] = res.ld if res is not None else 0
         i[rt.G_PRO], i[rt.G_GROUPS], i[rt.G_GSIZE], i[rt.G_PRO_SILU] = pro, groups, gsize, pro_silu
         i[rt.G_ACT], i[rt.G_M_MODE], i[rt.G_A_COL], i[rt.G_O_COL] = act, m_mode, a_col, o_col
+        i[rt.G_PHASES] = phases
         op.f[0] = eps
         self._emit(op)
         if count_flops:
-            self.flops += 2 * r_out * n * taps * cin
+            self.flops += 2 * r_out * n * taps * cin * max(phases, 1)
 
     def gn_stats(self, x: Ten, groups: int, gsize: int, eps: float) -> Ten:
         st = self._new(1, 2 * groups)
@@ -800,12 +802,20 @@ class UNetCompiler:
             y = self._new(x.rows * f, co)
             last = u == cfg.num_layers - 1
             res = skips_list[0][0] if last else None       # `x += skips_list.pop()` (modules.py:1176)
-            for ph in range(f):
-                shift = 1 if ph < f // 2 else 0
-                wp = torch.stack((wt[:, :, ph], wt[:, :, ph + f]), dim=0).permute(2, 0, 1)   # [Cout][2][Cin]
-                self.gemm(x, (f"{up}upsample.weight/phase{ph}", wp.reshape(co, 2 * ci)), co, y, cin=ci, bias_off=bias, taps=2,
-                          t_stride=1, t_dj=-1, t_off=shift, r_out=x.rows, o_stride=f, o_off=f * shift + ph - f // 2,
-                          res=res)
+            if self.convt_merge:
+                # all f phases in ONE launch (grid.z = phase): each phase alone is a 64..256-workgroup GEMM that runs
+                # at launch latency, and the phases are independent
+                wall = torch.cat([torch.stack((wt[:, :, ph], wt[:, :, ph + f]), dim=0).permute(2, 0, 1).reshape(co, 2 * ci)
+                                  for ph in range(f)])                                       # [f * Cout][2 * Cin]
+                self.gemm(x, (f"{up}upsample.weight/phases", wall), co, y, cin=ci, bias_off=bias, taps=2, t_stride=1,
+                          t_dj=-1, t_off=0, r_out=x.rows, o_stride=f, o_off=0, res=res, phases=f)
+            else:
+                for ph in range(f):
+                    shift = 1 if ph < f // 2 else 0
+                    wp = torch.stack((wt[:, :, ph], wt[:, :, ph + f]), dim=0).permute(2, 0, 1)   # [Cout][2][Cin]
+                    self.gemm(x, (f"{up}upsample.weight/phase{ph}", wp.reshape(co, 2 * ci)), co, y, cin=ci, bias_off=bias,
+                              taps=2, t_stride=1, t_dj=-1, t_off=shift, r_out=x.rows, o_stride=f,
+                              o_off=f * shift + ph - f // 2, res=res)
             self._free(x)
             x = y
         self._free(skips_list.pop()[0])

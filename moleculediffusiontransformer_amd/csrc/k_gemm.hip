@@ -48,6 +48,7 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs g) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
+  gemm_select_phase(g);
 
   // XCD-aware tile order: blocks are dealt round-robin over the 8 XCDs, so give each XCD a contiguous
   // run of logical tiles (neighbouring N-tiles of one M-tile then share that XCD's L2 copy of A).
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs g) {
 template <int PRO>
 static hipError_t launch_pro(const GemmArgs& g, hipStream_t s) {
   const int mt = (g.M + BM - 1) / BM, nt = (g.N + BN - 1) / BN;
-  dim3 grid((unsigned)(mt * nt)), block(NTHREADS);
+  dim3 grid((unsigned)(mt * nt), 1, (unsigned)(g.phases > 1 ? g.phases : 1)), block(NTHREADS);
   if (g.cin % 32 == 0)
     hipLaunchKernelGGL((k_gemm<PRO, 32>), grid, block, 0, s, g);
   else

@@ -222,7 +222,7 @@ static hipError_t launch_as(const GemmArgs& g, hipStream_t s) {
 }
 
 bool gemm_as_eligible(const GemmArgs& g) {
-  return g.W_lo && g.taps == 1 && g.t_stride == 1 && g.t_off == 0 && (g.cin == 128 || g.cin == 256) && g.N >= 128 &&
+  return g.phases <= 1 && g.W_lo && g.taps == 1 && g.t_stride == 1 && g.t_off == 0 && (g.cin == 128 || g.cin == 256) && g.N >= 128 &&
          g.pro >= 0 && g.pro <= 3 && (g.pro != 2 || g.p3);
 }
 

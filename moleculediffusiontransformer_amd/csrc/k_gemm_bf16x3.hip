@@ -57,6 +57,7 @@ __global__ __launch_bounds__(256) void k_gemm3(GemmArgs g) {
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* rstat = reinterpret_cast<float*>(smem + STAGES * STAGE);   // [BM][2], LayerNorm prologue only
+  gemm_select_phase(g);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nt = (g.N + BN - 1) / BN;
@@ -305,7 +306,7 @@ static hipError_t launch3(const GemmArgs& g, hipStream_t s) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_gemm3<PRO, TM, TN, BKT, STAGES>), dim3((unsigned)(mt * nt)), dim3(256), smem, s, g);
+  hipLaunchKernelGGL((k_gemm3<PRO, TM, TN, BKT, STAGES>), dim3((unsigned)(mt * nt), 1, (unsigned)(g.phases > 1 ? g.phases : 1)), dim3(256), smem, s, g);
   return hipGetLastError();
 }
 
@@ -332,7 +333,9 @@ static hipError_t launch3_pro(const GemmArgs& g, hipStream_t s) {
   }
   // Tile choice: the largest tile that still yields >= 2 workgroups per CU (256 CUs); otherwise 64x64 tiles
   // with the deepest K chunk the channel count allows (fewest iterations for the latency-bound small layers).
-  auto tiles = [&](int bm, int bn) { return (int64_t)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn); };
+  auto tiles = [&](int bm, int bn) {
+    return (int64_t)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * (g.phases > 1 ? g.phases : 1);
+  };
   int cfg, stages;
   if (g.N > 64 && tiles(128, 128) >= 512) cfg = 0;
   else if (g.cin % 64 == 0 && tiles(128, 64) >= 512) cfg = 1;

@@ -190,7 +190,7 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
         g.N = i[MDT_G_N]; g.ldc = i[MDT_G_LDC]; g.o_rows = i[MDT_G_O_ROWS]; g.o_stride = i[MDT_G_O_STRIDE];
         g.o_off = i[MDT_G_O_OFF]; g.ldr = i[MDT_G_LDR]; g.pro = i[MDT_G_PRO]; g.groups = i[MDT_G_GROUPS];
         g.gsize = i[MDT_G_GSIZE]; g.pro_silu = i[MDT_G_PRO_SILU]; g.act = i[MDT_G_ACT]; g.a_col = i[MDT_G_A_COL];
-        g.o_col = i[MDT_G_O_COL]; g.eps = o.f[MDT_GF_EPS];
+        g.o_col = i[MDT_G_O_COL]; g.eps = o.f[MDT_GF_EPS]; g.phases = i[MDT_G_PHASES];
         if (!missing) {
           static const bool no_as = getenv("MDT_NO_AS") != nullptr;   // tuning aid: disable the A-stationary kernel
           if (!g.W_lo) e = mdt::launch_gemm(g, stream);

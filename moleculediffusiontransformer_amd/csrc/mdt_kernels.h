@@ -20,8 +20,24 @@ struct GemmArgs {
   int M, r_out, r_in, lda, cin, taps, t_stride, t_dj, t_off;
   int N, ldc, o_rows, o_stride, o_off, ldr;
   int pro, groups, gsize, pro_silu, act, a_col, o_col;
+  int phases;  // > 1: ConvTranspose1d(k = 2 f, stride f, padding f / 2) as f output phases of 2 taps each in ONE launch:
+               // phase ph = blockIdx.z uses weights [ph][N][K], t_off = (ph < f/2), o_off = f t_off + ph - f/2
   float eps;
 };
+#ifdef __HIPCC__
+// per-phase view of a multi-phase GEMM (first statement of every GEMM kernel)
+__device__ __forceinline__ void gemm_select_phase(GemmArgs& g) {
+  if (g.phases > 1) {
+    const int ph = blockIdx.z, f = g.phases;
+    const int shift = ph < f / 2 ? 1 : 0;
+    const long wo = (long)ph * g.N * (g.taps * g.cin) / (g.W_lo ? 2 : 1);   // floats: bf16 planes hold 2 per float
+    g.W += wo;
+    if (g.W_lo) g.W_lo += wo;
+    g.t_off = shift;
+    g.o_off = f * shift + ph - f / 2;
+  }
+}
+#endif
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t s);          // exact fp32 MFMA (k_gemm.hip)
 hipError_t launch_gemm_bf16x3(const GemmArgs& g, hipStream_t s);   // split-bf16 MFMA (k_gemm_bf16x3.hip)
 bool gemm_as_eligible(const GemmArgs& g);                           // wide-N / small-K layers

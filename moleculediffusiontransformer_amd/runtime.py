@@ -19,7 +19,7 @@ PRO_NONE, PRO_LAYERNORM, PRO_GROUPNORM, PRO_SILU = 0, 1, 2, 3
 
 # integer slots (enum mdt_gemm_i etc. in mdt_hip.h)
 G_R_OUT, G_R_IN, G_LDA, G_CIN, G_TAPS, G_T_STRIDE, G_T_DJ, G_T_OFF, G_N, G_LDC, G_O_ROWS, G_O_STRIDE, \
-    G_O_OFF, G_LDR, G_PRO, G_GROUPS, G_GSIZE, G_PRO_SILU, G_ACT, G_M_MODE, G_A_COL, G_O_COL = range(22)
+    G_O_OFF, G_LDR, G_PRO, G_GROUPS, G_GSIZE, G_PRO_SILU, G_ACT, G_M_MODE, G_A_COL, G_O_COL, G_PHASES = range(23)
 N_ROWS, N_LD, N_GROUPS, N_GSIZE, N_SILU = range(5)
 A_T, A_TK, A_HEADS, A_LDQ, A_LDKV, A_LDO, A_KV_BSTRIDE = range(7)
 C_ROWS, C_CA, C_CB = range(3)

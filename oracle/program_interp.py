@@ -67,31 +67,38 @@ def run_program(ops, bufs: Buffers, B: int, n_shared_rows: int = 0) -> None:
                     a = _silu(a)
             elif pro == rt.PRO_SILU:
                 a = _silu(a)
+            nph = max(int(i[rt.G_PHASES]), 1)         # > 1: ConvTranspose1d phases sharing one op (include/mdt_hip.h)
             if op.a2.space != rt.SP_NONE:      # split-bf16 weights: two bf16 planes stored as raw bits
-                half = n * taps * cin // 2
+                half = nph * n * taps * cin // 2
                 hi = bufs.view(op.w, B, half).view(torch.bfloat16).float()
                 lo = bufs.view(op.a2, B, half).view(torch.bfloat16).float()
-                w = (hi + lo).view(n, taps, cin)
+                w_all = (hi + lo).view(nph, n, taps, cin)
             else:
-                w = bufs.view(op.w, B, n * taps * cin).view(n, taps, cin)
+                w_all = bufs.view(op.w, B, nph * n * taps * cin).view(nph, n, taps, cin)
             r = torch.arange(r_out)
-            acc = torch.zeros(batches, r_out, n)
-            for t in range(taps):
-                src = r * i[rt.G_T_STRIDE] + t * i[rt.G_T_DJ] + i[rt.G_T_OFF]
-                ok = (src >= 0) & (src < r_in)
-                rows = a[:, src.clamp(0, r_in - 1), :] * ok.view(1, -1, 1)
-                acc = acc + rows @ w[:, t, :].T
-            if op.bias.space != rt.SP_NONE:
-                acc = acc + bufs.view(op.bias, B, n)
-            if i[rt.G_ACT] == 1:
-                acc = F.gelu(acc)
-            orow = r * i[rt.G_O_STRIDE] + i[rt.G_O_OFF]
-            if op.res.space != rt.SP_NONE:
-                ldr = i[rt.G_LDR]
-                res = bufs.view(op.res, B, batches * o_rows * ldr).view(batches, o_rows, ldr)
-                acc = acc + res[:, orow, :n]
             out = bufs.view(op.out, B, batches * o_rows * ldc).view(batches, o_rows, ldc)
-            out[:, orow, i[rt.G_O_COL]: i[rt.G_O_COL] + n] = acc
+            for ph in range(nph):
+                w = w_all[ph]
+                t_off, o_off = i[rt.G_T_OFF], i[rt.G_O_OFF]
+                if nph > 1:
+                    t_off = 1 if ph < nph // 2 else 0
+                    o_off = nph * t_off + ph - nph // 2
+                acc = torch.zeros(batches, r_out, n)
+                for t in range(taps):
+                    src = r * i[rt.G_T_STRIDE] + t * i[rt.G_T_DJ] + t_off
+                    ok = (src >= 0) & (src < r_in)
+                    rows = a[:, src.clamp(0, r_in - 1), :] * ok.view(1, -1, 1)
+                    acc = acc + rows @ w[:, t, :].T
+                if op.bias.space != rt.SP_NONE:
+                    acc = acc + bufs.view(op.bias, B, n)
+                if i[rt.G_ACT] == 1:
+                    acc = F.gelu(acc)
+                orow = r * i[rt.G_O_STRIDE] + o_off
+                if op.res.space != rt.SP_NONE:
+                    ldr = i[rt.G_LDR]
+                    res = bufs.view(op.res, B, batches * o_rows * ldr).view(batches, o_rows, ldr)
+                    acc = acc + res[:, orow, :n]
+                out[:, orow, i[rt.G_O_COL]: i[rt.G_O_COL] + n] = acc
         elif op.kind == rt.OP_GN_STATS:
             rows, ld, G, gs = i[rt.N_ROWS], i[rt.N_LD], i[rt.N_GROUPS], i[rt.N_GSIZE]
             x = bufs.view(op.a, B, B * rows * ld).view(B, rows, ld)[:, :, : G * gs].reshape(B, rows, G, gs)
