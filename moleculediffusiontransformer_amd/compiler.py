@@ -139,6 +139,8 @@ class UNetCompiler:
         self.tb_chain = os.environ.get("MDT_TB_CHAIN", "0") == "1"
         self.use_rconv = os.environ.get("MDT_RCONV", "1") == "1"     # row-stationary convs (k_rconv) at C = 128 / 256
         self.convt_merge = os.environ.get("MDT_CONVT_MERGE", "1") == "1"   # ConvTranspose phases in one launch
+        # Transformer1d's closing 1x1 convolution folded into its last feed-forward block (ring kernels only)
+        self.fold_out = os.environ.get("MDT_FOLD_OUT", "1") == "1" and os.environ.get("MDT_TB_LW", "1") != "0"
         self.rconv_two = os.environ.get("MDT_RCONV2", "0") == "1"    # concatenated inputs as ONE two-source launch
         # cross-attention sub-blocks: "1" fuses the shapes whose K/V rows stream through the loader-wave ring
         # (k_tblock_lw: C = 128, at most 16 context rows per 16 token rows; k_tblock32: C = 256, at most 48),
@@ -512,7 +514,8 @@ class UNetCompiler:
         return torch.cat([hi.contiguous().view(-1), lo.contiguous().view(-1)]).view(torch.float32)
 
     def tblock(self, t: Ten, mode: int, p: str, cross_index: Optional[int] = None, variant: int = 0,
-               x_out: Optional[Ten] = None, p_in: Optional[Ten] = None, p_out: Optional[Ten] = None) -> None:
+               x_out: Optional[Ten] = None, p_in: Optional[Ten] = None, p_out: Optional[Ten] = None,
+               post=None) -> None:
         """One fused sub-block: MDT_OP_TBLOCK (self-attention / cross-attention / feed-forward), in place on t, or
         (variant 4) from t + p_in into x_out with the second head group's partial sum left in p_out."""
         cfg, sd = self.cfg, self.sd
@@ -526,8 +529,17 @@ class UNetCompiler:
             w1, b1 = sd[p + "0.weight"], sd[p + "0.bias"]          # [2C, C]
             w2, b2 = sd[p + "2.weight"], sd[p + "2.bias"]          # [C, 2C]
             nchunk = w1.shape[0] // 64
+            if post is not None:
+                # Transformer1d's closing Conv1d(k=1) (modules.py:524) folded in: y = Wout (x + W2 h + b2) + bout
+                #   = (Wout W2) h + Wout x + (Wout b2 + bout); the kernel adds the Wout x term from its raw-x operands
+                wout, bout = post[0].reshape(c, c).double(), post[1].double()
+                w2, b2 = (wout @ w2.double()).float(), (wout @ b2.double() + bout).float()
             for h in range(nchunk):
                 tiles += [self._tile(w1[64 * h: 64 * h + 64]), self._tile(w2[:, 64 * h: 64 * h + 64][:, perm])]
+            if post is not None:
+                assert variant in (0, 2) and x_out is None
+                tiles += [self._tile(post[0].reshape(c, c)[:, 64 * e: 64 * e + 64]) for e in range(c // 64)]
+                self.flops += 2 * rows * c * c
             bias = torch.cat([b1, b2])
             self.flops += 2 * 2 * rows * c * w1.shape[0]
         else:
@@ -565,7 +577,7 @@ class UNetCompiler:
             for k, tl in enumerate(tiles):
                 raw = tl.view(torch.bfloat16)
                 n = raw.numel() // 2
-                if k % tpc == tpc - 1:
+                if k % tpc == tpc - 1 or k >= nchunk * tpc:      # output tiles (incl. a folded closing convolution's)
                     hi, lo = raw[:n].view(c, 64), raw[n:].view(c, 64)
                     halves = [(hi[:128], lo[:128]), (hi[128:], lo[128:])]
                 else:
@@ -588,6 +600,9 @@ class UNetCompiler:
             op._kv = ("kv", cross_index)
             op.a2 = _ref(rt.SP_ACT, 0)
         part = None
+        if post is not None:
+            op.out = post[2].ref()
+            i[rt.B_POST] = (c // 64) * (2 if variant == 2 else 1)     # extra (sub-)tiles
         if variant == 4:
             assert x_out is not None and x_out is not t and (p_out is None or nchunk % 2 == 0)
             op.out = x_out.ref()
@@ -661,6 +676,7 @@ class UNetCompiler:
         # through ping-pong buffers, so the head split needs no reduce launch (every sub-block must be a ring kernel)
         chain = fused and split == 3 and self.tb_chain and (not cross or (self.fuse_cross in ("1", "all") and ring_x))
         pend: Optional[Ten] = None
+        y_fold: Optional[Ten] = None
         for i in range(layers):
             bp = p + f"blocks.{i}."
             if chain:
@@ -690,7 +706,13 @@ class UNetCompiler:
                         # q-GEMM + attention + out-GEMM (the pre-ring fused cross kernels measured slower than this:
                         # 78 us against ~62 us, their per-head K/V loads were not pipelined)
                         self.attention_layer(t, bp + "cross_attention.", len(self.cross_layers) - 1)
-                self.tblock(t, rt.TB_FF, bp + "feed_forward.", variant=split if self.ff_split else variant)
+                ffv = split if self.ff_split else variant
+                if i == layers - 1 and self.fold_out and ffv in (0, 2):
+                    y_fold = self._new(t.rows, c)
+                    self.tblock(t, rt.TB_FF, bp + "feed_forward.", variant=ffv,
+                                post=(self.sd[p + "to_out.1.weight"], self.sd[p + "to_out.1.bias"], y_fold))
+                else:
+                    self.tblock(t, rt.TB_FF, bp + "feed_forward.", variant=ffv)
                 continue
             self.attention_layer(t, bp + "attention.", None)
             if cross:
@@ -702,6 +724,9 @@ class UNetCompiler:
             self.gemm(h, self._lin_w(bp + "feed_forward.2.weight"), c, t, cin=c * cfg.ff_mult,
                       bias_off=self._vec(bp + "feed_forward.2.bias", c), res=t)
             self._free(h)
+        if y_fold is not None:                      # the last feed-forward block already produced to_out(t)
+            self._free(t)
+            return y_fold
         y = self._new(t.rows, c)
         if self.rconv_ok(t.rows, c, 1, 0):
             self.rconv(t, self.sd[p + "to_out.1.weight"], p + "to_out.1.weight", y, taps=1,

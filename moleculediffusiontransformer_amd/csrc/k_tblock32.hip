@@ -21,6 +21,7 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 enum { TB_SELF = 0, TB_CROSS = 1, TB_FF = 2 };
 enum { K_T = 0, K_N = 1, K_O = 2 };   // transposed projection, un-transposed projection, output projection
@@ -117,7 +118,8 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // head / hidden-chunk range of this workgroup: blockIdx.y of gridDim.y workgroups share the row block (nsplit)
   const int h0 = (int)blockIdx.y * (a.nchunk / (int)gridDim.y), h1 = h0 + a.nchunk / (int)gridDim.y;
-  const int NT = (h1 - h0) * SPC;                  // tau counts this workgroup's sub-tiles; the stream index is tau + h0 SPC
+  const int NX = (MODE == TB_FF) ? a.post : 0;     // extra output sub-tiles of a folded closing convolution (mdt_kernels.h)
+  const int NT = (h1 - h0) * SPC + NX;             // tau counts this workgroup's sub-tiles; the stream index is tau + h0 SPC
   const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(a.w);
 
   if (wave >= 4) {
@@ -171,14 +173,13 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
       const int wt = (MODE == TB_CROSS) ? 4 * (h0 + tau / SPC) + (j < 2 ? j : j - 2) : tau + h0 * SPC;   // index into the weight stream
       const unsigned char* tile = wsrc + (int64_t)wt * SLOT;       // wave-uniform
       unsigned char* slot = smem + (tau % NS) * SLOT + iw * 1024;
-      if (j < SPC - 2) {
+      // per element select (not two loops over two arrays: hipcc then indexes a merged array dynamically, puts it in
+      // scratch and waits for every scratch load with vmcnt(0), which serialises the whole DMA stream)
+      const bool ptile = (j < SPC - 2 && tau < (h1 - h0) * SPC);
 #pragma unroll
-        for (int q = 0; q < IPT; ++q)
-          __builtin_amdgcn_global_load_lds(tile + voffP[q], (__attribute__((address_space(3))) void*)(slot + q * 4096), 16, 0, 0);
-      } else {
-#pragma unroll
-        for (int q = 0; q < IPT; ++q)
-          __builtin_amdgcn_global_load_lds(tile + voffO[q], (__attribute__((address_space(3))) void*)(slot + q * 4096), 16, 0, 0);
+      for (int q = 0; q < IPT; ++q) {
+        const unsigned off = ptile ? voffP[q] : voffO[q];
+        __builtin_amdgcn_global_load_lds(tile + off, (__attribute__((address_space(3))) void*)(slot + q * 4096), 16, 0, 0);
       }
     };
     auto issue_tile = [&](int tau) {
@@ -595,7 +596,28 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
       split8_32(v, oh[0], ol[0]);
     }
     phase(kO, IC1{}, kO, true, accT, oh, ol);               // output rows 0..127
-    phase(kO, IC2{}, kT, more, accT + 8, oh, ol);           // output rows 128..255
+    if (NX > 0 && !more) phase(kO, IC2{}, kO, true, accT + 8, oh, ol);   // the folded convolution's sub-tiles follow
+    else phase(kO, IC2{}, kT, more, accT + 8, oh, ol);      // output rows 128..255
+  }
+  if constexpr (MODE == TB_FF) {
+    if (NX > 0) {
+      // + Wout x (folded closing convolution): per 64-channel k chunk of the raw x operands one output tile = two row-half
+      // sub-tiles; this wave's k-step is the chunk's half fh (a register select: fh is not a compile-time index)
+      bf16x8 oxh[1], oxl[1];
+      auto pick = [&](int kc) {
+        const i32x4 h0v = __builtin_bit_cast(i32x4, xh[2 * kc]), h1v = __builtin_bit_cast(i32x4, xh[2 * kc + 1]);
+        const i32x4 l0v = __builtin_bit_cast(i32x4, xl[2 * kc]), l1v = __builtin_bit_cast(i32x4, xl[2 * kc + 1]);
+        i32x4 hv, lv;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { hv[k] = fh ? h1v[k] : h0v[k]; lv[k] = fh ? l1v[k] : l0v[k]; }
+        oxh[0] = __builtin_bit_cast(bf16x8, hv);
+        oxl[0] = __builtin_bit_cast(bf16x8, lv);
+      };
+      pick(0); phase(kO, IC0{}, kO, true, accT, oxh, oxl); phase(kO, IC1{}, kO, true, accT + 8, oxh, oxl);
+      pick(1); phase(kO, IC2{}, kO, true, accT, oxh, oxl); phase(kO, IC0{}, kO, true, accT + 8, oxh, oxl);
+      pick(2); phase(kO, IC1{}, kO, true, accT, oxh, oxl); phase(kO, IC2{}, kO, true, accT + 8, oxh, oxl);
+      pick(3); phase(kO, IC0{}, kO, true, accT, oxh, oxl); phase(kO, IC1{}, kT, false, accT + 8, oxh, oxl);
+    }
   }
 
   // ---- sum the two feature halves' accumulators through LDS (the ring is idle now), add bias + residual ----
@@ -609,7 +631,7 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
   if (mvalid) {
     const float* xi = a.x + (int64_t)m * a.ldx + 4 * g;
     const float* pi = (CHAIN && a.pin) ? a.pin + (int64_t)m * C + 4 * g : nullptr;
-    float* xo = (CHAIN ? a.xout : a.x) + (int64_t)m * a.ldx + 4 * g;
+    float* xo = ((CHAIN || NX > 0) ? a.xout : a.x) + (int64_t)m * a.ldx + 4 * g;
     // who writes what: in-place / chained head group 0 -> block output (partial + bias + input); every other head
     // group -> its bare partial (variant 3: slot blockIdx.y of `part` for k_tb_reduce; chained: pout)
     const bool bare = gridDim.y > 1 && !(CHAIN && blockIdx.y == 0);
@@ -624,6 +646,7 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
         continue;
       }
       float4 xr = *reinterpret_cast<const float4*>(xi + 16 * ct);
+      if (NX > 0) xr = make_float4(0.f, 0.f, 0.f, 0.f);     // folded closing convolution: Wout x is already in the sum
       if (CHAIN && pi) {
         const float4 pr = *reinterpret_cast<const float4*>(pi + 16 * ct);
         xr.x += pr.x; xr.y += pr.y; xr.z += pr.z; xr.w += pr.w;
@@ -656,12 +679,13 @@ static hipError_t launch_32c(const TBlockArgs& a, hipStream_t s) {
 
 template <int MODE, int NPW = 0>
 static hipError_t launch_32(const TBlockArgs& a, hipStream_t s) {
-  return a.xout ? launch_32c<MODE, NPW, true>(a, s) : launch_32c<MODE, NPW, false>(a, s);
+  return (a.xout && !a.post) ? launch_32c<MODE, NPW, true>(a, s) : launch_32c<MODE, NPW, false>(a, s);
 }
 
 hipError_t launch_tblock32(const TBlockArgs& a, hipStream_t s) {
   if (a.M <= 0) return hipSuccess;
   if (a.C != 256 || a.T <= 0 || 16 % a.T || a.nchunk <= 0) return hipErrorInvalidValue;
+  if (a.post && (a.mode != TB_FF || a.post != 8 || a.nsplit > 1 || a.pin || !a.xout)) return hipErrorInvalidValue;
   if (a.nsplit > 1 && (a.nchunk % a.nsplit || !(a.xout ? (void*)a.pout : (void*)a.part))) return hipErrorInvalidValue;
   if (a.xout && (a.nsplit > 2 || a.xout == a.x)) return hipErrorInvalidValue;
   if (a.mode == TB_CROSS) {

@@ -101,7 +101,8 @@ __global__ __launch_bounds__(512) void k_tblock_lw(TBlockArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int NT = a.nchunk * TPC;
+  const int NX = (MODE == TB_FF) ? a.post : 0;     // extra output tiles of a folded 1x1 convolution (mdt_kernels.h)
+  const int NT = a.nchunk * TPC + NX;
   const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(a.w);
 
   if (wave >= 4) {
@@ -164,14 +165,13 @@ __global__ __launch_bounds__(512) void k_tblock_lw(TBlockArgs a) {
       const int j = tau % TPC;
       const int wt = (MODE == TB_CROSS) ? 2 * (tau >> 2) + (j == 3) : tau;      // index into the weight-tile stream
       const unsigned char* tile = wsrc + (int64_t)wt * SLOT;       // wave-uniform
-      if (j != TPC - 1) {
+      // per element select (not two loops over two arrays: hipcc then indexes a merged array dynamically, puts it in
+      // scratch and waits for every scratch load with vmcnt(0), which serialises the whole DMA stream)
+      const bool ptile = (j != TPC - 1 && tau < a.nchunk * TPC);
 #pragma unroll
-        for (int q = 0; q < IPT; ++q)
-          __builtin_amdgcn_global_load_lds(tile + voffP[q], (__attribute__((address_space(3))) void*)(slot + q * 4096), 16, 0, 0);
-      } else {
-#pragma unroll
-        for (int q = 0; q < IPT; ++q)
-          __builtin_amdgcn_global_load_lds(tile + voffO[q], (__attribute__((address_space(3))) void*)(slot + q * 4096), 16, 0, 0);
+      for (int q = 0; q < IPT; ++q) {
+        const unsigned off = ptile ? voffP[q] : voffO[q];
+        __builtin_amdgcn_global_load_lds(tile + off, (__attribute__((address_space(3))) void*)(slot + q * 4096), 16, 0, 0);
       }
     };
     auto issue_tile = [&](int tau) {
@@ -571,11 +571,26 @@ __global__ __launch_bounds__(512) void k_tblock_lw(TBlockArgs a) {
       for (int e = 0; e < 8; ++e) v[e] = oT[2 * sp + (e >> 2)][e & 3];
       split8_lw(v, oh[sp], ol[sp]);
     }
-    phase(kO, IC1{}, kT, more, accT, oh, ol);
+    if (NX > 0 && !more) phase(kO, IC1{}, kO, true, accT, oh, ol);   // the folded convolution's tiles follow
+    else phase(kO, IC1{}, kT, more, accT, oh, ol);
+  }
+  if constexpr (MODE == TB_FF) {
+    if (NX > 0) {                                    // + Wout x: two more output tiles on the raw x operands
+      phase(kO, IC0{}, kO, true, accT, xh, xl);
+      phase(kO, IC2{}, kT, false, accT, xh + 2, xl + 2);
+    }
   }
 
   // ---- residual + output bias: x[m][16 ct + 4 g + r] += accT[ct][r] + bo[..] ----
-  if (mvalid) {
+  if (mvalid && NX > 0) {                            // folded convolution: no residual, separate output tensor
+    float* yo = a.xout + (int64_t)m * a.ldx + 4 * g;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      const float4 bo = *reinterpret_cast<const float4*>(bias + bo_off + 16 * ct + 4 * g);
+      *reinterpret_cast<float4*>(yo + 16 * ct) =
+          make_float4(accT[ct][0] + bo.x, accT[ct][1] + bo.y, accT[ct][2] + bo.z, accT[ct][3] + bo.w);
+    }
+  } else if (mvalid) {
     float* xo = a.x + (int64_t)m * a.ldx + 4 * g;
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
@@ -603,6 +618,7 @@ static hipError_t launch_lw(const TBlockArgs& a, hipStream_t s) {
 
 bool tblock_lw_supported(const TBlockArgs& a) {
   if (a.C != 128 || a.T <= 0 || 16 % a.T || a.nchunk <= 0) return false;
+  if (a.post && (a.mode != TB_FF || a.post != 2 || !a.xout)) return false;
   if (a.mode == TB_CROSS) return a.Tk > 0 && (16 / a.T) * a.Tk <= 16;   // one key tile per wave, K / V tile <= 64 rows
   return a.mode == TB_SELF || a.mode == TB_FF;
 }

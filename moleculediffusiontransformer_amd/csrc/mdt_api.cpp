@@ -110,6 +110,8 @@ static const char* validate(const mdt_op& o, int idx, char* buf, size_t nbuf) {
         return bad("cross block needs K/V and at most 64 keys per 16 rows");
       if (!o.a.space || !o.w.space || !o.bias.space) return bad("missing operand");
       if (i[MDT_B_VARIANT] < 0 || i[MDT_B_VARIANT] > 4) return bad("unknown fused-block variant");
+      if (i[MDT_B_POST] && (i[MDT_B_MODE] != MDT_TB_FF || !o.out.space || i[MDT_B_VARIANT] == 1 || i[MDT_B_VARIANT] >= 3))
+        return bad("a folded closing convolution needs a feed-forward block of variant 0 or 2 and an output tensor");
       if (i[MDT_B_VARIANT] == 4 && (!o.out.space || (o.p2.space && i[MDT_B_NCHUNK] % 2)))
         return bad("variant 4 needs an output tensor (and an even chunk count when split)");
       if (i[MDT_B_VARIANT] == 3 && (!o.out.space || i[MDT_B_NCHUNK] % 2)) return bad("variant 3 needs a partial-sum buffer and an even chunk count");
@@ -255,6 +257,8 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
         a.kv_bstride = o.i[MDT_B_KV_BSTRIDE]; a.ldkv = o.i[MDT_B_LDKV]; a.nheads = o.i[MDT_B_HEADS]; a.nsamples = B;
         a.eps = o.f[MDT_BF_EPS]; a.scale = o.f[MDT_BF_SCALE];
         a.part = nullptr; a.nsplit = 1; a.xout = nullptr; a.pin = nullptr; a.pout = nullptr;
+        a.post = o.i[MDT_B_POST];
+        if (a.post) a.xout = ptr(o.out);
         if (o.i[MDT_B_VARIANT] == 3) { a.part = ptr(o.out); a.nsplit = 2; }
         if (o.i[MDT_B_VARIANT] == 4) {
           a.xout = ptr(o.out); a.pin = ptr(o.res); a.pout = ptr(o.p2);

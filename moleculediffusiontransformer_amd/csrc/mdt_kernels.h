@@ -103,6 +103,10 @@ struct TBlockArgs {
   float* xout;         // nullptr: in place on x (variants 2, 3)
   const float* pin;    // partial of the previous block's second head group, or nullptr
   float* pout;         // where this block's second head group leaves its partial (nsplit == 2)
+  // feed-forward with the transformer's closing 1x1 convolution folded in (post > 0, MODE_FF only):
+  //   xout = Wout (x + FF(x)) + bout = (Wout W2) gelu(W1 x + b1) + Wout x + (Wout b2 + bout)
+  // the host stores Wout W2 as the W2 tiles, Wout as `post` extra output tiles (natural k order) and the fused bias
+  int post;            // number of extra [C][64] output tiles (C / 64), 0 = plain residual feed-forward
   int mode, C, M, T, nchunk, nbias, ldx, Tk, kv_bstride, ldkv, nheads, nsamples;
   float eps, scale;
 };

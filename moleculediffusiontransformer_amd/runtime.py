@@ -26,7 +26,7 @@ C_ROWS, C_CA, C_CB = range(3)
 P_ROWS_IN, P_C_IN, P_LD_IN, P_LD_OUT, P_PATCH, P_INVERSE = range(6)
 T_HALF, T_LD = range(2)
 R_T, R_C, R_LDA, R_LDC, R_LDR, R_TAPS, R_GSIZE, R_SILU, R_FILM_LD, R_LDA2 = range(10)
-B_MODE, B_C, B_T, B_NCHUNK, B_NBIAS, B_TK, B_KV_BSTRIDE, B_LDKV, B_HEADS, B_VARIANT = range(10)
+B_MODE, B_C, B_T, B_NCHUNK, B_NBIAS, B_TK, B_KV_BSTRIDE, B_LDKV, B_HEADS, B_VARIANT, B_POST = range(11)
 
 
 class MdtRef(C.Structure):

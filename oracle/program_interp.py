@@ -247,7 +247,7 @@ def _tblock(op, bufs: Buffers, B: int) -> None:
         else:
             x_out[:] = x_in + hidden @ w_out.T + b_out
     tpc = 4 if mode == rt.TB_SELF else 2
-    stream = bufs.view(op.w, B, nchunk * tpc * 64 * C)
+    stream = bufs.view(op.w, B, (nchunk * tpc + (C // 64 if i[rt.B_POST] else 0)) * 64 * C)
     bias = bufs.view(op.bias, B, nbias)
     inv = torch.empty(64, dtype=torch.long)
     inv[torch.tensor(_SLOT_PERM)] = torch.arange(64)
@@ -269,6 +269,12 @@ def _tblock(op, bufs: Buffers, B: int) -> None:
 
     if mode == rt.TB_FF:
         h = F.gelu(x @ proj(0).T + bias[:mid])
+        if i[rt.B_POST]:
+            # closing 1x1 convolution folded in: the W2 tiles hold Wout W2, C/64 extra output tiles hold Wout (natural k
+            # order), the output bias holds Wout b2 + bout; no residual, result in `out`, x untouched
+            wout = torch.cat([tile(nchunk * tpc + e, C, 64) for e in range(C // 64)], dim=1)
+            bufs.view(op.out, B, B * T * C).view(B, T, C)[:] = h @ outw().T + x @ wout.T + bias[mid:]
+            return
         finish(h, outw(), bias[mid:])
         return
     xn = F.layer_norm(x, (C,), None, None, eps=float(f[0]))
