@@ -127,3 +127,29 @@ def test_lowering_matches_reference_golden(case, mode):
             mix = y + (y_cond[: y.shape[0]] - y) * 7.5
             assert (mix - torch.from_numpy(g["y_scale7p5"])[: y.shape[0]]).abs().max() < 10 * tol
     assert abs(cu.flops_per_sample_eval - {"cfg1": 388.7e6}.get(case, cu.flops_per_sample_eval)) < 1e6
+
+
+def test_ring_kernels_keep_their_arrays_in_registers():
+    """A register array that hipcc decides to index dynamically moves to scratch; in a loader wave every scratch load is
+    then waited for with vmcnt(0) and the whole LDS-DMA stream serialises (seen twice: 2-5x slower kernels, all tests
+    green).  Compile the ring kernels with resource remarks and bound their scratch use."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "moleculediffusiontransformer_amd", "csrc")
+    limits = {"k_tblock_lw": 0, "k_tblock32": 24, "k_rconv": 0}          # bytes per lane (a few spilled scalars at most)
+    for name, limit in limits.items():
+        r = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-mllvm", "-amdgpu-mfma-vgpr-form=1",
+                            "-I", os.path.join(root, "include"), "-c", os.path.join(csrc, name + ".hip"), "-o", os.devnull,
+                            "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        kernels = re.findall(r"Function Name: (\S+).*?ScratchSize \[bytes/lane\]: (\d+)", r.stderr, flags=re.S)
+        assert kernels, r.stderr[-500:]
+        for fn, scratch in kernels:
+            if name == "k_rconv" and fn.endswith("ELi2EEEvNS_9RConvArgsE"):
+                continue                                                 # two-source variant: not on the default path
+            assert int(scratch) <= limit, (fn, scratch)
