@@ -249,10 +249,16 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) { const float t = s[st][hf] + s[st + 1][hf]; s[st][hf] = t; s[st + 1][hf] = t; }
         }
-        if (a.T > 1) all_lanes([](float v) { return v + __shfl_xor(v, 1, 64); });
-        if (a.T > 2) all_lanes([](float v) { return v + __shfl_xor(v, 2, 64); });
-        if (a.T > 4) all_lanes([](float v) { return v + __shfl_xor(v, 4, 64); });
-        if (a.T > 8) all_lanes([](float v) { return v + __shfl_xor(v, 8, 64); });
+        // token lanes: DPP moves inside the 16-lane row (one VALU instruction each, no LDS round trip).  Once the quads
+        // are uniform, mirroring the half row / the row adds exactly the lanes that xor 4 / xor 8 would.
+        auto dpp_add = [](float v, auto ctrl) {
+          const int m = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xf, 0xf, true);
+          return v + __builtin_bit_cast(float, m);
+        };
+        if (a.T > 1) all_lanes([&](float v) { return dpp_add(v, std::integral_constant<int, 0xB1>{}); });   // quad_perm [1,0,3,2]
+        if (a.T > 2) all_lanes([&](float v) { return dpp_add(v, std::integral_constant<int, 0x4E>{}); });   // quad_perm [2,3,0,1]
+        if (a.T > 4) all_lanes([&](float v) { return dpp_add(v, std::integral_constant<int, 0x141>{}); });  // row_half_mirror
+        if (a.T > 8) all_lanes([&](float v) { return dpp_add(v, std::integral_constant<int, 0x140>{}); });  // row_mirror
       };
       const float inv_n = 1.0f / (float)(a.T * gs);
       float mean[NSTW][2], rstd[NSTW][2];
