@@ -32,6 +32,23 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// lane-group exchanges over +-16 / +-32 lanes with the gfx950 permlane swaps (VALU, no LDS round trip). The swap is in
+// place on two registers: fed the same value twice, v_permlane16_swap leaves (rows 0,0,2,2) and (rows 1,1,3,3),
+// v_permlane32_swap (halves lo,lo) and (hi,hi); combining the two gives every lane the pair it would get from xor 16 /
+// xor 32. Written as asm: through __builtin_amdgcn_permlane*_swap hipcc 7.2 folds the two results into one register.
+// The s_nop covers the VALU-write -> permlane-swap-read hazard for the copies the compiler places just before.
+#define MDT_XG(NAME, INSN, COMBINE)                                                      \
+  __device__ __forceinline__ float NAME(float v) {                                       \
+    float a = v, b = v;                                                                  \
+    asm("s_nop 1\n\t" INSN " %0, %1" : "+v"(a), "+v"(b));                                \
+    return COMBINE;                                                                      \
+  }
+MDT_XG(xg16_add, "v_permlane16_swap_b32", a + b)
+MDT_XG(xg32_add, "v_permlane32_swap_b32", a + b)
+MDT_XG(xg16_max, "v_permlane16_swap_b32", fmaxf(a, b))
+MDT_XG(xg32_max, "v_permlane32_swap_b32", fmaxf(a, b))
+#undef MDT_XG
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 #define MDT_MFMA_BF16 __builtin_amdgcn_mfma_f32_16x16x32_bf16
@@ -241,8 +258,8 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
             else s[st][1] = fn(s[st][1]);
           }
         };
-        if (gs >= 16) all_lanes([](float v) { return v + __shfl_xor(v, 16, 64); });
-        if (gs >= 32) all_lanes([](float v) { return v + __shfl_xor(v, 32, 64); });
+        if (gs >= 16) all_lanes([](float v) { return xg16_add(v); });
+        if (gs >= 32) all_lanes([](float v) { return xg32_add(v); });
         if (gs >= 64) {
 #pragma unroll
           for (int st = 0; st + 1 < NSTW; st += 2)

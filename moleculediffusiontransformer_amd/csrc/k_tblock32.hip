@@ -21,6 +21,23 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// lane-group exchanges over +-16 / +-32 lanes with the gfx950 permlane swaps (VALU, no LDS round trip). The swap is in
+// place on two registers: fed the same value twice, v_permlane16_swap leaves (rows 0,0,2,2) and (rows 1,1,3,3),
+// v_permlane32_swap (halves lo,lo) and (hi,hi); combining the two gives every lane the pair it would get from xor 16 /
+// xor 32. Written as asm: through __builtin_amdgcn_permlane*_swap hipcc 7.2 folds the two results into one register.
+// The s_nop covers the VALU-write -> permlane-swap-read hazard for the copies the compiler places just before.
+#define MDT_XG(NAME, INSN, COMBINE)                                                      \
+  __device__ __forceinline__ float NAME(float v) {                                       \
+    float a = v, b = v;                                                                  \
+    asm("s_nop 1\n\t" INSN " %0, %1" : "+v"(a), "+v"(b));                                \
+    return COMBINE;                                                                      \
+  }
+MDT_XG(xg16_add, "v_permlane16_swap_b32", a + b)
+MDT_XG(xg32_add, "v_permlane32_swap_b32", a + b)
+MDT_XG(xg16_max, "v_permlane16_swap_b32", fmaxf(a, b))
+MDT_XG(xg32_max, "v_permlane32_swap_b32", fmaxf(a, b))
+#undef MDT_XG
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 enum { TB_SELF = 0, TB_CROSS = 1, TB_FF = 2 };
@@ -245,8 +262,8 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
       for (int e = 0; e < 8; ++e) s += xr[st][e];
     float mean = 0.f, rstd = 1.f;
     if constexpr (MODE != TB_FF) {
-      s += __shfl_xor(s, 16, 64);
-      s += __shfl_xor(s, 32, 64);
+      s = xg16_add(s);
+      s = xg32_add(s);
       mean = s / (float)C;
       float ss = 0.f;
 #pragma unroll
@@ -256,8 +273,8 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
           const float d = xr[st][e] - mean;
           ss += d * d;
         }
-      ss += __shfl_xor(ss, 16, 64);
-      ss += __shfl_xor(ss, 32, 64);
+      ss = xg16_add(ss);
+      ss = xg32_add(ss);
       rstd = 1.0f / sqrtf(ss / (float)C + a.eps);
     }
 #pragma unroll
@@ -488,8 +505,8 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
           mx = fmaxf(mx, sv2);
         }
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = xg16_max(mx);
+      mx = xg32_max(mx);
       float sum = 0.f;
 #pragma unroll
       for (int kt = 0; kt < KTM; ++kt)
@@ -499,8 +516,8 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
           st[kt][r] = e;
           sum += e;
         }
-      sum += __shfl_xor(sum, 16, 64);
-      sum += __shfl_xor(sum, 32, 64);
+      sum = xg16_add(sum);
+      sum = xg32_add(sum);
       const float inv = __builtin_amdgcn_rcpf(sum);
       MDT_STAMP();
       oT[0] = zero4; oT[1] = zero4;
@@ -566,8 +583,8 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
         st[r] = sv;
         mx = fmaxf(mx, sv);
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = xg16_max(mx);
+      mx = xg32_max(mx);
       float sum = 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -575,8 +592,8 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
         st[r] = e;
         sum += e;
       }
-      sum += __shfl_xor(sum, 16, 64);
-      sum += __shfl_xor(sum, 32, 64);
+      sum = xg16_add(sum);
+      sum = xg32_add(sum);
       const float inv = __builtin_amdgcn_rcpf(sum);
       oT[0] = zero4; oT[1] = zero4;
 #pragma unroll
