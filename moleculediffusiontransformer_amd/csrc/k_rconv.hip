@@ -148,6 +148,7 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
       for (int q = 0; q < IPT; ++q)
         __builtin_amdgcn_global_load_lds(tile + voffP[q], (__attribute__((address_space(3))) void*)(slot + q * 4096), 16, 0, 0);
     };
+    __builtin_amdgcn_s_barrier();                                        // P: the compute waves' row loads are queued first
     issue_tile(0);
     if (TT > 1) issue_tile(1);
     if (RTW == 2) __builtin_amdgcn_s_barrier();                          // X: operand exchange of the compute waves
@@ -232,10 +233,41 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
     const int st0 = (RTW == 2) ? fh * NSTW : 0;
     float xr[NSTW][8];
     const float* xp = xsrc + (int64_t)mc * lda + 32 * st0 + 8 * g;
+    float4 xu[NSTW], xw[NSTW];
 #pragma unroll
     for (int st = 0; st < NSTW; ++st) {
-      const float4 u = *reinterpret_cast<const float4*>(xp + 32 * st);
-      const float4 w = *reinterpret_cast<const float4*>(xp + 32 * st + 4);
+      xu[st] = *reinterpret_cast<const float4*>(xp + 32 * st);
+      xw[st] = *reinterpret_cast<const float4*>(xp + 32 * st + 4);
+    }
+    // per-channel parameters of the lane's channels, requested together with the rows: behind the statistics (where
+    // they are used) their 32 loads sat in blocks of their own, each a round trip queued behind the loaders' stream
+    float4 ga[NSTW][2], be[NSTW][2], fs[NSTW][2], fsh[NSTW][2];
+    if (a.gsize > 0) {
+#pragma unroll
+      for (int st = 0; st < NSTW; ++st)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const int c = 32 * (st0 + st) + 8 * g + 4 * hf;
+          ga[st][hf] = *reinterpret_cast<const float4*>(gamma + c);
+          be[st][hf] = *reinterpret_cast<const float4*>(beta + c);
+        }
+      if (a.film) {
+#pragma unroll
+        for (int st = 0; st < NSTW; ++st)
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            const int c = 32 * (st0 + st) + 8 * g + 4 * hf;
+            fs[st][hf] = *reinterpret_cast<const float4*>(a.film + c);
+            fsh[st][hf] = *reinterpret_cast<const float4*>(a.film + a.film_ld + c);
+          }
+      }
+    }
+    // P: the loader waves start the weight stream only now, behind this wave's requests (a row load queued behind the
+    // stream's first tiles came back ~2000 cycles later)
+    if (src == 0) __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int st = 0; st < NSTW; ++st) {
+      const float4 u = xu[st], w = xw[st];
       const float sc = mvalid ? in_scale : 0.f;
       xr[st][0] = u.x * sc; xr[st][1] = u.y * sc; xr[st][2] = u.z * sc; xr[st][3] = u.w * sc;
       xr[st][4] = w.x * sc; xr[st][5] = w.y * sc; xr[st][6] = w.z * sc; xr[st][7] = w.w * sc;
@@ -302,31 +334,44 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
 #pragma unroll
       for (int st = 0; st < NSTW; ++st)
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) rstd[st][hf] = 1.0f / sqrtf(rstd[st][hf] * inv_n + a.eps);
+        for (int hf = 0; hf < 2; ++hf) rstd[st][hf] = __builtin_amdgcn_rsqf(rstd[st][hf] * inv_n + a.eps);   // v_rsq_f32: 1 ulp
 #pragma unroll
       for (int st = 0; st < NSTW; ++st)
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
-          const int c = 32 * (st0 + st) + 8 * g + 4 * hf;
-          const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
-          const float4 be = *reinterpret_cast<const float4*>(beta + c);
-          const float g4[4] = {ga.x, ga.y, ga.z, ga.w}, b4[4] = {be.x, be.y, be.z, be.w};
-          float f4[4] = {1.f, 1.f, 1.f, 1.f}, h4[4] = {0.f, 0.f, 0.f, 0.f};
-          if (a.film) {
-            const float4 fs = *reinterpret_cast<const float4*>(a.film + c);
-            const float4 fsh = *reinterpret_cast<const float4*>(a.film + a.film_ld + c);
-            f4[0] = fs.x + 1.0f; f4[1] = fs.y + 1.0f; f4[2] = fs.z + 1.0f; f4[3] = fs.w + 1.0f;
-            h4[0] = fsh.x; h4[1] = fsh.y; h4[2] = fsh.z; h4[3] = fsh.w;
-          }
+          const float4 gv = ga[st][hf], bv = be[st][hf];
+          const float g4[4] = {gv.x, gv.y, gv.z, gv.w}, b4[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const float sc = rstd[st][hf] * g4[e];
-            float t = xr[st][4 * hf + e] * sc + (b4[e] - sc * mean[st][hf]);
-            t = t * f4[e] + h4[e];
-            if (a.silu) t = t * __builtin_amdgcn_rcpf(1.0f + __expf(-t));
-            xr[st][4 * hf + e] = mvalid ? t : 0.f;
+            xr[st][4 * hf + e] = xr[st][4 * hf + e] * sc + (b4[e] - sc * mean[st][hf]);
           }
         }
+      // FiLM and SiLU as passes of their own under one uniform branch each (a per-element select otherwise).  Rows past
+      // M (clamped duplicates of the last row) are carried along: their columns are never stored.
+      if (a.film) {
+#pragma unroll
+        for (int st = 0; st < NSTW; ++st)
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            const float4 fv = fs[st][hf], hv = fsh[st][hf];
+            const float f4[4] = {fv.x, fv.y, fv.z, fv.w}, h4[4] = {hv.x, hv.y, hv.z, hv.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {              // t (scale + 1) + shift, with nothing to precompute on the loaded
+              const float t = xr[st][4 * hf + e];      // values alone (hipcc hoists `scale + 1` up to the loads and
+              xr[st][4 * hf + e] = t * f4[e] + (t + h4[e]);   // waits for them there, in front of barrier P)
+            }
+          }
+      }
+      if (a.silu) {
+#pragma unroll
+        for (int st = 0; st < NSTW; ++st)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float t = xr[st][e];
+            xr[st][e] = t * __builtin_amdgcn_rcpf(1.0f + __expf(-t));
+          }
+      }
     }
     if constexpr (RTW == 2) {
       // exchange: [wave][k-step][hi | lo][lane] 16-byte entries; every wave reads back all NST k-steps of its row tile

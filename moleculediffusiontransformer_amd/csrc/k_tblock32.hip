@@ -216,6 +216,7 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
         default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
       }
     };
+    __builtin_amdgcn_s_barrier();   // P: the compute waves' row and bias loads are queued ahead of the stream
     issue_tile(0);
     if (NT > 1) issue_tile(1);
     for (int k = 0; k < NT; ++k) {
@@ -235,25 +236,42 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
   const int mc = mvalid ? m : a.M - 1;
 
   bf16x8 xh[NST], xl[NST];
+  constexpr int NBV = 4;                 // per-chunk bias vectors: 64 (h1 - h0) floats over 256 lanes, nchunk <= 16
+  float bv[NBV];
   {
     float xr[NST][8];
     const float* xp = a.x + (int64_t)mc * a.ldx + 8 * g;
     float s = 0.f;
+    float4 xu[NST], xw[NST], pu[NST], pw[NST];
 #pragma unroll
     for (int st = 0; st < NST; ++st) {
-      const float4 u = *reinterpret_cast<const float4*>(xp + 32 * st);
-      const float4 w = *reinterpret_cast<const float4*>(xp + 32 * st + 4);
-      xr[st][0] = u.x; xr[st][1] = u.y; xr[st][2] = u.z; xr[st][3] = u.w;
-      xr[st][4] = w.x; xr[st][5] = w.y; xr[st][6] = w.z; xr[st][7] = w.w;
+      xu[st] = *reinterpret_cast<const float4*>(xp + 32 * st);
+      xw[st] = *reinterpret_cast<const float4*>(xp + 32 * st + 4);
     }
     if (CHAIN && a.pin) {                            // chained form (variant 4): block input = x + pin
       const float* pp = a.pin + (int64_t)mc * C + 8 * g;
 #pragma unroll
       for (int st = 0; st < NST; ++st) {
-        const float4 pu = *reinterpret_cast<const float4*>(pp + 32 * st);
-        const float4 pw = *reinterpret_cast<const float4*>(pp + 32 * st + 4);
-        xr[st][0] += pu.x; xr[st][1] += pu.y; xr[st][2] += pu.z; xr[st][3] += pu.w;
-        xr[st][4] += pw.x; xr[st][5] += pw.y; xr[st][6] += pw.z; xr[st][7] += pw.w;
+        pu[st] = *reinterpret_cast<const float4*>(pp + 32 * st);
+        pw[st] = *reinterpret_cast<const float4*>(pp + 32 * st + 4);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NBV; ++k) bv[k] = (tid + 256 * k < 64 * (h1 - h0)) ? a.bias[64 * h0 + tid + 256 * k] : 0.f;
+    // P: the loader waves start the weight stream only now, behind this wave's requests (queued behind the stream's
+    // first two tiles the rows came back ~1500 cycles later)
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+      const float4 u = xu[st], w = xw[st];
+      xr[st][0] = u.x; xr[st][1] = u.y; xr[st][2] = u.z; xr[st][3] = u.w;
+      xr[st][4] = w.x; xr[st][5] = w.y; xr[st][6] = w.z; xr[st][7] = w.w;
+    }
+    if (CHAIN && a.pin) {
+#pragma unroll
+      for (int st = 0; st < NST; ++st) {
+        xr[st][0] += pu[st].x; xr[st][1] += pu[st].y; xr[st][2] += pu[st].z; xr[st][3] += pu[st].w;
+        xr[st][4] += pw[st].x; xr[st][5] += pw[st].y; xr[st][6] += pw[st].z; xr[st][7] += pw[st].w;
       }
     }
 #pragma unroll
@@ -426,7 +444,9 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
 
   // this workgroup's per-chunk bias vectors (bq | b1 of chunks h0 .. h1-1) -> LDS behind the ring and the exchange area
   float* bias_s = reinterpret_cast<float*>(smem + NS * SLOT + (MODE == TB_CROSS ? 3 : 1) * 4 * 64 * 16);
-  for (int t = tid; t < 64 * (h1 - h0); t += 256) bias_s[t] = bias[64 * h0 + t];
+#pragma unroll
+  for (int k = 0; k < NBV; ++k)
+    if (tid + 256 * k < 64 * (h1 - h0)) bias_s[tid + 256 * k] = bv[k];
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                      // B(0)
   prefetch2(kT, slot_of(0), 0);
@@ -701,7 +721,7 @@ static hipError_t launch_32(const TBlockArgs& a, hipStream_t s) {
 
 hipError_t launch_tblock32(const TBlockArgs& a, hipStream_t s) {
   if (a.M <= 0) return hipSuccess;
-  if (a.C != 256 || a.T <= 0 || 16 % a.T || a.nchunk <= 0) return hipErrorInvalidValue;
+  if (a.C != 256 || a.T <= 0 || 16 % a.T || a.nchunk <= 0 || a.nchunk > 16) return hipErrorInvalidValue;
   if (a.post && (a.mode != TB_FF || a.post != 8 || a.nsplit > 1 || a.pin || !a.xout)) return hipErrorInvalidValue;
   if (a.nsplit > 1 && (a.nchunk % a.nsplit || !(a.xout ? (void*)a.pout : (void*)a.part))) return hipErrorInvalidValue;
   if (a.xout && (a.nsplit > 2 || a.xout == a.x)) return hipErrorInvalidValue;

@@ -209,6 +209,7 @@ __global__ __launch_bounds__(512) void k_tblock_lw(TBlockArgs a) {
         default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
       }
     };
+    __builtin_amdgcn_s_barrier();   // P: the compute waves' row and bias loads are queued ahead of the stream
     issue_tile(0);
     if (NT > 1) issue_tile(1);
 #ifdef MDT_STAMPS
@@ -246,14 +247,26 @@ __global__ __launch_bounds__(512) void k_tblock_lw(TBlockArgs a) {
 
   // this wave's 16 rows in MFMA operand layout: lane (i, g) holds x[i][32 st + 8 g + e]
   bf16x8 xh[NST], xl[NST];
+  constexpr int NBV = 4;                 // per-chunk bias vectors: 64 nchunk floats over 256 lanes, nchunk <= 16
+  float bv[NBV];
   {
     float xr[NST][8];
     const float* xp = a.x + (int64_t)mc * a.ldx + 8 * g;
     float s = 0.f;
+    float4 xu[NST], xw[NST];
 #pragma unroll
     for (int st = 0; st < NST; ++st) {
-      const float4 u = *reinterpret_cast<const float4*>(xp + 32 * st);
-      const float4 w = *reinterpret_cast<const float4*>(xp + 32 * st + 4);
+      xu[st] = *reinterpret_cast<const float4*>(xp + 32 * st);
+      xw[st] = *reinterpret_cast<const float4*>(xp + 32 * st + 4);
+    }
+#pragma unroll
+    for (int k = 0; k < NBV; ++k) bv[k] = (tid + 256 * k < 64 * a.nchunk) ? a.bias[tid + 256 * k] : 0.f;
+    // P: the loader waves start the weight stream only now, behind this wave's requests (queued behind the stream's
+    // first two tiles the rows came back ~1500 cycles later)
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+      const float4 u = xu[st], w = xw[st];
       xr[st][0] = u.x; xr[st][1] = u.y; xr[st][2] = u.z; xr[st][3] = u.w;
       xr[st][4] = w.x; xr[st][5] = w.y; xr[st][6] = w.z; xr[st][7] = w.w;
 #pragma unroll
@@ -440,7 +453,9 @@ __global__ __launch_bounds__(512) void k_tblock_lw(TBlockArgs a) {
 
   // the first 64 * nchunk bias entries (bq | b1: the per-chunk vectors) -> LDS behind the ring
   float* bias_s = reinterpret_cast<float*>(smem + NS * SLOT);
-  for (int t = tid; t < 64 * a.nchunk; t += 256) bias_s[t] = bias[t];
+#pragma unroll
+  for (int k = 0; k < NBV; ++k)
+    if (tid + 256 * k < 64 * a.nchunk) bias_s[tid + 256 * k] = bv[k];
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                      // B(0)
   prefetch2(kT, slot_of(0), 0);
@@ -634,7 +649,7 @@ static hipError_t launch_lw(const TBlockArgs& a, hipStream_t s) {
 }
 
 bool tblock_lw_supported(const TBlockArgs& a) {
-  if (a.C != 128 || a.T <= 0 || 16 % a.T || a.nchunk <= 0) return false;
+  if (a.C != 128 || a.T <= 0 || 16 % a.T || a.nchunk <= 0 || a.nchunk > 16) return false;
   if (a.post && (a.mode != TB_FF || a.post != 2 || !a.xout)) return false;
   if (a.mode == TB_CROSS) return a.Tk > 0 && (16 / a.T) * a.Tk <= 16;   // one key tile per wave, K / V tile <= 64 rows
   return a.mode == TB_SELF || a.mode == TB_FF;
