@@ -262,9 +262,43 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
           }
       }
     }
+    // the accumulators start from bias (+ residual), requested here with everything else: loaded in the epilogue they
+    // were one more exposed round trip per launch
+    float4 ib[NCH][NFT], ir[NCH][NFT];
+    if (src == 0) {
+      if (a.bias) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+          for (int q = 0; q < NFT; ++q)
+            ib[c][q] = *reinterpret_cast<const float4*>(a.bias + 64 * ((int)blockIdx.y * NCH + c) + 16 * (NFT * fh + q) + 4 * g);
+      }
+      if (a.res) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+          for (int q = 0; q < NFT; ++q)
+            ir[c][q] = *reinterpret_cast<const float4*>(a.res + (int64_t)mc * a.ldr + 64 * ((int)blockIdx.y * NCH + c) +
+                                                        16 * (NFT * fh + q) + 4 * g);
+      }
+    }
     // P: the loader waves start the weight stream only now, behind this wave's requests (a row load queued behind the
     // stream's first tiles came back ~2000 cycles later)
     if (src == 0) __builtin_amdgcn_s_barrier();
+    if (src == 0) {
+      if (a.bias) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+          for (int q = 0; q < NFT; ++q) acc[c][q] = f32x4{ib[c][q].x, ib[c][q].y, ib[c][q].z, ib[c][q].w};
+      }
+      if (a.res) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+          for (int q = 0; q < NFT; ++q) acc[c][q] += f32x4{ir[c][q].x, ir[c][q].y, ir[c][q].z, ir[c][q].w};
+      }
+    }
 #pragma unroll
     for (int st = 0; st < NSTW; ++st) {
       const float4 u = xu[st], w = xw[st];
@@ -495,23 +529,15 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
   }   // sources
 
   MDT_STAMP();
-  // ---- out[m][64 c + 16 ft + 4 g + r] = acc + bias (+ res) ----
+  // ---- out[m][64 c + 16 ft + 4 g + r] = acc (which started from bias + res) ----
   if (mvalid) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
 #pragma unroll
       for (int q = 0; q < NFT; ++q) {
         const int f = 64 * ((int)blockIdx.y * NCH + c) + 16 * (NFT * fh + q) + 4 * g;
-        float4 y = make_float4(acc[c][q][0], acc[c][q][1], acc[c][q][2], acc[c][q][3]);
-        if (a.bias) {
-          const float4 b = *reinterpret_cast<const float4*>(a.bias + f);
-          y.x += b.x; y.y += b.y; y.z += b.z; y.w += b.w;
-        }
-        if (a.res) {
-          const float4 r = *reinterpret_cast<const float4*>(a.res + (int64_t)m * a.ldr + f);
-          y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w;
-        }
-        *reinterpret_cast<float4*>(a.out + (int64_t)m * a.ldc + f) = y;
+        *reinterpret_cast<float4*>(a.out + (int64_t)m * a.ldc + f) =
+            make_float4(acc[c][q][0], acc[c][q][1], acc[c][q][2], acc[c][q][3]);
       }
   }
 }
