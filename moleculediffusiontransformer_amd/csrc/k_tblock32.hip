@@ -666,31 +666,50 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (mvalid) {
-    const float* xi = a.x + (int64_t)m * a.ldx + 4 * g;
-    const float* pi = (CHAIN && a.pin) ? a.pin + (int64_t)m * C + 4 * g : nullptr;
-    float* xo = ((CHAIN || NX > 0) ? a.xout : a.x) + (int64_t)m * a.ldx + 4 * g;
     // who writes what: in-place / chained head group 0 -> block output (partial + bias + input); every other head
     // group -> its bare partial (variant 3: slot blockIdx.y of `part` for k_tb_reduce; chained: pout)
     const bool bare = gridDim.y > 1 && !(CHAIN && blockIdx.y == 0);
-    float* po = CHAIN ? a.pout + (int64_t)m * C + 4 * g : a.part + ((int64_t)blockIdx.y * a.M + m) * C + 4 * g;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
+    auto halves = [&](int c) -> f32x4 {                       // feature half 0 first
       const int ct = 8 * fh + c;
-      const f32x4 p0 = part[((2 * rt) * NCT + ct) * 64 + lane], p1 = part[((2 * rt + 1) * NCT + ct) * 64 + lane];
-      const f32x4 sum = p0 + p1;                            // feature half 0 first
-      if (bare) {
-        *reinterpret_cast<float4*>(po + 16 * ct) = make_float4(sum[0], sum[1], sum[2], sum[3]);
-        continue;
+      return part[((2 * rt) * NCT + ct) * 64 + lane] + part[((2 * rt + 1) * NCT + ct) * 64 + lane];
+    };
+    if (bare) {
+      float* po = CHAIN ? a.pout + (int64_t)m * C + 4 * g : a.part + ((int64_t)blockIdx.y * a.M + m) * C + 4 * g;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const f32x4 sum = halves(c);
+        *reinterpret_cast<float4*>(po + 16 * (8 * fh + c)) = make_float4(sum[0], sum[1], sum[2], sum[3]);
       }
-      float4 xr = *reinterpret_cast<const float4*>(xi + 16 * ct);
-      if (NX > 0) xr = make_float4(0.f, 0.f, 0.f, 0.f);     // folded closing convolution: Wout x is already in the sum
-      if (CHAIN && pi) {
-        const float4 pr = *reinterpret_cast<const float4*>(pi + 16 * ct);
-        xr.x += pr.x; xr.y += pr.y; xr.z += pr.z; xr.w += pr.w;
+    } else {
+      // every load of the epilogue is requested before the first store: the output aliases the residual rows (in
+      // place), and with loads and stores alternating hipcc kept them in order -- eight exposed round trips
+      const float* xi = a.x + (int64_t)m * a.ldx + 4 * g + 128 * fh;
+      const float* bi = bias + bo_off + 4 * g + 128 * fh;
+      float* xo = ((CHAIN || NX > 0) ? a.xout : a.x) + (int64_t)m * a.ldx + 4 * g + 128 * fh;
+      float4 bo[8], xr[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) bo[c] = *reinterpret_cast<const float4*>(bi + 16 * c);
+      if (NX == 0) {                                         // folded closing convolution: Wout x is already in the sum
+#pragma unroll
+        for (int c = 0; c < 8; ++c) xr[c] = *reinterpret_cast<const float4*>(xi + 16 * c);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) xr[c] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      const float4 bo = *reinterpret_cast<const float4*>(bias + bo_off + 16 * ct + 4 * g);
-      *reinterpret_cast<float4*>(xo + 16 * ct) =
-          make_float4(sum[0] + bo.x + xr.x, sum[1] + bo.y + xr.y, sum[2] + bo.z + xr.z, sum[3] + bo.w + xr.w);
+      if (CHAIN && a.pin) {                                  // chained form: the block input was x + pin
+        const float* pi = a.pin + (int64_t)m * C + 4 * g + 128 * fh;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const float4 pr = *reinterpret_cast<const float4*>(pi + 16 * c);
+          xr[c].x += pr.x; xr[c].y += pr.y; xr[c].z += pr.z; xr[c].w += pr.w;
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const f32x4 sum = halves(c);
+        *reinterpret_cast<float4*>(xo + 16 * c) = make_float4(sum[0] + bo[c].x + xr[c].x, sum[1] + bo[c].y + xr[c].y,
+                                                              sum[2] + bo[c].z + xr[c].z, sum[3] + bo[c].w + xr[c].w);
+      }
     }
   }
 }

@@ -614,24 +614,26 @@ __global__ __launch_bounds__(512) void k_tblock_lw(TBlockArgs a) {
   }
 
   // ---- residual + output bias: x[m][16 ct + 4 g + r] += accT[ct][r] + bo[..] ----
-  if (mvalid && NX > 0) {                            // folded convolution: no residual, separate output tensor
-    float* yo = a.xout + (int64_t)m * a.ldx + 4 * g;
+  // Every load is requested before the first store: the output aliases the residual rows (and, for all hipcc knows,
+  // the bias), and with loads and stores alternating it kept them in order -- eight exposed round trips.
+  if (mvalid) {
+    const float* xi = a.x + (int64_t)m * a.ldx + 4 * g;
+    float* xo = (NX > 0 ? a.xout : a.x) + (int64_t)m * a.ldx + 4 * g;   // folded convolution: separate output tensor
+    float4 bo[NCT], xr[NCT];
 #pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) {
-      const float4 bo = *reinterpret_cast<const float4*>(bias + bo_off + 16 * ct + 4 * g);
-      *reinterpret_cast<float4*>(yo + 16 * ct) =
-          make_float4(accT[ct][0] + bo.x, accT[ct][1] + bo.y, accT[ct][2] + bo.z, accT[ct][3] + bo.w);
+    for (int ct = 0; ct < NCT; ++ct) bo[ct] = *reinterpret_cast<const float4*>(bias + bo_off + 16 * ct + 4 * g);
+    if (NX == 0) {
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) xr[ct] = *reinterpret_cast<const float4*>(xi + 16 * ct);
+    } else {                                         // folded convolution: no residual
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) xr[ct] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-  } else if (mvalid) {
-    float* xo = a.x + (int64_t)m * a.ldx + 4 * g;
 #pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) {
-      const float4 xr = *reinterpret_cast<const float4*>(xo + 16 * ct);
-      const float4 bo = *reinterpret_cast<const float4*>(bias + bo_off + 16 * ct + 4 * g);
+    for (int ct = 0; ct < NCT; ++ct)
       *reinterpret_cast<float4*>(xo + 16 * ct) =
-          make_float4(accT[ct][0] + bo.x + xr.x, accT[ct][1] + bo.y + xr.y, accT[ct][2] + bo.z + xr.z,
-                      accT[ct][3] + bo.w + xr.w);
-    }
+          make_float4(accT[ct][0] + bo[ct].x + xr[ct].x, accT[ct][1] + bo[ct].y + xr[ct].y,
+                      accT[ct][2] + bo[ct].z + xr[ct].z, accT[ct][3] + bo[ct].w + xr[ct].w);
   }
 }
 
