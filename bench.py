@@ -58,6 +58,9 @@ def op_flops(op, rt, B):
         return 4.0 * B * i[rt.A_T] * i[rt.A_TK] * 64 * i[rt.A_HEADS]
     if op.kind == rt.OP_RCONV:
         return 2.0 * B * i[rt.R_T] * i[rt.R_C] * i[rt.R_C] * i[rt.R_TAPS]
+    if op.kind == rt.OP_RESBLOCK:
+        cin, cout = i[rt.K_CIN], i[rt.K_COUT]
+        return 2.0 * B * i[rt.K_T] * (3 * cin * cout + 3 * cout * cout + cin * cout)
     if op.kind == rt.OP_TBLOCK:
         c, t, nch, tk = i[rt.B_C], i[rt.B_T], i[rt.B_NCHUNK], i[rt.B_TK]
         mid = 64 * nch
@@ -76,7 +79,8 @@ def kernel_breakdown(model, eng, torch, rt, B):
     ops = eng.c.programs["eval"]
     bind = eng._bind(xin=eng.xin, out=eng.pred)
     names = {rt.OP_GEMM: "k_gemm", rt.OP_GN_STATS: "k_gn_stats", rt.OP_ATTN: "k_attn", rt.OP_CONCAT: "k_concat",
-             rt.OP_PATCH: "k_patch", rt.OP_TBLOCK: "k_tblock", rt.OP_GN_ACT: "k_gn_act", rt.OP_RCONV: "k_rconv"}
+             rt.OP_PATCH: "k_patch", rt.OP_TBLOCK: "k_tblock", rt.OP_GN_ACT: "k_gn_act", rt.OP_RCONV: "k_rconv",
+             rt.OP_RESBLOCK: "k_resblock"}
     best = None
     for rep in range(3):
         timer = rt.EventTimer(len(ops))

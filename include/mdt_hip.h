@@ -71,6 +71,12 @@ enum mdt_op_kind {
                           half's gain / bias / weight tiles follow the first's);
                           a, w = weight tiles, bias | none, out, res | none, p0 = gain, p1 = bias of the GroupNorm | none,
                           p3 = [scale | shift] | none (modules.py:117-121, :193-205)                             */
+  MDT_OP_RESBLOCK = 10, /* a whole ResnetBlock1d with one GroupNorm group on a 64-token level (the U-Net's Patcher / Unpatcher,
+                          modules.py:145-205, 208-257) in one launch, (cin, cout) = (16, 64) | (64, 16):
+                          out = conv3(silu(gn(conv3(silu(gn(a))) + b1) (scale + 1) + shift)) + b2 + to_out(a);
+                          a [B][64][cin], w = bf16 hi/lo MFMA fragments (conv1 | conv2 | to_out k-steps),
+                          bias = gamma1 | beta1 | b1 | gamma2 | beta2 | (b2 + to_out bias), out [B][64][cout],
+                          p3 = [scale | shift] | none                                                              */
   MDT_OP_TBLOCK = 7    /* fused transformer sub-block, in place on x (TransformerBlock.forward, modules.py:456-461):
                           x += Attention(x) | x += Attention(x, context) | x += FeedForward(x); LayerNorm affine
                           folded into the projection weights, q/k/v/probabilities/hidden never leave registers */
@@ -123,6 +129,8 @@ enum mdt_rconv_i { MDT_R_T = 0, MDT_R_C = 1, MDT_R_LDA = 2, MDT_R_LDC = 3, MDT_R
                    MDT_R_FILM_LD = 8 /* floats between the scale and the shift row */,
                    MDT_R_LDA2 = 9 /* floats per row of the second source (a2), if any */ };
 enum mdt_rconv_f { MDT_RF_EPS = 0, MDT_RF_IN_SCALE = 1, MDT_RF_IN_SCALE2 = 2 };
+enum mdt_resblock_i { MDT_K_T = 0, MDT_K_CIN = 1, MDT_K_COUT = 2, MDT_K_FILM_LD = 3 };
+enum mdt_resblock_f { MDT_KF_EPS = 0 };
 
 enum mdt_attn_i {
   MDT_A_T = 0, MDT_A_TK = 1, MDT_A_HEADS = 2, MDT_A_LDQ = 3, MDT_A_LDKV = 4, MDT_A_LDO = 5,

@@ -138,6 +138,7 @@ class UNetCompiler:
         # buffers cost more than 5.4 us per block), so this is not the default.
         self.tb_chain = os.environ.get("MDT_TB_CHAIN", "0") == "1"
         self.use_rconv = os.environ.get("MDT_RCONV", "1") == "1"     # row-stationary convs (k_rconv) at C = 128 / 256
+        self.use_resblock = os.environ.get("MDT_RESBLOCK", "1") == "1"   # Patcher / Unpatcher ResNets as ONE launch (k_resblock)
         self.convt_merge = os.environ.get("MDT_CONVT_MERGE", "1") == "1"   # ConvTranspose phases in one launch
         # Transformer1d's closing 1x1 convolution folded into its last feed-forward block (ring kernels only)
         self.fold_out = os.environ.get("MDT_FOLD_OUT", "1") == "1" and os.environ.get("MDT_TB_LW", "1") != "0"
@@ -435,10 +436,72 @@ class UNetCompiler:
         return self.resnet(cat, p, 2 * c, c, groups)
 
     # ------------------------------------------------------------------ blocks
+    # ------------------------------------------------------------------ whole ResNet block in one launch
+    @staticmethod
+    def _resblock_steps(c: int, taps: int):
+        """k-steps of a convolution over c channels per tap as the kernel enumerates them (csrc/k_resblock.hip): every
+        step is 32 (tap, channel) pairs, None where the step is padded."""
+        if taps == 3:
+            if c == 64:
+                return [[(s // 2, 32 * (s % 2) + j) for j in range(32)] for s in range(6)]
+            return [[(j // 16, j % 16) for j in range(32)], [(2, j) if j < 16 else None for j in range(32)]]
+        if c == 64:
+            return [[(0, 32 * s + j) for j in range(32)] for s in range(2)]
+        return [[(0, j) if j < 16 else None for j in range(32)]]
+
+    @classmethod
+    def _resblock_frags(cls, w: torch.Tensor) -> List[torch.Tensor]:
+        """Conv1d weight [cout][c][taps] -> MFMA A-operand fragments, order (step, 16-row tile): lane i + 16 g of a
+        fragment holds W[16 rt + i][the step's pairs 8 g .. 8 g + 7]; bf16 hi plane then lo plane (1 KB each)."""
+        cout, c, taps = w.shape
+        frags = []
+        for step in cls._resblock_steps(c, taps):
+            m = torch.zeros(cout, 32)
+            for j, tc in enumerate(step):
+                if tc is not None:
+                    m[:, j] = w[:, tc[1], tc[0]]
+            for r in range(cout // 16):
+                frags.append(cls._tile(m[16 * r: 16 * r + 16].reshape(16, 4, 8).permute(1, 0, 2).contiguous()))
+        return frags
+
+    def resblock_ok(self, rows: int, cin: int, cout: int, groups: int, p: str) -> bool:
+        return (self.use_resblock and self.gemm_mode == "bf16x3" and self.fuse_blocks and groups == 1 and rows == 64
+                and (cin, cout) in ((16, 64), (64, 16)) and (p + "to_out.weight") in self.sd)
+
+    def resblock(self, x: Ten, p: str, cin: int, cout: int, free_input: bool) -> Ten:
+        """ResnetBlock1d with one GroupNorm group on the 64-token level as ONE launch (MDT_OP_RESBLOCK)."""
+        sd = self.sd
+        y = self._new(x.rows, cout, cout)
+        frags = (self._resblock_frags(sd[p + "block1.project.weight"].float())
+                 + self._resblock_frags(sd[p + "block2.project.weight"].float())
+                 + self._resblock_frags(sd[p + "to_out.weight"].float()))
+        vec = torch.cat([sd[p + "block1.groupnorm.weight"], sd[p + "block1.groupnorm.bias"], sd[p + "block1.project.bias"],
+                         sd[p + "block2.groupnorm.weight"], sd[p + "block2.groupnorm.bias"],
+                         sd[p + "block2.project.bias"] + sd[p + "to_out.bias"]]).float()
+        ss_off = self.ss_total                       # FiLM vectors of this block inside the shared (scale | shift) row
+        self.ss_offsets[p] = ss_off
+        self.ss_total += 2 * cout
+        op = rt.MdtOp()
+        op.kind = rt.OP_RESBLOCK
+        op.a, op.out = x.ref(), y.ref()
+        op.w = _ref(rt.SP_WEIGHT, self.W.add(p + "resblock.frags", torch.cat(frags)))
+        op.bias = _ref(rt.SP_WEIGHT, self.W.add(p + "resblock.vec", vec))
+        op._film = ("ss", ss_off)
+        i = op.i
+        i[rt.K_T], i[rt.K_CIN], i[rt.K_COUT], i[rt.K_FILM_LD] = x.rows, cin, cout, cout
+        op.f[0] = 1e-5
+        self._emit(op)
+        self.flops += 2 * x.rows * (3 * cin * cout + 3 * cout * cout + cin * cout)
+        if free_input:
+            self._free(x)
+        return y
+
     def resnet(self, x: Ten, p: str, cin: int, cout: int, groups: int, free_input: bool = True) -> Ten:
         """ResnetBlock1d.forward (modules.py:193-205); x has `cin` real channels."""
         cin_p, cout_p = pad16(cin), pad16(cout)
         assert x.ld == cin_p, (p, x.ld, cin_p)
+        if self.resblock_ok(x.rows, cin, cout, groups, p):
+            return self.resblock(x, p, cin, cout, free_input)
         if cin == cout and x.ld == cin and (p + "to_out.weight") not in self.sd and groups > 0 and cin % groups == 0 \
                 and self.rconv_ok(x.rows, cin, 3, cin // groups):
             return self._resnet_rconv(x, None, 1.0, p, cin, groups, free_input)
@@ -852,7 +915,7 @@ class UNetCompiler:
         y = self.resnet(x, "to_out.block.", c0 // ps, cin, 1)
         # the final resnet wrote into an arena buffer; retarget its last GEMM to the bound output tensor
         last_op = self.ops[-1]
-        assert last_op.kind == rt.OP_GEMM
+        assert last_op.kind in (rt.OP_GEMM, rt.OP_RESBLOCK)
         last_op.out = out.ref()
         self._free(y)
 
@@ -888,7 +951,7 @@ class UNetCompiler:
             for op in ops:
                 o = rt.MdtOp()
                 C_memmove(o, op)
-                if op.kind in (rt.OP_GEMM, rt.OP_GN_ACT, rt.OP_RCONV) and isinstance(getattr(op, "_film", None), tuple):
+                if op.kind in (rt.OP_GEMM, rt.OP_GN_ACT, rt.OP_RCONV, rt.OP_RESBLOCK) and isinstance(getattr(op, "_film", None), tuple):
                     o.p3 = _ref(rt.SP_SHR, ss_cur + op._film[1])
                 if op.kind in (rt.OP_ATTN, rt.OP_TBLOCK) and isinstance(getattr(op, "_kv", None), tuple):
                     idx = op._kv[1]

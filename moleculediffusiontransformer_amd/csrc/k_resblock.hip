@@ -1,0 +1,318 @@
+// MDT_OP_RESBLOCK: a whole ResnetBlock1d of the 64-token level (Patcher / Unpatcher of the U-Net, modules.py:145-205,
+// 208-257) in one launch:
+//     a1 = silu(GroupNorm_1group(x))                       h = conv_k3(a1) + b1
+//     a2 = silu(GroupNorm_1group(h) (scale + 1) + shift)   y = conv_k3(a2) + b2 + to_out_1x1(x) + b_out
+// for (CIN, COUT) = (16, 64) | (64, 16).  As separate launches (two GroupNorm-apply passes, three GEMMs) the five ops
+// move 16 MB tensors through HBM between launches of 10-20 us each: 76 + 72 us per U-Net evaluation at batch 1024.
+//
+// One sample (64 tokens) per group of 4 waves, two samples in flight per workgroup (8 waves = 2 per SIMD: while one
+// sample's waves sit in a reduction or a barrier the other's issue), persistent over the batch.  All weights (at most
+// 72 KB as bf16 hi/lo fragments) are staged into LDS once per workgroup.  Activations go through LDS as bf16 hi/lo
+// planes [token + 1][channel] with zero rows on both ends (the convolution's padding), row pitch 2 C + 16 bytes
+// (conflict-free ds_read_b128 of 16 consecutive rows).  Convolutions run transposed, out^T[n][t] = W[n][k] act^T[k][t]:
+// wave w owns tokens 16 w .. 16 w + 15 as MFMA columns, the accumulator of lane (i, g) holds 4 consecutive channels of
+// token 16 w + i -- the layout GroupNorm + FiLM + SiLU + the 8-byte LDS write of the next operand want, and the float4
+// the final store wants.  The k index of a 32-wide MFMA step enumerates (tap, channel) pairs; the host packs the weight
+// fragments in exactly that order (compiler.py: UNetCompiler.resblock), zero where a step is padded.
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "mdt_kernels.h"
+
+namespace mdt {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+#define MDT_MFMA_BF16 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+
+constexpr int T = 64;                    // tokens per sample
+constexpr int ROWS = T + 2;              // + one zero row on either end
+
+__host__ __device__ constexpr int pitch_of(int c) { return 2 * c + 16; }
+__host__ __device__ constexpr int ksteps_of(int c) { return c == 64 ? 6 : 2; }   // k = 3 convolution over c channels
+__host__ __device__ constexpr int rsteps_of(int c) { return c == 64 ? 2 : 1; }   // 1 x 1 convolution over c channels
+
+// +-16 / +-32 lane exchanges with the gfx950 permlane swaps (k_tblock_lw.hip), the rest of a wave sum with DPP moves
+// inside the 16-lane row: no LDS round trip per step
+#define MDT_XG(NAME, INSN)                                                               \
+  __device__ __forceinline__ float NAME(float v) {                                       \
+    float a = v, b = v;                                                                  \
+    asm("s_nop 1\n\t" INSN " %0, %1" : "+v"(a), "+v"(b));                                \
+    return a + b;                                                                        \
+  }
+MDT_XG(xg16_add, "v_permlane16_swap_b32")
+MDT_XG(xg32_add, "v_permlane32_swap_b32")
+#undef MDT_XG
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int m = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true);
+  return v + __builtin_bit_cast(float, m);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+  v = dpp_add<0xB1>(v);      // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);      // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);     // row_half_mirror (quads are uniform: adds the lanes xor 4 would)
+  v = dpp_add<0x140>(v);     // row_mirror
+  v = xg16_add(v);
+  return xg32_add(v);
+}
+
+__device__ __forceinline__ void split4(const float v[4], bf16x4& hi, bf16x4& lo) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const __bf16 h = (__bf16)v[e];
+    hi[e] = h;
+    lo[e] = (__bf16)(v[e] - (float)h);
+  }
+}
+
+__device__ __forceinline__ float silu(float t) { return t * __builtin_amdgcn_rcpf(1.0f + __expf(-t)); }
+
+// byte offset (inside a plane) of the 16-byte B fragment of lane (i, g) for k-step s of a k = 3 convolution over C
+// channels per tap; tokens 16 w + i.  Row r of a plane is token r - 1; row 0 is zero.
+template <int C>
+__device__ __forceinline__ int conv_frag_off(int s, int w, int i, int g) {
+  if constexpr (C == 64) {
+    const int tap = s >> 1;
+    return (16 * w + i + tap) * pitch_of(C) + (32 * (s & 1) + 8 * g) * 2;
+  } else {
+    const int tap = 2 * s + (g >> 1);                // step 0: taps 0 | 1, step 1: tap 2 | nothing
+    return (tap < 3 ? (16 * w + i + tap) * pitch_of(C) : 0) + 8 * (g & 1) * 2;
+  }
+}
+// ... of the 1 x 1 convolution (centre tap) over C channels
+template <int C>
+__device__ __forceinline__ int res_frag_off(int s, int w, int i, int g) {
+  if constexpr (C == 64) return (16 * w + i + 1) * pitch_of(C) + (32 * s + 8 * g) * 2;
+  else return (g < 2 ? (16 * w + i + 1) * pitch_of(C) : 0) + 8 * (g & 1) * 2;
+}
+
+}  // namespace
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(512) void k_resblock(ResBlockArgs a) {
+  constexpr int RT = COUT / 16;                          // 16-channel row tiles of both convolutions' outputs
+  constexpr int K1 = ksteps_of(CIN);                     // conv1 k-steps
+  constexpr int K2 = ksteps_of(COUT);                    // conv2 k-steps ...
+  constexpr int KR = rsteps_of(CIN);                     // ... followed by the 1 x 1 to_out steps on the raw input
+  constexpr int WBYTES = (K1 + K2 + KR) * RT * 2 * 1024; // fragment tiles: [step][row tile][hi | lo][64 lanes][16 B]
+  constexpr int PIN = pitch_of(CIN), POUT = pitch_of(COUT);
+  constexpr int PL_IN = ROWS * PIN, PL_OUT = ROWS * POUT;   // bytes per plane
+  constexpr int SAMPLE = 4 * PL_IN + 2 * PL_OUT;            // x hi | x lo | a1 hi | a1 lo | a2 hi | a2 lo
+  constexpr int NV = T * CIN / 4 / 256;                     // float4 per thread of one sample's input
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  unsigned char* wl = smem;
+  float* red = reinterpret_cast<float*>(smem + WBYTES + 2 * SAMPLE);   // [half][GroupNorm 0 | 1][wave 0..3] (mean, M2)
+
+  const int tid = threadIdx.x, lane = tid & 63, t = tid & 255;
+  const int half = tid >> 8, w = (tid >> 6) & 3;
+  const int i = lane & 15, g = lane >> 4;
+  unsigned char* sm = smem + WBYTES + half * SAMPLE;
+  unsigned char* xh = sm, *xl = sm + PL_IN, *a1h = sm + 2 * PL_IN, *a1l = sm + 3 * PL_IN;
+  unsigned char* a2h = sm + 4 * PL_IN, *a2l = sm + 4 * PL_IN + PL_OUT;
+
+  // ---- once per workgroup: weights -> LDS, zero rows, per-channel vectors -> registers ----
+  {
+    const float4* src = reinterpret_cast<const float4*>(a.w);
+    float4* dst = reinterpret_cast<float4*>(wl);
+    for (int k = tid; k < WBYTES / 16; k += 512) dst[k] = src[k];
+    // rows 0 and ROWS - 1 of the six planes of this half
+    for (int k = t; k < 4 * (PIN / 4) ; k += 256) {
+      const int pl = k / (PIN / 4), o = k % (PIN / 4);
+      reinterpret_cast<float*>(sm + pl * PL_IN)[o] = 0.f;
+      reinterpret_cast<float*>(sm + pl * PL_IN + (ROWS - 1) * PIN)[o] = 0.f;
+    }
+    for (int k = t; k < 2 * (POUT / 4); k += 256) {
+      const int pl = k / (POUT / 4), o = k % (POUT / 4);
+      reinterpret_cast<float*>(sm + 4 * PL_IN + pl * PL_OUT)[o] = 0.f;
+      reinterpret_cast<float*>(sm + 4 * PL_IN + pl * PL_OUT + (ROWS - 1) * POUT)[o] = 0.f;
+    }
+  }
+  // vec = gamma1[CIN] | beta1[CIN] | b1[COUT] | gamma2[COUT] | beta2[COUT] | bout[COUT]  (bout = b2 + to_out bias)
+  const int c4 = t % (CIN / 4);                           // the thread's input float4 column (the same for all its rows)
+  const float4 g1 = *reinterpret_cast<const float4*>(a.vec + 4 * c4);
+  const float4 be1 = *reinterpret_cast<const float4*>(a.vec + CIN + 4 * c4);
+  float4 b1[RT], fa[RT], fb[RT], bo[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const int c = 16 * rt + 4 * g;
+    b1[rt] = *reinterpret_cast<const float4*>(a.vec + 2 * CIN + c);
+    const float4 g2 = *reinterpret_cast<const float4*>(a.vec + 2 * CIN + COUT + c);
+    const float4 be2 = *reinterpret_cast<const float4*>(a.vec + 2 * CIN + 2 * COUT + c);
+    bo[rt] = *reinterpret_cast<const float4*>(a.vec + 2 * CIN + 3 * COUT + c);
+    float4 fs = make_float4(0.f, 0.f, 0.f, 0.f), fh = fs;
+    if (a.film) {
+      fs = *reinterpret_cast<const float4*>(a.film + c);
+      fh = *reinterpret_cast<const float4*>(a.film + a.film_ld + c);
+    }
+    // (n gamma + beta) (scale + 1) + shift = n [gamma (scale + 1)] + [beta (scale + 1) + shift]
+    fa[rt] = make_float4(g2.x * (fs.x + 1.0f), g2.y * (fs.y + 1.0f), g2.z * (fs.z + 1.0f), g2.w * (fs.w + 1.0f));
+    fb[rt] = make_float4(be2.x * (fs.x + 1.0f) + fh.x, be2.y * (fs.y + 1.0f) + fh.y, be2.z * (fs.z + 1.0f) + fh.z,
+                         be2.w * (fs.w + 1.0f) + fh.w);
+  }
+  // fragment addresses
+  int o1[K1], o2[K2], orr[KR];
+#pragma unroll
+  for (int s = 0; s < K1; ++s) o1[s] = conv_frag_off<CIN>(s, w, i, g);
+#pragma unroll
+  for (int s = 0; s < K2; ++s) o2[s] = conv_frag_off<COUT>(s, w, i, g);
+#pragma unroll
+  for (int s = 0; s < KR; ++s) orr[s] = res_frag_off<CIN>(s, w, i, g);
+  const unsigned char* wlane = wl + lane * 16;
+
+  // mean and 1 / sqrt(var + eps) over the sample (4 waves x 64 lanes x N values): two-pass inside the wave, then the
+  // waves' (mean, M2) pairs merged through LDS with ONE barrier (Chan et al.: M2 = sum M2_k + n sum (mean_k - mean)^2)
+  auto sample_stats = [&](auto&& value, auto nc, int slot, float& mean, float& rstd) {
+    constexpr int N = decltype(nc)::value;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < N; ++k) s += value(k);
+    const float mw = wave_sum(s) * (1.0f / (64 * N));
+    float m2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < N; ++k) { const float d = value(k) - mw; m2 += d * d; }
+    m2 = wave_sum(m2);
+    if (lane == 0) reinterpret_cast<float2*>(red)[(half * 2 + slot) * 4 + w] = make_float2(mw, m2);
+    __syncthreads();
+    const float4 p01 = reinterpret_cast<const float4*>(red)[(half * 2 + slot) * 2];
+    const float4 p23 = reinterpret_cast<const float4*>(red)[(half * 2 + slot) * 2 + 1];
+    mean = 0.25f * ((p01.x + p01.z) + (p23.x + p23.z));
+    const float d0 = p01.x - mean, d1 = p01.z - mean, d2 = p23.x - mean, d3 = p23.z - mean;
+    const float M2 = ((p01.y + p01.w) + (p23.y + p23.w)) + (64 * N) * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+    rstd = __builtin_amdgcn_rsqf(M2 * (1.0f / (256 * N)) + a.eps);
+  };
+
+  __syncthreads();
+  const int step = 2 * gridDim.x;
+  const int niter = (a.B - 2 * (int)blockIdx.x + step - 1) / step;      // the same for both halves (barriers)
+  float4 xn[NV];                                     // the next pass's input rows
+  auto request_rows = [&](int it) {
+    const int b = 2 * blockIdx.x + it * step + half;
+    const float4* xp = reinterpret_cast<const float4*>(a.x + (int64_t)(b < a.B ? b : a.B - 1) * T * CIN);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) xn[j] = xp[t + 256 * j];
+  };
+  request_rows(0);
+  for (int it = 0; it < niter; ++it) {
+    const int b = 2 * blockIdx.x + it * step + half;
+    const bool live = b < a.B;
+    // ---- input rows (requested during the previous pass), GroupNorm 1 (one group: the whole sample), SiLU, split ----
+    float xv[NV][4];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) { xv[j][0] = xn[j].x; xv[j][1] = xn[j].y; xv[j][2] = xn[j].z; xv[j][3] = xn[j].w; }
+    float mean1, rstd1;
+    sample_stats([&](int k) { return xv[k >> 2][k & 3]; }, std::integral_constant<int, 4 * NV>{}, 0, mean1, rstd1);
+    {
+      const float ga[4] = {g1.x, g1.y, g1.z, g1.w}, be[4] = {be1.x, be1.y, be1.z, be1.w};
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const int tok = (t + 256 * j) / (CIN / 4);
+        float av[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) av[e] = silu((xv[j][e] - mean1) * rstd1 * ga[e] + be[e]);
+        bf16x4 h, l;
+        split4(xv[j], h, l);
+        *reinterpret_cast<bf16x4*>(xh + (tok + 1) * PIN + 8 * c4) = h;
+        *reinterpret_cast<bf16x4*>(xl + (tok + 1) * PIN + 8 * c4) = l;
+        split4(av, h, l);
+        *reinterpret_cast<bf16x4*>(a1h + (tok + 1) * PIN + 8 * c4) = h;
+        *reinterpret_cast<bf16x4*>(a1l + (tok + 1) * PIN + 8 * c4) = l;
+      }
+    }
+    if (it + 1 < niter) request_rows(it + 1);        // lands under the two convolutions
+    __syncthreads();
+    // ---- conv1 (transposed): h^T[16 rt + 4 g + r][16 w + i] ----
+    f32x4 acc[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4{b1[rt].x, b1[rt].y, b1[rt].z, b1[rt].w};
+#pragma unroll
+    for (int s1 = 0; s1 < K1; ++s1) {
+      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(a1h + o1[s1]);
+      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(a1l + o1[s1]);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const bf16x8 wh = *reinterpret_cast<const bf16x8*>(wlane + ((s1 * RT + rt) * 2 + 0) * 1024);
+        const bf16x8 wlo = *reinterpret_cast<const bf16x8*>(wlane + ((s1 * RT + rt) * 2 + 1) * 1024);
+        acc[rt] = MDT_MFMA_BF16(wlo, bh, acc[rt], 0, 0, 0);
+        acc[rt] = MDT_MFMA_BF16(wh, bl, acc[rt], 0, 0, 0);
+        acc[rt] = MDT_MFMA_BF16(wh, bh, acc[rt], 0, 0, 0);
+      }
+    }
+    // ---- GroupNorm 2 + FiLM + SiLU on the accumulators, split -> a2 planes ----
+    float mean2, rstd2;
+    sample_stats([&](int k) { return acc[k >> 2][k & 3]; }, std::integral_constant<int, 4 * RT>{}, 1, mean2, rstd2);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const float fav[4] = {fa[rt].x, fa[rt].y, fa[rt].z, fa[rt].w}, fbv[4] = {fb[rt].x, fb[rt].y, fb[rt].z, fb[rt].w};
+      float av[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) av[r] = silu((acc[rt][r] - mean2) * rstd2 * fav[r] + fbv[r]);
+      bf16x4 h, l;
+      split4(av, h, l);
+      *reinterpret_cast<bf16x4*>(a2h + (16 * w + i + 1) * POUT + (16 * rt + 4 * g) * 2) = h;
+      *reinterpret_cast<bf16x4*>(a2l + (16 * w + i + 1) * POUT + (16 * rt + 4 * g) * 2) = l;
+    }
+    __syncthreads();
+    // ---- conv2 + to_out (1 x 1 on the raw input) ----
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4{bo[rt].x, bo[rt].y, bo[rt].z, bo[rt].w};
+#pragma unroll
+    for (int s2 = 0; s2 < K2 + KR; ++s2) {
+      const unsigned char* ph = s2 < K2 ? a2h + o2[s2 < K2 ? s2 : 0] : xh + orr[s2 < K2 ? 0 : s2 - K2];
+      const unsigned char* pl = s2 < K2 ? a2l + o2[s2 < K2 ? s2 : 0] : xl + orr[s2 < K2 ? 0 : s2 - K2];
+      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(ph);
+      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(pl);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const bf16x8 wh = *reinterpret_cast<const bf16x8*>(wlane + (((K1 + s2) * RT + rt) * 2 + 0) * 1024);
+        const bf16x8 wlo = *reinterpret_cast<const bf16x8*>(wlane + (((K1 + s2) * RT + rt) * 2 + 1) * 1024);
+        acc[rt] = MDT_MFMA_BF16(wlo, bh, acc[rt], 0, 0, 0);
+        acc[rt] = MDT_MFMA_BF16(wh, bl, acc[rt], 0, 0, 0);
+        acc[rt] = MDT_MFMA_BF16(wh, bh, acc[rt], 0, 0, 0);
+      }
+    }
+    if (live) {
+      float* yo = a.out + ((int64_t)b * T + 16 * w + i) * COUT + 4 * g;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+        *reinterpret_cast<float4*>(yo + 16 * rt) = make_float4(acc[rt][0], acc[rt][1], acc[rt][2], acc[rt][3]);
+    }
+    // the next iteration's plane writes come after its two reduction barriers: every wave is past its reads by then
+  }
+}
+
+bool resblock_supported(int T_, int cin, int cout) {
+  return T_ == T && ((cin == 16 && cout == 64) || (cin == 64 && cout == 16));
+}
+
+template <int CIN, int COUT>
+static hipError_t launch_rb(const ResBlockArgs& a, hipStream_t s) {
+  constexpr int RT = COUT / 16;
+  constexpr int WBYTES = (ksteps_of(CIN) + ksteps_of(COUT) + rsteps_of(CIN)) * RT * 2 * 1024;
+  constexpr int SAMPLE = 4 * ROWS * pitch_of(CIN) + 2 * ROWS * pitch_of(COUT);
+  const size_t smem = (size_t)WBYTES + 2 * SAMPLE + 2 * 4 * 4 * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resblock<CIN, COUT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(160 * 1024));
+    attr_set = true;
+  }
+  const int pairs = (a.B + 1) / 2;
+  hipLaunchKernelGGL((k_resblock<CIN, COUT>), dim3((unsigned)(pairs < 256 ? pairs : 256)), dim3(512), smem, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_resblock(const ResBlockArgs& a, hipStream_t s) {
+  if (a.B <= 0) return hipSuccess;
+  if (!resblock_supported(a.T, a.cin, a.cout)) return hipErrorInvalidValue;
+  return a.cin == 16 ? launch_rb<16, 64>(a, s) : launch_rb<64, 16>(a, s);
+}
+
+}  // namespace mdt

@@ -87,6 +87,11 @@ static const char* validate(const mdt_op& o, int idx, char* buf, size_t nbuf) {
       if (!o.a.space || !o.w.space || !o.out.space) return bad("missing operand");
       if (o.i[MDT_R_GSIZE] > 0 && (!o.p0.space || !o.p1.space)) return bad("GroupNorm prologue needs gain and bias");
       break;
+    case MDT_OP_RESBLOCK:
+      if (!mdt::resblock_supported(o.i[MDT_K_T], o.i[MDT_K_CIN], o.i[MDT_K_COUT]))
+        return bad("shape not supported by the fused ResNet block");
+      if (!o.a.space || !o.w.space || !o.bias.space || !o.out.space) return bad("missing operand");
+      break;
     case MDT_OP_ATTN:
       if (o.i[MDT_A_T] <= 0 || o.i[MDT_A_T] > 64 || o.i[MDT_A_TK] <= 0 || o.i[MDT_A_TK] > 64)
         return bad("attention supports 1..64 queries and keys per sample");
@@ -225,6 +230,14 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
         a.film_ld = o.i[MDT_R_FILM_LD]; a.eps = o.f[MDT_RF_EPS]; a.in_scale = o.f[MDT_RF_IN_SCALE];
         a.lda2 = o.i[MDT_R_LDA2]; a.in_scale2 = o.f[MDT_RF_IN_SCALE2];
         if (!missing) e = mdt::launch_rconv(a, stream);
+        break;
+      }
+      case MDT_OP_RESBLOCK: {
+        mdt::ResBlockArgs a;
+        a.x = ptr(o.a); a.out = ptr(o.out); a.w = ptr(o.w); a.vec = ptr(o.bias); a.film = ptr(o.p3);
+        a.B = B; a.T = o.i[MDT_K_T]; a.cin = o.i[MDT_K_CIN]; a.cout = o.i[MDT_K_COUT]; a.film_ld = o.i[MDT_K_FILM_LD];
+        a.eps = o.f[MDT_KF_EPS];
+        if (!missing) e = mdt::launch_resblock(a, stream);
         break;
       }
       case MDT_OP_ATTN: {

@@ -81,6 +81,19 @@ struct RConvArgs {
 bool rconv_supported(int C, int T, int taps, int gsize);
 hipError_t launch_rconv(const RConvArgs& a, hipStream_t s);
 
+// MDT_OP_RESBLOCK (k_resblock.hip): a whole ResnetBlock1d of the 64-token level (one GroupNorm group) in one launch
+struct ResBlockArgs {
+  const float* x;      // [B][64][cin]
+  float* out;          // [B][64][cout]
+  const float* w;      // bf16 hi/lo MFMA fragments [step][row tile][hi | lo][64 lanes][8], steps: conv1 | conv2 | to_out
+  const float* vec;    // gamma1[cin] | beta1[cin] | b1[cout] | gamma2[cout] | beta2[cout] | b2 + to_out bias [cout]
+  const float* film;   // [scale | shift] rows film_ld apart, or nullptr
+  int B, T, cin, cout, film_ld;
+  float eps;
+};
+bool resblock_supported(int T, int cin, int cout);
+hipError_t launch_resblock(const ResBlockArgs& a, hipStream_t s);
+
 struct AttnArgs {
   const float* q;
   const float* k;  // v = k + heads*64

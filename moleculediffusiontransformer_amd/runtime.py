@@ -14,6 +14,7 @@ from . import build as _build
 N_EXT = 8
 SP_NONE, SP_WEIGHT, SP_ACT, SP_SHR, SP_EXT0 = 0, 1, 2, 3, 4
 OP_GEMM, OP_GN_STATS, OP_ATTN, OP_CONCAT, OP_PATCH, OP_TIME_EMBED, OP_TBLOCK, OP_GN_ACT, OP_RCONV = 1, 2, 3, 4, 5, 6, 7, 8, 9
+OP_RESBLOCK = 10
 TB_SELF, TB_CROSS, TB_FF = 0, 1, 2
 PRO_NONE, PRO_LAYERNORM, PRO_GROUPNORM, PRO_SILU = 0, 1, 2, 3
 
@@ -26,6 +27,7 @@ C_ROWS, C_CA, C_CB = range(3)
 P_ROWS_IN, P_C_IN, P_LD_IN, P_LD_OUT, P_PATCH, P_INVERSE = range(6)
 T_HALF, T_LD = range(2)
 R_T, R_C, R_LDA, R_LDC, R_LDR, R_TAPS, R_GSIZE, R_SILU, R_FILM_LD, R_LDA2 = range(10)
+K_T, K_CIN, K_COUT, K_FILM_LD = range(4)
 B_MODE, B_C, B_T, B_NCHUNK, B_NBIAS, B_TK, B_KV_BSTRIDE, B_LDKV, B_HEADS, B_VARIANT, B_POST = range(11)
 
 

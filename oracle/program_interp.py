@@ -119,6 +119,8 @@ def run_program(ops, bufs: Buffers, B: int, n_shared_rows: int = 0) -> None:
             bufs.view(op.out, B, B * rows * ld).view(B, rows, ld)[:] = y
         elif op.kind == rt.OP_RCONV:
             _rconv(op, bufs, B)
+        elif op.kind == rt.OP_RESBLOCK:
+            _resblock(op, bufs, B)
         elif op.kind == rt.OP_ATTN:
             T, Tk, H = i[rt.A_T], i[rt.A_TK], i[rt.A_HEADS]
             ldq, ldkv, ldo, bs = i[rt.A_LDQ], i[rt.A_LDKV], i[rt.A_LDO], i[rt.A_KV_BSTRIDE]
@@ -221,6 +223,50 @@ def _rconv(op, bufs: Buffers, B: int) -> None:
     if op.res.space != rt.SP_NONE:
         o = o + bufs.view(op.res, B, B * T * ldr).view(B, T, ldr)[:, :, :C]
     bufs.view(op.out, B, B * T * ldc).view(B, T, ldc)[:, :, :C] = o
+
+
+def _resblock_steps(c: int, taps: int):
+    """k-step enumeration of MDT_OP_RESBLOCK (csrc/k_resblock.hip): 32 (tap, channel) pairs per step, None = padding."""
+    if taps == 3:
+        if c == 64:
+            return [[(s // 2, 32 * (s % 2) + j) for j in range(32)] for s in range(6)]
+        return [[(j // 16, j % 16) for j in range(32)], [(2, j) if j < 16 else None for j in range(32)]]
+    if c == 64:
+        return [[(0, 32 * s + j) for j in range(32)] for s in range(2)]
+    return [[(0, j) if j < 16 else None for j in range(32)]]
+
+
+def _resblock(op, bufs: Buffers, B: int) -> None:
+    """MDT_OP_RESBLOCK semantics (include/mdt_hip.h): the whole ResnetBlock1d (reference modules.py:145-205) with one
+    GroupNorm group, weights reconstructed from the packed MFMA fragments."""
+    i, f = op.i, op.f
+    T, cin, cout, fld = i[rt.K_T], i[rt.K_CIN], i[rt.K_COUT], i[rt.K_FILM_LD]
+    specs = [(cout, cin, 3), (cout, cout, 3), (cout, cin, 1)]
+    nfrag = sum(len(_resblock_steps(c, taps)) * (n // 16) for n, c, taps in specs)
+    stream = bufs.view(op.w, B, nfrag * 512)
+    ws, k = [], 0
+    for n, c, taps in specs:
+        w = torch.zeros(n, c, taps)
+        for step in _resblock_steps(c, taps):
+            for r in range(n // 16):
+                m = _untile(stream, k, 64, 8).view(4, 16, 8).permute(1, 0, 2).reshape(16, 32)   # lane 16 g + i -> [i][8 g + e]
+                k += 1
+                for j, tc in enumerate(step):
+                    if tc is not None:
+                        w[16 * r: 16 * r + 16, tc[1], tc[0]] = m[:, j]
+        ws.append(w)
+    vec = bufs.view(op.bias, B, 2 * cin + 4 * cout)
+    g1, be1, b1 = vec[:cin], vec[cin: 2 * cin], vec[2 * cin: 2 * cin + cout]
+    g2, be2, bo = (vec[2 * cin + cout: 2 * cin + 2 * cout], vec[2 * cin + 2 * cout: 2 * cin + 3 * cout],
+                   vec[2 * cin + 3 * cout:])
+    x = bufs.view(op.a, B, B * T * cin).view(B, T, cin).transpose(1, 2)
+    h = F.conv1d(_silu(F.group_norm(x, 1, g1, be1, float(f[0]))), ws[0], b1, padding=1)
+    h = F.group_norm(h, 1, g2, be2, float(f[0]))
+    if op.p3.space != rt.SP_NONE:
+        ss = bufs.view(op.p3, B, fld + cout)
+        h = h * (ss[:cout, None] + 1.0) + ss[fld: fld + cout, None]
+    y = F.conv1d(_silu(h), ws[1], bo, padding=1) + F.conv1d(x, ws[2])
+    bufs.view(op.out, B, B * T * cout).view(B, T, cout)[:] = y.transpose(1, 2)
 
 
 def _tblock(op, bufs: Buffers, B: int) -> None:

@@ -474,6 +474,58 @@ def test_row_stationary_conv(C, T, B, taps, gsize, film, silu, res, in_scale):
     assert (og.view(B, T, C) - y).abs().max() < 1e-4 * scale
 
 
+def _resblock_case(cin, cout, film):
+    """One MDT_OP_RESBLOCK op with seeded weights + the closed form of the reference block (modules.py:145-205)."""
+    from moleculediffusiontransformer_amd.compiler import Ten, UNetCompiler
+    from moleculediffusiontransformer_amd.netspec import inverse_unet_config
+    p = "blk."
+    sd = {p + "block1.groupnorm.weight": 1 + 0.1 * rnd(cin, seed=1), p + "block1.groupnorm.bias": 0.1 * rnd(cin, seed=2),
+          p + "block1.project.weight": rnd(cout, cin, 3, seed=3, scale=(3 * cin) ** -0.5),
+          p + "block1.project.bias": 0.1 * rnd(cout, seed=4),
+          p + "block2.groupnorm.weight": 1 + 0.1 * rnd(cout, seed=5), p + "block2.groupnorm.bias": 0.1 * rnd(cout, seed=6),
+          p + "block2.project.weight": rnd(cout, cout, 3, seed=7, scale=(3 * cout) ** -0.5),
+          p + "block2.project.bias": 0.1 * rnd(cout, seed=8),
+          p + "to_out.weight": rnd(cout, cin, 1, seed=9, scale=cin ** -0.5), p + "to_out.bias": 0.1 * rnd(cout, seed=10)}
+    comp = UNetCompiler(inverse_unet_config(16, 64, 128, 12), 64, 12, sd)
+    x = Ten(A, 0, 64, cin)
+    assert comp.resblock_ok(64, cin, cout, 1, p)
+    y = comp.resnet(x, p, cin, cout, 1, free_input=False)
+    assert len(comp.ops) == 1 and comp.ops[0].kind == rt.OP_RESBLOCK
+    op = comp.ops[0]
+    op.out = ref(A, 64 * cin)
+    op.p3 = ref(S, 0) if film else ref(0, 0)
+    shr = 0.3 * rnd(2 * cout, seed=11)
+
+    def closed_form(xin):                              # xin [B, 64, cin]
+        F = torch.nn.functional
+        xt = xin.transpose(1, 2)
+        h = F.conv1d(F.silu(F.group_norm(xt, 1, sd[p + "block1.groupnorm.weight"], sd[p + "block1.groupnorm.bias"], 1e-5)),
+                     sd[p + "block1.project.weight"], sd[p + "block1.project.bias"], padding=1)
+        h = F.group_norm(h, 1, sd[p + "block2.groupnorm.weight"], sd[p + "block2.groupnorm.bias"], 1e-5)
+        if film:
+            h = h * (shr[:cout].view(1, cout, 1) + 1) + shr[cout:].view(1, cout, 1)
+        yt = F.conv1d(F.silu(h), sd[p + "block2.project.weight"], sd[p + "block2.project.bias"], padding=1)
+        return (yt + F.conv1d(xt, sd[p + "to_out.weight"], sd[p + "to_out.bias"])).transpose(1, 2)
+    return comp, op, shr, closed_form
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 64), (64, 16)])
+@pytest.mark.parametrize("B,film", [(1, True), (2, False), (7, True), (1030, True)])
+def test_fused_resnet_block(cin, cout, B, film):
+    """k_resblock (the Patcher / Unpatcher ResnetBlock1d in one launch; odd batches leave half a workgroup idle, 1030
+    samples wrap the persistent loop) against the interpreter and against torch's group_norm / conv1d."""
+    comp, op, shr, closed_form = _resblock_case(cin, cout, film)
+    n_in, n_out = B * 64 * cin, B * 64 * cout
+    act = torch.cat([rnd(n_in, seed=12) * 1.5 + 0.3, torch.zeros(n_out)])
+    (ga, _, _), (ca, _, _) = run_both([op], comp.W.pack(), act, shr, {}, B)
+    og, oc = ga[n_in:], ca[n_in:]
+    scale = max(1.0, oc.abs().max().item())
+    assert torch.isfinite(og).all() and (og - oc).abs().max() < 1e-4 * scale, (og - oc).abs().max().item()
+    assert torch.equal(ga[:n_in], ca[:n_in])
+    y = closed_form(act[:n_in].view(B, 64, cin))
+    assert (og.view(B, 64, cout) - y).abs().max() < 1e-4 * scale
+
+
 @pytest.mark.parametrize("mode,split,with_pin", [(rt.TB_SELF, True, False), (rt.TB_SELF, True, True), (rt.TB_CROSS, True, True),
                                                  (rt.TB_FF, False, True), (rt.TB_FF, False, False)])
 @pytest.mark.parametrize("T,B", [(4, 37), (16, 3)])
