@@ -153,3 +153,41 @@ def test_ring_kernels_keep_their_arrays_in_registers():
             if name == "k_rconv" and fn.endswith("ELi2EEEvNS_9RConvArgsE"):
                 continue                                                 # two-source variant: not on the default path
             assert int(scratch) <= limit, (fn, scratch)
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 64), (64, 16)])
+def test_fused_resnet_block_lowering(cin, cout):
+    """MDT_OP_RESBLOCK on the CPU side: the compiler's MFMA-fragment packing (k-steps enumerate (tap, channel) pairs,
+    lane i + 16 g holds pairs 8 g .. 8 g + 7 of weight row i) and the interpreter's unpacking are inverse to each other,
+    and the interpreted op is the reference ResnetBlock1d (modules.py:145-205) with one GroupNorm group."""
+    from moleculediffusiontransformer_amd import runtime as rt
+    from moleculediffusiontransformer_amd.compiler import Ten, UNetCompiler
+    g = torch.Generator().manual_seed(7)
+    r = lambda *s, scale=1.0: torch.randn(*s, generator=g) * scale   # noqa: E731
+    p = "blk."
+    sd = {p + "block1.groupnorm.weight": 1 + 0.1 * r(cin), p + "block1.groupnorm.bias": 0.1 * r(cin),
+          p + "block1.project.weight": r(cout, cin, 3, scale=(3 * cin) ** -0.5), p + "block1.project.bias": 0.1 * r(cout),
+          p + "block2.groupnorm.weight": 1 + 0.1 * r(cout), p + "block2.groupnorm.bias": 0.1 * r(cout),
+          p + "block2.project.weight": r(cout, cout, 3, scale=(3 * cout) ** -0.5), p + "block2.project.bias": 0.1 * r(cout),
+          p + "to_out.weight": r(cout, cin, 1, scale=cin ** -0.5), p + "to_out.bias": 0.1 * r(cout)}
+    comp = UNetCompiler(inverse_unet_config(16, 64, 128, 12), 64, 12, sd)
+    comp.resnet(Ten(rt.SP_ACT, 0, 64, cin), p, cin, cout, 1, free_input=False)
+    assert [op.kind for op in comp.ops] == [rt.OP_RESBLOCK]
+    op = comp.ops[0]
+    op.out = rt.MdtRef(rt.SP_ACT, 0, 64 * cin)
+    op.p3 = rt.MdtRef(rt.SP_SHR, 0, 0)
+    B = 3
+    shr = 0.3 * r(2 * cout)
+    x = r(B, 64, cin) * 1.5 + 0.3
+    bufs = Buffers(comp.W.pack(), torch.cat([x.reshape(-1), torch.zeros(B * 64 * cout)]), shr, {})
+    run_program([op], bufs, B, 0)
+    F = torch.nn.functional
+    xt = x.transpose(1, 2)
+    h = F.conv1d(F.silu(F.group_norm(xt, 1, sd[p + "block1.groupnorm.weight"], sd[p + "block1.groupnorm.bias"], 1e-5)),
+                 sd[p + "block1.project.weight"], sd[p + "block1.project.bias"], padding=1)
+    h = F.group_norm(h, 1, sd[p + "block2.groupnorm.weight"], sd[p + "block2.groupnorm.bias"], 1e-5)
+    h = h * (shr[:cout].view(1, cout, 1) + 1) + shr[cout:].view(1, cout, 1)
+    y = F.conv1d(F.silu(h), sd[p + "block2.project.weight"], sd[p + "block2.project.bias"], padding=1)
+    y = (y + F.conv1d(xt, sd[p + "to_out.weight"], sd[p + "to_out.bias"])).transpose(1, 2)
+    got = bufs.act[B * 64 * cin:].view(B, 64, cout)
+    assert (got - y).abs().max() < 1e-4        # weights pass through bf16 hi + lo (2^-17 relative)
