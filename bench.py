@@ -111,7 +111,7 @@ def pmc_traffic(kernel_class):
     for line in open(files[-1]):
         if line.startswith("#") or line.startswith("kernel,"):
             continue
-        name, rest = line.rsplit(",", 5)[0], line.strip().rsplit(",", 5)[1:]
+        name, rest = line.rsplit(",", 5)[0].strip('"'), line.strip().rsplit(",", 5)[1:]
         if name.startswith("mdt::" + kernel_class):
             n += int(rest[0])
             mb += int(rest[0]) * float(rest[4])

@@ -57,7 +57,7 @@ def main():
             rows.append((k, d, raw, 2 * raw / 1024.0, w))
         rows.sort(key=lambda r: -(r[3] + r[4]) * r[1])
         for k, d, raw, fc, w in rows:
-            f.write(f"{k},{d},{raw:.1f},{fc:.2f},{w:.2f},{fc + w:.2f}\n")
+            f.write(f"\"{k}\",{d},{raw:.1f},{fc:.2f},{w:.2f},{fc + w:.2f}\n")
     # SQ pass: where the waves spend their cycles, MFMA pipe occupancy, LDS bank conflicts (per kernel, per dispatch)
     names = ["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_VALU_MFMA_BUSY_CYCLES",
              "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "GRBM_GUI_ACTIVE"]
@@ -90,7 +90,7 @@ def main():
                 gui = us * 2400.0                          # cycles at the nominal clock
                 mf = g("SQ_VALU_MFMA_BUSY_CYCLES") / d
                 lds = g("SQ_LDS_IDX_ACTIVE")
-                rows.append((wc, f"{k},{d},{g('SQ_WAIT_ANY') / wc:.3f},{g('SQ_WAIT_INST_ANY') / wc:.3f},"
+                rows.append((wc, f"\"{k}\",{d},{g('SQ_WAIT_ANY') / wc:.3f},{g('SQ_WAIT_INST_ANY') / wc:.3f},"
                                  f"{g('SQ_ACTIVE_INST_ANY') / wc:.3f},{mf:.0f},{us:.1f},"
                                  f"{mf / (gui * 1024) if gui else 0:.4f},{g('SQ_LDS_BANK_CONFLICT') / lds if lds else 0:.4f}\n"))
             for _, line in sorted(rows, key=lambda r: -r[0]):
