@@ -309,39 +309,56 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
     if (a.gsize > 0) {
       // group statistics over (tokens of the sample) x (gsize channels): the lane's 4-value halves, the lane groups g,
       // the paired k-steps, then the sample's token lanes.  Stage-major: every stage is one batch of independent
-      // shuffles with a compile-time distance (a dependent chain per value, value after value, cost 30k cycles).
+      // exchanges with a compile-time distance (a dependent chain per value, value after value, cost 30k cycles).
+      // Which stages apply depends on run-time gsize / T: every stage is computed and then selected with a uniform
+      // bit mask (or, for the DPP stages, added through an fma with a 0 / 1 factor) -- as `if (gs >= 16)` blocks the
+      // ~20 tiny basic blocks cost more in branches, phi copies and hazard nops (700 instructions) than the sums.
       const int gs = a.gsize;
-      auto group_sum = [&](float (&s)[NSTW][2]) {
-        if (gs >= 8) {
+      const unsigned m16 = gs >= 16 ? ~0u : 0u, m32 = gs >= 32 ? ~0u : 0u, m64 = gs >= 64 ? ~0u : 0u;
+      const float t1 = a.T > 1 ? 1.f : 0.f, t2 = a.T > 2 ? 1.f : 0.f, t4 = a.T > 4 ? 1.f : 0.f, t8 = a.T > 8 ? 1.f : 0.f;
+      auto sel = [](unsigned m, float x, float y) {
+        return __builtin_bit_cast(float, (m & __builtin_bit_cast(unsigned, x)) | (~m & __builtin_bit_cast(unsigned, y)));
+      };
+      // token lanes: DPP moves inside the 16-lane row (no LDS round trip).  Once the quads are uniform, mirroring the
+      // half row / the row adds exactly the lanes that xor 4 / xor 8 would.
+      auto dpp_fma = [](float v, float f, auto ctrl) {
+        const int m = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xf, 0xf, true);
+        return __builtin_fmaf(__builtin_bit_cast(float, m), f, v);
+      };
+      auto reduce = [&](auto nhc, float (&s)[NSTW][2]) {
+        constexpr int NH = decltype(nhc)::value;           // 1: the lane's two halves belong to one group (gsize >= 8)
+        auto all = [&](auto fn) {
 #pragma unroll
-          for (int st = 0; st < NSTW; ++st) { const float t = s[st][0] + s[st][1]; s[st][0] = t; s[st][1] = t; }
+          for (int st = 0; st < NSTW; ++st)
+#pragma unroll
+            for (int hf = 0; hf < NH; ++hf) s[st][hf] = fn(s[st][hf]);
+        };
+        if (NH == 1) {
+#pragma unroll
+          for (int st = 0; st < NSTW; ++st) s[st][0] += s[st][1];
         }
-        auto all_lanes = [&](auto fn) {
+        all([&](float v) { return sel(m16, xg16_add(v), v); });
+        all([&](float v) { return sel(m32, xg32_add(v), v); });
 #pragma unroll
-          for (int st = 0; st < NSTW; ++st) {
-            s[st][0] = fn(s[st][0]);
-            if (gs >= 8) s[st][1] = s[st][0];          // halves already merged: one shuffle serves both
-            else s[st][1] = fn(s[st][1]);
+        for (int st = 0; st + 1 < NSTW; st += 2)
+#pragma unroll
+          for (int hf = 0; hf < NH; ++hf) {
+            const float t = s[st][hf] + s[st + 1][hf];
+            s[st][hf] = sel(m64, t, s[st][hf]);
+            s[st + 1][hf] = sel(m64, t, s[st + 1][hf]);
           }
-        };
-        if (gs >= 16) all_lanes([](float v) { return xg16_add(v); });
-        if (gs >= 32) all_lanes([](float v) { return xg32_add(v); });
-        if (gs >= 64) {
+        all([&](float v) { return dpp_fma(v, t1, std::integral_constant<int, 0xB1>{}); });    // quad_perm [1,0,3,2]
+        all([&](float v) { return dpp_fma(v, t2, std::integral_constant<int, 0x4E>{}); });    // quad_perm [2,3,0,1]
+        all([&](float v) { return dpp_fma(v, t4, std::integral_constant<int, 0x141>{}); });   // row_half_mirror
+        all([&](float v) { return dpp_fma(v, t8, std::integral_constant<int, 0x140>{}); });   // row_mirror
+        if (NH == 1) {
 #pragma unroll
-          for (int st = 0; st + 1 < NSTW; st += 2)
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) { const float t = s[st][hf] + s[st + 1][hf]; s[st][hf] = t; s[st + 1][hf] = t; }
+          for (int st = 0; st < NSTW; ++st) s[st][1] = s[st][0];
         }
-        // token lanes: DPP moves inside the 16-lane row (one VALU instruction each, no LDS round trip).  Once the quads
-        // are uniform, mirroring the half row / the row adds exactly the lanes that xor 4 / xor 8 would.
-        auto dpp_add = [](float v, auto ctrl) {
-          const int m = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xf, 0xf, true);
-          return v + __builtin_bit_cast(float, m);
-        };
-        if (a.T > 1) all_lanes([&](float v) { return dpp_add(v, std::integral_constant<int, 0xB1>{}); });   // quad_perm [1,0,3,2]
-        if (a.T > 2) all_lanes([&](float v) { return dpp_add(v, std::integral_constant<int, 0x4E>{}); });   // quad_perm [2,3,0,1]
-        if (a.T > 4) all_lanes([&](float v) { return dpp_add(v, std::integral_constant<int, 0x141>{}); });  // row_half_mirror
-        if (a.T > 8) all_lanes([&](float v) { return dpp_add(v, std::integral_constant<int, 0x140>{}); });  // row_mirror
+      };
+      auto group_sum = [&](float (&s)[NSTW][2]) {
+        if (gs >= 8) reduce(std::integral_constant<int, 1>{}, s);
+        else reduce(std::integral_constant<int, 2>{}, s);
       };
       const float inv_n = 1.0f / (float)(a.T * gs);
       float mean[NSTW][2], rstd[NSTW][2];
