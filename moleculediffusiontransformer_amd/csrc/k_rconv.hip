@@ -284,7 +284,9 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
     }
     // P: the loader waves start the weight stream only now, behind this wave's requests (a row load queued behind the
     // stream's first tiles came back ~2000 cycles later)
+    __builtin_amdgcn_sched_barrier(0);               // the loads' first uses (and their waits) stay behind the barrier
     if (src == 0) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
     if (src == 0) {
       if (a.bias) {
 #pragma unroll

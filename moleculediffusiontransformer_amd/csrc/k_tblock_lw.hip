@@ -262,8 +262,11 @@ __global__ __launch_bounds__(512) void k_tblock_lw(TBlockArgs a) {
 #pragma unroll
     for (int k = 0; k < NBV; ++k) bv[k] = (tid + 256 * k < 64 * a.nchunk) ? a.bias[tid + 256 * k] : 0.f;
     // P: the loader waves start the weight stream only now, behind this wave's requests (queued behind the stream's
-    // first two tiles the rows came back ~1500 cycles later)
+    // first two tiles the rows came back ~1500 cycles later).  sched_barrier: without it hipcc moves the rows' first
+    // uses (and with them the wait for the loads) in front of the barrier, i.e. the stream starts a round trip late
+    __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int st = 0; st < NST; ++st) {
       const float4 u = xu[st], w = xw[st];
