@@ -32,6 +32,12 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// streaming store: the output is consumed by the next launch (through the memory side: the per-XCD L2s are written
+// back / invalidated at every kernel boundary anyway), so it need not stay dirty in this XCD's L2 until kernel end
+__device__ __forceinline__ void store_nt(float* p, float4 v) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  __builtin_nontemporal_store(f4{v.x, v.y, v.z, v.w}, reinterpret_cast<f4*>(p));
+}
 
 // lane-group exchanges over +-16 / +-32 lanes with the gfx950 permlane swaps (VALU, no LDS round trip). The swap is in
 // place on two registers: fed the same value twice, v_permlane16_swap leaves (rows 0,0,2,2) and (rows 1,1,3,3),
@@ -555,8 +561,7 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
 #pragma unroll
       for (int q = 0; q < NFT; ++q) {
         const int f = 64 * ((int)blockIdx.y * NCH + c) + 16 * (NFT * fh + q) + 4 * g;
-        *reinterpret_cast<float4*>(a.out + (int64_t)m * a.ldc + f) =
-            make_float4(acc[c][q][0], acc[c][q][1], acc[c][q][2], acc[c][q][3]);
+        store_nt(a.out + (int64_t)m * a.ldc + f, make_float4(acc[c][q][0], acc[c][q][1], acc[c][q][2], acc[c][q][3]));
       }
   }
 }

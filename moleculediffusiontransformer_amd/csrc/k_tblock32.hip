@@ -21,6 +21,12 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// streaming store: the output is consumed by the next launch (through the memory side: the per-XCD L2s are written
+// back / invalidated at every kernel boundary anyway), so it need not stay dirty in this XCD's L2 until kernel end
+__device__ __forceinline__ void store_nt(float* p, float4 v) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  __builtin_nontemporal_store(f4{v.x, v.y, v.z, v.w}, reinterpret_cast<f4*>(p));
+}
 
 // lane-group exchanges over +-16 / +-32 lanes with the gfx950 permlane swaps (VALU, no LDS round trip). The swap is in
 // place on two registers: fed the same value twice, v_permlane16_swap leaves (rows 0,0,2,2) and (rows 1,1,3,3),
@@ -117,7 +123,7 @@ __global__ __launch_bounds__(256) void k_tb_reduce(float* x, const float* part, 
   const float4 b = reinterpret_cast<const float4*>(bo)[c4];
   float4 xr = reinterpret_cast<float4*>(x)[t];
   xr.x = v.x + b.x + xr.x; xr.y = v.y + b.y + xr.y; xr.z = v.z + b.z + xr.z; xr.w = v.w + b.w + xr.w;
-  reinterpret_cast<float4*>(x)[t] = xr;
+  store_nt(x + 4 * t, xr);
 }
 
 // NPW (MODE_CROSS only): LDS-DMA pieces per loader wave per K / V tile = ceil(context rows of the workgroup / 16)
@@ -681,7 +687,7 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         const f32x4 sum = halves(c);
-        *reinterpret_cast<float4*>(po + 16 * (8 * fh + c)) = make_float4(sum[0], sum[1], sum[2], sum[3]);
+        store_nt(po + 16 * (8 * fh + c), make_float4(sum[0], sum[1], sum[2], sum[3]));
       }
     } else {
       // every load of the epilogue is requested before the first store: the output aliases the residual rows (in
@@ -710,8 +716,8 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         const f32x4 sum = halves(c);
-        *reinterpret_cast<float4*>(xo + 16 * c) = make_float4(sum[0] + bo[c].x + xr[c].x, sum[1] + bo[c].y + xr[c].y,
-                                                              sum[2] + bo[c].z + xr[c].z, sum[3] + bo[c].w + xr[c].w);
+        store_nt(xo + 16 * c, make_float4(sum[0] + bo[c].x + xr[c].x, sum[1] + bo[c].y + xr[c].y,
+                                          sum[2] + bo[c].z + xr[c].z, sum[3] + bo[c].w + xr[c].w));
       }
     }
   }

@@ -26,6 +26,12 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// streaming store: the output is consumed by the next launch (through the memory side: the per-XCD L2s are written
+// back / invalidated at every kernel boundary anyway), so it need not stay dirty in this XCD's L2 until kernel end
+__device__ __forceinline__ void store_nt(float* p, float4 v) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  __builtin_nontemporal_store(f4{v.x, v.y, v.z, v.w}, reinterpret_cast<f4*>(p));
+}
 
 // lane-group exchanges over +-16 / +-32 lanes with the gfx950 permlane swaps (VALU, no LDS round trip). The swap is in
 // place on two registers: fed the same value twice, v_permlane16_swap leaves (rows 0,0,2,2) and (rows 1,1,3,3),
@@ -634,9 +640,8 @@ __global__ __launch_bounds__(512) void k_tblock_lw(TBlockArgs a) {
     }
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct)
-      *reinterpret_cast<float4*>(xo + 16 * ct) =
-          make_float4(accT[ct][0] + bo[ct].x + xr[ct].x, accT[ct][1] + bo[ct].y + xr[ct].y,
-                      accT[ct][2] + bo[ct].z + xr[ct].z, accT[ct][3] + bo[ct].w + xr[ct].w);
+      store_nt(xo + 16 * ct, make_float4(accT[ct][0] + bo[ct].x + xr[ct].x, accT[ct][1] + bo[ct].y + xr[ct].y,
+                                         accT[ct][2] + bo[ct].z + xr[ct].z, accT[ct][3] + bo[ct].w + xr[ct].w));
   }
 }
 
