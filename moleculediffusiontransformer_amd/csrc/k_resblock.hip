@@ -282,7 +282,7 @@ __global__ __launch_bounds__(512) void k_resblock(ResBlockArgs a) {
       float* yo = a.out + ((int64_t)b * T + 16 * w + i) * COUT + 4 * g;
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
-        *reinterpret_cast<float4*>(yo + 16 * rt) = make_float4(acc[rt][0], acc[rt][1], acc[rt][2], acc[rt][3]);
+        __builtin_nontemporal_store(acc[rt], reinterpret_cast<f32x4*>(yo + 16 * rt));   // streaming: consumed by the next launch
     }
     // the next iteration's plane writes come after its two reduction barriers: every wave is past its reads by then
   }

@@ -144,31 +144,44 @@ hipError_t launch_time_embed(const float* cn, const float* w, float* out, int ro
 // tile is first parked in LDS as fp32 [BM][BN+4] and then written by the whole workgroup as 16-byte stores,
 // 16 consecutive lanes per 256-byte row segment; bias, exact GELU and the residual are applied on the way
 // (bias/residual become float4 loads too).
+// The residual may alias the output (in-place accumulation), so a load after a store stays after it: U row segments
+// are handled per pass with all their bias / residual loads requested before the first store (one round trip per pass
+// instead of one per segment), and the stores are streaming (nothing left dirty in L2 for the kernel-end write-back).
 template <int BM, int BN>
 __device__ __forceinline__ void store_tile_coalesced(const float* Cs, const GemmArgs& g, int m0, int n0) {
-  constexpr int C4 = BN / 4, LDC = BN + 4;
-  for (int idx = threadIdx.x; idx < BM * C4; idx += 256) {
-    const int row = idx / C4, c4 = idx - row * C4;
-    const int m = m0 + row, n = n0 + c4 * 4;
-    if (m >= g.M || n >= g.N) continue;
-    const int bb = m / g.r_out;
-    const int64_t orow = (int64_t)bb * g.o_rows + (int64_t)(m - bb * g.r_out) * g.o_stride + g.o_off;
-    float4 v = *reinterpret_cast<const float4*>(Cs + row * LDC + c4 * 4);
-    if (g.bias) {
-      const float4 b = *reinterpret_cast<const float4*>(g.bias + n);
-      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+  constexpr int C4 = BN / 4, LDC = BN + 4, U = 4;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  for (int base = threadIdx.x; base < BM * C4; base += 256 * U) {
+    float4 v[U], b[U], r[U];
+    int64_t oidx[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = base + 256 * u;
+      const int row = idx / C4, c4 = idx - row * C4;
+      const int m = m0 + row, n = n0 + c4 * 4;
+      ok[u] = idx < BM * C4 && m < g.M && n < g.N;
+      const int mm = ok[u] ? m : m0, nn = ok[u] ? n : n0;                      // clamped: loads stay in bounds
+      const int bb = mm / g.r_out;
+      const int64_t orow = (int64_t)bb * g.o_rows + (int64_t)(mm - bb * g.r_out) * g.o_stride + g.o_off;
+      oidx[u] = orow * g.ldc + g.o_col + nn;
+      v[u] = ok[u] ? *reinterpret_cast<const float4*>(Cs + row * LDC + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      b[u] = g.bias ? *reinterpret_cast<const float4*>(g.bias + nn) : make_float4(0.f, 0.f, 0.f, 0.f);
+      r[u] = g.res ? *reinterpret_cast<const float4*>(g.res + orow * g.ldr + nn) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if (g.act == 1) {
-      v.x = 0.5f * v.x * (1.0f + erff(v.x * 0.70710678118654752440f));
-      v.y = 0.5f * v.y * (1.0f + erff(v.y * 0.70710678118654752440f));
-      v.z = 0.5f * v.z * (1.0f + erff(v.z * 0.70710678118654752440f));
-      v.w = 0.5f * v.w * (1.0f + erff(v.w * 0.70710678118654752440f));
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float4 w = v[u];
+      if (g.bias) { w.x += b[u].x; w.y += b[u].y; w.z += b[u].z; w.w += b[u].w; }
+      if (g.act == 1) {
+        w.x = 0.5f * w.x * (1.0f + erff(w.x * 0.70710678118654752440f));
+        w.y = 0.5f * w.y * (1.0f + erff(w.y * 0.70710678118654752440f));
+        w.z = 0.5f * w.z * (1.0f + erff(w.z * 0.70710678118654752440f));
+        w.w = 0.5f * w.w * (1.0f + erff(w.w * 0.70710678118654752440f));
+      }
+      if (g.res) { w.x += r[u].x; w.y += r[u].y; w.z += r[u].z; w.w += r[u].w; }
+      if (ok[u]) __builtin_nontemporal_store(f4{w.x, w.y, w.z, w.w}, reinterpret_cast<f4*>(g.out + oidx[u]));
     }
-    if (g.res) {
-      const float4 r = *reinterpret_cast<const float4*>(g.res + orow * g.ldr + n);
-      v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-    }
-    *reinterpret_cast<float4*>(g.out + orow * g.ldc + g.o_col + n) = v;
   }
 }
 #endif
