@@ -120,9 +120,16 @@ __global__ __launch_bounds__(512) void k_resblock(ResBlockArgs a) {
 
   // ---- once per workgroup: weights -> LDS, zero rows, per-channel vectors -> registers ----
   {
+    // all requests first: as a rolled load -> wait -> store loop the staging was 9 round trips in a row
     const float4* src = reinterpret_cast<const float4*>(a.w);
     float4* dst = reinterpret_cast<float4*>(wl);
-    for (int k = tid; k < WBYTES / 16; k += 512) dst[k] = src[k];
+    constexpr int NW = (WBYTES / 16 + 511) / 512;
+    float4 wv[NW];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) wv[k] = src[(tid + 512 * k < WBYTES / 16) ? tid + 512 * k : 0];
+#pragma unroll
+    for (int k = 0; k < NW; ++k)
+      if (tid + 512 * k < WBYTES / 16) dst[tid + 512 * k] = wv[k];
     // rows 0 and ROWS - 1 of the six planes of this half
     for (int k = t; k < 4 * (PIN / 4) ; k += 256) {
       const int pl = k / (PIN / 4), o = k % (PIN / 4);
@@ -140,22 +147,33 @@ __global__ __launch_bounds__(512) void k_resblock(ResBlockArgs a) {
   const float4 g1 = *reinterpret_cast<const float4*>(a.vec + 4 * c4);
   const float4 be1 = *reinterpret_cast<const float4*>(a.vec + CIN + 4 * c4);
   float4 b1[RT], fa[RT], fb[RT], bo[RT];
+  {
+    float4 g2[RT], be2[RT], fs[RT], fh[RT];
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    const int c = 16 * rt + 4 * g;
-    b1[rt] = *reinterpret_cast<const float4*>(a.vec + 2 * CIN + c);
-    const float4 g2 = *reinterpret_cast<const float4*>(a.vec + 2 * CIN + COUT + c);
-    const float4 be2 = *reinterpret_cast<const float4*>(a.vec + 2 * CIN + 2 * COUT + c);
-    bo[rt] = *reinterpret_cast<const float4*>(a.vec + 2 * CIN + 3 * COUT + c);
-    float4 fs = make_float4(0.f, 0.f, 0.f, 0.f), fh = fs;
-    if (a.film) {
-      fs = *reinterpret_cast<const float4*>(a.film + c);
-      fh = *reinterpret_cast<const float4*>(a.film + a.film_ld + c);
+    for (int rt = 0; rt < RT; ++rt) {
+      const int c = 16 * rt + 4 * g;
+      b1[rt] = *reinterpret_cast<const float4*>(a.vec + 2 * CIN + c);
+      g2[rt] = *reinterpret_cast<const float4*>(a.vec + 2 * CIN + COUT + c);
+      be2[rt] = *reinterpret_cast<const float4*>(a.vec + 2 * CIN + 2 * COUT + c);
+      bo[rt] = *reinterpret_cast<const float4*>(a.vec + 2 * CIN + 3 * COUT + c);
+      fs[rt] = make_float4(0.f, 0.f, 0.f, 0.f);
+      fh[rt] = fs[rt];
     }
-    // (n gamma + beta) (scale + 1) + shift = n [gamma (scale + 1)] + [beta (scale + 1) + shift]
-    fa[rt] = make_float4(g2.x * (fs.x + 1.0f), g2.y * (fs.y + 1.0f), g2.z * (fs.z + 1.0f), g2.w * (fs.w + 1.0f));
-    fb[rt] = make_float4(be2.x * (fs.x + 1.0f) + fh.x, be2.y * (fs.y + 1.0f) + fh.y, be2.z * (fs.z + 1.0f) + fh.z,
-                         be2.w * (fs.w + 1.0f) + fh.w);
+    if (a.film) {                                          // one block for all row tiles: one round trip
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        fs[rt] = *reinterpret_cast<const float4*>(a.film + 16 * rt + 4 * g);
+        fh[rt] = *reinterpret_cast<const float4*>(a.film + a.film_ld + 16 * rt + 4 * g);
+      }
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      // (n gamma + beta) (scale + 1) + shift = n [gamma (scale + 1)] + [beta (scale + 1) + shift]
+      fa[rt] = make_float4(g2[rt].x * (fs[rt].x + 1.0f), g2[rt].y * (fs[rt].y + 1.0f), g2[rt].z * (fs[rt].z + 1.0f),
+                           g2[rt].w * (fs[rt].w + 1.0f));
+      fb[rt] = make_float4(be2[rt].x * (fs[rt].x + 1.0f) + fh[rt].x, be2[rt].y * (fs[rt].y + 1.0f) + fh[rt].y,
+                           be2[rt].z * (fs[rt].z + 1.0f) + fh[rt].z, be2[rt].w * (fs[rt].w + 1.0f) + fh[rt].w);
+    }
   }
   // fragment addresses
   int o1[K1], o2[K2], orr[KR];
