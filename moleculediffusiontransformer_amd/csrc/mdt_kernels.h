@@ -153,7 +153,8 @@ __device__ __forceinline__ void store_tile_coalesced(const float* Cs, const Gemm
   typedef float f4 __attribute__((ext_vector_type(4)));
   for (int base = threadIdx.x; base < BM * C4; base += 256 * U) {
     float4 v[U], b[U], r[U];
-    int64_t oidx[U];
+    int64_t oidx[U], ridx[U];
+    int ncol[U];
     bool ok[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -165,9 +166,17 @@ __device__ __forceinline__ void store_tile_coalesced(const float* Cs, const Gemm
       const int bb = mm / g.r_out;
       const int64_t orow = (int64_t)bb * g.o_rows + (int64_t)(mm - bb * g.r_out) * g.o_stride + g.o_off;
       oidx[u] = orow * g.ldc + g.o_col + nn;
+      ridx[u] = orow * g.ldr + nn;
+      ncol[u] = nn;
       v[u] = ok[u] ? *reinterpret_cast<const float4*>(Cs + row * LDC + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-      b[u] = g.bias ? *reinterpret_cast<const float4*>(g.bias + nn) : make_float4(0.f, 0.f, 0.f, 0.f);
-      r[u] = g.res ? *reinterpret_cast<const float4*>(g.res + orow * g.ldr + nn) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (g.bias) {                                    // one block per kind of load: one round trip each
+#pragma unroll
+      for (int u = 0; u < U; ++u) b[u] = *reinterpret_cast<const float4*>(g.bias + ncol[u]);
+    }
+    if (g.res) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) r[u] = *reinterpret_cast<const float4*>(g.res + ridx[u]);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
