@@ -567,7 +567,9 @@ class UNetCompiler:
             return False
         if (c * self.cfg.ff_mult) % 64:
             return False
-        return not cross or (16 // rows) * self.n_ctx <= 64
+        # cross-attention with more context rows than any fused kernel takes (configs[2]: 64 keys per sample, 1..4 tokens)
+        # runs layer by layer between the fused self-attention and feed-forward blocks
+        return True
 
     @staticmethod
     def _tile(w: torch.Tensor) -> torch.Tensor:
@@ -762,7 +764,7 @@ class UNetCompiler:
                 if cross:
                     self.cross_layers.append(bp + "cross_attention.")
                     xv = split if ring_x else (1 if variant == 2 else variant)
-                    if self.fuse_cross == "all" or (self.fuse_cross == "1" and ring_x):
+                    if (self.fuse_cross == "all" and keys16 <= 64) or (self.fuse_cross == "1" and ring_x):
                         self.tblock(t, rt.TB_CROSS, bp + "cross_attention.", len(self.cross_layers) - 1,
                                     variant=xv)
                     else:
