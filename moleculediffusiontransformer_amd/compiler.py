@@ -136,7 +136,7 @@ class UNetCompiler:
         # ... partial sums handed to the next sub-block instead of a reduce launch.  Measured: 2511 molecules/s against
         # 2578 with the 28 reduce launches (the extra dependent loads in every prologue / epilogue and the ping-pong
         # buffers cost more than 5.4 us per block), so this is not the default.
-        self.tb_chain = os.environ.get("MDT_TB_CHAIN", "0") == "1"
+        self.tb_chain = os.environ.get("MDT_TB_CHAIN", "1") == "1"
         self.use_rconv = os.environ.get("MDT_RCONV", "1") == "1"     # row-stationary convs (k_rconv) at C = 128 / 256
         self.use_resblock = os.environ.get("MDT_RESBLOCK", "1") == "1"   # Patcher / Unpatcher ResNets as ONE launch (k_resblock)
         self.convt_merge = os.environ.get("MDT_CONVT_MERGE", "1") == "1"   # ConvTranspose phases in one launch
@@ -602,7 +602,7 @@ class UNetCompiler:
             for h in range(nchunk):
                 tiles += [self._tile(w1[64 * h: 64 * h + 64]), self._tile(w2[:, 64 * h: 64 * h + 64][:, perm])]
             if post is not None:
-                assert variant in (0, 2) and x_out is None
+                assert variant in (0, 2, 4) and (x_out is None or (variant == 4 and p_out is None))
                 tiles += [self._tile(post[0].reshape(c, c)[:, 64 * e: 64 * e + 64]) for e in range(c // 64)]
                 self.flops += 2 * rows * c * c
             bias = torch.cat([b1, b2])
@@ -667,7 +667,7 @@ class UNetCompiler:
         part = None
         if post is not None:
             op.out = post[2].ref()
-            i[rt.B_POST] = (c // 64) * (2 if variant == 2 else 1)     # extra (sub-)tiles
+            i[rt.B_POST] = (c // 64) * (2 if variant in (2, 4) else 1)     # extra (sub-)tiles
         if variant == 4:
             assert x_out is not None and x_out is not t and (p_out is None or nchunk % 2 == 0)
             op.out = x_out.ref()
@@ -753,7 +753,13 @@ class UNetCompiler:
                 for mode, name, ci, two in steps:
                     nxt = self._new(t.rows, c)
                     po = self._new(t.rows, c) if two else None
-                    self.tblock(t, mode, name, ci, variant=4, x_out=nxt, p_in=pend, p_out=po)
+                    if mode == rt.TB_FF and i == layers - 1 and self.fold_out:
+                        # the transformer's closing 1x1 convolution rides on the last feed-forward block (below)
+                        self.tblock(t, mode, name, ci, variant=4, x_out=nxt, p_in=pend, p_out=None,
+                                    post=(self.sd[p + "to_out.1.weight"], self.sd[p + "to_out.1.bias"], nxt))
+                        y_fold = nxt
+                    else:
+                        self.tblock(t, mode, name, ci, variant=4, x_out=nxt, p_in=pend, p_out=po)
                     self._free(t)
                     if pend is not None:
                         self._free(pend)
@@ -790,7 +796,8 @@ class UNetCompiler:
                       bias_off=self._vec(bp + "feed_forward.2.bias", c), res=t)
             self._free(h)
         if y_fold is not None:                      # the last feed-forward block already produced to_out(t)
-            self._free(t)
+            if y_fold is not t:
+                self._free(t)
             return y_fold
         y = self._new(t.rows, c)
         if self.rconv_ok(t.rows, c, 1, 0):

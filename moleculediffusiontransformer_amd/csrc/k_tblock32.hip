@@ -705,7 +705,7 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) xr[c] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      if (CHAIN && a.pin) {                                  // chained form: the block input was x + pin
+      if (CHAIN && a.pin && NX == 0) {                       // chained form: the block input was x + pin
         const float* pi = a.pin + (int64_t)m * C + 4 * g + 128 * fh;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
@@ -744,13 +744,14 @@ static hipError_t launch_32c(const TBlockArgs& a, hipStream_t s) {
 
 template <int MODE, int NPW = 0>
 static hipError_t launch_32(const TBlockArgs& a, hipStream_t s) {
-  return (a.xout && !a.post) ? launch_32c<MODE, NPW, true>(a, s) : launch_32c<MODE, NPW, false>(a, s);
+  // the chained instantiation also serves a folded closing convolution whose input is x + pin
+  return (a.xout && (!a.post || a.pin)) ? launch_32c<MODE, NPW, true>(a, s) : launch_32c<MODE, NPW, false>(a, s);
 }
 
 hipError_t launch_tblock32(const TBlockArgs& a, hipStream_t s) {
   if (a.M <= 0) return hipSuccess;
   if (a.C != 256 || a.T <= 0 || 16 % a.T || a.nchunk <= 0 || a.nchunk > 16) return hipErrorInvalidValue;
-  if (a.post && (a.mode != TB_FF || a.post != 8 || a.nsplit > 1 || a.pin || !a.xout)) return hipErrorInvalidValue;
+  if (a.post && (a.mode != TB_FF || a.post != 8 || a.nsplit > 1 || !a.xout)) return hipErrorInvalidValue;
   if (a.nsplit > 1 && (a.nchunk % a.nsplit || !(a.xout ? (void*)a.pout : (void*)a.part))) return hipErrorInvalidValue;
   if (a.xout && (a.nsplit > 2 || a.xout == a.x)) return hipErrorInvalidValue;
   if (a.mode == TB_CROSS) {

@@ -115,8 +115,9 @@ static const char* validate(const mdt_op& o, int idx, char* buf, size_t nbuf) {
         return bad("cross block needs K/V and at most 64 keys per 16 rows");
       if (!o.a.space || !o.w.space || !o.bias.space) return bad("missing operand");
       if (i[MDT_B_VARIANT] < 0 || i[MDT_B_VARIANT] > 4) return bad("unknown fused-block variant");
-      if (i[MDT_B_POST] && (i[MDT_B_MODE] != MDT_TB_FF || !o.out.space || i[MDT_B_VARIANT] == 1 || i[MDT_B_VARIANT] >= 3))
-        return bad("a folded closing convolution needs a feed-forward block of variant 0 or 2 and an output tensor");
+      if (i[MDT_B_POST] && (i[MDT_B_MODE] != MDT_TB_FF || !o.out.space || i[MDT_B_VARIANT] == 1 || i[MDT_B_VARIANT] == 3 ||
+                            (i[MDT_B_VARIANT] == 4 && o.p2.space)))
+        return bad("a folded closing convolution needs an unsplit feed-forward block of variant 0, 2 or 4 and an output tensor");
       if (i[MDT_B_VARIANT] == 4 && (!o.out.space || (o.p2.space && i[MDT_B_NCHUNK] % 2)))
         return bad("variant 4 needs an output tensor (and an even chunk count when split)");
       if (i[MDT_B_VARIANT] == 3 && (!o.out.space || i[MDT_B_NCHUNK] % 2)) return bad("variant 3 needs a partial-sum buffer and an even chunk count");
