@@ -132,7 +132,7 @@ class UNetCompiler:
         self.fuse_c256 = os.environ.get("MDT_FUSE_C256", "1") == "1"
         self.tb32 = os.environ.get("MDT_TB32", "1") == "1"           # C = 256 blocks on 32-row workgroups (k_tblock32)
         self.tb_split = os.environ.get("MDT_TB_SPLIT", "1") == "1"   # ... their heads split over two workgroups
-        self.ff_split = os.environ.get("MDT_FF_SPLIT", "0") == "1"   # ... also the feed-forward's hidden chunks
+        self.ff_split = os.environ.get("MDT_FF_SPLIT", "1") == "1"   # ... also the feed-forward's hidden chunks
         # ... partial sums handed to the next sub-block instead of a reduce launch.  Measured: 2511 molecules/s against
         # 2578 with the 28 reduce launches (the extra dependent loads in every prologue / epilogue and the ping-pong
         # buffers cost more than 5.4 us per block), so this is not the default.
@@ -749,7 +749,9 @@ class UNetCompiler:
                 if cross:
                     self.cross_layers.append(bp + "cross_attention.")
                     steps.append((rt.TB_CROSS, bp + "cross_attention.", len(self.cross_layers) - 1, True))
-                steps.append((rt.TB_FF, bp + "feed_forward.", None, False))
+                # the hidden chunks of a feed-forward block split like heads (MDT_FF_SPLIT), except in the transformer's last
+                # block, whose output leaves the chain (and may carry the folded closing convolution)
+                steps.append((rt.TB_FF, bp + "feed_forward.", None, self.ff_split and i + 1 < layers))
                 for mode, name, ci, two in steps:
                     nxt = self._new(t.rows, c)
                     po = self._new(t.rows, c) if two else None
