@@ -142,7 +142,8 @@ class UNetCompiler:
         self.convt_merge = os.environ.get("MDT_CONVT_MERGE", "1") == "1"   # ConvTranspose phases in one launch
         # Transformer1d's closing 1x1 convolution folded into its last feed-forward block (ring kernels only)
         self.fold_out = os.environ.get("MDT_FOLD_OUT", "1") == "1" and os.environ.get("MDT_TB_LW", "1") != "0"
-        self.rconv_two = os.environ.get("MDT_RCONV2", "0") == "1"    # concatenated inputs as ONE two-source launch
+        self.rconv_two = os.environ.get("MDT_RCONV2", "k1") == "1"   # concatenated inputs as ONE two-source launch ...
+        self.rconv_two_k1 = os.environ.get("MDT_RCONV2", "k1") in ("1", "k1")   # ... only their 1x1 residual convolution
         # cross-attention sub-blocks: "1" fuses the shapes whose K/V rows stream through the loader-wave ring
         # (k_tblock_lw: C = 128, at most 16 context rows per 16 token rows; k_tblock32: C = 256, at most 48),
         # "all" also the older kernels' shapes
@@ -401,7 +402,7 @@ class UNetCompiler:
             wr = sd[p + "to_out.weight"]                              # [c, 2c, 1]
             r = self._new(xa.rows, c)
             br = self._vec(p + "to_out.bias", c)
-            if self.rconv_two:
+            if self.rconv_two_k1:
                 self.rconv(xa, wr, p + "to_out.weight", r, taps=1, bias_off=br, x2=xb, in_scale2=scale_b)
             else:
                 self.rconv(xa, wr[:, :c], p + "to_out.weight/a", r, taps=1, bias_off=br)

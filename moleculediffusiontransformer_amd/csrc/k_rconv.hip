@@ -112,7 +112,9 @@ __device__ __forceinline__ bf16x8 row_shift(const bf16x8& v, bool keep) {
 
 // NSPLIT workgroups (blockIdx.y) share a row block, each producing C / NSPLIT of the output channels: no reduction,
 // half the weight stream per workgroup, twice the workgroups (the 4096-row level has only 128 row blocks).
-template <int RTW, int C, int TAPS, int NSPLIT, int NSRC>
+// GN = false: an instantiation without the GroupNorm / FiLM / SiLU prologue (its parameter registers are what pushes
+// the two-source form over the register budget)
+template <int RTW, int C, int TAPS, int NSPLIT, int NSRC, bool GN>
 __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
   constexpr int NST = C / 32;               // k-steps of the input channels
   constexpr int NKH = C / CS;               // K halves (tiles per tap per chunk)
@@ -223,6 +225,10 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
 #pragma unroll
     for (int q = 0; q < NFT; ++q) acc[c][q] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // two sources without a GroupNorm prologue: the second source's rows are requested together with the first's (in
+  // front of barrier P) and wait in registers while the first source's tiles run
+  constexpr bool EARLY2 = NSRC == 2 && !GN;
+  float4 xu2[EARLY2 ? NSTW : 1], xw2[EARLY2 ? NSTW : 1];
 #pragma unroll 1
   for (int src = 0; src < nsrc; ++src) {
   const float* xsrc = src ? a.x2 : a.x;
@@ -240,15 +246,28 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
     float xr[NSTW][8];
     const float* xp = xsrc + (int64_t)mc * lda + 32 * st0 + 8 * g;
     float4 xu[NSTW], xw[NSTW];
+    if (EARLY2 && src == 1) {
 #pragma unroll
-    for (int st = 0; st < NSTW; ++st) {
-      xu[st] = *reinterpret_cast<const float4*>(xp + 32 * st);
-      xw[st] = *reinterpret_cast<const float4*>(xp + 32 * st + 4);
+      for (int st = 0; st < NSTW; ++st) { xu[st] = xu2[EARLY2 ? st : 0]; xw[st] = xw2[EARLY2 ? st : 0]; }
+    } else {
+#pragma unroll
+      for (int st = 0; st < NSTW; ++st) {
+        xu[st] = *reinterpret_cast<const float4*>(xp + 32 * st);
+        xw[st] = *reinterpret_cast<const float4*>(xp + 32 * st + 4);
+      }
+      if constexpr (EARLY2) {
+        const float* xq = a.x2 + (int64_t)mc * a.lda2 + 32 * st0 + 8 * g;
+#pragma unroll
+        for (int st = 0; st < NSTW; ++st) {
+          xu2[st] = *reinterpret_cast<const float4*>(xq + 32 * st);
+          xw2[st] = *reinterpret_cast<const float4*>(xq + 32 * st + 4);
+        }
+      }
     }
     // per-channel parameters of the lane's channels, requested together with the rows: behind the statistics (where
     // they are used) their 32 loads sat in blocks of their own, each a round trip queued behind the loaders' stream
     float4 ga[NSTW][2], be[NSTW][2], fs[NSTW][2], fsh[NSTW][2];
-    if (a.gsize > 0) {
+    if (GN && a.gsize > 0) {
 #pragma unroll
       for (int st = 0; st < NSTW; ++st)
 #pragma unroll
@@ -314,7 +333,7 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
       xr[st][0] = u.x * sc; xr[st][1] = u.y * sc; xr[st][2] = u.z * sc; xr[st][3] = u.w * sc;
       xr[st][4] = w.x * sc; xr[st][5] = w.y * sc; xr[st][6] = w.z * sc; xr[st][7] = w.w * sc;
     }
-    if (a.gsize > 0) {
+    if (GN && a.gsize > 0) {
       // group statistics over (tokens of the sample) x (gsize channels): the lane's 4-value halves, the lane groups g,
       // the paired k-steps, then the sample's token lanes.  Stage-major: every stage is one batch of independent
       // exchanges with a compile-time distance (a dependent chain per value, value after value, cost 30k cycles).
@@ -566,23 +585,24 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
   }
 }
 
-template <int RTW, int C, int TAPS, int NSPLIT, int NSRC>
+template <int RTW, int C, int TAPS, int NSPLIT, int NSRC, bool GN>
 static hipError_t launch_rc2(const RConvArgs& a, hipStream_t s) {
   const size_t smem = (size_t)NS * SLOT + (RTW == 2 ? SLOT : 0);      // ring (+ operand exchange area)
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rconv<RTW, C, TAPS, NSPLIT, NSRC>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rconv<RTW, C, TAPS, NSPLIT, NSRC, GN>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
     attr_set = true;
   }
   const int rows = 16 * RTW;
-  hipLaunchKernelGGL((k_rconv<RTW, C, TAPS, NSPLIT, NSRC>), dim3((unsigned)((a.M + rows - 1) / rows), NSPLIT), dim3(512), smem, s, a);
+  hipLaunchKernelGGL((k_rconv<RTW, C, TAPS, NSPLIT, NSRC, GN>), dim3((unsigned)((a.M + rows - 1) / rows), NSPLIT), dim3(512), smem, s, a);
   return hipGetLastError();
 }
 
 template <int RTW, int C, int TAPS, int NSPLIT>
 static hipError_t launch_rc(const RConvArgs& a, hipStream_t s) {
-  return a.x2 ? launch_rc2<RTW, C, TAPS, NSPLIT, 2>(a, s) : launch_rc2<RTW, C, TAPS, NSPLIT, 1>(a, s);
+  if (!a.x2) return launch_rc2<RTW, C, TAPS, NSPLIT, 1, true>(a, s);
+  return a.gsize > 0 ? launch_rc2<RTW, C, TAPS, NSPLIT, 2, true>(a, s) : launch_rc2<RTW, C, TAPS, NSPLIT, 2, false>(a, s);
 }
 
 bool rconv_supported(int C, int T, int taps, int gsize) {
