@@ -112,9 +112,9 @@ __device__ __forceinline__ bf16x8 row_shift(const bf16x8& v, bool keep) {
 
 // NSPLIT workgroups (blockIdx.y) share a row block, each producing C / NSPLIT of the output channels: no reduction,
 // half the weight stream per workgroup, twice the workgroups (the 4096-row level has only 128 row blocks).
-// GN = false: an instantiation without the GroupNorm / FiLM / SiLU prologue (its parameter registers are what pushes
-// the two-source form over the register budget)
-template <int RTW, int C, int TAPS, int NSPLIT, int NSRC, bool GN>
+// PRO: 2 = GroupNorm + FiLM + SiLU prologue (all run-time optional), 1 = without FiLM, 0 = no prologue at all -- the
+// leaner instantiations exist for the two-source form, which the parameter registers push over the register budget
+template <int RTW, int C, int TAPS, int NSPLIT, int NSRC, int PRO>
 __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
   constexpr int NST = C / 32;               // k-steps of the input channels
   constexpr int NKH = C / CS;               // K halves (tiles per tap per chunk)
@@ -227,6 +227,7 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
 
   // two sources without a GroupNorm prologue: the second source's rows are requested together with the first's (in
   // front of barrier P) and wait in registers while the first source's tiles run
+  constexpr bool GN = PRO > 0;
   constexpr bool EARLY2 = NSRC == 2 && !GN;
   float4 xu2[EARLY2 ? NSTW : 1], xw2[EARLY2 ? NSTW : 1];
 #pragma unroll 1
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
           ga[st][hf] = *reinterpret_cast<const float4*>(gamma + c);
           be[st][hf] = *reinterpret_cast<const float4*>(beta + c);
         }
-      if (a.film) {
+      if (PRO == 2 && a.film) {
 #pragma unroll
         for (int st = 0; st < NSTW; ++st)
 #pragma unroll
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
         }
       // FiLM and SiLU as passes of their own under one uniform branch each (a per-element select otherwise).  Rows past
       // M (clamped duplicates of the last row) are carried along: their columns are never stored.
-      if (a.film) {
+      if (PRO == 2 && a.film) {
 #pragma unroll
         for (int st = 0; st < NSTW; ++st)
 #pragma unroll
@@ -585,24 +586,25 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
   }
 }
 
-template <int RTW, int C, int TAPS, int NSPLIT, int NSRC, bool GN>
+template <int RTW, int C, int TAPS, int NSPLIT, int NSRC, int PRO>
 static hipError_t launch_rc2(const RConvArgs& a, hipStream_t s) {
   const size_t smem = (size_t)NS * SLOT + (RTW == 2 ? SLOT : 0);      // ring (+ operand exchange area)
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rconv<RTW, C, TAPS, NSPLIT, NSRC, GN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rconv<RTW, C, TAPS, NSPLIT, NSRC, PRO>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
     attr_set = true;
   }
   const int rows = 16 * RTW;
-  hipLaunchKernelGGL((k_rconv<RTW, C, TAPS, NSPLIT, NSRC, GN>), dim3((unsigned)((a.M + rows - 1) / rows), NSPLIT), dim3(512), smem, s, a);
+  hipLaunchKernelGGL((k_rconv<RTW, C, TAPS, NSPLIT, NSRC, PRO>), dim3((unsigned)((a.M + rows - 1) / rows), NSPLIT), dim3(512), smem, s, a);
   return hipGetLastError();
 }
 
 template <int RTW, int C, int TAPS, int NSPLIT>
 static hipError_t launch_rc(const RConvArgs& a, hipStream_t s) {
-  if (!a.x2) return launch_rc2<RTW, C, TAPS, NSPLIT, 1, true>(a, s);
-  return a.gsize > 0 ? launch_rc2<RTW, C, TAPS, NSPLIT, 2, true>(a, s) : launch_rc2<RTW, C, TAPS, NSPLIT, 2, false>(a, s);
+  if (!a.x2) return launch_rc2<RTW, C, TAPS, NSPLIT, 1, 2>(a, s);
+  if (a.film) return hipErrorInvalidValue;            // a concatenated input never carries FiLM (block1 of a ResNet)
+  return a.gsize > 0 ? launch_rc2<RTW, C, TAPS, NSPLIT, 2, 1>(a, s) : launch_rc2<RTW, C, TAPS, NSPLIT, 2, 0>(a, s);
 }
 
 bool rconv_supported(int C, int T, int taps, int gsize) {

@@ -150,11 +150,12 @@ def test_ring_kernels_keep_their_arrays_in_registers():
         kernels = re.findall(r"Function Name: (\S+).*?ScratchSize \[bytes/lane\]: (\d+)", r.stderr, flags=re.S)
         assert kernels, r.stderr[-500:]
         for fn, scratch in kernels:
-            if name == "k_rconv" and "ELi2ELb" in fn:
-                # two-source instantiations: only the 1x1 form without GroupNorm is on the default path (the concatenated
-                # inputs' residual convolution; C = 128, or C = 256 with the output channels split over two workgroups)
-                if not (fn.endswith("ELi4ELi128ELi1ELi1ELi2ELb0EEEvNS_9RConvArgsE") or
-                        fn.endswith("ELi2ELi256ELi1ELi2ELi2ELb0EEEvNS_9RConvArgsE")):
+            if name == "k_rconv" and re.search(r"ELi2ELi[01]EEEvNS_9RConvArgsE$", fn):
+                # two-source instantiations <..., NSRC = 2, PRO>: only the 1x1 form without a prologue (PRO = 0) is on the
+                # default path (the concatenated inputs' residual convolution; C = 128, or C = 256 with the output channels
+                # split over two workgroups)
+                if not (fn.endswith("ELi4ELi128ELi1ELi1ELi2ELi0EEEvNS_9RConvArgsE") or
+                        fn.endswith("ELi2ELi256ELi1ELi2ELi2ELi0EEEvNS_9RConvArgsE")):
                     continue
             assert int(scratch) <= limit, (fn, scratch)
 
