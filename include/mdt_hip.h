@@ -153,6 +153,9 @@ enum mdt_tblock_i {
   MDT_B_T = 2,                      /* tokens per sample (must divide 16)                                */
   MDT_B_NCHUNK = 3,                 /* heads (attention) or hidden/64 (feed-forward)                     */
   MDT_B_NBIAS = 4, MDT_B_TK = 5, MDT_B_KV_BSTRIDE = 6, MDT_B_LDKV = 7, MDT_B_HEADS = 8,
+  MDT_B_KV2 = 11,                   /* cross blocks, 1: dual batch (both passes of classifier-free guidance in one launch,
+                                       UNetCFG1d.forward, modules.py:1248-1253): the second half of the samples reads the
+                                       batch-invariant K / V rows p1 (FixedEmbedding) instead of a2; B % 16 == 0        */
   MDT_B_POST = 10,                  /* feed-forward only, > 0: Transformer1d's closing Conv1d(k=1) folded in (modules.py:524):
                                        out = Wout (x + FF(x)) + bout; the W2 tiles hold Wout W2, POST = C/64 extra output
                                        tiles hold Wout (natural k order), the output bias holds Wout b2 + bout; x is left

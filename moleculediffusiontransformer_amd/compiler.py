@@ -977,6 +977,22 @@ class UNetCompiler:
             return out
 
         programs = {"eval": resolve(eval_ops, False), "eval_fixed": resolve(eval_ops, True)}
+        # Both passes of classifier-free guidance as ONE evaluation of a batch of 2B (UNetCFG1d.forward, modules.py:1248-1253:
+        # the masked pass sees the same x and time, only the context differs): the first half of the samples attends to its
+        # hoisted K/V, the second half to the FixedEmbedding's.  Needs every cross-attention block on a ring kernel (the
+        # only ones that take the second K/V pointer); otherwise the engine falls back to two passes.
+        tb_lw = os.environ.get("MDT_TB_LW", "1") != "0"
+        cross = [op for op in eval_ops if isinstance(getattr(op, "_kv", None), tuple)]
+        ring = all(op.kind == rt.OP_TBLOCK and (op.i[rt.B_VARIANT] >= 2 or (op.i[rt.B_VARIANT] == 0 and tb_lw and op.i[rt.B_C] == 128
+                                                                       and (16 // op.i[rt.B_T]) * op.i[rt.B_TK] <= 16))
+                   for op in cross)
+        if cross and ring and os.environ.get("MDT_CFG_DUAL", "1") == "1":
+            dual = resolve(eval_ops, False)
+            for o, op in zip(dual, eval_ops):
+                if isinstance(getattr(op, "_kv", None), tuple):
+                    o.p1 = _ref(rt.SP_SHR, self.kv_fixed[op._kv[1]])
+                    o.i[rt.B_KV2] = 1
+            programs["eval_dual"] = dual
 
         # ---- time program (m_mode 1) ----
         self.ops, self.flops = [], 0

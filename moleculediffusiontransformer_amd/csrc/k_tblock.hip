@@ -532,7 +532,7 @@ hipError_t launch_tblock(const TBlockArgs& a, hipStream_t s) {
   if (a.M <= 0) return hipSuccess;
   static const bool use_lw = !(getenv("MDT_TB_LW") && atoi(getenv("MDT_TB_LW")) == 0);   // loader-wave kernels (default)
   if (use_lw && tblock_lw_supported(a)) return launch_tblock_lw(a, s);
-  if (a.post) return hipErrorInvalidValue;          // folded closing convolution: ring kernels only
+  if (a.post || a.kv2) return hipErrorInvalidValue; // folded closing convolution / dual batch: ring kernels only
   if ((a.C != 128 && a.C != 256) || a.T <= 0 || 16 % a.T || a.nchunk <= 0) return hipErrorInvalidValue;
   if (a.mode == TB_CROSS && (a.Tk <= 0 || (16 / a.T) * a.Tk > 64)) return hipErrorInvalidValue;
 #define MDT_TB_CASE(MD)                                                         \

@@ -422,7 +422,7 @@ static hipError_t launch_tb16(const TBlockArgs& a, hipStream_t s) {
 
 hipError_t launch_tblock16(const TBlockArgs& a, hipStream_t s) {
   if (a.M <= 0) return hipSuccess;
-  if ((a.C != 128 && a.C != 256) || a.T <= 0 || 16 % a.T || a.nchunk <= 0 || a.post) return hipErrorInvalidValue;
+  if ((a.C != 128 && a.C != 256) || a.T <= 0 || 16 % a.T || a.nchunk <= 0 || a.post || a.kv2) return hipErrorInvalidValue;
   if (a.mode == TB16_CROSS && (a.Tk <= 0 || (16 / a.T) * a.Tk > 64)) return hipErrorInvalidValue;
 #define MDT_TB16_CASE(MD)                                                         \
   case MD:                                                                        \

@@ -171,12 +171,15 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
     unsigned voffKV[8];                              // NPW <= 8 used (fixed bound, see k_tblock_lw.hip)
     if constexpr (MODE == TB_CROSS) {
       const int sample0 = blockIdx.x * (32 / a.T);
+      // dual batch (classifier-free guidance, both passes in one launch): the samples of the second half read the
+      // batch-invariant K / V rows a.kv2 (a workgroup never straddles the halves: the host checks B % 16 == 0)
+      const int bstr = (a.kv2 && sample0 >= a.nsamples / 2) ? 0 : a.kv_bstride;
 #pragma unroll
       for (int q = 0; q < NPW; ++q) {
         const int R = 4 * (iw + 4 * q) + (lane >> 4);
         const int Rc = min(R, kv_rows - 1);
         const int sm = min(Rc / a.Tk, a.nsamples - 1 - sample0), key = Rc % a.Tk;
-        voffKV[q] = (unsigned)(((sm * a.kv_bstride + key) * a.ldkv + 4 * ((lane & 15) ^ (R & 15))) * 4);
+        voffKV[q] = (unsigned)(((sm * bstr + key) * a.ldkv + 4 * ((lane & 15) ^ (R & 15))) * 4);
       }
     }
     auto is_kv = [&](int tau) -> bool { return (MODE == TB_CROSS) && ((tau % SPC) == 2 || (tau % SPC) == 3); };
@@ -184,8 +187,9 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
       if constexpr (MODE == TB_CROSS) {
         unsigned char* slot = smem + (tau % NS) * SLOT + iw * 1024;
         const int sample0 = blockIdx.x * (32 / a.T);
+        const bool second = a.kv2 && sample0 >= a.nsamples / 2;
         const unsigned char* base = reinterpret_cast<const unsigned char*>(
-            a.kv + (int64_t)sample0 * a.kv_bstride * a.ldkv + 64 * (h0 + tau / SPC) + ((tau % SPC) == 3 ? 64 * a.nheads : 0));
+            (second ? a.kv2 : a.kv + (int64_t)sample0 * a.kv_bstride * a.ldkv) + 64 * (h0 + tau / SPC) + ((tau % SPC) == 3 ? 64 * a.nheads : 0));
 #pragma unroll
         for (int q = 0; q < NPW; ++q)
           __builtin_amdgcn_global_load_lds(base + voffKV[q], (__attribute__((address_space(3))) void*)(slot + q * 4096), 16, 0, 0);

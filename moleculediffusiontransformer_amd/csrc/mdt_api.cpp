@@ -271,6 +271,8 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
         a.kv_bstride = o.i[MDT_B_KV_BSTRIDE]; a.ldkv = o.i[MDT_B_LDKV]; a.nheads = o.i[MDT_B_HEADS]; a.nsamples = B;
         a.eps = o.f[MDT_BF_EPS]; a.scale = o.f[MDT_BF_SCALE];
         a.part = nullptr; a.nsplit = 1; a.xout = nullptr; a.pin = nullptr; a.pout = nullptr;
+        a.kv2 = o.i[MDT_B_KV2] ? ptr(o.p1) : nullptr;
+        if (o.i[MDT_B_KV2] && (B % 16 || !o.p1.space)) return fail("mdt_program_run: a dual-batch cross block needs B % 16 == 0 and the shared K/V rows");
         a.post = o.i[MDT_B_POST];
         if (a.post) a.xout = ptr(o.out);
         if (o.i[MDT_B_VARIANT] == 3) { a.part = ptr(o.out); a.nsplit = 2; }

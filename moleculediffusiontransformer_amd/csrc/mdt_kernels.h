@@ -108,6 +108,7 @@ struct TBlockArgs {
   const float* w;      // weight tile stream (bf16 hi/lo planes, 256*C bytes per tile)
   const float* bias;   // SELF [bq|bk|bv|bo], CROSS [bq|bo], FF [b1|b2]
   const float* kv;     // CROSS: hoisted K|V rows [sample][Tk][ldkv]
+  const float* kv2;    // dual batch: batch-invariant K / V rows of the second half of the samples (stride 0), or nullptr
   const float* dbgbuf; // diagnostic stamps (MDT_DBG & 8), normally nullptr
   float* part;         // k_tblock32 with nsplit > 1: partial outputs [nsplit][M][C] (no bias / residual), summed by k_tb_reduce
   int nsplit;          // workgroups sharing a row block, each taking nchunk / nsplit heads or hidden chunks

@@ -151,10 +151,13 @@ def run_adpm2(engine, embedding: Tensor, pred_dim: int, num_steps: int, noise: N
     sigmas, steps = adpm2_plan(num_steps, schedule, sampler, sigma_data)
     guided = embedding_scale != 1.0
 
+    # guidance: both passes as one evaluation of the doubled batch [samples | samples] when the engine has that program
+    # (every cross-attention block on a ring kernel) and the kernels' workgroups cannot straddle the halves
+    dual = guided and engine.has_dual and B % 8 == 0 and B > 0
     with torch.cuda.device(dev):
         st = rt.current_stream()
-        engine.reserve(B)
-        engine.prepare_context(embedding)
+        engine.reserve(2 * B if dual else B)
+        engine.prepare_context(torch.cat([embedding, embedding]) if dual else embedding)
         c_noise = torch.tensor([v for s in steps for v in (s.w.c_noise, s.w_mid.c_noise)], dtype=torch.float32)
         engine.prepare_times(c_noise)
 
@@ -171,11 +174,18 @@ def run_adpm2(engine, embedding: Tensor, pred_dim: int, num_steps: int, noise: N
             engine.select_time(row)
             if timer is not None:
                 timer.start()
-            pred = engine.eval(False)
-            if guided:
-                um = engine.eval(True)
+            if dual:
+                engine.xin[B:].copy_(engine.xin[:B], non_blocking=True)
+                both = engine.eval(dual=True)
+                pred, um = both[:B], both[B:]
                 rt.check(lib.mdt_cfg_mix(rt.ptr(pred), rt.ptr(um), rt.ptr(pred), float(embedding_scale),
                                          pred.numel(), st))
+            else:
+                pred = engine.eval(False)
+                if guided:
+                    um = engine.eval(True)
+                    rt.check(lib.mdt_cfg_mix(rt.ptr(pred), rt.ptr(um), rt.ptr(pred), float(embedding_scale),
+                                             pred.numel(), st))
             if timer is not None:
                 timer.stop()
             return pred

@@ -102,12 +102,20 @@ class UNetEngine:
             self._fixed_ready = True
 
     # ------------------------------------------------------------------ evaluation
-    def eval(self, fixed: bool = False) -> torch.Tensor:
-        """One U-Net evaluation of self.xin for the whole batch -> self.pred (or self.pred_fixed)."""
-        name = "eval_fixed" if fixed else "eval"
+    @property
+    def has_dual(self) -> bool:
+        """Both guidance passes as one evaluation of a doubled batch (program "eval_dual", see compiler.py)."""
+        return "eval_dual" in self.programs
+
+    def eval(self, fixed: bool = False, dual: bool = False) -> torch.Tensor:
+        """One U-Net evaluation of self.xin for the whole batch -> self.pred (or self.pred_fixed).  dual: the batch is
+        [conditional samples | the same samples again]; the second half attends to the fixed embedding."""
+        name = "eval_dual" if dual else ("eval_fixed" if fixed else "eval")
         out = self.pred_fixed if fixed else self.pred
-        if fixed:
+        if fixed or dual:
             self.prepare_fixed()
+        if dual and self.B % 16:
+            raise ValueError("the dual guidance batch needs an even number of samples that is a multiple of 16")
         if not self.use_graph:
             self.programs[name].run(self._bind(xin=self.xin, out=out), self.B)
             return out

@@ -29,6 +29,7 @@ T_HALF, T_LD = range(2)
 R_T, R_C, R_LDA, R_LDC, R_LDR, R_TAPS, R_GSIZE, R_SILU, R_FILM_LD, R_LDA2 = range(10)
 K_T, K_CIN, K_COUT, K_FILM_LD = range(4)
 B_MODE, B_C, B_T, B_NCHUNK, B_NBIAS, B_TK, B_KV_BSTRIDE, B_LDKV, B_HEADS, B_VARIANT, B_POST = range(11)
+B_KV2 = 11
 
 
 class MdtRef(C.Structure):

@@ -336,6 +336,9 @@ def _tblock(op, bufs: Buffers, B: int) -> None:
             kv = bufs.view(op.a2, B, Tk * ldkv).view(1, Tk, ldkv).expand(B, -1, -1)
         else:
             kv = bufs.view(op.a2, B, B * Tk * ldkv).view(B, Tk, ldkv)
+        if i[rt.B_KV2]:                 # dual guidance batch: the second half attends to the batch-invariant rows p1
+            kvf = bufs.view(op.p1, B, Tk * ldkv).view(1, Tk, ldkv).expand(B - B // 2, -1, -1)
+            kv = torch.cat([kv[: B // 2], kvf])
         k = kv[:, :, : H * D].reshape(B, Tk, H, D).transpose(1, 2)
         v = kv[:, :, H * D: 2 * H * D].reshape(B, Tk, H, D).transpose(1, 2)
         bo = bias[mid:]

@@ -117,6 +117,26 @@ def test_seeded_sampling_is_reproducible_and_shard_invariant(models):
     assert torch.isfinite(full).all()
 
 
+def test_guidance_as_one_doubled_batch_equals_two_passes(models):
+    """cond_scale != 1: both passes of UNetCFG1d.forward (modules.py:1248-1253) run as ONE evaluation of the batch
+    [samples | samples] whose second half attends to the FixedEmbedding's K/V (program "eval_dual").  Same kernels, same
+    per-row arithmetic: bitwise equal to the two-pass form; B = 12 (not a multiple of 8) takes the two-pass form."""
+    m = models("cfg1")
+    seq = synth_normal("dual/seq", (16, 12))
+    eng = m.engine(DEV, 12)
+    if not eng.has_dual:
+        pytest.skip("layer-by-layer program (exact-fp32 mode): no dual-batch form")
+    one = m.sample(seq, DEV, cond_scale=2.0, timesteps=4, noise=NoiseSource(seed=11, sample0=0)).cpu()
+    dual_prog = eng.programs.pop("eval_dual")
+    try:
+        two = m.sample(seq, DEV, cond_scale=2.0, timesteps=4, noise=NoiseSource(seed=11, sample0=0)).cpu()
+    finally:
+        eng.programs["eval_dual"] = dual_prog
+    assert torch.isfinite(one).all() and torch.equal(one, two)
+    part = m.sample(seq[:12], DEV, cond_scale=2.0, timesteps=4, noise=NoiseSource(seed=11, sample0=0)).cpu()
+    assert torch.equal(part, one[:12])
+
+
 def test_default_rng_mode_consumes_cpu_generator_like_the_reference(models):
     m = models("tiny")
     seq = synth_normal("rng/seq", (2, 12))
