@@ -139,6 +139,32 @@ def _f32(t: Tensor, device) -> Tensor:
     return t.to(device=device, dtype=torch.float32).contiguous()
 
 
+def _guided_setup(engine, embedding: Tensor, guided: bool) -> bool:
+    """reserve() + prepare_context() for a sampling run.  Guidance runs both passes of UNetCFG1d.forward
+    (modules.py:1248-1253) as ONE evaluation of the doubled batch [samples | samples] when the engine has that program
+    (every cross-attention block on a ring kernel) and the kernels' workgroups cannot straddle the halves.
+    Returns whether the doubled batch is in use."""
+    B = embedding.shape[0]
+    dual = guided and engine.has_dual and B % 8 == 0 and B > 0
+    engine.reserve(2 * B if dual else B)
+    engine.prepare_context(torch.cat([embedding, embedding]) if dual else embedding)
+    return dual
+
+
+def _guided_eval(engine, lib, B: int, guided: bool, dual: bool, embedding_scale: float, st) -> Tensor:
+    """net(x, t, embedding, embedding_scale) of engine.xin[:B] -> prediction rows [:B] (UNetCFG1d.forward)."""
+    if dual:
+        engine.xin[B:].copy_(engine.xin[:B], non_blocking=True)
+        both = engine.eval(dual=True)
+        pred, um = both[:B], both[B:]
+    else:
+        pred = engine.eval(False)
+        um = engine.eval(True) if guided else None
+    if guided:
+        rt.check(lib.mdt_cfg_mix(rt.ptr(pred), rt.ptr(um), rt.ptr(pred), float(embedding_scale), pred.numel(), st))
+    return pred
+
+
 def run_adpm2(engine, embedding: Tensor, pred_dim: int, num_steps: int, noise: NoiseSource,
               schedule: KarrasSchedule, sampler: ADPM2Sampler, sigma_data: float, embedding_scale: float = 1.0,
               clamp: bool = False, trace: Optional[dict] = None, timer=None) -> Tensor:
@@ -151,13 +177,9 @@ def run_adpm2(engine, embedding: Tensor, pred_dim: int, num_steps: int, noise: N
     sigmas, steps = adpm2_plan(num_steps, schedule, sampler, sigma_data)
     guided = embedding_scale != 1.0
 
-    # guidance: both passes as one evaluation of the doubled batch [samples | samples] when the engine has that program
-    # (every cross-attention block on a ring kernel) and the kernels' workgroups cannot straddle the halves
-    dual = guided and engine.has_dual and B % 8 == 0 and B > 0
     with torch.cuda.device(dev):
         st = rt.current_stream()
-        engine.reserve(2 * B if dual else B)
-        engine.prepare_context(torch.cat([embedding, embedding]) if dual else embedding)
+        dual = _guided_setup(engine, embedding, guided)
         c_noise = torch.tensor([v for s in steps for v in (s.w.c_noise, s.w_mid.c_noise)], dtype=torch.float32)
         engine.prepare_times(c_noise)
 
@@ -174,18 +196,7 @@ def run_adpm2(engine, embedding: Tensor, pred_dim: int, num_steps: int, noise: N
             engine.select_time(row)
             if timer is not None:
                 timer.start()
-            if dual:
-                engine.xin[B:].copy_(engine.xin[:B], non_blocking=True)
-                both = engine.eval(dual=True)
-                pred, um = both[:B], both[B:]
-                rt.check(lib.mdt_cfg_mix(rt.ptr(pred), rt.ptr(um), rt.ptr(pred), float(embedding_scale),
-                                         pred.numel(), st))
-            else:
-                pred = engine.eval(False)
-                if guided:
-                    um = engine.eval(True)
-                    rt.check(lib.mdt_cfg_mix(rt.ptr(pred), rt.ptr(um), rt.ptr(pred), float(embedding_scale),
-                                             pred.numel(), st))
+            pred = _guided_eval(engine, lib, B, guided, dual, embedding_scale, st)
             if timer is not None:
                 timer.stop()
             return pred
@@ -233,8 +244,7 @@ def run_adpm2_inpaint(engine, embedding: Tensor, source: Tensor, mask: Tensor, n
 
     with torch.cuda.device(dev):
         st = rt.current_stream()
-        engine.reserve(B)
-        engine.prepare_context(embedding)
+        dual = _guided_setup(engine, embedding, guided)
         c_noise = torch.tensor([v for s in steps for v in (s.w.c_noise, s.w_mid.c_noise)], dtype=torch.float32)
         engine.prepare_times(c_noise)
         src = _f32(source, dev)
@@ -247,12 +257,7 @@ def run_adpm2_inpaint(engine, embedding: Tensor, source: Tensor, mask: Tensor, n
 
         def unet(row: int) -> Tensor:
             engine.select_time(row)
-            pred = engine.eval(False)
-            if guided:
-                um = engine.eval(True)
-                rt.check(lib.mdt_cfg_mix(rt.ptr(pred), rt.ptr(um), rt.ptr(pred), float(embedding_scale),
-                                         pred.numel(), st))
-            return pred
+            return _guided_eval(engine, lib, B, guided, dual, embedding_scale, st)
 
         for i, s in enumerate(steps):
             src_nz, src_k = next_draw()                   # source_noisy = source + sigmas[i] * randn_like(source)
