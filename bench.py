@@ -1,29 +1,35 @@
 #!/usr/bin/env python3
 """Headline benchmark: molecules/sec at 64 diffusion steps (QM9-shaped inverse model) on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
 
 A "step" is one full QMDiffusion.sample() call over one batch: BASELINE.json configs[1] = inverse model
 channels=64, pred_dim=16, max_len=64, cond_len=12, batch 1024 per GPU, 64 timesteps (126 U-Net
 evaluations + 63 ADPM2 updates), fp32, cond_scale=1.0, synthetic weights/conditioning, inputs resident in
-HBM, on-device counter-based noise.  For N > 1 the driver launches one rank per GPU through
-torch.distributed.run; every rank samples its own 1024 molecules (weak scaling, no collective in the
-loop) and the generated samples are all-gathered once per call over RCCL.
+HBM, on-device counter-based noise.  `--batch 8192` is the per-GPU shard of configs[3] (65,536 over 8 GPUs).
+
+N > 1: one rank per GPU over RCCL.  Either the driver launches the ranks itself (torch.distributed.run sets
+RANK / WORLD_SIZE) or this script does: `python bench.py --gpus N` without RANK in the environment starts
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process before anything touches a
+GPU, relays rank 0's JSON line and exits with the child's return code.  Every rank samples its own batch (weak
+scaling, no collective in the step loop) and the generated samples are all-gathered once per call over RCCL.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  "roofline":     the dominant kernel class (k_gemm: fp32-MFMA implicit GEMM), HIP-event timed per launch
-  "cpu_baseline": the CPU oracle (PyTorch restatement pinned to the reference) on a bounded sample
+  "roofline":     the dominant kernel class of one U-Net evaluation, HIP-event timed per launch
+  "exact_f32":    the same workload with exact fp32 MFMA products (MDT_GEMM=f32), a few steps          (N = 1)
+  "cpu_baseline": the CPU oracle (PyTorch restatement pinned to the reference) on a bounded sample       (N = 1)
+  "multi_gpu":    ranks seen by the all-gather and the bitwise shard-invariance check                    (N > 1)
 """
 import argparse
 import contextlib
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA (not the 2:1-sparse headline)
@@ -31,56 +37,80 @@ HBM_PEAK_GBS = 8000.0
 REF_FLOPS_PER_SAMPLE_EVAL = 455.3e6   # reference op graph (incl. per-eval cross-attn K/V + time mapping)
 REF_OPGRAPH_BYTES_PER_SAMPLE_EVAL = 13.21e6
 
+WORKLOADS = {
+    "cfg1": "QMDiffusion inverse sample(): channels=64 pred_dim=16 max_len=64 cond_len=12, ",
+    "cfg3": "QMDiffusionForward sample(): channels=64 pred_dim=1 max_len=64 cond_len=64, ",
+    "cfg5": "QMDiffusion inverse sample(): channels=256 pred_dim=32 max_len=128 cond_len=12, ",
+    "nb": "QMDiffusion inverse sample() of the reference notebook's model: channels=128 pred_dim=22 max_len=32 cond_len=12, ",
+}
+
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=1024, help="molecules per GPU per step")
+    ap.add_argument("--batch", type=int, default=1024, help="molecules per GPU per step (8192 = configs[3]'s shard)")
     ap.add_argument("--timesteps", type=int, default=64)
-    ap.add_argument("--workload", default="cfg1", choices=["cfg1", "cfg3", "cfg5"],
+    ap.add_argument("--workload", default="cfg1", choices=sorted(WORKLOADS),
                     help="cfg1 = BASELINE configs[1] (the headline metric, default); cfg3 = QMDiffusionForward "
                          "(configs[2]: --batch 4096 --timesteps 100); cfg5 = deep U-Net architecture of configs[4] "
                          "(channels 256, max_len 128).  Other workloads are informational: no CPU baseline / parity leg")
     ap.add_argument("--cond-scale", type=float, default=1.0, help="classifier-free guidance scale (2 U-Net passes if != 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
+    ap.add_argument("--no-exact-f32", action="store_true")
+    ap.add_argument("--master-port", type=int, default=29511, help="rendezvous port when this script launches its own ranks")
     return ap.parse_args()
+
+
+def self_launch(a) -> int:
+    """--gpus N > 1 without a rank environment: start the ranks as a child torch.distributed.run (this process has not
+    imported torch or touched a GPU), stream the child's output through, return its exit code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(a.master_port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    child = subprocess.Popen(cmd, env=env, cwd=ROOT)
+    try:
+        return child.wait()
+    except KeyboardInterrupt:
+        child.terminate()
+        return child.wait()
 
 
 def op_flops(op, rt, B):
     """Algorithmic FLOPs (2*MAC, fp32-equivalent) of one op of the eval program for batch B."""
     i = op.i
     if op.kind == rt.OP_GEMM:
-        return 2.0 * B * i[rt.G_R_OUT] * i[rt.G_N] * i[rt.G_TAPS] * i[rt.G_CIN]
+        return 2.0 * B * i[rt.G_R_OUT] * i[rt.G_N] * i[rt.G_TAPS] * i[rt.G_CIN] * max(i[rt.G_PHASES], 1)
     if op.kind == rt.OP_ATTN:
         return 4.0 * B * i[rt.A_T] * i[rt.A_TK] * 64 * i[rt.A_HEADS]
     if op.kind == rt.OP_RCONV:
-        return 2.0 * B * i[rt.R_T] * i[rt.R_C] * i[rt.R_C] * i[rt.R_TAPS]
+        return 2.0 * B * i[rt.R_T] * i[rt.R_C] * i[rt.R_C] * i[rt.R_TAPS] * (2 if op.a2.space else 1)
     if op.kind == rt.OP_RESBLOCK:
         cin, cout = i[rt.K_CIN], i[rt.K_COUT]
         return 2.0 * B * i[rt.K_T] * (3 * cin * cout + 3 * cout * cout + cin * cout)
     if op.kind == rt.OP_TBLOCK:
         c, t, nch, tk = i[rt.B_C], i[rt.B_T], i[rt.B_NCHUNK], i[rt.B_TK]
         mid = 64 * nch
+        post = 2.0 * B * t * c * c if i[rt.B_POST] else 0.0
         if i[rt.B_MODE] == rt.TB_FF:
-            return 4.0 * B * t * c * mid
+            return 4.0 * B * t * c * mid + post
         if i[rt.B_MODE] == rt.TB_SELF:
             return B * (2.0 * t * c * 3 * mid + 4.0 * t * t * mid + 2.0 * t * mid * c)
         return B * (2.0 * t * c * mid + 4.0 * t * tk * mid + 2.0 * t * mid * c)
-    return 0.0
+    flops = getattr(op, "_flops", None)     # multi-sub-block ops carry their own count per sample
+    return float(flops) * B if flops else 0.0
 
 
-def kernel_breakdown(model, eng, torch, rt, B):
+def kernel_breakdown(eng, rt, B):
     """HIP-event time of every op of ONE U-Net evaluation (plain launches, one interval per launch),
     grouped by kernel class.  Returns dict class -> (launches, total_ms, flops)."""
     prog = eng.programs["eval"]
     ops = eng.c.programs["eval"]
     bind = eng._bind(xin=eng.xin, out=eng.pred)
-    names = {rt.OP_GEMM: "k_gemm", rt.OP_GN_STATS: "k_gn_stats", rt.OP_ATTN: "k_attn", rt.OP_CONCAT: "k_concat",
-             rt.OP_PATCH: "k_patch", rt.OP_TBLOCK: "k_tblock", rt.OP_GN_ACT: "k_gn_act", rt.OP_RCONV: "k_rconv",
-             rt.OP_RESBLOCK: "k_resblock"}
     best = None
     for rep in range(3):
         timer = rt.EventTimer(len(ops))
@@ -93,36 +123,100 @@ def kernel_breakdown(model, eng, torch, rt, B):
             best = ms
     out = {}
     for op, t in zip(ops, best):
-        k = names[op.kind]
+        k = rt.OP_NAMES.get(op.kind, f"kind{op.kind}")
         n, tot, fl = out.get(k, (0, 0.0, 0.0))
         out[k] = (n + 1, tot + t, fl + op_flops(op, rt, B))
     return out
 
 
-def pmc_traffic(kernel_class):
-    """HBM bytes per launch of one kernel class, from the committed PMC summary of this same workload
-    (profiles/r*_pmc_hbm_traffic.csv: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes)."""
+def pmc_summary():
+    """Rows of the newest committed PMC traffic summary (profiles/r*_pmc_hbm_traffic.csv: FETCH_SIZE x2 gfx950
+    correction + WRITE_SIZE, separate rocprofv3 passes of THIS workload at batch 1024): (kernel name, launches in the
+    profiled run, MB per launch)."""
     import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                                          "r*_pmc_hbm_traffic.csv")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.csv")))
     if not files:
-        return None, None
-    n, mb = 0, 0.0
+        return None, []
+    rows = []
     for line in open(files[-1]):
         if line.startswith("#") or line.startswith("kernel,"):
             continue
         name, rest = line.rsplit(",", 5)[0].strip('"'), line.strip().rsplit(",", 5)[1:]
-        if name.startswith("mdt::" + kernel_class):
-            n += int(rest[0])
-            mb += int(rest[0]) * float(rest[4])
-    if n == 0:
+        rows.append((name, int(rest[0]), float(rest[4])))
+    return os.path.basename(files[-1]), rows
+
+
+def pmc_traffic(kernel_class):
+    """HBM bytes per launch of one kernel class from the committed PMC summary, or (None, None)."""
+    fname, rows = pmc_summary()
+    n = sum(r[1] for r in rows if r[0].startswith("mdt::" + kernel_class))
+    if not n:
         return None, None
-    return round(mb / n * 1e6), ("bytes per launch; profiles/" + os.path.basename(files[-1]) +
+    mb = sum(r[1] * r[2] for r in rows if r[0].startswith("mdt::" + kernel_class))
+    return round(mb / n * 1e6), ("bytes per launch; profiles/" + fname +
                                  " (rocprofv3 PMC passes of this workload, recorded earlier, not collected live)")
+
+
+def cpu_baseline_leg(torch, model, device, evals):
+    """the reference path restated on PyTorch CPU ops (oracle/unet_oracle.py, pinned bit-exact to the
+    reference by tests/golden) at B = 4 and B = 256, fp32, no_grad; thread count picked by a short sweep; one warm-up +
+    median of 3; bounded to a few timesteps and scaled to the 126 evaluations of a 64-step call.  Also the checker of this
+    run: the same bounded B = 256 sample goes through the HIP path on identical noise."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import oracle_cfg, synth_sd
+    from oracle import unet_oracle as O
+    from moleculediffusiontransformer_amd import NoiseSource
+    from moleculediffusiontransformer_amd.synth import synth_normal
+    sd, cfg = synth_sd("cfg1"), oracle_cfg("cfg1")
+
+    def run(cb, ct, tag):
+        cseq = synth_normal(f"bench/cpu/seq{tag}", (cb, 12))
+        init = synth_normal(f"bench/cpu/init{tag}", (cb, 16, 64))
+        nz = [synth_normal(f"bench/cpu/step{tag}/{i}", (cb, 16, 64)) for i in range(ct - 1)]
+        c0 = time.perf_counter()
+        out = O.sample(sd, cfg, cseq, init, lambda i, x: nz[i], ct, 1.0, False)
+        return time.perf_counter() - c0, (cseq, init, nz, out)
+
+    ncpu = os.cpu_count() or 1
+    cands = sorted({n for n in (8, 16, 32, 64, 128, ncpu) if n <= ncpu})
+    sweep = {}
+    for n in cands:                                   # short sweep: one 2-timestep call (2 evaluations) at B = 256
+        torch.set_num_threads(n)
+        run(256, 2, "sweep")
+        sweep[n] = round(run(256, 2, "sweep")[0], 3)
+    threads = min(sweep, key=sweep.get)
+    torch.set_num_threads(threads)
+    points = {}
+    keep = None
+    for cb, ct in ((4, 12), (256, 4)):
+        run(cb, 2, "warm")
+        times = []
+        for rep in range(3):
+            dt, data = run(cb, ct, "")
+            times.append(dt)
+            keep = data
+        med = sorted(times)[1]
+        per_eval = med / (2 * (ct - 1))
+        points[cb] = {"timesteps_timed": ct, "evals_timed": 2 * (ct - 1), "median_s": round(med, 3),
+                      "ms_per_eval": round(1e3 * per_eval, 2), "molecules_per_s_at_64_steps": round(cb / (per_eval * evals), 3)}
+    cseq, init, nz, cpu_out = keep                    # the B = 256 sample, last repetition
+    hip_out = model.sample(cseq, device, cond_scale=1.0, timesteps=len(nz) + 1, clamp=False,
+                           noise=NoiseSource(init=init, steps=lambda i: nz[i])).cpu()
+    parity = {"max_abs_vs_cpu_reference_path": float((hip_out - cpu_out).abs().max()), "tolerance": 1e-4,
+              "sample": f"batch 256, {len(nz) + 1} timesteps, identical noise"}
+    base = {"value": points[256]["molecules_per_s_at_64_steps"], "unit": "molecules/s", "cores": threads, "kind": "port",
+            "sample": "oracle/unet_oracle.py (PyTorch CPU fp32, bit-exact to the reference on the golden vectors): batch 256, "
+                      f"{points[256]['timesteps_timed']} timesteps = {points[256]['evals_timed']} U-Net evals, warm-up + median of 3, "
+                      f"scaled to {evals} evals; batch 4 (BASELINE configs[0]) in `points`",
+            "host_cpus": ncpu, "thread_sweep_s_per_2_evals_b256": sweep, "points": points}
+    return base, parity
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(self_launch(a))
+
     import torch
     import torch.distributed as dist
 
@@ -130,7 +224,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the sampling path has no CPU fallback")
     # test hook (one-GPU boxes): MDT_BENCH_SHARE_GPU=1 puts every rank on cuda:0 over gloo to exercise the N > 1 logic
@@ -144,20 +238,18 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=device)
 
-    from gpu_util import make_model
     from moleculediffusiontransformer_amd import NoiseSource, runtime as rt
     from moleculediffusiontransformer_amd.distributed import all_gather_samples
-    from moleculediffusiontransformer_amd.synth import synth_normal
+    from moleculediffusiontransformer_amd.synth import make_synth_model, synth_normal
 
-    import gpu_util
-    gpu_util.DEV = str(device)
     with contextlib.redirect_stdout(sys.stderr):     # the class prints "Using unet type" like the reference does
-        model = make_model(a.workload)               # cfg1: inverse c=64, pred_dim=16, L=64, cond_len=12; synthetic weights
+        model = make_synth_model(a.workload, device)  # synthetic weights (no network for checkpoints)
     B, T = a.batch, a.timesteps
     n_cond = model.unet.config.ctx_max_length
-    seq = synth_normal(f"bench/seq/rank{rank}", (B, n_cond)).to(device)
+    seq_of = lambda r: synth_normal(f"bench/seq/rank{r}", (B, n_cond))     # noqa: E731
+    seq = seq_of(rank).to(device)
     if a.workload != "cfg1" or a.cond_scale != 1.0:
-        a.no_cpu_baseline = True
+        a.no_cpu_baseline = a.no_exact_f32 = True
     evals = 2 * (T - 1)
     eval_timer = rt.EventTimer(evals * (a.steps + a.warmup) + 8)
 
@@ -207,7 +299,7 @@ def main():
                 "mfma_dtype": "bf16 (3 MFMAs per fp32 product, fp32 accumulate)" if split else "f32"}
         extra = {}
         if not a.no_breakdown:
-            bd = kernel_breakdown(model, eng, torch, rt, B)
+            bd = kernel_breakdown(eng, rt, B)
             dom = max((k for k in bd if bd[k][2] > 0), key=lambda k: bd[k][1])
             n_dom, ms_dom, fl_dom = bd[dom]
             alg = fl_dom / (ms_dom * 1e-3) / 1e12
@@ -224,19 +316,36 @@ def main():
             alg = flops_exec * B / (avg_eval_ms * 1e-3) / 1e12
             roof.update({"kernel": "whole U-Net eval", "achieved": round(alg * mult, 2),
                          "frac": round(alg * mult / peak, 4)})
-        extra["unet_eval"] = {
-            "ms_avg_graph_replay": round(avg_eval_ms, 4), "evals_timed": len(eval_ms),
-            "flops_per_sample_executed": flops_exec,
-            "tflops_executed": round(flops_exec * B / (avg_eval_ms * 1e-3) / 1e12, 2),
-            "mfma_fraction_executed": round(flops_exec * B / (avg_eval_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
-            "mfma_fraction_reference_opgraph": round(REF_FLOPS_PER_SAMPLE_EVAL * B / (avg_eval_ms * 1e-3) / 1e12
-                                                     / FP32_MFMA_PEAK_TFLOPS, 4),
-            "hbm_fraction_reference_opgraph": round(REF_OPGRAPH_BYTES_PER_SAMPLE_EVAL * B / (avg_eval_ms * 1e-3) / 1e9
-                                                    / HBM_PEAK_GBS, 4),
-        }
-        if a.workload != "cfg1":
-            for k in ("mfma_fraction_reference_opgraph", "hbm_fraction_reference_opgraph"):
-                extra["unet_eval"].pop(k, None)
+        ue = {"ms_avg_graph_replay": round(avg_eval_ms, 4), "evals_timed": len(eval_ms),
+              "launches": len(eng.c.programs["eval"]),
+              "flops_per_sample_executed": flops_exec,
+              "tflops_executed_fp32_equiv": round(flops_exec * B / (avg_eval_ms * 1e-3) / 1e12, 2)}
+        if split:
+            ue["bf16_mfma_fraction_executed"] = round(3.0 * flops_exec * B / (avg_eval_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4)
+        else:
+            ue["fp32_mfma_fraction_executed"] = round(flops_exec * B / (avg_eval_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)
+        if a.workload == "cfg1":
+            # NOT a roofline: the byte count of the reference's UNFUSED op graph (SURVEY §8d, 13.21 MB / sample / eval)
+            # divided by this path's time, as a fraction of the HBM peak.  The fused kernels move far fewer bytes.
+            ue["reference_unfused_opgraph_bytes_per_s_over_hbm_peak"] = round(
+                REF_OPGRAPH_BYTES_PER_SAMPLE_EVAL * B / (avg_eval_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            if B == 1024:
+                fname, rows = pmc_summary()
+                evals_profiled = None
+                for nm, n, mb in rows:                      # launches per eval are known for the sampler-update kernels
+                    if "k_adpm2_mid" in nm:
+                        evals_profiled = 2 * n
+                if rows and evals_profiled:
+                    # every kernel of the profiled run that belongs to a U-Net evaluation (not the sampler / setup kernels)
+                    unet_mb = sum(n * mb for nm, n, mb in rows
+                                  if not any(s in nm for s in ("k_adpm2", "k_precond", "k_init_noise", "k_cond_embed",
+                                                               "k_time_embed", "k_argmax", "k_clamp")))
+                    per_eval = unet_mb / evals_profiled
+                    ue["hbm_measured_mb_per_eval"] = round(per_eval, 1)
+                    ue["hbm_measured_frac"] = round(per_eval * 1e6 / (avg_eval_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                    ue["hbm_measured_source"] = f"profiles/{fname}: PMC bytes (FETCH_SIZE x2 + WRITE_SIZE) of the profiled run " \
+                                                f"/ its U-Net evaluations, over THIS run's evaluation time"
+        extra["unet_eval"] = ue
         result = {
             "metric": "molecules/sec @64 diffusion steps (QM9 max_len=64)" if a.workload == "cfg1"
                       else f"molecules/sec @{T} diffusion steps ({a.workload})", "value": round(value, 2),
@@ -245,38 +354,49 @@ def main():
             "vs_baseline": None,
             "dtype": "f32 storage/accumulate; GEMM products as split-bf16 (bf16x3) MFMA" if split else "f32",
             "data": "synthetic",
-            "config": {"workload": {"cfg1": "QMDiffusion inverse sample(): channels=64 pred_dim=16 max_len=64 cond_len=12, ",
-                                    "cfg3": "QMDiffusionForward sample(): channels=64 pred_dim=1 max_len=64 cond_len=64, ",
-                                    "cfg5": "QMDiffusion inverse sample(): channels=256 pred_dim=32 max_len=128 cond_len=12, "}[a.workload]
+            "config": {"workload": WORKLOADS[a.workload]
                                    + f"batch={B}/GPU, {T} timesteps ({evals} U-Net evals), cond_scale={a.cond_scale}, fp32",
                        "global_batch": world * B, "timesteps": T, "parallelism": f"batch-shard x{world}"},
             "roofline": roof,
         }
         result.update(extra)
 
-        if not a.no_cpu_baseline and world == 1:
-            from helpers import oracle_cfg, synth_sd
-            from oracle import unet_oracle as O
-            cb, ct = 128, 8                                   # bounded sample: 128 molecules, 8 timesteps = 14 evals
-            sd, cfg = synth_sd("cfg1"), oracle_cfg("cfg1")
-            cseq = synth_normal("bench/cpu/seq", (cb, 12))
-            init = synth_normal("bench/cpu/init", (cb, 16, 64))
-            nz = [synth_normal(f"bench/cpu/step{i}", (cb, 16, 64)) for i in range(ct - 1)]
-            O.sample(sd, cfg, cseq[:4], init[:4], lambda i, x: nz[i][:4], 3, 1.0, False)   # warm-up
+        if world > 1:
+            # the gathered tensor holds every rank's rows; counter-based noise is keyed by the GLOBAL sample index, so the
+            # last rank's first rows must equal, bit for bit, a 1-rank run of those global indices with the same seed
+            probe = min(64, B)
+            r_last = world - 1
+            alone = model.sample(seq_of(r_last)[:probe].to(device), device, cond_scale=a.cond_scale, timesteps=T, clamp=False,
+                                 noise=NoiseSource(seed=1234 + a.warmup + a.steps - 1, sample0=r_last * B))
+            rows = out[r_last * B: r_last * B + probe]
+            result["multi_gpu"] = {
+                "backend": "gloo (test hook: ranks share cuda:0)" if share else "nccl (RCCL over xGMI)",
+                "rccl_ranks_seen": dist.get_world_size(), "gathered_rows": int(out.shape[0]),
+                "collectives_per_step": 1, "all_gather_bytes_per_rank": int(B * out.shape[1] * out.shape[2] * 4),
+                "shard_invariance": {"rank": r_last, "rows": probe, "bitwise_equal_to_1_rank_run": bool(torch.equal(rows, alone))}}
+
+        if not a.no_exact_f32 and world == 1:
+            # the strict-fp32 number: same workload with exact v_mfma_f32_32x32x2_f32 products (layer-by-layer program)
+            with contextlib.redirect_stdout(sys.stderr):
+                m32 = make_synth_model(a.workload, device)
+            m32.gemm_mode = "f32"
+            f32_steps = 2
+            m32.sample(seq, device, cond_scale=1.0, timesteps=4, clamp=False, noise=NoiseSource(seed=7, sample0=0))  # compile + graphs
+            torch.cuda.synchronize(device)
             c0 = time.perf_counter()
-            cpu_out = O.sample(sd, cfg, cseq, init, lambda i, x: nz[i], ct, 1.0, False)
-            cdt = time.perf_counter() - c0
-            # the same bounded sample through the HIP path on the identical noise: the checker of this run
-            hip_out = model.sample(cseq, device, cond_scale=1.0, timesteps=ct, clamp=False,
-                                   noise=NoiseSource(init=init, steps=lambda i: nz[i])).cpu()
-            result["parity"] = {"max_abs_vs_cpu_reference_path": float((hip_out - cpu_out).abs().max()),
-                                "tolerance": 1e-4, "sample": f"batch {cb}, {ct} timesteps, identical noise"}
-            per_eval = cdt / (2 * (ct - 1))
-            result["cpu_baseline"] = {
-                "value": round(cb / (per_eval * evals), 3), "unit": "molecules/s", "cores": torch.get_num_threads(),
-                "kind": "port",
-                "sample": f"oracle/unet_oracle.py (PyTorch CPU fp32, bit-exact to the reference): batch {cb}, {ct} "
-                          f"timesteps = {2 * (ct - 1)} U-Net evals in {cdt:.2f} s, scaled to {evals} evals"}
+            for k in range(f32_steps):
+                o32 = m32.sample(seq, device, cond_scale=1.0, timesteps=T, clamp=False, noise=NoiseSource(seed=1234 + k, sample0=0))
+            torch.cuda.synchronize(device)
+            dt32 = time.perf_counter() - c0
+            ref_step = model.sample(seq, device, cond_scale=1.0, timesteps=T, clamp=False,
+                                    noise=NoiseSource(seed=1234 + f32_steps - 1, sample0=0))
+            result["exact_f32"] = {"value": round(B * f32_steps / dt32, 2), "unit": "molecules/s", "steps": f32_steps,
+                                   "ms_per_step": round(1e3 * dt32 / f32_steps, 2), "dtype": "f32 (exact fp32 MFMA products)",
+                                   "max_abs_vs_default_mode_same_noise": float((o32 - ref_step).abs().max())}
+            del m32
+
+        if not a.no_cpu_baseline and world == 1:
+            result["cpu_baseline"], result["parity"] = cpu_baseline_leg(torch, model, device, evals)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

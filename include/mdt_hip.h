@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MDT_ABI_VERSION 1
+#define MDT_ABI_VERSION 2
 
 int mdt_abi_version(void);
 const char *mdt_last_error(void);
@@ -155,7 +155,8 @@ enum mdt_tblock_i {
   MDT_B_NBIAS = 4, MDT_B_TK = 5, MDT_B_KV_BSTRIDE = 6, MDT_B_LDKV = 7, MDT_B_HEADS = 8,
   MDT_B_KV2 = 11,                   /* cross blocks, 1: dual batch (both passes of classifier-free guidance in one launch,
                                        UNetCFG1d.forward, modules.py:1248-1253): the second half of the samples reads the
-                                       batch-invariant K / V rows p1 (FixedEmbedding) instead of a2; B % 16 == 0        */
+                                       batch-invariant K / V rows p1 (FixedEmbedding) instead of a2; the first half must be
+                                       whole workgroups: (B / 2) % (64 / T) == 0 (C = 128), % (32 / T) (variants >= 2)  */
   MDT_B_POST = 10,                  /* feed-forward only, > 0: Transformer1d's closing Conv1d(k=1) folded in (modules.py:524):
                                        out = Wout (x + FF(x)) + bout; the W2 tiles hold Wout W2, POST = C/64 extra output
                                        tiles hold Wout (natural k order), the output bias holds Wout b2 + bout; x is left
@@ -238,11 +239,21 @@ int mdt_adpm2_mid(const float *x, const float *pred, float *x_mid, float *xin_mi
  *   x = x + d_mid * dt_down;  x = x + noise * sigma_up   (in place on x)
  * and xin_next = c_in_next * x.  noise == NULL selects the counter-based generator:
  * Philox4x32-10 keyed by (seed, step), counter = global element index
- * (sample0 + b) * C * L + c * L + l, Box-Muller -- independent of how the batch is sharded. */
+ * (sample0 + b) * C * L + c * L + l, Box-Muller -- independent of how the batch is sharded.
+ * tokens != NULL (only with xin_next == NULL, i.e. on the last update of a call): the decode step after the
+ * path fused in, tokens[b,l] = argmax_c x[b,c,l] of the final x as int32 (generative.py:1212-1213, :1690-1691:
+ * permute(0,2,1) -> argmax(dim=2); first maximum as torch.argmax). */
 int mdt_adpm2_next(float *x, const float *x_mid, const float *pred, const float *noise, float *xin_next,
                    float c_skip, float c_out, float sigma_mid, float dt_down, float sigma_up,
                    float c_in_next, uint64_t seed, uint32_t step, int64_t sample0, int32_t B, int32_t C,
-                   int32_t L, int32_t Cp, void *stream);
+                   int32_t L, int32_t Cp, int32_t *tokens, void *stream);
+/* One Euler move of ADPM2Sampler.step when the denoised tensor comes from a caller-supplied fn
+ * (Sampler.forward(noise, fn, sigmas, num_steps) seam, diffusion.py:352, :502-515); all tensors (B, C, L):
+ *   out = x_base + ((x_from - denoised) / sigma) * dt   [+ noise * sigma_up]
+ * noise_mode 0: no noise term; 1: explicit `noise` tensor; 2: counter-based generator (seed, step, sample0). */
+int mdt_adpm2_euler(const float *x_base, const float *x_from, const float *denoised, const float *noise,
+                    float *out, float sigma, float dt, float sigma_up, int32_t noise_mode, uint64_t seed,
+                    uint32_t step, int64_t sample0, int32_t B, int32_t C, int32_t L, void *stream);
 /* x = sigma0 * noise (diffusion.py:520); noise == NULL: counter-based generator as above. */
 int mdt_init_noise(float *x, const float *noise, float sigma0, uint64_t seed, uint32_t step,
                    int64_t sample0, int32_t B, int32_t C, int32_t L, void *stream);

@@ -7,8 +7,10 @@ Drop-in classes (same names and call signatures as the reference's MoleculeDiffu
 The sampling hot path (QMDiffusion.sample -> ADPM2 sampler -> 1-D conditional U-Net) runs in
 hand-written gfx950 kernels (csrc/, C ABI in include/mdt_hip.h).
 """
-from .diffusion import ADPM2Sampler, KarrasSchedule, LogNormalDistribution, NoiseSource  # noqa: F401
-from .generative import KDiffusion_mod, QMDiffusion, QMDiffusionForward, XDiffusion_x  # noqa: F401
+from .diffusion import (ADPM2Sampler, DiffusionInpainter, DiffusionSampler, KarrasSchedule,  # noqa: F401
+                        LogNormalDistribution, NoiseSource, Sampler)
+from .generative import (KDiffusion_mod, QMDiffusion, QMDiffusionForward, XDiffusion_x,  # noqa: F401
+                         generate_and_validate, predict_properties_from_tokens, tokens_to_forward_input)
 from .modules import PositionalEncoding1D, UNetCFG1d  # noqa: F401
 from .netspec import UNetConfig, forward_unet_config, inverse_unet_config  # noqa: F401
 

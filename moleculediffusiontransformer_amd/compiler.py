@@ -123,11 +123,15 @@ class CompiledUNet:
     flops_ctx_per_sample: int
     gemm_mode: str = "bf16x3"
     weight_index: Dict[str, int] = field(default_factory=dict)
+    # "eval_dual" (both guidance passes as one doubled batch): a cross-attention workgroup serves 64 / T (C = 128 ring kernel)
+    # or 32 / T (C = 256) samples and picks conditional vs fixed K/V per WORKGROUP, so the number of samples must be a
+    # multiple of the largest such group or a workgroup would straddle the two halves
+    dual_multiple: int = 1
 
 
 class UNetCompiler:
     def __init__(self, cfg: UNetConfig, length: int, cond_len: int, sd: Dict[str, torch.Tensor],
-                 max_time_rows: int = 512, gemm_mode: str = "bf16x3", fuse_blocks: bool = True):
+                 max_time_rows: int = 1024, gemm_mode: str = "bf16x3", fuse_blocks: bool = True):
         self.fuse_blocks = fuse_blocks
         self.fuse_c256 = os.environ.get("MDT_FUSE_C256", "1") == "1"
         self.tb32 = os.environ.get("MDT_TB32", "1") == "1"           # C = 256 blocks on 32-row workgroups (k_tblock32)
@@ -986,7 +990,9 @@ class UNetCompiler:
         ring = all(op.kind == rt.OP_TBLOCK and (op.i[rt.B_VARIANT] >= 2 or (op.i[rt.B_VARIANT] == 0 and tb_lw and op.i[rt.B_C] == 128
                                                                        and (16 // op.i[rt.B_T]) * op.i[rt.B_TK] <= 16))
                    for op in cross)
+        dual_multiple = 1
         if cross and ring and os.environ.get("MDT_CFG_DUAL", "1") == "1":
+            dual_multiple = max((32 if op.i[rt.B_VARIANT] >= 2 else 64) // op.i[rt.B_T] for op in cross)
             dual = resolve(eval_ops, False)
             for o, op in zip(dual, eval_ops):
                 if isinstance(getattr(op, "_kv", None), tuple):
@@ -1051,7 +1057,7 @@ class UNetCompiler:
                             programs=programs, act_floats=act_floats, shr_floats=self.shr_top,
                             max_time_rows=rows, shr=dict(self.shr), ss_total=self.ss_total, n_cross=n_cross,
                             flops_per_sample_eval=flops_eval, flops_ctx_per_sample=flops_ctx, gemm_mode=self.gemm_mode,
-                            weight_index=dict(self.W.index))
+                            weight_index=dict(self.W.index), dual_multiple=dual_multiple)
 
 
 def C_memmove(dst: rt.MdtOp, src: rt.MdtOp) -> None:
@@ -1067,5 +1073,5 @@ def _prod(xs) -> int:
 
 
 def compile_unet(cfg: UNetConfig, length: int, cond_len: int, sd: Dict[str, torch.Tensor],
-                 max_time_rows: int = 512, gemm_mode: str = "bf16x3", fuse_blocks: bool = True) -> CompiledUNet:
+                 max_time_rows: int = 1024, gemm_mode: str = "bf16x3", fuse_blocks: bool = True) -> CompiledUNet:
     return UNetCompiler(cfg, length, cond_len, sd, max_time_rows, gemm_mode, fuse_blocks).build()

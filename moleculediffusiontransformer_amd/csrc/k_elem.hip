@@ -148,16 +148,20 @@ __global__ __launch_bounds__(256) void k_adpm2_mid(const float* x, const float* 
 }
 
 // Second half of ADPM2Sampler.step                                        (diffusion.py:510-515)
+// tokens != nullptr (last step of a call): also the decode step after the path, tokens[b,l] = argmax_c x[b,c,l] of the
+// final x (generative.py:1212-1213, :1690-1691: permute(0,2,1) -> argmax(dim=2); first maximum, NaN wins, as torch.argmax),
+// taken from the values this kernel has in LDS anyway instead of a second pass over the (B, C, L) result.
 __global__ __launch_bounds__(256) void k_adpm2_next(float* x, const float* x_mid, const float* pred,
                                                      const float* noise, float* xin_next, float c_skip, float c_out,
                                                      float sigma_mid, float dt_down, float sigma_up, float c_in_next,
                                                      uint64_t seed, uint32_t step, int64_t sample0, int C, int L,
-                                                     int Cp) {
+                                                     int Cp, int32_t* tokens) {
   extern __shared__ float tile[];
   const int b = blockIdx.x;
   tile_load(tile, pred + (int64_t)b * L * Cp, L, Cp);
   __syncthreads();
   const int l4n = L / 4;
+  const bool keep_x = tokens && !xin_next;       // the tile then carries x itself (not c_in_next * x) for the argmax
   for (int e = threadIdx.x; e < C * l4n; e += blockDim.x) {
     const int c = e / l4n, l = (e - c * l4n) * 4;
     const int64_t o = (int64_t)b * C * L + c * L + l;
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(256) void k_adpm2_next(float* x, const float* x_mid
       float xx = xv[q] + d * dt_down;
       xx = xx + nv[q] * sigma_up;
       xn[q] = xx;
-      *t = c_in_next * xx;
+      *t = keep_x ? xx : c_in_next * xx;
     }
     *reinterpret_cast<float4*>(x + o) = make_float4(xn[0], xn[1], xn[2], xn[3]);
   }
@@ -184,6 +188,18 @@ __global__ __launch_bounds__(256) void k_adpm2_next(float* x, const float* x_mid
     tile_zero_pad(tile, C, L, Cp);
     __syncthreads();
     tile_store(tile, xin_next + (int64_t)b * L * Cp, L, Cp);
+  } else if (tokens) {
+    __syncthreads();
+    for (int l = threadIdx.x; l < L; l += blockDim.x) {
+      const float* t = tile + l * (Cp + 1);
+      float best = t[0];
+      int arg = 0;
+      for (int c = 1; c < C; ++c) {
+        const float v = t[c];
+        if (v > best || (v != v && best == best)) { best = v; arg = c; }
+      }
+      tokens[(int64_t)b * L + l] = arg;
+    }
   }
 }
 
@@ -203,6 +219,27 @@ __global__ __launch_bounds__(256) void k_add_noise(float* x, const float* noise,
     float4 v = reinterpret_cast<float4*>(x)[i];
     v.x = v.x + s * nz.x; v.y = v.y + s * nz.y; v.z = v.z + s * nz.z; v.w = v.w + s * nz.w;
     reinterpret_cast<float4*>(x)[i] = v;
+  }
+}
+
+// One Euler move of ADPM2Sampler.step with the denoised tensor supplied by the caller's fn (diffusion.py:506-515):
+//   out = x_base + ((x_from - den) / sigma) * dt   [+ noise * sigma_up]
+// first half: x_base = x_from = x, dt = sigma_mid - sigma; second half: x_base = x, x_from = x_mid, dt = sigma_down - sigma
+__global__ __launch_bounds__(256) void k_adpm2_euler(const float* xb, const float* xf, const float* den, const float* noise,
+                                                      float* out, float sigma, float dt, float sigma_up, int noise_mode,
+                                                      uint64_t seed, uint32_t step, int64_t elem0, int64_t n4) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 b = reinterpret_cast<const float4*>(xb)[i], f = reinterpret_cast<const float4*>(xf)[i];
+    const float4 d = reinterpret_cast<const float4*>(den)[i];
+    float4 o;
+    o.x = b.x + ((f.x - d.x) / sigma) * dt; o.y = b.y + ((f.y - d.y) / sigma) * dt;
+    o.z = b.z + ((f.z - d.z) / sigma) * dt; o.w = b.w + ((f.w - d.w) / sigma) * dt;
+    if (noise_mode) {
+      const float4 nz = noise_mode == 1 ? reinterpret_cast<const float4*>(noise)[i]
+                                        : normal4(seed, step, (uint64_t)((elem0 >> 2) + i));
+      o.x = o.x + nz.x * sigma_up; o.y = o.y + nz.y * sigma_up; o.z = o.z + nz.z * sigma_up; o.w = o.w + nz.w * sigma_up;
+    }
+    reinterpret_cast<float4*>(out)[i] = o;
   }
 }
 
@@ -436,11 +473,13 @@ int mdt_adpm2_mid(const float* x, const float* pred, float* x_mid, float* xin_mi
 
 int mdt_adpm2_next(float* x, const float* x_mid, const float* pred, const float* noise, float* xin_next, float c_skip,
                    float c_out, float sigma_mid, float dt_down, float sigma_up, float c_in_next, uint64_t seed,
-                   uint32_t step, int64_t sample0, int32_t B, int32_t C, int32_t L, int32_t Cp, void* stream) {
+                   uint32_t step, int64_t sample0, int32_t B, int32_t C, int32_t L, int32_t Cp, int32_t* tokens,
+                   void* stream) {
   MDT_CHECK_TILE("mdt_adpm2_next")
+  if (tokens && xin_next) return bad("mdt_adpm2_next: tokens are decoded on the LAST update of a call (xin_next == NULL)");
   hipLaunchKernelGGL(mdt::k_adpm2_next, dim3(B), dim3(256), tile_bytes(L, Cp), (hipStream_t)stream, x, x_mid, pred,
                      noise, xin_next, c_skip, c_out, sigma_mid, dt_down, sigma_up, c_in_next, seed, step, sample0, C, L,
-                     Cp);
+                     Cp, tokens);
   return finish("mdt_adpm2_next");
 }
 
@@ -472,6 +511,18 @@ int mdt_inpaint_merge(float* x, const float* src, const uint8_t* mask, const flo
   hipLaunchKernelGGL(mdt::k_inpaint_merge, dim3(mdt::grid_for(n4)), dim3(256), 0, (hipStream_t)stream, x, src, mask,
                      noise, sigma, seed, step, sample0 * C * L, n4);
   return finish("mdt_inpaint_merge");
+}
+
+int mdt_adpm2_euler(const float* x_base, const float* x_from, const float* denoised, const float* noise, float* out,
+                    float sigma, float dt, float sigma_up, int32_t noise_mode, uint64_t seed, uint32_t step,
+                    int64_t sample0, int32_t B, int32_t C, int32_t L, void* stream) {
+  if (B <= 0) return 0;
+  if (L % 4) return bad("mdt_adpm2_euler: L % 4 != 0");
+  if (noise_mode < 0 || noise_mode > 2 || (noise_mode == 1 && !noise)) return bad("mdt_adpm2_euler: bad noise mode");
+  const int64_t n4 = (int64_t)B * C * L / 4;
+  hipLaunchKernelGGL(mdt::k_adpm2_euler, dim3(mdt::grid_for(n4)), dim3(256), 0, (hipStream_t)stream, x_base, x_from,
+                     denoised, noise, out, sigma, dt, sigma_up, noise_mode, seed, step, sample0 * C * L, n4);
+  return finish("mdt_adpm2_euler");
 }
 
 int mdt_clamp(float* x, float lo, float hi, int64_t n, void* stream) {

@@ -272,7 +272,13 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
         a.eps = o.f[MDT_BF_EPS]; a.scale = o.f[MDT_BF_SCALE];
         a.part = nullptr; a.nsplit = 1; a.xout = nullptr; a.pin = nullptr; a.pout = nullptr;
         a.kv2 = o.i[MDT_B_KV2] ? ptr(o.p1) : nullptr;
-        if (o.i[MDT_B_KV2] && (B % 16 || !o.p1.space)) return fail("mdt_program_run: a dual-batch cross block needs B % 16 == 0 and the shared K/V rows");
+        if (o.i[MDT_B_KV2]) {
+          // the kernels pick conditional vs shared K/V per WORKGROUP (64 rows at C = 128, 32 rows in the C = 256 kernels):
+          // the first half of the samples must be whole workgroups
+          const int per_wg = (o.i[MDT_B_VARIANT] >= 2 ? 32 : 64) / a.T;
+          if (!o.p1.space || B % 2 || (B / 2) % (per_wg > 0 ? per_wg : 1))
+            return fail("mdt_program_run: a dual-batch cross block needs the shared K/V rows and B = 2 x (a multiple of the samples per workgroup)");
+        }
         a.post = o.i[MDT_B_POST];
         if (a.post) a.xout = ptr(o.out);
         if (o.i[MDT_B_VARIANT] == 3) { a.part = ptr(o.out); a.nsplit = 2; }

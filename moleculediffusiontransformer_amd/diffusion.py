@@ -49,8 +49,37 @@ class KarrasSchedule(nn.Module):
         return F.pad(sigmas, pad=(0, 1), value=0.0)
 
 
-class ADPM2Sampler(nn.Module):
-    """diffusion.py:486-549.  Holds rho; the update itself is mdt_adpm2_mid / mdt_adpm2_next."""
+class _KAlias:
+    """Stands for the reference's diffusion classes in Sampler.diffusion_types (only their alias is consulted,
+    diffusion.py:571-575)."""
+
+    def __init__(self, alias: str):
+        self.alias = alias
+
+
+class Sampler(nn.Module):
+    """diffusion.py:347-366."""
+
+    diffusion_types: list = []
+
+    def forward(self, noise: Tensor, fn: Callable, sigmas: Tensor, num_steps: int) -> Tensor:
+        raise NotImplementedError()
+
+    def inpaint(self, source: Tensor, mask: Tensor, fn: Callable, sigmas: Tensor, num_steps: int,
+                num_resamples: int) -> Tensor:
+        raise NotImplementedError("Inpainting not available with current sampler")
+
+
+class ADPM2Sampler(Sampler):
+    """diffusion.py:486-549: second-order ancestral DPM-2 sampler.
+
+    ``fn(x, sigma=...)`` is any denoiser on HIP tensors.  When it is the denoiser of a QMDiffusion* model (the closure
+    DiffusionSampler / DiffusionInpainter build), forward()/inpaint() run the whole loop on the fused path (run_adpm2:
+    per-step scalars precomputed on the host, preconditioning + update fused, the U-Net as a replayed HIP graph); with any
+    other ``fn`` every step is two calls of ``fn`` and two mdt_adpm2_euler launches (the reference's arithmetic, fp32, no
+    contraction), drawing the step noise with torch.randn_like on the device exactly as diffusion.py:514 does."""
+
+    diffusion_types = [_KAlias("k"), _KAlias("vk")]
 
     def __init__(self, rho: float = 1.0):
         super().__init__()
@@ -62,6 +91,60 @@ class ADPM2Sampler(nn.Module):
         sigma_down = math.sqrt(sigma_next ** 2 - sigma_up ** 2)
         sigma_mid = ((sigma ** (1 / r) + sigma_down ** (1 / r)) / 2) ** r
         return sigma_up, sigma_down, sigma_mid
+
+    def step(self, x: Tensor, fn: Callable, sigma, sigma_next, *, noise: Optional[Tensor] = None) -> Tensor:
+        """diffusion.py:502-515 for one step; ``noise`` replaces the torch.randn_like(x) draw (parity tests)."""
+        lib = rt.load_library()
+        sigma = torch.as_tensor(sigma, dtype=torch.float32).cpu().reshape(())
+        sigma_next = torch.as_tensor(sigma_next, dtype=torch.float32).cpu().reshape(())
+        sigma_up, sigma_down, sigma_mid = self.get_sigmas(sigma, sigma_next)
+        dt_mid, dt_down = float(sigma_mid - sigma), float(sigma_down - sigma)     # fp32 tensor arithmetic, as the reference
+        up32 = float(torch.tensor(sigma_up, dtype=torch.float32))
+        if x.device.type != "cuda":
+            raise RuntimeError("ADPM2Sampler.step runs on an AMD GPU through libmdt_hip.so (no CPU fallback)")
+        x = x.detach().float().contiguous()
+        B, C, L = x.shape
+        with torch.no_grad(), torch.cuda.device(x.device):
+            st = rt.current_stream()
+            den = fn(x, sigma=sigma).float().contiguous()
+            x_mid = torch.empty_like(x)
+            rt.check(lib.mdt_adpm2_euler(rt.ptr(x), rt.ptr(x), rt.ptr(den), 0, rt.ptr(x_mid), float(sigma), dt_mid, 0.0, 0,
+                                         0, 0, 0, B, C, L, st))
+            den_mid = fn(x_mid, sigma=torch.as_tensor(sigma_mid, dtype=torch.float32)).float().contiguous()
+            nz = (torch.randn_like(x) if noise is None else noise.to(device=x.device, dtype=torch.float32)).contiguous()
+            out = torch.empty_like(x)
+            rt.check(lib.mdt_adpm2_euler(rt.ptr(x), rt.ptr(x_mid), rt.ptr(den_mid), rt.ptr(nz), rt.ptr(out),
+                                         float(sigma_mid), dt_down, up32, 1, 0, 0, 0, B, C, L, st))
+        return out
+
+    def forward(self, noise, fn: Callable, sigmas: Tensor, num_steps: int) -> Tensor:
+        """diffusion.py:517-524.  ``noise`` is the initial draw (B, C, L) or, on the fused path, a NoiseSource."""
+        fused = getattr(fn, "fused", None)
+        if fused is not None:
+            return fused.sample(noise, self, sigmas, num_steps)
+        if isinstance(noise, NoiseSource):
+            raise TypeError("a NoiseSource drives the fused path only; pass the initial noise tensor with a custom fn")
+        x = float(sigmas[0]) * noise
+        for i in range(num_steps - 1):
+            x = self.step(x, fn=fn, sigma=sigmas[i], sigma_next=sigmas[i + 1])
+        return x
+
+    def inpaint(self, source: Tensor, mask: Tensor, fn: Callable, sigmas: Tensor, num_steps: int,
+                num_resamples: int) -> Tensor:
+        """diffusion.py:526-549."""
+        fused = getattr(fn, "fused", None)
+        if fused is not None:
+            return fused.inpaint(source, mask, self, sigmas, num_steps, num_resamples)
+        x = float(sigmas[0]) * torch.randn_like(source)
+        for i in range(num_steps - 1):
+            source_noisy = source + float(sigmas[i]) * torch.randn_like(source)
+            for r in range(num_resamples):
+                x = source_noisy * mask + x * ~mask
+                x = self.step(x, fn=fn, sigma=sigmas[i], sigma_next=sigmas[i + 1])
+                if r < num_resamples - 1:
+                    sigma = math.sqrt(sigmas[i] ** 2 - sigmas[i + 1] ** 2)
+                    x = x + sigma * torch.randn_like(x)
+        return source * mask + x * ~mask
 
 
 @dataclass
@@ -98,10 +181,10 @@ class StepScalars:
     renoise: float           # sqrt(sigma^2 - sigma_next^2) for inpaint resampling (diffusion.py:546)
 
 
-def adpm2_plan(num_steps: int, schedule: KarrasSchedule, sampler: ADPM2Sampler, sigma_data: float):
+def adpm2_plan(num_steps: int, schedule, sampler: ADPM2Sampler, sigma_data: float):
     """Per-step scalars of ADPM2Sampler.forward/step (diffusion.py:502-524), bit-for-bit as the reference
-    computes them on CPU."""
-    sigmas = schedule(num_steps)
+    computes them on CPU.  ``schedule`` is a KarrasSchedule or an already evaluated (num_steps + 1,) sigma tensor."""
+    sigmas = schedule.detach().float().cpu() if isinstance(schedule, torch.Tensor) else schedule(num_steps)
     steps: List[StepScalars] = []
     for i in range(num_steps - 1):
         sigma, sigma_next = sigmas[i], sigmas[i + 1]
@@ -132,6 +215,64 @@ class NoiseSource:
         self.init, self.steps, self.seed, self.sample0 = init, steps, seed, sample0
 
 
+class BoundDenoise:
+    """The closure ``fn = lambda *a, **ka: denoise_fn(*a, **{**ka, **kwargs})`` of DiffusionSampler.forward /
+    DiffusionInpainter.forward (diffusion.py:587, :614) as an object: calling it evaluates the denoiser; ``fused`` is the
+    owning model's fused-loop adapter when the denoiser is a QMDiffusion* model's (else None), which lets
+    ADPM2Sampler.forward / inpaint take the whole loop instead of calling back per step."""
+
+    def __init__(self, denoise_fn: Callable, kwargs: dict, extra: Optional[dict] = None):
+        self.denoise_fn, self.kwargs = denoise_fn, dict(kwargs)
+        owner = getattr(getattr(denoise_fn, "__self__", None), "_owner", None)
+        self.fused = owner._fused_adapter(self.kwargs, extra or {}) if owner is not None else None
+
+    def __call__(self, *a, **ka):
+        return self.denoise_fn(*a, **{**ka, **self.kwargs})
+
+
+class DiffusionSampler(nn.Module):
+    """diffusion.py:554-591."""
+
+    def __init__(self, diffusion, *, sampler: Sampler, sigma_schedule, num_steps: Optional[int] = None, clamp: bool = True):
+        super().__init__()
+        self.denoise_fn = diffusion.denoise_fn
+        self.sampler = sampler
+        self.sigma_schedule = sigma_schedule
+        self.num_steps = num_steps
+        self.clamp = clamp
+        message = f"{sampler.__class__.__name__} incompatible with {diffusion.__class__.__name__}"
+        assert diffusion.alias in [t.alias for t in sampler.diffusion_types], message
+
+    @torch.no_grad()
+    def forward(self, noise, num_steps: Optional[int] = None, *, trace=None, timer=None, tokens=None, **kwargs) -> Tensor:
+        num_steps = self.num_steps if num_steps is None else num_steps
+        assert num_steps is not None, "Parameter `num_steps` must be provided"
+        sigmas = self.sigma_schedule(num_steps)
+        fn = BoundDenoise(self.denoise_fn, kwargs, dict(trace=trace, timer=timer, tokens=tokens, clamp=self.clamp))
+        x = self.sampler(noise, fn=fn, sigmas=sigmas, num_steps=num_steps)
+        if fn.fused is None and self.clamp:          # the fused loop applies the final clamp itself (mdt_clamp)
+            x = x.clamp(-1.0, 1.0)
+        return x
+
+
+class DiffusionInpainter(nn.Module):
+    """diffusion.py:594-625."""
+
+    def __init__(self, diffusion, *, num_steps: int, num_resamples: int, sampler: Sampler, sigma_schedule):
+        super().__init__()
+        self.denoise_fn = diffusion.denoise_fn
+        self.num_steps = num_steps
+        self.num_resamples = num_resamples
+        self.inpaint_fn = sampler.inpaint
+        self.sigma_schedule = sigma_schedule
+
+    @torch.no_grad()
+    def forward(self, inpaint: Tensor, inpaint_mask: Tensor, *, draw=None, seed=None, **kwargs) -> Tensor:
+        fn = BoundDenoise(self.denoise_fn, kwargs, dict(draw=draw, seed=seed))
+        return self.inpaint_fn(source=inpaint, mask=inpaint_mask, fn=fn, sigmas=self.sigma_schedule(self.num_steps),
+                               num_steps=self.num_steps, num_resamples=self.num_resamples)
+
+
 # ----------------------------------------------------------------------------------------------
 # the fused sampling loop
 # ----------------------------------------------------------------------------------------------
@@ -142,10 +283,11 @@ def _f32(t: Tensor, device) -> Tensor:
 def _guided_setup(engine, embedding: Tensor, guided: bool) -> bool:
     """reserve() + prepare_context() for a sampling run.  Guidance runs both passes of UNetCFG1d.forward
     (modules.py:1248-1253) as ONE evaluation of the doubled batch [samples | samples] when the engine has that program
-    (every cross-attention block on a ring kernel) and the kernels' workgroups cannot straddle the halves.
+    (every cross-attention block on a ring kernel) and no cross-attention workgroup would straddle the halves (B a
+    multiple of the samples per workgroup, CompiledUNet.dual_multiple); otherwise two passes.
     Returns whether the doubled batch is in use."""
     B = embedding.shape[0]
-    dual = guided and engine.has_dual and B % 8 == 0 and B > 0
+    dual = guided and engine.has_dual and B > 0 and B % engine.c.dual_multiple == 0
     engine.reserve(2 * B if dual else B)
     engine.prepare_context(torch.cat([embedding, embedding]) if dual else embedding)
     return dual
@@ -166,10 +308,12 @@ def _guided_eval(engine, lib, B: int, guided: bool, dual: bool, embedding_scale:
 
 
 def run_adpm2(engine, embedding: Tensor, pred_dim: int, num_steps: int, noise: NoiseSource,
-              schedule: KarrasSchedule, sampler: ADPM2Sampler, sigma_data: float, embedding_scale: float = 1.0,
-              clamp: bool = False, trace: Optional[dict] = None, timer=None) -> Tensor:
+              schedule, sampler: ADPM2Sampler, sigma_data: float, embedding_scale: float = 1.0,
+              clamp: bool = False, trace: Optional[dict] = None, timer=None, tokens: Optional[Tensor] = None) -> Tensor:
     """DiffusionSampler.forward (diffusion.py:577-591) + ADPM2Sampler.forward (:517-524) +
-    KDiffusion_mod.denoise_fn (:798-814) + UNetCFG1d.forward (modules.py:1228-1255) on the GPU."""
+    KDiffusion_mod.denoise_fn (:798-814) + UNetCFG1d.forward (modules.py:1228-1255) on the GPU.
+    ``tokens`` (B, L) int32: also the decode step after the path, argmax over channels of the final sample
+    (generative.py:1212-1213), written by the last update kernel."""
     lib = rt.load_library()
     dev = engine.device
     B = embedding.shape[0]
@@ -189,7 +333,10 @@ def run_adpm2(engine, embedding: Tensor, pred_dim: int, num_steps: int, noise: N
         init = None if noise.init is None else _f32(noise.init, dev)
         rt.check(lib.mdt_init_noise(rt.ptr(x), rt.ptr(init), float(sigmas[0]), seed, 0, noise.sample0, B, C, L, st))
         if not steps:
-            return x.clamp(-1.0, 1.0) if clamp else x
+            x = x.clamp(-1.0, 1.0) if clamp else x
+            if tokens is not None:
+                rt.check(lib.mdt_argmax_tokens(rt.ptr(x), rt.ptr(tokens), B, C, L, st))
+            return x
         rt.check(lib.mdt_precond_in(rt.ptr(x), rt.ptr(engine.xin), steps[0].w.c_in, B, C, L, Cp, st))
 
         def unet(row: int) -> Tensor:
@@ -212,16 +359,18 @@ def run_adpm2(engine, embedding: Tensor, pred_dim: int, num_steps: int, noise: N
             rt.check(lib.mdt_adpm2_next(rt.ptr(x), rt.ptr(x_mid), rt.ptr(pred), rt.ptr(nz),
                                         0 if last else rt.ptr(engine.xin), s.w_mid.c_skip, s.w_mid.c_out,
                                         s.sigma_mid, s.dt_down, s.sigma_up, c_in_next, seed, i + 1, noise.sample0,
-                                        B, C, L, Cp, st))
+                                        B, C, L, Cp, rt.ptr(tokens) if (last and not clamp) else 0, st))
             if trace is not None and (i + 1) in trace.get("want", ()):
                 trace[i + 1] = x.clone()
         if clamp:
             rt.check(lib.mdt_clamp(rt.ptr(x), -1.0, 1.0, x.numel(), st))
+            if tokens is not None:        # clamping creates ties (first maximum wins): decode the clamped sample
+                rt.check(lib.mdt_argmax_tokens(rt.ptr(x), rt.ptr(tokens), B, C, L, st))
     return x
 
 
 def run_adpm2_inpaint(engine, embedding: Tensor, source: Tensor, mask: Tensor, num_steps: int, num_resamples: int,
-                      draw: Optional[Callable[[], Tensor]], seed: Optional[int], schedule: KarrasSchedule,
+                      draw: Optional[Callable[[], Tensor]], seed: Optional[int], schedule,
                       sampler: ADPM2Sampler, sigma_data: float, embedding_scale: float = 1.0,
                       sample0: int = 0) -> Tensor:
     """ADPM2Sampler.inpaint (diffusion.py:526-549) behind DiffusionInpainter.forward (:612-625).
@@ -272,7 +421,7 @@ def run_adpm2_inpaint(engine, embedding: Tensor, source: Tensor, mask: Tensor, n
                 nz, k = next_draw()
                 rt.check(lib.mdt_adpm2_next(rt.ptr(x), rt.ptr(x_mid), rt.ptr(pred), rt.ptr(nz), 0, s.w_mid.c_skip,
                                             s.w_mid.c_out, s.sigma_mid, s.dt_down, s.sigma_up, 0.0, sd, k, sample0,
-                                            B, C, L, Cp, st))
+                                            B, C, L, Cp, 0, st))
                 if r < num_resamples - 1:
                     nz, k = next_draw()
                     rt.check(lib.mdt_add_noise(rt.ptr(x), rt.ptr(nz), s.renoise, sd, k, sample0, B, C, L, st))

@@ -35,7 +35,19 @@ class UNetEngine:
         with torch.cuda.device(device):
             self.weights = compiled.weights.to(device)
             self.shr = torch.zeros(compiled.shr_floats, device=device)
-            self.programs: Dict[str, rt.Program] = {k: rt.Program(v) for k, v in compiled.programs.items()}
+            try:
+                self.programs: Dict[str, rt.Program] = {k: rt.Program(v) for k, v in compiled.programs.items()}
+            except RuntimeError as e:
+                raise RuntimeError(
+                    f"U-Net configuration outside the envelope of the MI355X kernels (max_length={compiled.length}, "
+                    f"channels={compiled.cfg.channels}, patch_size={compiled.cfg.patch_size}): {e}.  Supported: self-attention "
+                    "levels with at most 64 tokens per sample unless they run on the fused blocks (C in {128, 256}, tokens "
+                    "dividing 16), head_features 64, channels a multiple of 16 -- see DESIGN.md section 8") from e
+            tile = compiled.length * (compiled.in_pad + 1) * 4
+            if tile > 64 * 1024:
+                raise RuntimeError(f"max_length={compiled.length} with {compiled.in_pad} (padded) channels needs a {tile}-byte "
+                                   "sampler tile; the preconditioning / update kernels stage one sample in 64 KiB of LDS "
+                                   "(max_length * (pred_dim_padded + 1) * 4 <= 65536) -- see DESIGN.md section 8")
         if use_graph is None:
             use_graph = os.environ.get("MDT_GRAPH", "1") != "0"
         self.use_graph = use_graph
@@ -74,7 +86,9 @@ class UNetEngine:
         (rows are identical across the batch: sigma is a scalar broadcast by to_batch, diffusion.py:91-102)."""
         n = c_noise.numel()
         if n > self.c.max_time_rows:
-            raise ValueError(f"{n} timesteps exceed max_time_rows={self.c.max_time_rows}")
+            raise ValueError(f"{n} U-Net evaluations per call (timesteps = {n // 2 + 1}) exceed the time table of "
+                             f"{self.c.max_time_rows} rows this engine was compiled with (at most "
+                             f"{self.c.max_time_rows // 2 + 1} timesteps); compile_unet(max_time_rows=...) sets it")
         off = self.c.shr["c_noise"]
         self.shr[off: off + n].copy_(c_noise.to(device=self.device, dtype=torch.float32), non_blocking=True)
         self.programs["time"].run(self._bind(), max(self.B, 1), n)
@@ -114,8 +128,9 @@ class UNetEngine:
         out = self.pred_fixed if fixed else self.pred
         if fixed or dual:
             self.prepare_fixed()
-        if dual and self.B % 16:
-            raise ValueError("the dual guidance batch needs an even number of samples that is a multiple of 16")
+        if dual and (self.B % 2 or (self.B // 2) % self.c.dual_multiple):
+            raise ValueError(f"the dual guidance batch needs 2 x (a multiple of {self.c.dual_multiple}) samples: a cross-attention "
+                             "workgroup must not straddle the conditional and the unconditional half")
         if not self.use_graph:
             self.programs[name].run(self._bind(xin=self.xin, out=out), self.B)
             return out

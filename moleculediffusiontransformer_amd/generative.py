@@ -15,8 +15,8 @@ import torch.nn as nn
 
 from . import runtime as rt
 from .compiler import compile_unet
-from .diffusion import (ADPM2Sampler, KarrasSchedule, LogNormalDistribution, NoiseSource, run_adpm2,
-                        run_adpm2_inpaint, scale_weights)
+from .diffusion import (ADPM2Sampler, DiffusionInpainter, DiffusionSampler, KarrasSchedule, LogNormalDistribution,
+                        NoiseSource, run_adpm2, run_adpm2_inpaint, scale_weights)
 from .engine import UNetEngine, _require_gpu
 from .modules import PositionalEncoding1D, UNetCFG1d
 from .netspec import forward_unet_config, inverse_unet_config
@@ -41,13 +41,26 @@ class KDiffusion_mod(nn.Module):
 
     def denoise_fn(self, x_noisy: Tensor, sigmas: Optional[Tensor] = None, sigma=None, *, embedding: Tensor,
                    embedding_scale: float = 1.0) -> Tensor:
-        """diffusion.py:798-814 for a scalar sigma (the sampling case)."""
-        if sigma is None:
-            raise NotImplementedError("per-sample sigmas belong to the training path, which is out of scope")
-        return self._owner._denoise(x_noisy, sigma, embedding, embedding_scale)
+        """diffusion.py:798-814: a scalar ``sigma`` (the sampling case) or one sigma per sample (``sigmas``, the
+        training-time form; samples sharing a sigma are evaluated together)."""
+        if sigma is None and sigmas is None:
+            raise AssertionError("Either sigma or sigmas must be provided")       # to_batch, diffusion.py:97
+        if sigma is not None:
+            return self._owner._denoise(x_noisy, sigma, embedding, embedding_scale)
+        sig = torch.as_tensor(sigmas, dtype=torch.float32).flatten().cpu()
+        if sig.numel() != x_noisy.shape[0]:
+            raise AssertionError("sigmas must hold one value per sample")
+        out = torch.empty_like(x_noisy, dtype=torch.float32)
+        for v in torch.unique(sig):
+            rows = (sig == v).nonzero().flatten().to(x_noisy.device)
+            out[rows] = self._owner._denoise(x_noisy[rows], v, embedding[rows], embedding_scale)
+        return out
 
-    def forward(self, *a, **k):
-        raise NotImplementedError("training loss (KDiffusion_mod.forward) is outside the MI355X sampling path")
+    def forward(self, x: Tensor, noise: Optional[Tensor] = None, *, embedding: Tensor, **kwargs) -> Tensor:
+        """Training loss of KDiffusion_mod.forward (diffusion.py:820-844) -- plain PyTorch with autograd (train.py);
+        the MI355X kernels serve sampling only."""
+        from .train import kdiffusion_loss
+        return kdiffusion_loss(self._owner, x, noise, embedding, **kwargs)
 
 
 class XDiffusion_x(nn.Module):
@@ -64,15 +77,50 @@ class XDiffusion_x(nn.Module):
     def forward(self, *args, **kwargs):
         return self.diffusion(*args, **kwargs)
 
-    def sample(self, noise, num_steps: int, sigma_schedule: KarrasSchedule, sampler: ADPM2Sampler, clamp: bool,
-               *, embedding: Tensor, embedding_scale: float = 1.0, **extra) -> Tensor:
-        return self.diffusion._owner._sample(noise, num_steps, sigma_schedule, sampler, clamp, embedding,
-                                             embedding_scale, **extra)
+    def sample(self, noise, num_steps: int, sigma_schedule, sampler, clamp: bool, **kwargs) -> Tensor:
+        """diffusion.py:724-741: builds a DiffusionSampler and calls it.  ``noise``: the initial draw (B, C, L) as in the
+        reference, a NoiseSource, or None (drawn like generative.py:853)."""
+        diffusion_sampler = DiffusionSampler(diffusion=self.diffusion, sampler=sampler, sigma_schedule=sigma_schedule,
+                                             num_steps=num_steps, clamp=clamp)
+        return diffusion_sampler(noise, **kwargs)
 
-    def inpaint(self, sigma_schedule, sampler, inpaint, in_paint_mask, num_steps: int, num_resamples: int, *,
-                embedding: Tensor, embedding_scale: float = 1.0, **extra) -> Tensor:
-        return self.diffusion._owner._inpaint(inpaint, in_paint_mask, num_steps, num_resamples, sigma_schedule,
-                                              sampler, embedding, embedding_scale, **extra)
+    def inpaint(self, sigma_schedule, sampler, inpaint, in_paint_mask, num_steps: int, num_resamples: int,
+                **kwargs) -> Tensor:
+        """diffusion.py:744-767: builds a DiffusionInpainter and calls it."""
+        inpainter = DiffusionInpainter(diffusion=self.diffusion, sampler=sampler, sigma_schedule=sigma_schedule,
+                                       num_steps=num_steps, num_resamples=num_resamples)
+        return inpainter(inpaint, inpaint_mask, **kwargs)
+
+
+class _FusedLoop:
+    """What ADPM2Sampler.forward / inpaint call when the denoiser belongs to a QMDiffusion* model: the whole loop on
+    the fused path (run_adpm2 / run_adpm2_inpaint) instead of one callback per evaluation."""
+
+    def __init__(self, owner, kwargs: dict, extra: dict):
+        unknown = set(kwargs) - {"embedding", "embedding_scale"}
+        if unknown or "embedding" not in kwargs:
+            raise TypeError(f"denoise_fn takes embedding= and embedding_scale= (got {sorted(kwargs)})")
+        self.owner, self.kw, self.extra = owner, kwargs, extra
+
+    def sample(self, noise, sampler, sigmas, num_steps):
+        o, emb = self.owner, self.kw["embedding"]
+        if emb.shape[0] == 0:                       # nothing to generate (the reference returns an empty tensor too)
+            return torch.empty(0, o.pred_dim, o.max_length, device=emb.device)
+        eng = o.engine(emb.device, emb.shape[1])
+        ns = o._noise_source(noise, emb.shape[0], emb.device)
+        x = self.extra
+        return run_adpm2(eng, emb, o.pred_dim, num_steps, ns, sigmas, sampler, o.diffusion.diffusion.sigma_data,
+                         self.kw.get("embedding_scale", 1.0), bool(x.get("clamp", False)), x.get("trace"), x.get("timer"),
+                         x.get("tokens"))
+
+    def inpaint(self, source, mask, sampler, sigmas, num_steps, num_resamples):
+        o, emb = self.owner, self.kw["embedding"]
+        eng = o.engine(emb.device, emb.shape[1])
+        draw, seed = self.extra.get("draw"), self.extra.get("seed")
+        if draw is None and seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        return run_adpm2_inpaint(eng, emb, source, mask, num_steps, num_resamples, draw, seed, sigmas, sampler,
+                                 o.diffusion.diffusion.sigma_data, self.kw.get("embedding_scale", 1.0))
 
 
 class _QMBase(nn.Module):
@@ -166,39 +214,25 @@ class _QMBase(nn.Module):
         ns.init = init
         return ns
 
-    def _sample(self, noise, num_steps, sigma_schedule, sampler, clamp, embedding, embedding_scale, trace=None,
-                timer=None):
-        if not isinstance(sampler, ADPM2Sampler) or not isinstance(sigma_schedule, KarrasSchedule):
-            raise NotImplementedError("the MI355X path implements ADPM2Sampler with KarrasSchedule")
-        device = embedding.device
-        if embedding.shape[0] == 0:                 # nothing to generate (the reference returns an empty tensor too)
-            return torch.empty(0, self.pred_dim, self.max_length, device=device)
-        eng = self.engine(device, embedding.shape[1])
-        ns = self._noise_source(noise, embedding.shape[0], device)
-        with torch.no_grad():
-            return run_adpm2(eng, embedding, self.pred_dim, num_steps, ns, sigma_schedule, sampler,
-                             self.diffusion.diffusion.sigma_data, embedding_scale, clamp, trace, timer)
-
-    def _inpaint(self, source, mask, num_steps, num_resamples, sigma_schedule, sampler, embedding, embedding_scale,
-                 draw: Optional[Callable[[], Tensor]] = None, seed: Optional[int] = None):
-        if not isinstance(sampler, ADPM2Sampler) or not isinstance(sigma_schedule, KarrasSchedule):
-            raise NotImplementedError("the MI355X path implements ADPM2Sampler with KarrasSchedule")
-        eng = self.engine(embedding.device, embedding.shape[1])
-        if draw is None and seed is None:
-            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-        with torch.no_grad():
-            return run_adpm2_inpaint(eng, embedding, source, mask, num_steps, num_resamples, draw, seed,
-                                     sigma_schedule, sampler, self.diffusion.diffusion.sigma_data, embedding_scale)
+    def _fused_adapter(self, kwargs: dict, extra: dict) -> _FusedLoop:
+        return _FusedLoop(self, kwargs, extra)
 
     def _unet_call(self, x: Tensor, time, embedding: Tensor, embedding_scale: float = 1.0) -> Tensor:
-        """net(x, time, embedding=..., embedding_scale=...) (modules.py:1228-1255) for a time value shared
-        by the batch; x is (B, C, L) as in the reference."""
+        """net(x, time, embedding=..., embedding_scale=...) (modules.py:1228-1255); x is (B, C, L) as in the reference,
+        ``time`` a scalar or one value per row (rows sharing a time value are evaluated together)."""
+        t = torch.as_tensor(time, dtype=torch.float32).flatten().cpu()
+        B = x.shape[0]
+        if t.numel() not in (1, B):
+            raise ValueError(f"time must be a scalar or hold one value per sample (got {t.numel()} for batch {B})")
+        if t.numel() > 1 and not bool((t == t[0]).all()):
+            out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+            for v in torch.unique(t):
+                rows = (t == v).nonzero().flatten().to(x.device)
+                out[rows] = self._unet_call(x[rows], v, embedding[rows], embedding_scale)
+            return out
         lib = rt.load_library()
         device = x.device
         eng = self.engine(device, embedding.shape[1])
-        t = torch.as_tensor(time, dtype=torch.float32).flatten().cpu()
-        if t.numel() > 1 and not bool((t == t[0]).all()):
-            raise NotImplementedError("the MI355X path evaluates one time value per batch")
         B, C, L = x.shape
         Cp = eng.c.in_pad
         with torch.no_grad(), torch.cuda.device(device):
@@ -242,16 +276,31 @@ class _QMBase(nn.Module):
 
     # ------------------------------------------------------------------ public API (reference signatures)
     def forward(self, sequences, output):
-        raise NotImplementedError(
-            "training loss (QMDiffusion*.forward, generative.py:812-833 / :120-143) is outside the MI355X "
-            "sampling path; train with the reference and load the checkpoint with load_state_dict()")
+        """Training loss (generative.py:812-833 / :120-143): conditioning prelude + KDiffusion_mod.forward, plain PyTorch
+        with autograd on whatever device the parameters live on (train.py).  Not on the MI355X sampling path."""
+        from .train import conditioning_embedding
+        x = conditioning_embedding(self, sequences)
+        return self.diffusion(output, embedding=x)
 
-    def _do_sample(self, sequences, device, cond_scale, timesteps, clamp, noise=None, trace=None, timer=None):
+    def _do_sample(self, sequences, device, cond_scale, timesteps, clamp, noise=None, trace=None, timer=None, tokens=None):
         emb = self._embed(sequences, device)
         return self.diffusion.sample(num_steps=timesteps, sampler=ADPM2Sampler(rho=1),
                                      sigma_schedule=KarrasSchedule(sigma_min=0.001, sigma_max=9.0, rho=3.0),
                                      clamp=clamp, noise=noise, embedding=emb, embedding_scale=cond_scale,
-                                     trace=trace, timer=timer)
+                                     trace=trace, timer=timer, tokens=tokens)
+
+    def sample_tokens(self, sequences, device, cond_scale=None, timesteps=100, clamp=False, *, noise=None,
+                      return_sample: bool = False):
+        """sample() followed by the decode step of the reference's callers (sample_loop_generative / generate_from_conditioning,
+        generative.py:1212-1213, :1690-1691: ``permute(0, 2, 1)`` then ``argmax(dim=2)``), with the argmax taken inside the
+        last sampler update: returns (B, max_length) int64 token ids on ``device`` (and the fp32 sample if asked)."""
+        if cond_scale is None:
+            cond_scale = 7.5 if self._inverse else 1.0
+        B = sequences.shape[0]
+        tok = torch.zeros(B, self.max_length, dtype=torch.int32, device=device)
+        x = self._do_sample(sequences, device, cond_scale, timesteps, clamp, noise, tokens=tok if B else None)
+        tok = tok.long()
+        return (tok, x) if return_sample else tok
 
     def inpaint(self, sequences, device, cond_scale=7.5, timesteps=100, num_resamples=1, inpaint=None,
                 in_paint_mask=None, *, draw=None, seed=None):
@@ -295,3 +344,47 @@ class QMDiffusionForward(_QMBase):
     def sample(self, sequences, device, cond_scale=1.0, timesteps=100, clamp=False, *, noise=None, trace=None,
                timer=None):
         return self._do_sample(sequences, device, cond_scale, timesteps, clamp, noise, trace, timer)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the inverse -> forward validation chain of the reference's callers, kept on the device
+# ----------------------------------------------------------------------------------------------------------------------
+def tokens_to_forward_input(tokens: Tensor, max_length: int, X_norm_factor: float = 1.0) -> Tensor:
+    """What the reference does between the two models with strings (generative.py:1229 reverse_tokenize ->
+    predict_properties_from_SMILES :425-429 texts_to_sequences + pad_sequences(maxlen, padding='post',
+    truncating='post') / X_norm_factor), restated on token ids: id 0 is "no character" (keras' sequences_to_texts skips
+    it), so every row is compacted to its non-zero ids in order, truncated / zero-padded at the end to ``max_length`` and
+    scaled.  Assumes every id 1..pred_dim-1 is in the tokenizer's vocabulary (as produced by the one-hot training data)."""
+    tok = tokens.long()
+    B, L = tok.shape
+    keep = tok != 0
+    order = torch.argsort((~keep).to(torch.int8), dim=1, stable=True)          # non-zero ids first, original order kept
+    packed = torch.gather(tok * keep, 1, order)
+    out = torch.zeros(B, max_length, dtype=torch.float32, device=tok.device)
+    n = min(L, max_length)
+    out[:, :n] = packed[:, :n].float()
+    return out / X_norm_factor
+
+
+def predict_properties_from_tokens(model_forward: "QMDiffusionForward", tokens: Tensor, device, cond_scale: float = 1.0,
+                                   timesteps: int = 100, clamp: bool = False, X_norm_factor: float = 1.0,
+                                   context_embedding_max_length: int = 12, noise=None) -> Tensor:
+    """predict_properties_from_SMILES (generative.py:404-451) for molecules given as token ids on the device: the forward
+    model's sample() on the re-tokenised ids, first ``context_embedding_max_length`` positions = the (scaled) properties.
+    Returns (B, context_embedding_max_length) on ``device`` (the caller applies scaler.inverse_transform)."""
+    data = tokens_to_forward_input(tokens.to(device), model_forward.max_length, X_norm_factor)
+    result = model_forward.sample(data, device, cond_scale=cond_scale, timesteps=timesteps, clamp=clamp, noise=noise)
+    return result[:, 0, :context_embedding_max_length]
+
+
+def generate_and_validate(model: "QMDiffusion", model_forward: "QMDiffusionForward", conditioning: Tensor, device,
+                          cond_scale: float = 1.0, timesteps: int = 100, forward_timesteps: int = 100,
+                          X_norm_factor: float = 1.0, noise=None, forward_noise=None):
+    """generate_from_conditioning's core (generative.py:1685-1713) without leaving the GPU: sample molecules for the
+    conditioning, decode them inside the last sampler update, re-predict their properties with the forward model.
+    Returns (tokens (B, L) int64, predicted properties (B, n_cond))."""
+    tokens = model.sample_tokens(conditioning, device, cond_scale=cond_scale, timesteps=timesteps, noise=noise)
+    props = predict_properties_from_tokens(model_forward, tokens, device, cond_scale=1.0, timesteps=forward_timesteps,
+                                           X_norm_factor=X_norm_factor,
+                                           context_embedding_max_length=conditioning.shape[1], noise=forward_noise)
+    return tokens, props

@@ -12,9 +12,13 @@ from typing import Optional
 from . import build as _build
 
 N_EXT = 8
+ABI_VERSION = 2        # MDT_ABI_VERSION of include/mdt_hip.h this binding was written against
 SP_NONE, SP_WEIGHT, SP_ACT, SP_SHR, SP_EXT0 = 0, 1, 2, 3, 4
 OP_GEMM, OP_GN_STATS, OP_ATTN, OP_CONCAT, OP_PATCH, OP_TIME_EMBED, OP_TBLOCK, OP_GN_ACT, OP_RCONV = 1, 2, 3, 4, 5, 6, 7, 8, 9
 OP_RESBLOCK = 10
+OP_NAMES = {OP_GEMM: "k_gemm", OP_GN_STATS: "k_gn_stats", OP_ATTN: "k_attn", OP_CONCAT: "k_concat", OP_PATCH: "k_patch",
+            OP_TIME_EMBED: "k_time_embed", OP_TBLOCK: "k_tblock", OP_GN_ACT: "k_gn_act", OP_RCONV: "k_rconv",
+            OP_RESBLOCK: "k_resblock"}
 TB_SELF, TB_CROSS, TB_FF = 0, 1, 2
 PRO_NONE, PRO_LAYERNORM, PRO_GROUPNORM, PRO_SILU = 0, 1, 2, 3
 
@@ -62,7 +66,8 @@ SYMBOLS = {
     "mdt_precond_out": (_I, [_P, _P, _P, _F, _F, _I, _I, _I, _I, _P]),
     "mdt_cfg_mix": (_I, [_P, _P, _P, _F, _L, _P]),
     "mdt_adpm2_mid": (_I, [_P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _I, _I, _I, _P]),
-    "mdt_adpm2_next": (_I, [_P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _U64, _U32, _L, _I, _I, _I, _I, _P]),
+    "mdt_adpm2_next": (_I, [_P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _U64, _U32, _L, _I, _I, _I, _I, _P, _P]),
+    "mdt_adpm2_euler": (_I, [_P, _P, _P, _P, _P, _F, _F, _F, _I, _U64, _U32, _L, _I, _I, _I, _P]),
     "mdt_init_noise": (_I, [_P, _P, _F, _U64, _U32, _L, _I, _I, _I, _P]),
     "mdt_clamp": (_I, [_P, _F, _F, _L, _P]),
     "mdt_inpaint_merge": (_I, [_P, _P, _P, _P, _F, _U64, _U32, _L, _I, _I, _I, _P]),
@@ -87,9 +92,14 @@ def load_library(allow_build: bool = True) -> C.CDLL:
     if allow_build and not _build.is_fresh():
         try:
             _build.build_library()
-        except Exception as e:  # a stale-but-present library is still usable on a box without hipcc
-            if not os.path.exists(path):
-                raise RuntimeError(f"libmdt_hip.so is missing and could not be built: {e}") from e
+        except Exception as e:
+            # A present-but-stale library would run OLD kernels against the current op encoding (confusing launch errors,
+            # or tests passing against stale code), so it is refused unless explicitly allowed.
+            if not os.path.exists(path) or os.environ.get("MDT_ALLOW_STALE", "0") != "1":
+                raise RuntimeError(f"libmdt_hip.so is missing or older than its sources and could not be rebuilt: {e} "
+                                   "(set MDT_ALLOW_STALE=1 to load the stale library anyway)") from e
+            import warnings
+            warnings.warn(f"libmdt_hip.so is STALE (sources changed, rebuild failed: {e}); loading it because MDT_ALLOW_STALE=1")
     if not os.path.exists(path):
         raise RuntimeError("libmdt_hip.so not found; run `python -c 'import __graft_entry__ as g; g.build()'`")
     lib = C.CDLL(path)
@@ -97,8 +107,8 @@ def load_library(allow_build: bool = True) -> C.CDLL:
         fn = getattr(lib, name)   # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.mdt_abi_version() != 1:
-        raise RuntimeError("libmdt_hip.so ABI version mismatch")
+    if lib.mdt_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libmdt_hip.so ABI version {lib.mdt_abi_version()} != {ABI_VERSION} expected by this package: rebuild it")
     _lib = lib
     return lib
 

@@ -77,3 +77,35 @@ def synth_normal(name: str, shape: Tuple[int, ...]) -> torch.Tensor:
 def synth_uniform(name: str, shape: Tuple[int, ...]) -> torch.Tensor:
     n = int(np.prod(shape))
     return torch.from_numpy(_hash_uniform(name, n).astype(np.float32)).reshape(shape)
+
+
+# BASELINE.json configurations (and the small parity-test models) by name: (kind, wrapper keyword arguments)
+MODEL_CASES = {
+    "cfg1": ("inverse", dict(max_length=64, pred_dim=16, channels=64, context_embedding_max_length=12)),
+    "cfg3": ("forward", dict(max_length=64, pred_dim=1, channels=64, context_embedding_max_length=64)),
+    "tiny": ("inverse", dict(max_length=32, pred_dim=16, channels=16, context_embedding_max_length=12)),
+    "pd22": ("inverse", dict(max_length=32, pred_dim=22, channels=32, context_embedding_max_length=12)),
+    # BASELINE.json configs[4] architecture (deep U-Net): channels=256, pred_dim=32, max_len=128
+    "cfg5": ("inverse", dict(max_length=128, pred_dim=32, channels=256, context_embedding_max_length=12)),
+    # the inverse model as trained in the reference's notebook (Inverse_Diffusion.ipynb:1587-1604; 90,965,554 parameters)
+    "nb": ("inverse", dict(max_length=32, pred_dim=22, channels=128, context_embedding_max_length=12)),
+    # an AnalogDiffusionSparse-shaped U-Net (graphmodel.py:266-283: patch_size 8, attentions [1, 1], no pre-transformer)
+    "sparse": ("sparse", dict(max_length=128, pred_dim=3, channels=128, context_embedding_max_length=12)),
+}
+
+
+def make_synth_model(case: str, device=None):
+    """QMDiffusion / QMDiffusionForward of a named configuration with the deterministic synthetic weights loaded
+    (text_embed_dim=64 + embed_dim_position=64 = the 128 context features every notebook of the reference uses)."""
+    from .generative import QMDiffusion, QMDiffusionForward
+    kind, kw = MODEL_CASES[case]
+    if kind == "sparse":
+        from .modules import UNetCFG1d
+        from .netspec import sparse_unet_config
+        unet = UNetCFG1d(sparse_unet_config(kw["pred_dim"], kw["channels"], 128, kw["context_embedding_max_length"]))
+        m = QMDiffusion(text_embed_dim=64, embed_dim_position=64, unet=unet, **kw)
+    else:
+        cls = QMDiffusion if kind == "inverse" else QMDiffusionForward
+        m = cls(text_embed_dim=64, embed_dim_position=64, **kw)
+    m.load_state_dict(synth_state_dict([(k, tuple(v.shape)) for k, v in m.state_dict().items()]))
+    return m if device is None else m.to(device)

@@ -35,11 +35,5 @@ def run_both(ops, weights, act, shr, ext, B, n_shr=0):
 
 
 def make_model(case, cls_kw=None):
-    from helpers import CASES
-    from moleculediffusiontransformer_amd import QMDiffusion, QMDiffusionForward
-    kind, kw = CASES[case]
-    cls = QMDiffusion if kind == "inverse" else QMDiffusionForward
-    m = cls(text_embed_dim=64, embed_dim_position=64, **kw)
-    sd = synth_state_dict([(k, tuple(v.shape)) for k, v in m.state_dict().items()])
-    m.load_state_dict(sd)
-    return m.to(DEV)
+    from moleculediffusiontransformer_amd.synth import make_synth_model
+    return make_synth_model(case, DEV)

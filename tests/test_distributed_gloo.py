@@ -11,13 +11,21 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from moleculediffusiontransformer_amd.distributed import all_gather_samples, sample_sharded, shard_bounds
+from moleculediffusiontransformer_amd.distributed import (all_gather_samples, sample_sharded, sample_tokens_sharded,
+                                                          shard_bounds)
 
 
 def _fake_local_sample(seq, first):
     b = seq.shape[0]
     idx = torch.arange(first, first + b, dtype=torch.float32).view(b, 1, 1)
     return seq.sum(dim=1).view(b, 1, 1) + idx * torch.ones(b, 3, 8) + torch.arange(8.0).view(1, 1, 8) * 0.25
+
+
+def _fake_local_tokens(seq, first):
+    """decoded ids (b, 8) in [0, 16): a function of the global sample index only"""
+    b = seq.shape[0]
+    idx = torch.arange(first, first + b).view(b, 1)
+    return (idx * 5 + torch.arange(8).view(1, 8) * 3) % 16
 
 
 def _worker(rank, world, port, total, q):
@@ -28,7 +36,9 @@ def _worker(rank, world, port, total, q):
         out = sample_sharded(_fake_local_sample, seq)
         lo, hi = shard_bounds(total, world, rank)
         again = all_gather_samples(_fake_local_sample(seq[lo:hi], lo), total)
-        q.put((rank, out.numpy(), again.numpy()))    # by value: a tensor would travel as a shared-memory handle that
+        tok = sample_tokens_sharded(_fake_local_tokens, seq, vocab=16)     # one byte per id on the wire
+        assert tok.dtype == torch.int64
+        q.put((rank, out.numpy(), again.numpy(), tok.numpy()))    # by value: a tensor would travel as a shared-memory handle that
                                                       # dies with this process if the parent is slow to open it
     finally:
         dist.destroy_process_group()
@@ -50,8 +60,9 @@ def test_two_rank_result_equals_single_rank(total):
         assert p.exitcode == 0
     seq = torch.arange(total * 4, dtype=torch.float32).view(total, 4) * 0.01
     want = _fake_local_sample(seq, 0)
-    for rank, out, again in results:
+    for rank, out, again, tok in results:
         assert torch.equal(torch.from_numpy(out), want) and torch.equal(torch.from_numpy(again), want), rank
+        assert torch.equal(torch.from_numpy(tok), _fake_local_tokens(seq, 0)), rank
 
 
 def test_shard_bounds_cover_the_batch():

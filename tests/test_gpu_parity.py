@@ -30,7 +30,7 @@ def models(request):
     return get
 
 
-@pytest.mark.parametrize("case", ["tiny", "pd22", "cfg3", "cfg1"])
+@pytest.mark.parametrize("case", ["tiny", "pd22", "cfg3", "cfg1", "nb", "sparse"])
 def test_unet_eval_and_denoise_match_reference(models, case):
     g = load_golden(f"{case}_unet.npz")
     m = models(case)
@@ -53,6 +53,9 @@ def test_unet_eval_and_denoise_match_reference(models, case):
     ("cfg3_b2_t10", "cfg3", ()),
     ("cfg1_b2_t12_cfg7p5", "cfg1", ()),
     ("cfg1_b4_t64", "cfg1", (1, 2, 32, 63)),
+    ("nb_b2_t6", "nb", ()),              # the notebook's trained configuration (Inverse_Diffusion.ipynb:1587-1604)
+    ("nb_b2_t5_cfg2", "nb", ()),
+    ("sparse_b2_t5", "sparse", ()),      # AnalogDiffusionSparse-shaped U-Net (graphmodel.py:266-283)
 ])
 def test_sample_matches_reference(models, name, case, want):
     g = load_golden(f"{name}_sample.npz")
@@ -188,20 +191,25 @@ def test_edge_batches_single_and_empty():
 
 
 def test_bench_two_rank_logic_on_one_gpu():
-    """bench.py's N > 1 path (barriers, one all-gather per call, max-over-ranks timing, ONE JSON line from rank 0):
-    two ranks share cuda:0 over gloo (test hook MDT_BENCH_SHARE_GPU; the real thing is one rank per GPU over RCCL)."""
+    """bench.py's N > 1 path as the driver invokes it (`python bench.py --gpus 2`, no torchrun around it): the script
+    launches its own ranks as a child process, barriers, one all-gather per call, max-over-ranks timing, ONE JSON line from
+    rank 0, and the gathered rows of the last rank equal a 1-rank run of those global sample indices bit for bit.
+    Two ranks share cuda:0 over gloo here (test hook MDT_BENCH_SHARE_GPU; the real thing is one rank per GPU over RCCL)."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MDT_BENCH_SHARE_GPU="1")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
-                        "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "64", "--timesteps", "4",
-                        "--no-breakdown"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--batch", "64", "--timesteps", "4", "--no-breakdown", "--master-port", "29533"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["scaling"] == "weak" and d["value"] > 0
+    mg = d["multi_gpu"]
+    assert mg["rccl_ranks_seen"] == 2 and mg["gathered_rows"] == 128 and mg["collectives_per_step"] == 1
+    assert mg["shard_invariance"]["bitwise_equal_to_1_rank_run"] is True and mg["shard_invariance"]["rank"] == 1

@@ -1,0 +1,124 @@
+"""-m gpu: the class-surface seams around the fused loop (SURVEY section 8 b / f3): per-row time in net(x, time), per-sample
+sigmas in denoise_fn, ADPM2Sampler.step / forward with a caller-supplied fn, DiffusionSampler as a callable object, the
+decode step fused into the last update, the on-device inverse -> forward chain, the doubled guidance batch's guard."""
+import pytest
+import torch
+
+from conftest import load_golden
+from gpu_util import DEV, make_model
+from helpers import noise_fns, to_t
+from moleculediffusiontransformer_amd import (ADPM2Sampler, DiffusionSampler, KarrasSchedule, NoiseSource, QMDiffusion,
+                                              generate_and_validate, predict_properties_from_tokens)
+from moleculediffusiontransformer_amd.synth import synth_normal, synth_state_dict, synth_uniform
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("case", ["tiny", "cfg1"])
+def test_net_takes_one_time_value_per_row(case):
+    """modules.py:1228: net(x, time) with a (B,) time vector -- the golden batch uses a different time per row."""
+    g = load_golden(f"{case}_unet.npz")
+    m = make_model(case)
+    emb = m._embed(to_t(g["seq"]), DEV)
+    x, t = to_t(g["x"]).to(DEV), to_t(g["t"])
+    y = m.unet(x, t, embedding=emb, embedding_scale=1.0)
+    assert (y.cpu() - to_t(g["y_scale1"])).abs().max() < 5e-5
+    # per-sample sigmas (the training-time form of denoise_fn, diffusion.py:798-808) == one call per row
+    sig = torch.tensor([2.5, 0.7, 2.5, 0.05][: x.shape[0]])
+    d = m.diffusion.diffusion.denoise_fn(x, sigmas=sig, embedding=emb)
+    for b in range(x.shape[0]):
+        one = m.diffusion.diffusion.denoise_fn(x[b:b + 1], sigma=sig[b], embedding=emb[b:b + 1])
+        assert torch.equal(d[b:b + 1], one)
+
+
+def test_sampler_step_with_a_caller_supplied_fn_equals_the_fused_loop():
+    """ADPM2Sampler.forward(noise, fn, sigmas, num_steps) (diffusion.py:517-524) with an opaque fn runs step() per
+    iteration on mdt_adpm2_euler; with the model's own denoiser bound by DiffusionSampler it takes the fused loop.  Same
+    arithmetic in the same order: equal bit for bit, and equal to the reference's golden sample."""
+    g = load_golden("tiny_b3_t8_sample.npz")
+    m = make_model("tiny")
+    seq, T = to_t(g["seq"]), int(g["timesteps"])
+    init, step = noise_fns("tiny_b3_t8", tuple(g["out"].shape))
+    fused = m.sample(seq, DEV, cond_scale=1.0, timesteps=T, noise=NoiseSource(init=init, steps=lambda i: step(i, init)))
+    emb = m._embed(seq, DEV)
+    kd = m.diffusion.diffusion
+    calls = {"n": 0}
+
+    def fn(x, sigma):                       # an opaque callable: no `fused` attribute
+        calls["n"] += 1
+        return kd.denoise_fn(x, sigma=sigma, embedding=emb, embedding_scale=1.0)
+
+    s = ADPM2Sampler(rho=1)
+    sigmas = KarrasSchedule(0.001, 9.0, 3.0)(T)
+    x = (float(sigmas[0]) * init).to(DEV)
+    for i in range(T - 1):
+        x = s.step(x, fn, sigmas[i], sigmas[i + 1], noise=step(i, init))
+    assert calls["n"] == 2 * (T - 1)
+    assert torch.equal(x, fused)
+    assert (x.cpu() - to_t(g["out"])).abs().max() < 1e-4
+    # the object form of the reference: DiffusionSampler(diffusion, sampler=..., sigma_schedule=...)(noise, **kwargs)
+    ds = DiffusionSampler(kd, sampler=s, sigma_schedule=KarrasSchedule(0.001, 9.0, 3.0), num_steps=T, clamp=False)
+    y = ds(NoiseSource(init=init, steps=lambda i: step(i, init)), embedding=emb, embedding_scale=1.0)
+    assert torch.equal(y, fused)
+    # forward() with an opaque fn draws its step noise from torch's device generator, like diffusion.py:514
+    torch.manual_seed(5)
+    a = s(init.to(DEV), fn=fn, sigmas=sigmas, num_steps=4)
+    torch.manual_seed(5)
+    b = s(init.to(DEV), fn=fn, sigmas=sigmas, num_steps=4)
+    assert torch.equal(a, b) and torch.isfinite(a).all()
+
+
+@pytest.mark.parametrize("name,case", [("tiny_b3_t8", "tiny"), ("cfg1_b2_t12_cfg7p5", "cfg1"), ("pd22_b2_t6", "pd22")])
+def test_tokens_decoded_in_the_last_update_are_bit_exact(name, case):
+    """generative.py:1212-1213: permute(0, 2, 1) -> argmax(dim=2) of the fp32 sample == the ids written by the last
+    mdt_adpm2_next, through the Python API; also on the clamped sample (ties at +-1: first maximum)."""
+    g = load_golden(f"{name}_sample.npz")
+    m = make_model(case)
+    seq, T, cs = to_t(g["seq"]), int(g["timesteps"]), float(g["cond_scale"])
+    init, step = noise_fns(name, tuple(g["out"].shape))
+    ns = lambda: NoiseSource(init=init, steps=lambda i: step(i, init))     # noqa: E731
+    tok, x = m.sample_tokens(seq, DEV, cond_scale=cs, timesteps=T, noise=ns(), return_sample=True)
+    assert tok.dtype == torch.int64 and tok.shape == (x.shape[0], x.shape[2]) and tok.device.type == "cuda"
+    assert torch.equal(tok, torch.argmax(torch.permute(x, (0, 2, 1)), dim=2))
+    assert torch.equal(tok.cpu(), torch.argmax(torch.permute(to_t(g["out"]), (0, 2, 1)), dim=2))
+    tokc, xc = m.sample_tokens(seq, DEV, cond_scale=cs, timesteps=T, clamp=True, noise=ns(), return_sample=True)
+    assert float(xc.abs().max()) <= 1.0 and torch.equal(tokc, torch.argmax(torch.permute(xc, (0, 2, 1)), dim=2))
+
+
+def test_inverse_to_forward_chain_stays_on_the_device():
+    """generate_from_conditioning's core (generative.py:1685-1713): sample -> argmax -> re-tokenise -> forward model."""
+    inv, fwd = make_model("tiny"), make_model("cfg3")
+    cond = synth_normal("chain/cond", (4, 12))
+    tokens, props = generate_and_validate(inv, fwd, cond, DEV, cond_scale=1.0, timesteps=5, forward_timesteps=4,
+                                          X_norm_factor=16.0, noise=NoiseSource(seed=3), forward_noise=NoiseSource(seed=4))
+    assert tokens.shape == (4, 32) and props.shape == (4, 12) and props.device.type == "cuda"
+    assert torch.isfinite(props).all()
+    # the same through the two public calls
+    again = predict_properties_from_tokens(fwd, tokens, DEV, timesteps=4, X_norm_factor=16.0, noise=NoiseSource(seed=4))
+    assert torch.equal(again, props)
+
+
+def test_doubled_guidance_batch_never_straddles_a_workgroup():
+    """max_length=32, channels=64, 6 conditioning tokens: the C = 256 level has 2 tokens per sample, i.e. 16 samples per
+    32-row cross-attention workgroup.  B = 16 runs both guidance passes as one doubled batch; B = 24 would put conditional
+    and unconditional samples into one workgroup and must take the two-pass form.  Both equal the two-pass result."""
+    m = QMDiffusion(max_length=32, pred_dim=16, channels=64, context_embedding_max_length=6, text_embed_dim=64,
+                    embed_dim_position=64)
+    m.load_state_dict(synth_state_dict([(k, tuple(v.shape)) for k, v in m.state_dict().items()]))
+    m = m.to(DEV)
+    eng = m.engine(DEV, 6)
+    if not eng.has_dual:
+        pytest.skip("no doubled-batch program for this configuration")
+    assert eng.c.dual_multiple == 16
+    seq = synth_normal("dual16/seq", (32, 6))
+    run = lambda s: m.sample(s, DEV, cond_scale=3.0, timesteps=4, noise=NoiseSource(seed=21, sample0=0)).cpu()   # noqa: E731
+    d32, d16, d24 = run(seq), run(seq[:16]), run(seq[:24])
+    prog = eng.programs.pop("eval_dual")
+    try:
+        two = run(seq)
+    finally:
+        eng.programs["eval_dual"] = prog
+    assert torch.equal(d32, two) and torch.equal(d16, two[:16]) and torch.equal(d24, two[:24])
+    eng.reserve(48)
+    with pytest.raises(ValueError, match="straddle"):
+        eng.eval(dual=True)

@@ -13,7 +13,7 @@ from moleculediffusiontransformer_amd import (ADPM2Sampler, KarrasSchedule, QMDi
                                               runtime as rt)
 from moleculediffusiontransformer_amd.compiler import compile_unet
 from moleculediffusiontransformer_amd.diffusion import adpm2_plan, scale_weights
-from moleculediffusiontransformer_amd.netspec import forward_unet_config, inverse_unet_config
+from moleculediffusiontransformer_amd.netspec import forward_unet_config, inverse_unet_config, sparse_unet_config
 from oracle import unet_oracle as O
 from oracle.program_interp import Buffers, run_program
 
@@ -25,7 +25,7 @@ def test_c_abi_exports_every_declared_symbol():
     assert declared == set(rt.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.mdt_abi_version() == 1
+    assert lib.mdt_abi_version() == rt.ABI_VERSION == 2
     assert ctypes.sizeof(rt.MdtOp) == 8 + 10 * 16 + 24 * 4 + 8 * 4
     bad = rt.MdtOp()
     bad.kind = 1   # GEMM with cin == 0
@@ -80,21 +80,104 @@ def test_class_surface_and_checkpoint_layout(capsys):
     assert sum(p.numel() for p in big.parameters()) == 90965554         # Inverse_Diffusion.ipynb:1580
 
 
+def test_sparse_unet_keeps_the_reference_checkpoint_layout():
+    """QMDiffusion(unet=UNetCFG1d(sparse_unet_config(...))): same state_dict keys and parameter count as the reference's
+    AnalogDiffusionSparse(unet_type='cfg') (graphmodel.py:225-296), so its checkpoints load."""
+    from moleculediffusiontransformer_amd.synth import make_synth_model
+    g = load_golden("sparse_keys.npz")
+    m = make_synth_model("sparse")
+    assert list(m.state_dict().keys()) == list(g["keys"])
+    assert sum(p.numel() for p in m.parameters()) == int(g["nparams"])
+
+
 def test_no_cpu_fallback():
     m = QMDiffusion(max_length=32, pred_dim=16, channels=16, context_embedding_max_length=12,
                     text_embed_dim=64, embed_dim_position=64)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m.sample(torch.randn(2, 12), "cpu", cond_scale=1.0, timesteps=4)
-    with pytest.raises(NotImplementedError):
-        m(torch.randn(2, 12), torch.randn(2, 16, 32))
+    # the sampler seams need a HIP device too
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ADPM2Sampler(rho=1).step(torch.randn(2, 16, 32), lambda x, sigma: x, 1.0, 0.5)
+
+
+def test_training_loss_matches_reference_formula():
+    """QMDiffusion.forward (generative.py:812-833) -> KDiffusion_mod.forward (diffusion.py:820-844) as plain PyTorch with
+    autograd (train.py): equal to the loss assembled from the pinned oracle's denoiser on the same sigmas / noise, and every
+    parameter except the (unused at mask probability 0) FixedEmbedding receives a gradient, as in the reference."""
+    from moleculediffusiontransformer_amd.synth import make_synth_model, synth_normal, synth_uniform
+    from moleculediffusiontransformer_amd.train import conditioning_embedding, kdiffusion_loss
+    for case in ("tiny", "cfg3"):
+        kind, kw = CASES[case]
+        m = make_synth_model(case)
+        sd, cfg = synth_sd(case), oracle_cfg(case)
+        B = 3
+        seq = synth_normal(f"train/{case}/seq", (B, kw["context_embedding_max_length"]))
+        x0 = synth_normal(f"train/{case}/x0", (B, kw["pred_dim"], kw["max_length"])).clamp(-1, 1) * 0.5
+        noise = synth_normal(f"train/{case}/noise", tuple(x0.shape))
+        sigmas = (-1.2 + 1.2 * synth_normal(f"train/{case}/sig", (B,))).exp()
+        emb = conditioning_embedding(m, seq)
+        assert (emb - O.cond_embed(sd, cfg, seq)).abs().max() < 1e-6
+        loss = kdiffusion_loss(m, x0, noise, emb, sigmas=sigmas)
+        with torch.no_grad():
+            xn = x0 + sigmas.view(-1, 1, 1) * noise
+            den = torch.cat([O.denoise(sd, cfg, xn[b:b + 1], sigmas[b], O.cond_embed(sd, cfg, seq[b:b + 1])) for b in range(B)])
+            per = ((den - x0) ** 2).flatten(1).mean(1) * ((sigmas ** 2 + 0.01) * (sigmas * 0.1) ** -2)
+        assert abs(float(loss.detach()) - float(per.mean())) < 1e-4 * max(1.0, float(per.mean()))
+        loss.backward()
+        missing = [n for n, p_ in m.named_parameters() if p_.grad is None]
+        assert missing == ["unet.fixed_embedding.embedding.weight"]
+        assert all(torch.isfinite(p_.grad).all() for p_ in m.parameters() if p_.grad is not None)
+    # the public call: random sigmas / noise from the global generator, reproducible under a seed
+    torch.manual_seed(3)
+    a = m(seq, x0)
+    torch.manual_seed(3)
+    b = m(seq, x0)
+    assert a.requires_grad and torch.equal(a.detach(), b.detach())
+
+
+def test_sampler_seams_exist_with_reference_signatures():
+    """diffusion.py:347-366 (Sampler), :486-549 (ADPM2Sampler), :554-591 (DiffusionSampler), :594-625 (DiffusionInpainter),
+    :724-767 (XDiffusion_x.sample / inpaint): the mix-and-match seams of SURVEY section 8(b)."""
+    import inspect
+    from moleculediffusiontransformer_amd import DiffusionInpainter, DiffusionSampler, Sampler
+    s = ADPM2Sampler(rho=1)
+    assert isinstance(s, Sampler) and "k" in [t.alias for t in s.diffusion_types]
+    assert list(inspect.signature(s.forward).parameters) == ["noise", "fn", "sigmas", "num_steps"]
+    assert list(inspect.signature(s.step).parameters)[:4] == ["x", "fn", "sigma", "sigma_next"]
+    assert list(inspect.signature(s.inpaint).parameters) == ["source", "mask", "fn", "sigmas", "num_steps", "num_resamples"]
+    m = QMDiffusion(max_length=32, pred_dim=16, channels=16, context_embedding_max_length=12, text_embed_dim=64,
+                    embed_dim_position=64)
+    ds = DiffusionSampler(m.diffusion.diffusion, sampler=s, sigma_schedule=KarrasSchedule(0.001, 9.0, 3.0), num_steps=4,
+                          clamp=False)
+    assert ds.denoise_fn == m.diffusion.diffusion.denoise_fn
+    DiffusionInpainter(m.diffusion.diffusion, num_steps=4, num_resamples=1, sampler=s,
+                       sigma_schedule=KarrasSchedule(0.001, 9.0, 3.0))
+
+    class Other:
+        alias = "v"
+        denoise_fn = None
+    with pytest.raises(AssertionError, match="incompatible"):
+        DiffusionSampler(Other(), sampler=s, sigma_schedule=KarrasSchedule(0.001, 9.0, 3.0))
+    with pytest.raises(AssertionError, match="sigma"):
+        m.diffusion.diffusion.denoise_fn(torch.zeros(1, 16, 32), embedding=torch.zeros(1, 12, 128))
+
+
+def test_token_chain_between_the_two_models():
+    """reverse_tokenize -> texts_to_sequences -> pad_sequences(post, post) -> / X_norm_factor (generative.py:1069-1078,
+    :425-429) restated on ids: zeros dropped, order kept, padded / truncated at the end."""
+    from moleculediffusiontransformer_amd import tokens_to_forward_input
+    t = torch.tensor([[3, 0, 5, 0, 1, 7], [0, 0, 0, 2, 2, 0], [0, 0, 0, 0, 0, 0]])
+    out = tokens_to_forward_input(t, 8, 2.0)
+    assert out.tolist() == [[1.5, 2.5, 0.5, 3.5, 0, 0, 0, 0], [1.0, 1.0, 0, 0, 0, 0, 0, 0], [0.0] * 8]
+    assert tokens_to_forward_input(t, 3).tolist() == [[3.0, 5.0, 1.0], [2.0, 2.0, 0.0], [0.0, 0.0, 0.0]]
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16x3"])
-@pytest.mark.parametrize("case", ["tiny", "pd22", "cfg3", "cfg1"])
+@pytest.mark.parametrize("case", ["tiny", "pd22", "cfg3", "cfg1", "sparse"])
 def test_lowering_matches_reference_golden(case, mode):
     """compiler.py's op program, executed by the CPU interpreter, reproduces the reference U-Net output."""
     kind, kw = CASES[case]
-    mk = inverse_unet_config if kind == "inverse" else forward_unet_config
+    mk = {"inverse": inverse_unet_config, "forward": forward_unet_config, "sparse": sparse_unet_config}[kind]
     ucfg = mk(kw["pred_dim"], kw["channels"], 128, kw["context_embedding_max_length"])
     usd = {k[5:]: v for k, v in synth_sd(case).items() if k.startswith("unet.")}
     cu = compile_unet(ucfg, kw["max_length"], kw["context_embedding_max_length"], usd, max_time_rows=4,

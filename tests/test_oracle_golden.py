@@ -10,7 +10,7 @@ from oracle import unet_oracle as O
 TOL = 2e-6   # oracle and reference issue the same ATen ops; observed difference is exactly 0
 
 
-@pytest.mark.parametrize("case", ["cfg1", "cfg3", "tiny", "pd22"])
+@pytest.mark.parametrize("case", ["cfg1", "cfg3", "tiny", "pd22", "nb", "sparse"])
 def test_unet_eval_matches_reference(case):
     g = load_golden(f"{case}_unet.npz")
     sd, cfg = synth_sd(case), oracle_cfg(case)
@@ -40,6 +40,9 @@ def test_unet_eval_matches_reference(case):
     ("tiny_b3_t8", "tiny", (1, 7)),
     ("tiny_b3_t8_cfg2", "tiny", ()),
     ("pd22_b2_t6", "pd22", ()),
+    ("nb_b2_t6", "nb", ()),
+    ("nb_b2_t5_cfg2", "nb", ()),
+    ("sparse_b2_t5", "sparse", ()),
 ])
 def test_sample_matches_reference(name, case, want):
     g = load_golden(f"{name}_sample.npz")

@@ -1,5 +1,17 @@
+"""Race screen for the fused transformer sub-block kernels (run on the GPU box: python tools/tblock_repeat_probe.py).
+
+Every (mode, C, T, B) case is launched six times from identical buffers and compared with the CPU interpreter of the
+op program (oracle/program_interp.py): a ring-protocol race (a fragment read overtaking the LDS-DMA that fills its
+slot) shows up as a deviation that comes and goes between repetitions, with the offending rows / columns printed.
+History: written in round 1 while the loader-wave ring of k_tblock_lw.hip was brought up (the first version read tile
+k+1 one unit before its barrier); the shipped kernels print six equal deviations ~1e-6 for every case.
+"""
+import os
 import sys
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from gpu_util import ref, rnd, run_both
 from moleculediffusiontransformer_amd import runtime as rt
