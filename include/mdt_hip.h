@@ -77,6 +77,14 @@ enum mdt_op_kind {
                           a [B][64][cin], w = bf16 hi/lo MFMA fragments (conv1 | conv2 | to_out k-steps),
                           bias = gamma1 | beta1 | b1 | gamma2 | beta2 | (b2 + to_out bias), out [B][64][cout],
                           p3 = [scale | shift] | none                                                              */
+  MDT_OP_TF128 = 11,   /* a whole Transformer1d (modules.py:469-524) of a 128-channel level in ONE launch: to_in (GroupNorm(32) +
+                          Conv1d k=1), every TransformerBlock (self-attention, [cross-attention], feed-forward, :456-461) and
+                          to_out (folded into the last feed-forward block); the residual stream never leaves the registers.
+                          a = input [B][T][128], out = output, w = weight tile stream of all sub-blocks in consumption order
+                          (projection tiles with their K columns permuted to the accumulator layout, see k_tf128.hip),
+                          bias = every sub-block's vectors, p0 = tile descriptors (uint32 per tile: kind | aux << 2),
+                          a2 = hoisted K|V rows of the FIRST cross-attention layer (layer l at + l * KV_LSTRIDE per-sample
+                          floats), p1 = batch-invariant K|V rows for the second half of a dual batch; ints: enum mdt_tf128_i */
   MDT_OP_TBLOCK = 7    /* fused transformer sub-block, in place on x (TransformerBlock.forward, modules.py:456-461):
                           x += Attention(x) | x += Attention(x, context) | x += FeedForward(x); LayerNorm affine
                           folded into the projection weights, q/k/v/probabilities/hidden never leave registers */
@@ -171,6 +179,23 @@ enum mdt_tblock_i {
                                        (never aliasing a), p2 = second head group's partial | none (one workgroup)   */
 };
 enum mdt_tblock_f { MDT_BF_EPS = 0, MDT_BF_SCALE = 1 };
+
+/* MDT_OP_TF128 */
+enum mdt_tf128_i {
+  MDT_F_C = 0,           /* 128                                                                              */
+  MDT_F_T = 1,           /* tokens per sample (divides 16)                                                    */
+  MDT_F_NT = 2,          /* tiles in the stream (weight tiles + K / V tiles)                                  */
+  MDT_F_NVEC = 3,        /* floats of vectors (multiple of 256, <= 7168): [to_in bias 128] then per block
+                            [bq 64 heads | bo 128] (self), the same (cross), [b1 64 nff | b2 128] (feed-forward)  */
+  MDT_F_TK = 4, MDT_F_KV_BSTRIDE = 5, MDT_F_LDKV = 6, MDT_F_HEADS = 7,
+  MDT_F_HAS_IN = 8,      /* 1: starts with to_in (two projection tiles, GroupNorm gain / bias folded into them)  */
+  MDT_F_NBLOCKS = 9, MDT_F_NFF = 10 /* hidden / 64 */,
+  MDT_F_NPOST = 11,      /* 2: to_out folded into the last feed-forward block (two extra output tiles), 0: none   */
+  MDT_F_KV2 = 12,        /* 1: dual batch, as MDT_B_KV2 (first half = whole 64-row workgroups)                    */
+  MDT_F_CROSS = 13,      /* 1: the blocks have a cross-attention sub-block                                        */
+  MDT_F_KV_LSTRIDE = 14  /* per-sample floats between consecutive cross layers' K|V rows                         */
+};
+enum mdt_tf128_f { MDT_FF_EPS_LN = 0, MDT_FF_SCALE = 1, MDT_FF_EPS_GN = 2 };
 
 typedef struct mdt_op {
   int32_t kind;

@@ -125,6 +125,18 @@ static const char* validate(const mdt_op& o, int idx, char* buf, size_t nbuf) {
         return bad("variant 2 (32-row workgroups) serves C = 256, cross blocks with at most 48 keys per 16 rows");
       break;
     }
+    case MDT_OP_TF128: {
+      const int32_t* i = o.i;
+      if (i[MDT_F_C] != 128) return bad("fused transformer needs C = 128");
+      if (!mdt::tf128_supported(i[MDT_F_T], i[MDT_F_TK], i[MDT_F_NVEC], i[MDT_F_CROSS] != 0))
+        return bad("shape not supported by the fused transformer (tokens per sample must divide 16, <= 16 context rows per 16 tokens, <= 7168 vector floats)");
+      if (i[MDT_F_NBLOCKS] <= 0 || i[MDT_F_NT] <= 0 || i[MDT_F_HEADS] <= 0 || i[MDT_F_HEADS] > 16 || i[MDT_F_NFF] <= 0)
+        return bad("bad block / tile / head counts");
+      if (i[MDT_F_NPOST] != 0 && i[MDT_F_NPOST] != 2) return bad("npost must be 0 or 2");
+      if (!o.a.space || !o.out.space || !o.w.space || !o.bias.space || !o.p0.space) return bad("missing operand");
+      if (i[MDT_F_CROSS] && !o.a2.space) return bad("cross-attention blocks need the hoisted K/V rows");
+      break;
+    }
     default:
       return bad("unknown op kind");
   }
@@ -290,6 +302,29 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
           e = o.i[MDT_B_VARIANT] >= 2   ? mdt::launch_tblock32(a, stream)
               : o.i[MDT_B_VARIANT] == 1 ? mdt::launch_tblock16(a, stream)
                                         : mdt::launch_tblock(a, stream);
+        break;
+      }
+      case MDT_OP_TF128: {
+        const int32_t* i = o.i;
+        mdt::TFArgs a;
+        a.x = ptr(o.a); a.out = ptr(o.out); a.w = ptr(o.w); a.vec = ptr(o.bias);
+        a.tiles = reinterpret_cast<const unsigned*>(ptr(o.p0));
+        a.kv = i[MDT_F_CROSS] ? ptr(o.a2) : nullptr;
+        a.kv2 = i[MDT_F_KV2] ? ptr(o.p1) : nullptr;
+        a.dbgbuf = nullptr;
+        a.T = i[MDT_F_T]; a.M = B * a.T; a.NT = i[MDT_F_NT]; a.nvec = i[MDT_F_NVEC]; a.Tk = i[MDT_F_TK];
+        a.kv_bstride = i[MDT_F_KV_BSTRIDE]; a.ldkv = i[MDT_F_LDKV]; a.nheads = i[MDT_F_HEADS]; a.nsamples = B;
+        a.has_in = i[MDT_F_HAS_IN]; a.nblocks = i[MDT_F_NBLOCKS]; a.nff = i[MDT_F_NFF]; a.npost = i[MDT_F_NPOST];
+        // K|V rows of consecutive cross layers: per-sample arena -> scaled by B; shared arena (fixed embedding) -> as is
+        a.kv_lstride = (int64_t)i[MDT_F_KV_LSTRIDE] * (o.a2.space == MDT_SP_ACT ? B : 1);
+        a.kv2_lstride = (int64_t)i[MDT_F_KV_LSTRIDE] * (o.p1.space == MDT_SP_ACT ? B : 1);
+        a.eps_ln = o.f[MDT_FF_EPS_LN]; a.scale = o.f[MDT_FF_SCALE]; a.eps_gn = o.f[MDT_FF_EPS_GN];
+        if (i[MDT_F_KV2]) {
+          const int per_wg = 64 / a.T;
+          if (!o.p1.space || B % 2 || (B / 2) % (per_wg > 0 ? per_wg : 1))
+            return fail("mdt_program_run: a dual-batch fused transformer needs the shared K/V rows and B = 2 x (a multiple of the samples per workgroup)");
+        }
+        if (!missing) e = mdt::launch_tf128(a, stream);
         break;
       }
       case MDT_OP_TIME_EMBED: {

@@ -130,6 +130,29 @@ hipError_t launch_tblock_lw(const TBlockArgs& a, hipStream_t s);
 hipError_t launch_tblock32(const TBlockArgs& a, hipStream_t s);   // 32-row workgroups, C = 256, sub-tile stream (k_tblock32.hip)
 hipError_t launch_tblock16(const TBlockArgs& a, hipStream_t s);   // 16-row workgroups, waves split the features (k_tblock16.hip)
 
+// MDT_OP_TF128 (k_tf128.hip): a whole Transformer1d of a C = 128 level in one launch
+struct TFArgs {
+  const float* x;        // [M][128] transformer input
+  float* out;            // [M][128] transformer output (may alias x: rows are read before the first store of the same wave)
+  const float* w;        // weight tile stream of every segment (32 KB tiles: bf16 hi plane + lo plane), consumption order
+  const float* vec;      // vectors, nvec floats, staged into LDS: [to_in bias 128] then per block [bq 64 heads | bo 128] (self),
+                         // the same (cross), [b1 64 nff | b2 128] (feed-forward)
+  const unsigned* tiles; // per tile: kind (0 projection, 1 output, 2 K rows, 3 V rows) | aux << 2; aux = index into the
+                         // weight stream, or (cross layer << 4 | head) for K / V tiles
+  const float* kv;       // hoisted K | V rows of this transformer's first cross layer [sample][Tk][ldkv]; layer l at + l * kv_lstride
+  const float* kv2;      // dual batch: batch-invariant K | V rows of the second half of the samples (layer stride kv2_lstride)
+  const float* dbgbuf;
+  int64_t kv_lstride, kv2_lstride;
+  int M, T, NT, nvec, Tk, kv_bstride, ldkv, nheads, nsamples;
+  int has_in;            // 1: the stream starts with GroupNorm(32) + Conv1d(k = 1) (Transformer1d.to_in, 2 projection tiles)
+  int nblocks;           // TransformerBlocks: self-attention, cross-attention (iff kv), feed-forward each
+  int nff;               // hidden chunks of 64 of the feed-forward blocks
+  int npost;             // 2: Transformer1d.to_out folded into the LAST feed-forward block (two extra output tiles), 0: none
+  float eps_ln, eps_gn, scale;
+};
+bool tf128_supported(int T, int Tk, int nvec, bool cross);
+hipError_t launch_tf128(const TFArgs& a, hipStream_t s);
+
 hipError_t launch_concat(const float* a, const float* b, float* out, int64_t rows, int ca, int cb, float scale_b,
                          hipStream_t s);
 hipError_t launch_patch(const float* in, float* out, int batch, int rows_in, int c_in, int ld_in, int ld_out,

@@ -89,7 +89,7 @@ class XDiffusion_x(nn.Module):
         """diffusion.py:744-767: builds a DiffusionInpainter and calls it."""
         inpainter = DiffusionInpainter(diffusion=self.diffusion, sampler=sampler, sigma_schedule=sigma_schedule,
                                        num_steps=num_steps, num_resamples=num_resamples)
-        return inpainter(inpaint, inpaint_mask, **kwargs)
+        return inpainter(inpaint, in_paint_mask, **kwargs)
 
 
 class _FusedLoop:

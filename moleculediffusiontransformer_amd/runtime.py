@@ -16,9 +16,10 @@ ABI_VERSION = 2        # MDT_ABI_VERSION of include/mdt_hip.h this binding was w
 SP_NONE, SP_WEIGHT, SP_ACT, SP_SHR, SP_EXT0 = 0, 1, 2, 3, 4
 OP_GEMM, OP_GN_STATS, OP_ATTN, OP_CONCAT, OP_PATCH, OP_TIME_EMBED, OP_TBLOCK, OP_GN_ACT, OP_RCONV = 1, 2, 3, 4, 5, 6, 7, 8, 9
 OP_RESBLOCK = 10
+OP_TF128 = 11
 OP_NAMES = {OP_GEMM: "k_gemm", OP_GN_STATS: "k_gn_stats", OP_ATTN: "k_attn", OP_CONCAT: "k_concat", OP_PATCH: "k_patch",
             OP_TIME_EMBED: "k_time_embed", OP_TBLOCK: "k_tblock", OP_GN_ACT: "k_gn_act", OP_RCONV: "k_rconv",
-            OP_RESBLOCK: "k_resblock"}
+            OP_RESBLOCK: "k_resblock", OP_TF128: "k_tf128"}
 TB_SELF, TB_CROSS, TB_FF = 0, 1, 2
 PRO_NONE, PRO_LAYERNORM, PRO_GROUPNORM, PRO_SILU = 0, 1, 2, 3
 
@@ -34,6 +35,9 @@ R_T, R_C, R_LDA, R_LDC, R_LDR, R_TAPS, R_GSIZE, R_SILU, R_FILM_LD, R_LDA2 = rang
 K_T, K_CIN, K_COUT, K_FILM_LD = range(4)
 B_MODE, B_C, B_T, B_NCHUNK, B_NBIAS, B_TK, B_KV_BSTRIDE, B_LDKV, B_HEADS, B_VARIANT, B_POST = range(11)
 B_KV2 = 11
+# MDT_OP_TF128 (enum mdt_tf128_i)
+(F_C, F_T, F_NT, F_NVEC, F_TK, F_KV_BSTRIDE, F_LDKV, F_HEADS, F_HAS_IN, F_NBLOCKS, F_NFF, F_NPOST, F_KV2, F_CROSS,
+ F_KV_LSTRIDE) = range(15)
 
 
 class MdtRef(C.Structure):

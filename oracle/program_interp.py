@@ -168,6 +168,8 @@ def run_program(ops, bufs: Buffers, B: int, n_shared_rows: int = 0) -> None:
             out[:, 1 + half: 1 + 2 * half] = fr.cos()
         elif op.kind == rt.OP_TBLOCK:
             _tblock(op, bufs, B)
+        elif op.kind == rt.OP_TF128:
+            _tf128(op, bufs, B)
         else:
             raise ValueError(f"unknown op kind {op.kind}")
 
@@ -345,3 +347,103 @@ def _tblock(op, bufs: Buffers, B: int) -> None:
     sim = (q @ k.transpose(-1, -2)) * float(f[1])
     o = (sim.softmax(-1) @ v).transpose(1, 2).reshape(B, T, H * D)
     finish(o, outw(), bo)
+
+
+_ACC_PERM = [16 * (2 * (k >> 5) + ((k & 7) >> 2)) + 4 * ((k >> 3) & 3) + (k & 3) for k in range(128)]
+
+
+def _tf128(op, bufs: Buffers, B: int) -> None:
+    """MDT_OP_TF128 semantics (include/mdt_hip.h): a whole Transformer1d of a 128-channel level, reconstructed from the tile
+    stream by following the tile descriptors (projection tiles: K columns in accumulator order; output tiles: slot order)."""
+    i, f = op.i, op.f
+    C, T, NT, nvec = i[rt.F_C], i[rt.F_T], i[rt.F_NT], i[rt.F_NVEC]
+    Tk, bs, ldkv, H = i[rt.F_TK], i[rt.F_KV_BSTRIDE], i[rt.F_LDKV], i[rt.F_HEADS]
+    nblocks, nff, npost, cross = i[rt.F_NBLOCKS], i[rt.F_NFF], i[rt.F_NPOST], bool(i[rt.F_CROSS])
+    desc = bufs.view(op.p0, B, NT).contiguous().view(torch.int32).tolist()
+    nw = sum(1 for d in desc if (d & 3) < 2)
+    stream = bufs.view(op.w, B, nw * 64 * C)
+    vec = bufs.view(op.bias, B, nvec)
+    inv_acc = torch.empty(128, dtype=torch.long)
+    inv_acc[torch.tensor(_ACC_PERM)] = torch.arange(128)
+    inv_slot = torch.empty(64, dtype=torch.long)
+    inv_slot[torch.tensor(_SLOT_PERM)] = torch.arange(64)
+    cur = {"t": 0, "v": 0}
+
+    def P():                       # next projection tile -> [64, C] in natural K order
+        d = desc[cur["t"]]
+        cur["t"] += 1
+        assert d & 3 == 0, "expected a projection tile"
+        return _untile(stream, d >> 2, 64, C)[:, inv_acc]
+
+    def O(natural_from: Optional[int] = None):     # next output tile -> [C, 64]
+        d = desc[cur["t"]]
+        cur["t"] += 1
+        assert d & 3 == 1, "expected an output tile"
+        t = _untile(stream, d >> 2, C, 64)
+        if natural_from is None:
+            return t[:, inv_slot]
+        cols = torch.tensor(_ACC_PERM[natural_from: natural_from + 64]) - natural_from     # accumulator order inside the chunk
+        inv = torch.empty(64, dtype=torch.long)
+        inv[cols] = torch.arange(64)
+        return t[:, inv]
+
+    def KV(kind, layer, h):
+        d = desc[cur["t"]]
+        cur["t"] += 1
+        assert d & 3 == kind and (d >> 2) == (layer << 4 | h), "K / V tile descriptor out of order"
+
+    def V(n):
+        out = vec[cur["v"]: cur["v"] + n]
+        cur["v"] += n
+        return out
+
+    x = bufs.view(op.a, B, B * T * C).view(B, T, C)
+    if i[rt.F_HAS_IN]:
+        xn = F.group_norm(x.transpose(1, 2), 32, None, None, eps=float(f[2])).transpose(1, 2)
+        w = torch.cat([P() for _ in range(C // 64)])
+        x = xn @ w.T + V(C)
+    mid, D = 64 * H, 64
+    for blk in range(nblocks):
+        xn = F.layer_norm(x, (C,), None, None, eps=float(f[0]))
+        wq, wk, wv, wo = [], [], [], []
+        for h in range(H):
+            wq.append(P()), wk.append(P()), wv.append(P()), wo.append(O())
+        bq, bo = V(mid), V(C)
+        q = (xn @ torch.cat(wq).T + bq).view(B, T, H, D).transpose(1, 2)
+        k = (xn @ torch.cat(wk).T).view(B, T, H, D).transpose(1, 2)
+        v = (xn @ torch.cat(wv).T).view(B, T, H, D).transpose(1, 2)
+        o = (((q @ k.transpose(-1, -2)) * float(f[1])).softmax(-1) @ v).transpose(1, 2).reshape(B, T, mid)
+        x = x + o @ torch.cat(wo, dim=1).T + bo
+        if cross:
+            xn = F.layer_norm(x, (C,), None, None, eps=float(f[0]))
+            wq, wo = [], []
+            for h in range(H):
+                wq.append(P()), KV(2, blk, h), KV(3, blk, h), wo.append(O())
+            bq, bo = V(mid), V(C)
+            lstride = i[rt.F_KV_LSTRIDE]
+            if bs == 0:
+                base = bufs.view(op.a2, B, (blk + 1) * lstride)[blk * lstride:]
+                kv = base[: Tk * ldkv].view(1, Tk, ldkv).expand(B, -1, -1)
+            else:
+                base = bufs.view(op.a2, B, (blk + 1) * lstride * B)[blk * lstride * B:]
+                kv = base.view(B, Tk, ldkv)
+            if i[rt.F_KV2]:
+                kvf = bufs.view(op.p1, B, (blk + 1) * lstride)[blk * lstride:][: Tk * ldkv].view(1, Tk, ldkv)
+                kv = torch.cat([kv[: B // 2], kvf.expand(B - B // 2, -1, -1)])
+            q = (xn @ torch.cat(wq).T + bq).view(B, T, H, D).transpose(1, 2)
+            k = kv[:, :, :mid].reshape(B, Tk, H, D).transpose(1, 2)
+            v = kv[:, :, mid: 2 * mid].reshape(B, Tk, H, D).transpose(1, 2)
+            o = (((q @ k.transpose(-1, -2)) * float(f[1])).softmax(-1) @ v).transpose(1, 2).reshape(B, T, mid)
+            x = x + o @ torch.cat(wo, dim=1).T + bo
+        w1, w2 = [], []
+        for h in range(nff):
+            w1.append(P()), w2.append(O())
+        b1, b2 = V(64 * nff), V(C)
+        hdn = F.gelu(x @ torch.cat(w1).T + b1)
+        if blk == nblocks - 1 and npost:
+            wout = torch.cat([O(natural_from=64 * e) for e in range(npost)], dim=1)
+            x = hdn @ torch.cat(w2, dim=1).T + x @ wout.T + b2
+        else:
+            x = x + hdn @ torch.cat(w2, dim=1).T + b2
+    assert cur["t"] == NT, (cur["t"], NT)
+    bufs.view(op.out, B, B * T * C).view(B, T, C)[:] = x

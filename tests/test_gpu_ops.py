@@ -222,7 +222,7 @@ def test_sampler_kernels_match_reference_arithmetic():
         assert float(xin_mid[:, :, C:].abs().max()) == 0.0
         x2 = gx.clone()
         rt.check(lib.mdt_adpm2_next(rt.ptr(x2), rt.ptr(gxm), rt.ptr(gp), rt.ptr(gnz), rt.ptr(xin_mid), c_skip, c_out,
-                                    sigma_mid, dt_down, up, c_in, 0, 0, 0, B, C, L, Cp, st))
+                                    sigma_mid, dt_down, up, c_in, 0, 0, 0, B, C, L, Cp, 0, st))
         den2 = (c_skip * xm + c_out * p).clamp(-1.0, 1.0)
         want = x + ((xm - den2) / torch.tensor(sigma_mid)) * torch.tensor(dt_down)
         want = want + nz * torch.tensor(up)
@@ -564,3 +564,100 @@ def test_chained_split_sub_block(mode, split, with_pin, T, B):
         assert (pg - pc).abs().max() < 1e-4 * max(1.0, pc.abs().max().item()) and pc.abs().max() > 0
     assert torch.equal(ga[: lo], ca[: lo])              # x and K/V untouched
     assert torch.equal(ga[lo + B * n_x: lo + 2 * B * n_x], ca[lo + B * n_x: lo + 2 * B * n_x])   # p_in untouched
+
+
+def _transformer_sd(p, C, layers, cross, ctx=128, mid=512, seed0=100):
+    """Random Transformer1d parameters with the reference's key names (modules.py:469-524)."""
+    k = [seed0]
+
+    def r(*shape, scale=1.0):
+        k[0] += 1
+        return rnd(*shape, seed=k[0], scale=scale)
+    sd = {p + "to_in.0.weight": 1 + 0.2 * r(C), p + "to_in.0.bias": 0.2 * r(C),
+          p + "to_in.1.weight": r(C, C, 1, scale=C ** -0.5), p + "to_in.1.bias": 0.1 * r(C),
+          p + "to_out.1.weight": r(C, C, 1, scale=C ** -0.5), p + "to_out.1.bias": 0.1 * r(C)}
+    for li in range(layers):
+        for name, cf in (("attention.", C),) + ((("cross_attention.", ctx),) if cross else ()):
+            q = p + f"blocks.{li}." + name
+            sd.update({q + "norm.weight": 1 + 0.2 * r(C), q + "norm.bias": 0.2 * r(C),
+                       q + "norm_context.weight": 1 + 0.2 * r(cf), q + "norm_context.bias": 0.2 * r(cf),
+                       q + "to_q.weight": r(mid, C, scale=C ** -0.5), q + "to_kv.weight": r(2 * mid, cf, scale=cf ** -0.5),
+                       q + "attention.to_out.weight": r(C, mid, scale=mid ** -0.5), q + "attention.to_out.bias": 0.1 * r(C)})
+        q = p + f"blocks.{li}.feed_forward."
+        sd.update({q + "0.weight": r(2 * C, C, scale=C ** -0.5), q + "0.bias": 0.1 * r(2 * C),
+                   q + "2.weight": r(C, 2 * C, scale=(2 * C) ** -0.5), q + "2.bias": 0.1 * r(C)})
+    return sd
+
+
+@pytest.mark.parametrize("T,B,layers,cross,fixed", [(16, 5, 2, False, False), (16, 70, 4, True, False), (4, 16, 2, False, False),
+                                                    (16, 3, 2, True, True), (8, 9, 1, False, False), (2, 33, 1, False, False),
+                                                    (16, 1030, 1, True, False)])
+def test_fused_transformer_128(T, B, layers, cross, fixed):
+    """MDT_OP_TF128 (k_tf128.hip): a whole Transformer1d of a 128-channel level in one launch, against (i) the CPU
+    interpreter of the op (tile order, K-column permutation to the accumulator layout, vector layout) and (ii) the
+    reference's module arithmetic written out with torch ops (modules.py:469-524, :401-410, :350-364, :314-320)."""
+    from moleculediffusiontransformer_amd.compiler import Ten, UNetCompiler
+    from moleculediffusiontransformer_amd.netspec import inverse_unet_config
+    import torch.nn.functional as F
+    C, n_ctx, mid, H = 128, 12, 512, 8
+    cfg = inverse_unet_config(16, 64, 128, n_ctx)
+    p = "tf."
+    sd = _transformer_sd(p, C, layers, cross)
+    comp = UNetCompiler(cfg, 64, n_ctx, sd)
+    if not comp.tf128_ok(C, T, layers, cross):
+        pytest.skip("shape outside the fused transformer's envelope")
+    x = Ten(A, 0, T, C)
+    y = comp.transformer(x, p, C, layers, cross, free_input=False)
+    assert [o.kind for o in comp.ops] == [rt.OP_TF128]
+    op = comp.ops[0]
+    kv_floats = n_ctx * 2 * mid
+    act_x = rnd(B * T * C, seed=13) * 1.5 + 0.3
+    kv_all = rnd(layers * B * kv_floats, seed=14) if cross else torch.zeros(0)
+    shr = rnd(layers * kv_floats, seed=15) if cross else torch.zeros(4)
+    # per-sample arena: [x | y | K/V layer 0 | K/V layer 1 ...]
+    op.out = ref(A, T * C)
+    if cross:
+        if fixed:
+            op.a2 = ref(S, 0)
+            op.i[rt.F_KV_BSTRIDE] = 0
+        else:
+            op.a2 = ref(A, 2 * T * C)
+    act = torch.cat([act_x, torch.zeros(B * T * C), kv_all])
+    (ga, _, _), (ca, _, _) = run_both([op], comp.W.pack(), act, shr, {}, B)
+    yg, yc = ga[B * T * C: 2 * B * T * C].view(B, T, C), ca[B * T * C: 2 * B * T * C].view(B, T, C)
+    assert torch.isfinite(yg).all()
+    tol = 2e-4 * max(1.0, yc.abs().max().item())
+    assert (yg - yc).abs().max() < tol, (yg - yc).abs().max().item()
+    assert torch.equal(ga[: B * T * C], act_x) and torch.equal(ga[2 * B * T * C:], kv_all)     # inputs untouched
+
+    # (ii) the module arithmetic, independent of the packing
+    def attn(q_, x_, ctx, kv=None):
+        xn = F.layer_norm(x_, (C,), sd[q_ + "norm.weight"], sd[q_ + "norm.bias"], 1e-5)
+        qq = (xn @ sd[q_ + "to_q.weight"].T).view(B, T, H, 64).transpose(1, 2)
+        if kv is None:
+            cn = F.layer_norm(ctx, (ctx.shape[-1],), sd[q_ + "norm_context.weight"], sd[q_ + "norm_context.bias"], 1e-5)
+            kv = cn @ sd[q_ + "to_kv.weight"].T
+        k_, v_ = kv.chunk(2, dim=-1)
+        k_ = k_.reshape(B, -1, H, 64).transpose(1, 2)
+        v_ = v_.reshape(B, -1, H, 64).transpose(1, 2)
+        o = ((qq @ k_.transpose(-1, -2)) * 0.125).softmax(-1) @ v_
+        return o.transpose(1, 2).reshape(B, T, mid) @ sd[q_ + "attention.to_out.weight"].T + sd[q_ + "attention.to_out.bias"]
+    xt = act_x.view(B, T, C)
+    h = F.group_norm(xt.transpose(1, 2), 32, sd[p + "to_in.0.weight"], sd[p + "to_in.0.bias"], 1e-6)
+    h = F.conv1d(h, sd[p + "to_in.1.weight"], sd[p + "to_in.1.bias"]).transpose(1, 2)
+    for li in range(layers):
+        bp = p + f"blocks.{li}."
+        h = h + attn(bp + "attention.", h, h)
+        if cross:
+            if fixed:
+                kv = shr[li * kv_floats: (li + 1) * kv_floats].view(1, n_ctx, 2 * mid).expand(B, -1, -1)
+            else:
+                kv = kv_all[li * B * kv_floats: (li + 1) * B * kv_floats].view(B, n_ctx, 2 * mid)
+            h = h + attn(bp + "cross_attention.", h, None, kv)
+        f_ = bp + "feed_forward."
+        h = h + F.gelu(h @ sd[f_ + "0.weight"].T + sd[f_ + "0.bias"]) @ sd[f_ + "2.weight"].T + sd[f_ + "2.bias"]
+    want = F.conv1d(h.transpose(1, 2), sd[p + "to_out.1.weight"], sd[p + "to_out.1.bias"]).transpose(1, 2)
+    assert (yg - want).abs().max() < tol, (yg - want).abs().max().item()
+    # same launch again from the same buffers: the ring protocol has no race that a second run would expose differently
+    (ga2, _, _), _ = run_both([op], comp.W.pack(), act, shr, {}, B)
+    assert torch.equal(ga2, ga)
