@@ -85,6 +85,13 @@ enum mdt_op_kind {
                           bias = every sub-block's vectors, p0 = tile descriptors (uint32 per tile: kind | aux << 2),
                           a2 = hoisted K|V rows of the FIRST cross-attention layer (layer l at + l * KV_LSTRIDE per-sample
                           floats), p1 = batch-invariant K|V rows for the second half of a dual batch; ints: enum mdt_tf128_i */
+  MDT_OP_TF256 = 12,   /* the same for a 256-channel level (32-row workgroups whose wave pairs split every chunk's features; the pair's
+                          partial sums meet in scratch tiles of the ring).  Stream differences: 32 KB SUB-tiles (a [64][256]
+                          projection tile = its two K halves, a [256][64] output tile = its two row halves), descriptors
+                          kind (3 bits: 0 projection, 1 output, 2 K rows, 3 V rows, 4 scratch, 5 scratch + vectors of the next
+                          sub-block) | aux << 3, two scratch descriptors after every sub-block; vectors: 768 floats per
+                          sub-block ([bias 256] / [bq 512 | bo 256] / [b1 512 | b2 256]); NPOST = 8 sub-tiles; ints and
+                          floats as MDT_OP_TF128 with C = 256                                                     */
   MDT_OP_TBLOCK = 7    /* fused transformer sub-block, in place on x (TransformerBlock.forward, modules.py:456-461):
                           x += Attention(x) | x += Attention(x, context) | x += FeedForward(x); LayerNorm affine
                           folded into the projection weights, q/k/v/probabilities/hidden never leave registers */

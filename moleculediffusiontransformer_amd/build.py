@@ -27,6 +27,7 @@ SOURCES = [
     ("k_tblock_lw.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("k_tblock32.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("k_tf128.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
+    ("k_tf256.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("k_rconv.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("k_resblock.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("k_norm.hip", []),

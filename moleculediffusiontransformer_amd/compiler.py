@@ -154,6 +154,7 @@ class UNetCompiler:
         self.fuse_cross = os.environ.get("MDT_FUSE_CROSS", "1")
         self.use_gn_act = os.environ.get("MDT_GN_ACT", "1") == "1"
         self.tf128 = os.environ.get("MDT_TF128", "1") == "1"         # a whole C = 128 Transformer1d as ONE launch (k_tf128)
+        self.tf256 = os.environ.get("MDT_TF256", "1") == "1"         # ... and a whole C = 256 one (k_tf256, 32-row workgroups)
         if gemm_mode not in ("f32", "bf16x3"):
             raise ValueError("gemm_mode must be 'f32' (exact fp32 MFMA) or 'bf16x3' (split-bf16 MFMA)")
         self.gemm_mode = gemm_mode
@@ -808,6 +809,129 @@ class UNetCompiler:
             self._free(x)
         return y
 
+    def tf256_ok(self, c: int, rows: int, layers: int, cross: bool) -> bool:
+        if not (self.tf256 and self.gemm_mode == "bf16x3" and self.fuse_blocks and self.fold_out):
+            return False
+        if c != 256 or rows > 16 or 16 % rows or self.cfg.head_features != 64 or layers < 1:
+            return False
+        if self.cfg.mid_features != 512 or c * self.cfg.ff_mult != 512:
+            return False
+        return not (cross and (16 // rows) * self.n_ctx > 48)
+
+    def transformer_fused256(self, x: Ten, p: str, c: int, layers: int, cross: bool, free_input: bool) -> Ten:
+        """Transformer1d.forward (modules.py:519-524) of a 256-channel level as ONE MDT_OP_TF256 (csrc/k_tf256.hip): 32 KB
+        sub-tiles in consumption order, two scratch descriptors behind every sub-block (the wave pairs' partial sums meet
+        there; the first one carries the next sub-block's vectors), K columns of residual-stream consumers in accumulator
+        order."""
+        cfg, sd = self.cfg, self.sd
+        rows, mid = x.rows, cfg.mid_features
+        heads, nff = mid // 64, c * cfg.ff_mult // 64
+        acc = torch.tensor([16 * (2 * (k >> 5) + ((k & 7) >> 2)) + 4 * ((k >> 3) & 3) + (k & 3) for k in range(c)])
+        slot = torch.tensor(self._SLOT_PERM)
+        P, O, K, V, SCR, SCRV = 0, 1, 2, 3, 4, 5
+        tiles: List[torch.Tensor] = []
+        desc: List[int] = []
+        vecs: List[torch.Tensor] = []
+
+        def sub(t: torch.Tensor, kind: int) -> None:
+            desc.append(kind | (len(tiles) << 3))
+            tiles.append(self._tile(t))
+
+        def ptile(w: torch.Tensor) -> None:                  # [64][256] projection tile -> its two K halves
+            wp = w[:, acc]
+            sub(wp[:, :128], P)
+            sub(wp[:, 128:], P)
+
+        def otile(w: torch.Tensor) -> None:                  # [256][64] output tile -> its two row halves
+            sub(w[:128], O)
+            sub(w[128:], O)
+
+        def end_subblock(v: List[torch.Tensor], last: bool = False) -> None:
+            flat = torch.cat([t.float().reshape(-1) for t in v])
+            assert flat.numel() <= 768
+            vecs.append(torch.cat([flat, torch.zeros(768 - flat.numel())]))
+            nxt = len(vecs)                                  # index of the next sub-block's vectors
+            desc.append(SCR if last else (SCRV | ((((768 * nxt) // 256) << 1 | (nxt & 1)) << 3)))
+            desc.append(SCR)
+
+        g_in, b_in = sd[p + "to_in.0.weight"].double(), sd[p + "to_in.0.bias"].double()
+        w_in = sd[p + "to_in.1.weight"].reshape(c, c).double()
+        w_in_f = (w_in * g_in.unsqueeze(0)).float()
+        for ch in range(c // 64):
+            ptile(w_in_f[64 * ch: 64 * ch + 64])
+        end_subblock([(w_in @ b_in + sd[p + "to_in.1.bias"].double()).float()])
+        self.flops += 2 * rows * c * c
+        cross0 = len(self.cross_layers)
+        for li in range(layers):
+            bp = p + f"blocks.{li}."
+            ap = bp + "attention."
+            g_q, b_q = sd[ap + "norm.weight"], sd[ap + "norm.bias"]
+            g_c, b_c = sd[ap + "norm_context.weight"], sd[ap + "norm_context.bias"]
+            wq, wkv = sd[ap + "to_q.weight"], sd[ap + "to_kv.weight"]
+            wo, bo = sd[ap + "attention.to_out.weight"], sd[ap + "attention.to_out.bias"]
+            wq_f, bq_f = wq * g_q.unsqueeze(0), wq @ b_q
+            wkv_f, bkv_f = wkv * g_c.unsqueeze(0), wkv @ b_c
+            for h in range(heads):
+                ptile(wq_f[64 * h: 64 * h + 64])
+                ptile(wkv_f[64 * h: 64 * h + 64])
+                ptile(wkv_f[mid + 64 * h: mid + 64 * h + 64])
+                otile(wo[:, 64 * h: 64 * h + 64][:, slot])
+            end_subblock([bq_f, bo + wo @ bkv_f[mid:]])
+            self.flops += 2 * rows * c * 3 * mid + 4 * rows * rows * mid + 2 * rows * mid * c
+            if cross:
+                cp = bp + "cross_attention."
+                self.cross_layers.append(cp)
+                layer = len(self.cross_layers) - 1 - cross0
+                g_q, b_q = sd[cp + "norm.weight"], sd[cp + "norm.bias"]
+                wq = sd[cp + "to_q.weight"]
+                wo, bo = sd[cp + "attention.to_out.weight"], sd[cp + "attention.to_out.bias"]
+                wq_f, bq_f = wq * g_q.unsqueeze(0), wq @ b_q
+                for h in range(heads):
+                    ptile(wq_f[64 * h: 64 * h + 64])
+                    desc.append(K | ((layer << 4 | h) << 3))
+                    desc.append(V | ((layer << 4 | h) << 3))
+                    otile(wo[:, 64 * h: 64 * h + 64][:, slot])
+                end_subblock([bq_f, bo])
+                self.flops += 2 * rows * c * mid + 4 * rows * self.n_ctx * mid + 2 * rows * mid * c
+            fp = bp + "feed_forward."
+            w1, b1 = sd[fp + "0.weight"], sd[fp + "0.bias"]
+            w2, b2 = sd[fp + "2.weight"], sd[fp + "2.bias"]
+            last = li == layers - 1
+            if last:
+                wout, bout = sd[p + "to_out.1.weight"].reshape(c, c).double(), sd[p + "to_out.1.bias"].double()
+                w2, b2 = (wout @ w2.double()).float(), (wout @ b2.double() + bout).float()
+            for h in range(nff):
+                ptile(w1[64 * h: 64 * h + 64])
+                otile(w2[:, 64 * h: 64 * h + 64][:, slot])
+            if last:
+                wout_f = sd[p + "to_out.1.weight"].reshape(c, c)
+                for e in range(c // 64):
+                    otile(wout_f[:, acc[64 * e: 64 * e + 64]])
+                self.flops += 2 * rows * c * c
+            end_subblock([b1, b2], last=last)
+            self.flops += 2 * 2 * rows * c * w1.shape[0]
+        y = self._new(rows, c)
+        op = rt.MdtOp()
+        op.kind = rt.OP_TF256
+        op.a, op.out = x.ref(), y.ref()
+        v = torch.cat(vecs)
+        op.w = _ref(rt.SP_WEIGHT, self.W.add(p + "tf256.tiles", torch.cat(tiles)))
+        op.bias = _ref(rt.SP_WEIGHT, self.W.add(p + "tf256.vec", v))
+        op.p0 = _ref(rt.SP_WEIGHT, self.W.add(p + "tf256.desc", torch.tensor(desc, dtype=torch.int32).view(torch.float32)))
+        i = op.i
+        i[rt.F_C], i[rt.F_T], i[rt.F_NT], i[rt.F_NVEC] = c, rows, len(desc), v.numel()
+        i[rt.F_TK], i[rt.F_KV_BSTRIDE], i[rt.F_LDKV], i[rt.F_HEADS] = self.n_ctx, self.n_ctx, 2 * mid, heads
+        i[rt.F_HAS_IN], i[rt.F_NBLOCKS], i[rt.F_NFF], i[rt.F_NPOST] = 1, layers, nff, 2 * (c // 64)
+        i[rt.F_CROSS], i[rt.F_KV_LSTRIDE] = int(cross), self.n_ctx * 2 * mid
+        op.f[0], op.f[1], op.f[2] = 1e-5, float(cfg.head_features) ** -0.5, 1e-6
+        if cross:
+            op._kv = ("kv", cross0)
+            op.a2 = _ref(rt.SP_ACT, 0)
+        self._emit(op)
+        if free_input:
+            self._free(x)
+        return y
+
     def attention_layer(self, t: Ten, p: str, cross_index: Optional[int]) -> None:
         """x = Attention(x[, context]) + x, in place on t (modules.py:401-410, :457-459)."""
         cfg = self.cfg
@@ -836,6 +960,8 @@ class UNetCompiler:
         assert x.ld == c and c % 32 == 0
         if self.tf128_ok(c, x.rows, layers, cross):
             return self.transformer_fused128(x, p, c, layers, cross, free_input)
+        if self.tf256_ok(c, x.rows, layers, cross):
+            return self.transformer_fused256(x, p, c, layers, cross, free_input)
         t = self._new(x.rows, c)
         gi, bi = self._vec(p + "to_in.0.weight", c), self._vec(p + "to_in.0.bias", c)
         wi, bias_i = self._conv_w(p + "to_in.1.weight", c, c), self._vec(p + "to_in.1.bias", c)
@@ -1091,9 +1217,10 @@ class UNetCompiler:
                 C_memmove(o, op)
                 if op.kind in (rt.OP_GEMM, rt.OP_GN_ACT, rt.OP_RCONV, rt.OP_RESBLOCK) and isinstance(getattr(op, "_film", None), tuple):
                     o.p3 = _ref(rt.SP_SHR, ss_cur + op._film[1])
-                if op.kind in (rt.OP_ATTN, rt.OP_TBLOCK, rt.OP_TF128) and isinstance(getattr(op, "_kv", None), tuple):
+                if op.kind in (rt.OP_ATTN, rt.OP_TBLOCK, rt.OP_TF128, rt.OP_TF256) and isinstance(getattr(op, "_kv", None), tuple):
                     idx = op._kv[1]
-                    slot = {rt.OP_ATTN: rt.A_KV_BSTRIDE, rt.OP_TBLOCK: rt.B_KV_BSTRIDE, rt.OP_TF128: rt.F_KV_BSTRIDE}[op.kind]
+                    slot = {rt.OP_ATTN: rt.A_KV_BSTRIDE, rt.OP_TBLOCK: rt.B_KV_BSTRIDE, rt.OP_TF128: rt.F_KV_BSTRIDE,
+                            rt.OP_TF256: rt.F_KV_BSTRIDE}[op.kind]
                     if fixed:
                         o.a2 = _ref(rt.SP_SHR, self.kv_fixed[idx])
                         o.i[slot] = 0
@@ -1109,19 +1236,19 @@ class UNetCompiler:
         # only ones that take the second K/V pointer); otherwise the engine falls back to two passes.
         tb_lw = os.environ.get("MDT_TB_LW", "1") != "0"
         cross = [op for op in eval_ops if isinstance(getattr(op, "_kv", None), tuple)]
-        ring = all(op.kind == rt.OP_TF128 or
+        ring = all(op.kind in (rt.OP_TF128, rt.OP_TF256) or
                    (op.kind == rt.OP_TBLOCK and (op.i[rt.B_VARIANT] >= 2 or (op.i[rt.B_VARIANT] == 0 and tb_lw and op.i[rt.B_C] == 128
                                                                          and (16 // op.i[rt.B_T]) * op.i[rt.B_TK] <= 16)))
                    for op in cross)
         dual_multiple = 1
         if cross and ring and os.environ.get("MDT_CFG_DUAL", "1") == "1":
-            dual_multiple = max(64 // op.i[rt.F_T] if op.kind == rt.OP_TF128 else
-                                (32 if op.i[rt.B_VARIANT] >= 2 else 64) // op.i[rt.B_T] for op in cross)
+            dual_multiple = max(64 // op.i[rt.F_T] if op.kind == rt.OP_TF128 else 32 // op.i[rt.F_T] if op.kind == rt.OP_TF256
+                                else (32 if op.i[rt.B_VARIANT] >= 2 else 64) // op.i[rt.B_T] for op in cross)
             dual = resolve(eval_ops, False)
             for o, op in zip(dual, eval_ops):
                 if isinstance(getattr(op, "_kv", None), tuple):
                     o.p1 = _ref(rt.SP_SHR, self.kv_fixed[op._kv[1]])
-                    o.i[rt.F_KV2 if op.kind == rt.OP_TF128 else rt.B_KV2] = 1
+                    o.i[rt.F_KV2 if op.kind in (rt.OP_TF128, rt.OP_TF256) else rt.B_KV2] = 1
             programs["eval_dual"] = dual
 
         # ---- time program (m_mode 1) ----

@@ -1,0 +1,797 @@
+// A whole Transformer1d (modules.py:469-524) of a C = 256 level in ONE launch (MDT_OP_TF256), 32-row workgroups:
+//
+//   x = Conv1d_1x1(GroupNorm32(x))                       to_in            (:485-490, :520)
+//   per TransformerBlock (:456-461):  x += Attention(x);  [x += Attention(x, context);]  x += FeedForward(x)
+//   x = Conv1d_1x1(x)                                    to_out           (:512-516, :524), folded into the last FF
+//
+// Why: the 256-channel level has 4 tokens per sample, 4096 rows at B = 1024.  As one launch per sub-block (k_tblock32.hip)
+// every launch pays ~5 us of prologue / epilogue plus the launch gap for 13..23 us of work, the heads are split over two
+// workgroups to fill the chip and the partial sums travel through HBM between the launches.  Here a workgroup keeps its 32
+// rows for the whole transformer: no split, no partial-sum tensors, one prologue and one epilogue per transformer, and the
+// loader waves stream the weights of ALL sub-blocks through the LDS ring.  (128 workgroups at B = 1024: the launch is bound
+// by the per-CU L2 -> LDS stream either way, which does not depend on how many rows share a workgroup.)
+//
+//   * compute wave w = (row tile rt = w >> 1, feature half fh = w & 1) as in k_tblock32.hip: 16 rows x 32 of each chunk's
+//     64 features; partial S^T = K Q^T is exchanged through LDS; the output projection accumulates PARTIAL sums over the
+//     wave's 32-feature k-slice for all 256 output channels;
+//   * the residual stream lives in those accumulators (lane (i, g): x[row i][16 ct + 4 g + r], as in k_tf128.hip): wave
+//     fh = 0 starts a sub-block from x + bias, wave fh = 1 from 0; at the end of the sub-block the two partial sums are
+//     exchanged through two SCRATCH TILES of the ring (descriptor kind 4 / 5: the loaders issue no weight DMA for them, the
+//     slots carry the accumulators instead) and added in a fixed order, so both waves hold the identical new row;
+//   * the next projection's operands come from the accumulators without lane movement (K columns of the consuming tiles
+//     permuted on the host, k_tf128.hip); each sub-block's vectors (biases) arrive in a double-buffered 3 KB LDS area by
+//     LDS-DMA with the scratch tile in front of the sub-block.
+//
+// Ring protocol, sub-tile formats and the attention core are those of k_tblock32.hip / k_tblock_lw.hip.
+#include <cstdlib>
+#include <type_traits>
+
+#include "mdt_kernels.h"
+
+namespace mdt {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(4))) const unsigned* cu32p;   // constant address space: scalar loads
+
+__device__ __forceinline__ void store_nt(float* p, float4 v) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  __builtin_nontemporal_store(f4{v.x, v.y, v.z, v.w}, reinterpret_cast<f4*>(p));
+}
+
+#define MDT_XG(NAME, INSN, COMBINE)                                                      \
+  __device__ __forceinline__ float NAME(float v) {                                       \
+    float a = v, b = v;                                                                  \
+    asm("s_nop 1\n\t" INSN " %0, %1" : "+v"(a), "+v"(b));                                \
+    return COMBINE;                                                                      \
+  }
+MDT_XG(xg16_add, "v_permlane16_swap_b32", a + b)
+MDT_XG(xg32_add, "v_permlane32_swap_b32", a + b)
+MDT_XG(xg16_max, "v_permlane16_swap_b32", fmaxf(a, b))
+MDT_XG(xg32_max, "v_permlane32_swap_b32", fmaxf(a, b))
+#undef MDT_XG
+
+enum { K_T = 0, K_N = 1, K_O = 2 };   // transposed projection, un-transposed projection, output projection
+enum { D_P = 0, D_O = 1, D_K = 2, D_V = 3, D_SCRATCH = 4, D_SCRATCH_VEC = 5 };   // tile descriptor kinds (3 bits)
+
+#define MDT_MFMA_BF16 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define MDT_MFMA_F32 __builtin_amdgcn_mfma_f32_16x16x4f32
+
+__device__ __forceinline__ float gelu_tf(float x) {   // exact-erf GELU, branch-free erf (A&S 7.1.26), see k_tblock.hip
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float erfa = 1.0f - poly * __expf(-z * z);
+  return 0.5f * x * (1.0f + copysignf(erfa, x));
+}
+
+__device__ __forceinline__ void split8_tf(const float v[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const __bf16 h = (__bf16)v[e];
+    hi[e] = h;
+    lo[e] = (__bf16)(v[e] - (float)h);
+  }
+}
+
+template <int OFF>
+__device__ __forceinline__ void lds_read16_off(bf16x8& dst, unsigned addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read_b128 offset field");
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+
+template <int OFF>
+__device__ __forceinline__ void lds_read_f4_off(f32x4& dst, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+
+__device__ __forceinline__ unsigned lds_addr(const unsigned char* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)p;
+}
+
+template <int N>
+__device__ __forceinline__ void lgkm_wait() {   // at most N LDS/scalar operations still in flight
+  if constexpr (N >= 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+  else if constexpr (N >= 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+constexpr int C = 256;          // channels
+constexpr int CS = 128;         // sub-tile width (k_tblock32.hip)
+constexpr int SLOT = 256 * CS;  // bytes per sub-tile (bf16 hi plane + lo plane)
+constexpr int NS = 4;           // ring slots
+constexpr int IPT = CS / 16;    // DMA pieces per sub-tile per loader wave
+constexpr int NST = C / 32;     // k-steps of a full projection
+constexpr int NCT = C / 16;     // 16-row tiles of the output projection
+constexpr int NU = 4;           // units (4 fragment reads + 6 MFMAs) per sub-tile per wave
+constexpr int KTM = 3;          // key tiles per wave (cross): at most 48 context rows per 16 token rows
+constexpr int RED_BYTES = KTM * 4 * 64 * 16;   // partial S^T exchange [key tile][4 waves][64 lanes] f32x4
+constexpr int VEC_FLOATS = 768;                // vectors of one sub-block: [bq 512 | bo 256], [b1 512 | b2 256], [b_in 256]
+constexpr int VEC_BYTES = VEC_FLOATS * 4;
+
+}  // namespace
+
+// NPW: LDS-DMA pieces per loader wave per K / V tile = ceil(context rows of the workgroup / 16); 0 = no cross-attention
+template <int NPW>
+__global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  unsigned char* red_b = smem + NS * SLOT;
+  unsigned char* vec_b = red_b + RED_BYTES;          // two parities of VEC_BYTES
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int NT = a.NT;
+  const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(a.w);
+
+  if (wave >= 4) {
+    // ================= loader waves (k_tblock32.hip, descriptor-driven as k_tf128.hip) =================
+    const int iw = wave - 4;
+    __builtin_amdgcn_s_setprio(3);
+    const cu32p tiles = (cu32p)a.tiles;              // kind (3 bits) | aux << 3
+    const int lpP = lane >> 5;
+    const int xP = (lane & 15) ^ lpP;
+    const int baseP = ((lane >> 4) & 1) * (128 * CS) + lpP * (2 * CS);
+    const int xO = (lane & 7) ^ (lane >> 4);
+    const int baseO = (lane >> 3) * 128;
+    unsigned voffP[IPT], voffO[IPT];
+#pragma unroll
+    for (int q = 0; q < IPT; ++q) {
+      const int inst = iw + 4 * q;
+      const int U = 2 * inst;
+      voffP[q] = (unsigned)(U * (2 * CS) + ((xP ^ (U & 15)) << 4) + baseP);
+      voffO[q] = (unsigned)(((inst * 8) / CS) * (128 * CS) + ((inst * 8) % CS) * 128 + ((xO ^ (4 * (inst & 1))) << 4) + baseO);
+    }
+    const int sample0 = blockIdx.x * (32 / a.T);
+    const bool second = a.kv2 && sample0 >= a.nsamples / 2;      // dual batch: shared K / V rows for the second half
+    unsigned voffKV[8];
+    if constexpr (NPW > 0) {
+      const int kv_rows = (32 / a.T) * a.Tk;
+      const int bstr = second ? 0 : a.kv_bstride;
+#pragma unroll
+      for (int q = 0; q < NPW; ++q) {
+        const int R = 4 * (iw + 4 * q) + (lane >> 4);
+        const int Rc = min(R, kv_rows - 1);
+        const int sm = min(Rc / a.Tk, a.nsamples - 1 - sample0), key = Rc % a.Tk;
+        voffKV[q] = (unsigned)(((sm * bstr + key) * a.ldkv + 4 * ((lane & 15) ^ (R & 15))) * 4);
+      }
+    }
+    // vector-memory operations THIS wave issues for a tile (the counted waits below are per wave)
+    auto pieces_of = [&](unsigned d) -> int {
+      const unsigned kind = d & 7u;
+      if (kind == D_SCRATCH) return 0;
+      if (kind == D_SCRATCH_VEC) return iw < VEC_BYTES / 1024 ? 1 : 0;
+      if (kind >= D_K) return NPW;
+      return IPT;
+    };
+    auto issue_vec = [&](unsigned aux) {             // aux = (float offset / 256) << 1 | parity
+      if (iw < VEC_BYTES / 1024)
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const unsigned char*>(a.vec) + (aux >> 1) * 1024 + iw * 1024 + lane * 16,
+                                         (__attribute__((address_space(3))) void*)(vec_b + (aux & 1u) * VEC_BYTES + iw * 1024), 16, 0, 0);
+    };
+    auto issue_tile = [&](int tau, unsigned d) {
+      unsigned char* slot = smem + (tau % NS) * SLOT + iw * 1024;
+      const unsigned kind = d & 7u, aux = d >> 3;
+      if (kind == D_SCRATCH) return;
+      if (kind == D_SCRATCH_VEC) { issue_vec(aux); return; }
+      if (kind >= D_K) {
+        if constexpr (NPW > 0) {
+          const int layer = (int)(aux >> 4), head = (int)(aux & 15u);
+          const float* lb = second ? a.kv2 + (int64_t)layer * a.kv2_lstride
+                                   : a.kv + (int64_t)layer * a.kv_lstride + (int64_t)sample0 * a.kv_bstride * a.ldkv;
+          const unsigned char* base = reinterpret_cast<const unsigned char*>(lb + 64 * head + (kind == D_V ? 64 * a.nheads : 0));
+#pragma unroll
+          for (int q = 0; q < NPW; ++q)
+            __builtin_amdgcn_global_load_lds(base + voffKV[q], (__attribute__((address_space(3))) void*)(slot + q * 4096), 16, 0, 0);
+        }
+        return;
+      }
+      const unsigned char* tile = wsrc + (int64_t)aux * SLOT;   // wave-uniform
+      const bool ptile = kind == D_P;
+#pragma unroll
+      for (int q = 0; q < IPT; ++q) {
+        const unsigned off = ptile ? voffP[q] : voffO[q];
+        __builtin_amdgcn_global_load_lds(tile + off, (__attribute__((address_space(3))) void*)(slot + q * 4096), 16, 0, 0);
+      }
+    };
+    auto wait_vm = [&](int allow) {
+      switch (allow) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      }
+    };
+    const unsigned d0 = tiles[0], d1 = NT > 1 ? tiles[1] : 0u;
+    __builtin_amdgcn_s_barrier();   // P: the compute waves' row loads are queued ahead of the stream
+    issue_vec(0u);                  // the first sub-block's vectors (parity 0), ahead of tile 0: covered by the first wait
+    issue_tile(0, d0);
+    if (NT > 1) issue_tile(1, d1);
+    unsigned dn = d1;                                                    // descriptor of tile k + 1
+    for (int k = 0; k < NT; ++k) {
+      const unsigned d2 = k + 2 < NT ? tiles[k + 2] : 0u;
+      wait_vm(k + 1 < NT ? pieces_of(dn) : 0);                           // tile k landed; tile k+1 may be in flight
+      __builtin_amdgcn_s_barrier();                                      // B(k)
+      if (k + 2 < NT) issue_tile(k + 2, d2);
+      dn = d2;
+    }
+    return;
+  }
+
+  // ================= compute waves =================
+  const int i = lane & 15, g = lane >> 4;
+  const int rt = wave >> 1, fh = wave & 1;
+  const int row0 = blockIdx.x * 32 + rt * 16;
+  const int m = row0 + i;
+  const bool mvalid = m < a.M;
+  const int mc = mvalid ? m : a.M - 1;
+  f32x4* red = reinterpret_cast<f32x4*>(red_b);
+
+  // the residual stream: accT[ct][r] = x[row i][16 ct + 4 g + r]; both waves of a row tile hold the whole row
+  f32x4 accT[NCT];
+  {
+    const float* xp = a.x + (int64_t)mc * C + 4 * g;
+    float4 xr[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) xr[ct] = *reinterpret_cast<const float4*>(xp + 16 * ct);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();                    // P
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) accT[ct] = f32x4{xr[ct].x, xr[ct].y, xr[ct].z, xr[ct].w};
+  }
+
+  // fragment addressing inside a sub-tile (k_tblock32.hip), this wave's feature half folded in
+  int aP[4];
+#pragma unroll
+  for (int st = 0; st < 4; ++st) {
+    const int lc = 4 * st + g;
+    aP[st] = fh * (2 * 16 * 4 * CS) + i * (4 * CS) + ((lc & ~15) | ((lc & 15) ^ i)) * 16;
+  }
+  const int aO = i * 128 + ((4 * fh + g) ^ ((i >> 1) & 7)) * 16;
+
+  bf16x8 frh[3][2], frl[3][2];
+  auto frag_read = [&](auto kind, unsigned base, auto uc, int set, auto jc) {
+    constexpr int KIND = decltype(kind)::value, u = decltype(uc)::value, j = decltype(jc)::value;
+    constexpr int q = j >> 1, lo = j & 1;
+    constexpr int off = (KIND == K_O) ? ((2 * u + q) * 16 * 128 + lo * (CS * 128)) : (q * 16 * 4 * CS + lo * (2 * CS));
+    lds_read16_off<off>(lo ? frl[set][q] : frh[set][q], base);
+  };
+  using J0 = std::integral_constant<int, 0>;
+  using J1 = std::integral_constant<int, 1>;
+  using J2 = std::integral_constant<int, 2>;
+  using J3 = std::integral_constant<int, 3>;
+  auto prefetch2 = [&](auto kind, const unsigned char* slot, int off) {
+    constexpr int KIND = decltype(kind)::value;
+    const unsigned l = lds_addr(slot);
+    const unsigned b0 = l + (KIND == K_O ? aO : aP[0]), b1 = l + (KIND == K_O ? aO : aP[1]);
+    frag_read(kind, b0, J0{}, off % 3, J0{}); frag_read(kind, b0, J0{}, off % 3, J1{});
+    frag_read(kind, b0, J0{}, off % 3, J2{}); frag_read(kind, b0, J0{}, off % 3, J3{});
+    frag_read(kind, b1, J1{}, (off + 1) % 3, J0{}); frag_read(kind, b1, J1{}, (off + 1) % 3, J1{});
+    frag_read(kind, b1, J1{}, (off + 1) % 3, J2{}); frag_read(kind, b1, J1{}, (off + 1) % 3, J3{});
+  };
+
+  int tau = 0;
+  auto slot_of = [&](int t) -> unsigned char* { return smem + (t % NS) * SLOT; };
+
+  // One MFMA phase over a sub-tile (k_tblock32.hip): 4 units of 4 fragment reads + 6 MFMAs
+  auto phase = [&](auto kind, auto offc, auto nkind, bool has_next, f32x4* acc, const bf16x8* bh, const bf16x8* bl) {
+    constexpr int KIND = decltype(kind)::value, OFF = decltype(offc)::value, NK = decltype(nkind)::value;
+    const unsigned lc = lds_addr(slot_of(tau)), ln = lds_addr(slot_of(tau + 1));
+    unsigned bc[4], bn[2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bc[k] = lc + (KIND == K_O ? aO : aP[k]);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) bn[k] = ln + (NK == K_O ? aO : aP[k]);
+    auto unit = [&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      if (u == NU - 2 && has_next) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                // B(tau + 1)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      constexpr int s0 = (OFF + u) % 3, s2 = (OFF + u + 2) % 3;
+      constexpr bool in_phase = u + 2 < NU;
+      const bool pre = in_phase || has_next;
+      const bool later = (u + 1 < NU) || has_next;
+      if (later) lgkm_wait<4>(); else lgkm_wait<0>();
+      constexpr int ia = (KIND == K_O) ? 2 * u : 0, ib = (KIND == K_O) ? 0 : u;
+      auto rd = [&](auto jc) {
+        if (!pre) return;
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (in_phase) frag_read(kind, bc[u + 2], std::integral_constant<int, u + 2>{}, s2, jc);
+        else frag_read(nkind, bn[u + 2 - NU], std::integral_constant<int, u + 2 - NU>{}, s2, jc);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      auto mm = [&](const bf16x8& w, const bf16x8& x, int q) {
+        if constexpr (KIND == K_N) acc[ia + q] = MDT_MFMA_BF16(x, w, acc[ia + q], 0, 0, 0);
+        else acc[ia + q] = MDT_MFMA_BF16(w, x, acc[ia + q], 0, 0, 0);
+      };
+      mm(frl[s0][0], bh[ib], 0); rd(J0{});
+      mm(frl[s0][1], bh[ib], 1); rd(J1{});
+      mm(frh[s0][0], bl[ib], 0); rd(J2{});
+      mm(frh[s0][1], bl[ib], 1); rd(J3{});
+      mm(frh[s0][0], bh[ib], 0);
+      mm(frh[s0][1], bh[ib], 1);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    unit(std::integral_constant<int, 0>{}); unit(std::integral_constant<int, 1>{});
+    unit(std::integral_constant<int, 2>{}); unit(std::integral_constant<int, 3>{});
+    ++tau;
+  };
+  using IC0 = std::integral_constant<int, 0>;
+  using IC1 = std::integral_constant<int, 1>;
+  using IC2 = std::integral_constant<int, 2>;
+  const IC0 kT{};
+  const IC1 kN{};
+  const IC2 kO{};
+
+  const int samp_q = i / a.T;
+  float kmask[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) kmask[r] = ((4 * g + r) / a.T == samp_q) ? 0.f : -INFINITY;
+  const float scale2 = a.scale * 1.44269504088896340736f;
+  int nkeys = 0, Rw = 0;
+  unsigned okbits = 0;
+  if constexpr (NPW > 0) {
+    nkeys = (16 / a.T) * a.Tk;
+    Rw = rt * nkeys;
+#pragma unroll
+    for (int kt = 0; kt < KTM; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int jj = 16 * kt + 4 * g + r;
+        if (jj < nkeys && (jj / a.Tk) == samp_q) okbits |= 1u << (4 * kt + r);
+      }
+  }
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float t1 = a.T > 1 ? 1.f : 0.f, t2 = a.T > 2 ? 1.f : 0.f, t4 = a.T > 4 ? 1.f : 0.f, t8 = a.T > 8 ? 1.f : 0.f;
+  auto dpp_fma = [](float v, float f, auto ctrl) {
+    const int mm_ = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xf, 0xf, true);
+    return __builtin_fmaf(__builtin_bit_cast(float, mm_), f, v);
+  };
+  auto token_sum = [&](float (&s)[NCT]) {            // sums over the sample's token lanes (k_rconv.hip)
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) s[ct] = dpp_fma(s[ct], t1, std::integral_constant<int, 0xB1>{});
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) s[ct] = dpp_fma(s[ct], t2, std::integral_constant<int, 0x4E>{});
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) s[ct] = dpp_fma(s[ct], t4, std::integral_constant<int, 0x141>{});
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) s[ct] = dpp_fma(s[ct], t8, std::integral_constant<int, 0x140>{});
+  };
+
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                      // B(0)
+  prefetch2(kT, slot_of(0), 0);
+  const unsigned vec_l0 = lds_addr(vec_b);
+  int vpar = 0;                                      // parity of the current sub-block's vector area
+
+  bf16x8 xh[NST], xl[NST];
+  auto make_operands = [&](bool layernorm) {
+    float mean = 0.f, rstd = 1.f;
+    if (layernorm) {
+      float s = 0.f;
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) s += (accT[ct][0] + accT[ct][1]) + (accT[ct][2] + accT[ct][3]);
+      s = xg16_add(s);
+      s = xg32_add(s);
+      mean = s / (float)C;
+      float ss = 0.f;
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d = accT[ct][r] - mean;
+          ss += d * d;
+        }
+      ss = xg16_add(ss);
+      ss = xg32_add(ss);
+      rstd = 1.0f / sqrtf(ss / (float)C + a.eps_ln);
+    }
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = mvalid ? (accT[2 * st + (e >> 2)][e & 3] - mean) * rstd : 0.f;
+      split8_tf(v, xh[st], xl[st]);
+    }
+  };
+  // start of a sub-block: wave fh = 0 carries residual + output bias (or the bias alone), wave fh = 1 starts from zero
+  auto start_acc = [&](int off, bool keep_residual) {
+    const float* p = reinterpret_cast<const float*>(vec_b + vpar * VEC_BYTES) + off + 4 * g;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      const float4 b = *reinterpret_cast<const float4*>(p + 16 * ct);
+      const f32x4 bb = f32x4{b.x, b.y, b.z, b.w};
+      const f32x4 mine = keep_residual ? accT[ct] + bb : bb;
+      accT[ct] = fh ? zero4 : mine;
+    }
+  };
+  // end of a sub-block: the two feature-half waves of a row tile add their partial accumulators through the two scratch
+  // tiles that follow the sub-block in the stream (8 accumulator tiles = 8 KB per wave and round); fixed order
+  // (half 0 + half 1), so both waves end up with bitwise identical rows.  With `last` the barriers of the scratch tiles are
+  // still executed (the loaders count them) but nothing follows.
+  auto exchange_half = [&](auto rdc) {               // accumulator tiles 8 rd .. 8 rd + 7 (compile-time register indices)
+    constexpr int rd_ = decltype(rdc)::value;
+    f32x4* ex = reinterpret_cast<f32x4*>(slot_of(tau));
+#pragma unroll
+    for (int c = 0; c < 8; ++c) ex[(wave * 8 + c) * 64 + lane] = accT[8 * rd_ + c];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                    // B(scratch tile): the partner's partials (and the next vectors) are in LDS
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const f32x4 other = ex[((wave ^ 1) * 8 + c) * 64 + lane];
+      accT[8 * rd_ + c] = fh ? (other + accT[8 * rd_ + c]) : (accT[8 * rd_ + c] + other);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // read before the slot can be refilled (two barriers later)
+    ++tau;
+  };
+  auto exchange = [&]() {
+    exchange_half(std::integral_constant<int, 0>{});
+    exchange_half(std::integral_constant<int, 1>{});
+    vpar ^= 1;
+  };
+  auto next_subblock = [&]() {                       // first tile of the next sub-block: always a projection sub-tile
+    __builtin_amdgcn_s_barrier();                    // B(tau)
+    prefetch2(kT, slot_of(tau), 0);
+  };
+
+  // ---- Transformer1d.to_in: GroupNorm(32 groups of 8 channels, over the sample's tokens) + Conv1d(k = 1) ----
+  if (a.has_in) {
+    float gm[NCT], gv[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) gm[ct] = xg16_add((accT[ct][0] + accT[ct][1]) + (accT[ct][2] + accT[ct][3]));   // lanes g, g ^ 1
+    token_sum(gm);
+    const float inv_n = 1.0f / (float)(8 * a.T);
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      gm[ct] *= inv_n;
+      float ss = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = accT[ct][r] - gm[ct];
+        ss += d * d;
+      }
+      gv[ct] = xg16_add(ss);
+    }
+    token_sum(gv);
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      const float rs = __builtin_amdgcn_rsqf(gv[ct] * inv_n + a.eps_gn);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) accT[ct][r] = (accT[ct][r] - gm[ct]) * rs;
+    }
+    make_operands(false);
+    // this wave produces output channels 64 c + 32 fh + 16 q + (4 g + r), i.e. accumulator tiles 4 c + 2 fh + q, complete
+    // sums (both K halves); the other half of the tiles stays zero and arrives through the exchange; bias on wave 0 only
+    const float* bp = reinterpret_cast<const float*>(vec_b + vpar * VEC_BYTES) + 4 * g;
+    auto in_chunk = [&](auto cc, auto o0, auto o1, bool more) {
+      constexpr int c = decltype(cc)::value;
+      f32x4 t[2] = {zero4, zero4};
+      phase(kT, o0, kT, true, t, xh, xl);            // K half 0
+      phase(kT, o1, kT, more, t, xh + 4, xl + 4);    // K half 1
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 b = *reinterpret_cast<const float4*>(bp + 16 * (4 * c + q));
+        const f32x4 bb = fh ? zero4 : f32x4{b.x, b.y, b.z, b.w};
+        const f32x4 mine = (q >> 1) == 0 ? (fh ? zero4 : t[q & 1]) : (fh ? t[q & 1] : zero4);
+        accT[4 * c + q] = mine + bb;
+      }
+    };
+    in_chunk(IC0{}, IC0{}, IC1{}, true);
+    in_chunk(IC1{}, IC2{}, IC0{}, true);
+    in_chunk(IC2{}, IC1{}, IC2{}, true);
+    in_chunk(std::integral_constant<int, 3>{}, IC0{}, IC1{}, false);
+    exchange();
+    next_subblock();
+  }
+
+  const int nheads = a.nheads, nff = a.nff;
+  for (int blk = 0; blk < a.nblocks; ++blk) {
+    const bool last_blk = blk + 1 == a.nblocks;
+    const unsigned bias_l = 128u * (unsigned)fh + 16u * (unsigned)g;     // + parity base + 256 h
+    // ================= x += Attention(x) =================
+    {
+      make_operands(true);
+      start_acc(64 * nheads, true);
+      const unsigned bl = vec_l0 + vpar * VEC_BYTES + bias_l;
+      for (int h = 0; h < nheads; ++h) {
+        const bool more = h + 1 < nheads;
+        f32x4 oT[2];
+        f32x4 qT[2], kTt[2], vT[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { kTt[q] = zero4; vT[q] = zero4; qT[q] = zero4; }
+        phase(kT, IC0{}, kT, true, qT, xh, xl);
+        phase(kT, IC1{}, kT, true, qT, xh + 4, xl + 4);
+        phase(kT, IC2{}, kT, true, kTt, xh, xl);
+        phase(kT, IC0{}, kN, true, kTt, xh + 4, xl + 4);
+        phase(kN, IC1{}, kN, true, vT, xh, xl);
+        phase(kN, IC2{}, kN, false, vT, xh + 4, xl + 4);
+        {
+          f32x4 bq[2];
+          lds_read_f4_off<0>(bq[0], bl + 256 * h); lds_read_f4_off<64>(bq[1], bl + 256 * h);
+          lgkm_wait<0>();
+          qT[0] += bq[0];
+          qT[1] += bq[1];
+        }
+        f32x4 sp0 = zero4, sp1 = zero4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          sp0 = MDT_MFMA_F32(kTt[0][r], qT[0][r], sp0, 0, 0, 0);
+          sp1 = MDT_MFMA_F32(kTt[1][r], qT[1][r], sp1, 0, 0, 0);
+        }
+        const f32x4 mine = sp0 + sp1;
+        red[wave * 64 + lane] = mine;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                         // B(first output sub-tile) + partial exchange
+        const f32x4 other = red[(wave ^ 1) * 64 + lane];
+        prefetch2(kO, slot_of(tau), 1);
+        const f32x4 s01 = fh ? (other + mine) : (mine + other);
+        f32x4 st;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float sv = s01[r] * scale2 + kmask[r];
+          st[r] = sv;
+          mx = fmaxf(mx, sv);
+        }
+        mx = xg16_max(mx);
+        mx = xg32_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = __builtin_amdgcn_exp2f(st[r] - mx);
+          st[r] = e;
+          sum += e;
+        }
+        sum = xg16_add(sum);
+        sum = xg32_add(sum);
+        const float inv = __builtin_amdgcn_rcpf(sum);
+        oT[0] = zero4; oT[1] = zero4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = st[r] * inv;
+          oT[0] = MDT_MFMA_F32(vT[0][r], p, oT[0], 0, 0, 0);
+          oT[1] = MDT_MFMA_F32(vT[1][r], p, oT[1], 0, 0, 0);
+        }
+        bf16x8 oh[1], ol[1];
+        {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = oT[e >> 2][e & 3];
+          split8_tf(v, oh[0], ol[0]);
+        }
+        phase(kO, IC1{}, kO, true, accT, oh, ol);               // output rows 0..127
+        phase(kO, IC2{}, kT, more, accT + 8, oh, ol);           // output rows 128..255
+      }
+      exchange();
+      next_subblock();
+    }
+    // ================= x += Attention(x, context) =================
+    if constexpr (NPW > 0) {
+      make_operands(true);
+      start_acc(64 * nheads, true);
+      const unsigned bl = vec_l0 + vpar * VEC_BYTES + bias_l;
+      for (int h = 0; h < nheads; ++h) {
+        const bool more = h + 1 < nheads;
+        f32x4 oT[2];
+        f32x4 qT[2];
+        qT[0] = zero4; qT[1] = zero4;
+        phase(kT, IC0{}, kT, true, qT, xh, xl);
+        phase(kT, IC1{}, kT, false, qT, xh + 4, xl + 4);
+        __builtin_amdgcn_s_barrier();                         // B(K tile)
+        const unsigned char* sk = slot_of(tau);
+        {
+          f32x4 bq[2];
+          lds_read_f4_off<0>(bq[0], bl + 256 * h); lds_read_f4_off<64>(bq[1], bl + 256 * h);
+          lgkm_wait<0>();
+          qT[0] += bq[0];
+          qT[1] += bq[1];
+        }
+        f32x4 st[KTM];
+        float4 k0[KTM], k1[KTM];
+#pragma unroll
+        for (int kt = 0; kt < KTM; ++kt) {
+          const int R = Rw + min(16 * kt + i, nkeys - 1);
+          const unsigned char* kp = sk + R * 256;
+          k0[kt] = *reinterpret_cast<const float4*>(kp + (((8 * fh + g) ^ (R & 15)) << 4));
+          k1[kt] = *reinterpret_cast<const float4*>(kp + (((8 * fh + 4 + g) ^ (R & 15)) << 4));
+        }
+        f32x4 sp0[KTM], sp1[KTM];
+#pragma unroll
+        for (int kt = 0; kt < KTM; ++kt) { sp0[kt] = zero4; sp1[kt] = zero4; }
+#pragma unroll
+        for (int kt = 0; kt < KTM; ++kt) { sp0[kt] = MDT_MFMA_F32(k0[kt].x, qT[0][0], sp0[kt], 0, 0, 0); sp1[kt] = MDT_MFMA_F32(k1[kt].x, qT[1][0], sp1[kt], 0, 0, 0); }
+#pragma unroll
+        for (int kt = 0; kt < KTM; ++kt) { sp0[kt] = MDT_MFMA_F32(k0[kt].y, qT[0][1], sp0[kt], 0, 0, 0); sp1[kt] = MDT_MFMA_F32(k1[kt].y, qT[1][1], sp1[kt], 0, 0, 0); }
+#pragma unroll
+        for (int kt = 0; kt < KTM; ++kt) { sp0[kt] = MDT_MFMA_F32(k0[kt].z, qT[0][2], sp0[kt], 0, 0, 0); sp1[kt] = MDT_MFMA_F32(k1[kt].z, qT[1][2], sp1[kt], 0, 0, 0); }
+#pragma unroll
+        for (int kt = 0; kt < KTM; ++kt) { sp0[kt] = MDT_MFMA_F32(k0[kt].w, qT[0][3], sp0[kt], 0, 0, 0); sp1[kt] = MDT_MFMA_F32(k1[kt].w, qT[1][3], sp1[kt], 0, 0, 0); }
+#pragma unroll
+        for (int kt = 0; kt < KTM; ++kt) {
+          st[kt] = sp0[kt] + sp1[kt];
+          red[(kt * 4 + wave) * 64 + lane] = st[kt];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        ++tau;
+        __builtin_amdgcn_s_barrier();                         // B(V tile) + partial exchange
+        const unsigned char* sv = slot_of(tau);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < KTM; ++kt) {
+          const f32x4 other = red[(kt * 4 + (wave ^ 1)) * 64 + lane];
+          const f32x4 s01 = fh ? (other + st[kt]) : (st[kt] + other);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float sv2 = ((okbits >> (4 * kt + r)) & 1u) ? s01[r] * scale2 : -INFINITY;
+            st[kt][r] = sv2;
+            mx = fmaxf(mx, sv2);
+          }
+        }
+        mx = xg16_max(mx);
+        mx = xg32_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KTM; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e = __builtin_amdgcn_exp2f(st[kt][r] - mx);
+            st[kt][r] = e;
+            sum += e;
+          }
+        sum = xg16_add(sum);
+        sum = xg32_add(sum);
+        const float inv = __builtin_amdgcn_rcpf(sum);
+        oT[0] = zero4; oT[1] = zero4;
+        f32x4 v0[KTM], v1[KTM];
+#pragma unroll
+        for (int kt = 0; kt < KTM; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int R = Rw + min(16 * kt + 4 * g + r, nkeys - 1);
+            const unsigned char* vp = sv + R * 256 + (i & 3) * 4;
+            v0[kt][r] = *reinterpret_cast<const float*>(vp + (((8 * fh + (i >> 2)) ^ (R & 15)) << 4));
+            v1[kt][r] = *reinterpret_cast<const float*>(vp + (((8 * fh + 4 + (i >> 2)) ^ (R & 15)) << 4));
+          }
+#pragma unroll
+        for (int kt = 0; kt < KTM; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = st[kt][r] * inv;
+            oT[0] = MDT_MFMA_F32(v0[kt][r], p, oT[0], 0, 0, 0);
+            oT[1] = MDT_MFMA_F32(v1[kt][r], p, oT[1], 0, 0, 0);
+          }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // V reads complete before the slot can be refilled
+        ++tau;
+        __builtin_amdgcn_s_barrier();                         // B(first output sub-tile)
+        prefetch2(kO, slot_of(tau), 1);
+        bf16x8 oh[1], ol[1];
+        {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = oT[e >> 2][e & 3];
+          split8_tf(v, oh[0], ol[0]);
+        }
+        phase(kO, IC1{}, kO, true, accT, oh, ol);
+        phase(kO, IC2{}, kT, more, accT + 8, oh, ol);
+      }
+      exchange();
+      next_subblock();
+    }
+    // ================= x += FeedForward(x)  (last block: the closing convolution folded in) =================
+    {
+      const int npost = last_blk ? a.npost : 0;
+      make_operands(false);
+      start_acc(64 * nff, npost == 0);               // folded closing convolution: no residual (Wout x rides as tiles)
+      const unsigned bl = vec_l0 + vpar * VEC_BYTES + bias_l;
+      for (int h = 0; h < nff; ++h) {
+        const bool more = h + 1 < nff;
+        f32x4 oT[2];
+        oT[0] = zero4; oT[1] = zero4;
+        phase(kT, IC0{}, kT, true, oT, xh, xl);               // K half 0
+        phase(kT, IC1{}, kT, false, oT, xh + 4, xl + 4);      // K half 1
+        __builtin_amdgcn_s_barrier();                         // B(first W2 sub-tile)
+        prefetch2(kO, slot_of(tau), 1);
+        {
+          f32x4 b1[2];
+          lds_read_f4_off<0>(b1[0], bl + 256 * h); lds_read_f4_off<64>(b1[1], bl + 256 * h);
+          lgkm_wait<0>();
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) oT[q][r] = gelu_tf(oT[q][r] + b1[q][r]);
+        }
+        bf16x8 oh[1], ol[1];
+        {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = oT[e >> 2][e & 3];
+          split8_tf(v, oh[0], ol[0]);
+        }
+        phase(kO, IC1{}, kO, true, accT, oh, ol);
+        if (npost > 0 && !more) phase(kO, IC2{}, kO, true, accT + 8, oh, ol);   // the folded convolution's sub-tiles follow
+        else phase(kO, IC2{}, kT, more, accT + 8, oh, ol);
+      }
+      if (npost > 0) {
+        // + Wout x: per 64-channel k chunk of the raw-x operands one output tile = two row-half sub-tiles; this wave's
+        // k-step is the chunk's half fh (a register select: fh is not a compile-time index)
+        bf16x8 oxh[1], oxl[1];
+        auto pick = [&](int kc) {
+          const i32x4 h0v = __builtin_bit_cast(i32x4, xh[2 * kc]), h1v = __builtin_bit_cast(i32x4, xh[2 * kc + 1]);
+          const i32x4 l0v = __builtin_bit_cast(i32x4, xl[2 * kc]), l1v = __builtin_bit_cast(i32x4, xl[2 * kc + 1]);
+          i32x4 hv, lv;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { hv[k] = fh ? h1v[k] : h0v[k]; lv[k] = fh ? l1v[k] : l0v[k]; }
+          oxh[0] = __builtin_bit_cast(bf16x8, hv);
+          oxl[0] = __builtin_bit_cast(bf16x8, lv);
+        };
+        pick(0); phase(kO, IC0{}, kO, true, accT, oxh, oxl); phase(kO, IC1{}, kO, true, accT + 8, oxh, oxl);
+        pick(1); phase(kO, IC2{}, kO, true, accT, oxh, oxl); phase(kO, IC0{}, kO, true, accT + 8, oxh, oxl);
+        pick(2); phase(kO, IC1{}, kO, true, accT, oxh, oxl); phase(kO, IC2{}, kO, true, accT + 8, oxh, oxl);
+        pick(3); phase(kO, IC0{}, kO, true, accT, oxh, oxl); phase(kO, IC1{}, kT, false, accT + 8, oxh, oxl);
+      }
+      exchange();
+      if (!last_blk) next_subblock();
+    }
+  }
+
+  // ---- the residual stream leaves the kernel once: wave (rt, fh) stores channels 128 fh .. 128 fh + 127 of its rows ----
+  if (mvalid) {
+    float* xo = a.out + (int64_t)m * C + 4 * g + 128 * fh;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      // (component-wise value selects: a select between the two array ELEMENTS becomes a select of their addresses and
+      //  keeps the whole accumulator array in scratch memory)
+      const f32x4 lo_ = accT[c], hi_ = accT[8 + c];
+      store_nt(xo + 16 * c, make_float4(fh ? hi_[0] : lo_[0], fh ? hi_[1] : lo_[1], fh ? hi_[2] : lo_[2], fh ? hi_[3] : lo_[3]));
+    }
+  }
+}
+
+template <int NPW>
+static hipError_t launch_tf2(const TFArgs& a, hipStream_t s) {
+  const size_t smem = (size_t)NS * SLOT + RED_BYTES + 2 * VEC_BYTES;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tf256<NPW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_tf256<NPW>), dim3((unsigned)((a.M + 31) / 32)), dim3(512), smem, s, a);
+  return hipGetLastError();
+}
+
+bool tf256_supported(int T, int Tk, int nheads, int nff, bool cross) {
+  if (T <= 0 || 16 % T || nheads != 8 || nff != 8) return false;        // vectors: [bq 512 | bo 256] / [b1 512 | b2 256]
+  if (cross && (Tk <= 0 || (16 / T) * Tk > 48)) return false;           // three key tiles per wave (k_tblock32.hip)
+  return true;
+}
+
+hipError_t launch_tf256(const TFArgs& a, hipStream_t s) {
+  if (a.M <= 0) return hipSuccess;
+  const bool cross = a.kv != nullptr;
+  if (!tf256_supported(a.T, a.Tk, a.nheads, a.nff, cross) || a.nblocks <= 0 || a.NT <= 0) return hipErrorInvalidValue;
+  if (a.npost != 0 && a.npost != 8) return hipErrorInvalidValue;
+  if (!cross) return launch_tf2<0>(a, s);
+  switch (((32 / a.T) * a.Tk + 15) / 16) {
+    case 1: return launch_tf2<1>(a, s);
+    case 2: return launch_tf2<2>(a, s);
+    case 3: return launch_tf2<3>(a, s);
+    case 4: return launch_tf2<4>(a, s);
+    case 5: return launch_tf2<5>(a, s);
+    case 6: return launch_tf2<6>(a, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace mdt

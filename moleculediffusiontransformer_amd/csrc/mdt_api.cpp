@@ -137,6 +137,17 @@ static const char* validate(const mdt_op& o, int idx, char* buf, size_t nbuf) {
       if (i[MDT_F_CROSS] && !o.a2.space) return bad("cross-attention blocks need the hoisted K/V rows");
       break;
     }
+    case MDT_OP_TF256: {
+      const int32_t* i = o.i;
+      if (i[MDT_F_C] != 256) return bad("fused transformer (32-row form) needs C = 256");
+      if (!mdt::tf256_supported(i[MDT_F_T], i[MDT_F_TK], i[MDT_F_HEADS], i[MDT_F_NFF], i[MDT_F_CROSS] != 0))
+        return bad("shape not supported by the fused transformer (tokens per sample must divide 16, 8 heads, hidden 512, <= 48 context rows per 16 tokens)");
+      if (i[MDT_F_NBLOCKS] <= 0 || i[MDT_F_NT] <= 0 || i[MDT_F_NVEC] <= 0 || i[MDT_F_NVEC] % 768) return bad("bad block / tile / vector counts");
+      if (i[MDT_F_NPOST] != 0 && i[MDT_F_NPOST] != 8) return bad("npost must be 0 or 8");
+      if (!o.a.space || !o.out.space || !o.w.space || !o.bias.space || !o.p0.space) return bad("missing operand");
+      if (i[MDT_F_CROSS] && !o.a2.space) return bad("cross-attention blocks need the hoisted K/V rows");
+      break;
+    }
     default:
       return bad("unknown op kind");
   }
@@ -304,8 +315,10 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
                                         : mdt::launch_tblock(a, stream);
         break;
       }
-      case MDT_OP_TF128: {
+      case MDT_OP_TF128:
+      case MDT_OP_TF256: {
         const int32_t* i = o.i;
+        const bool wide = o.kind == MDT_OP_TF256;
         mdt::TFArgs a;
         a.x = ptr(o.a); a.out = ptr(o.out); a.w = ptr(o.w); a.vec = ptr(o.bias);
         a.tiles = reinterpret_cast<const unsigned*>(ptr(o.p0));
@@ -320,11 +333,11 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
         a.kv2_lstride = (int64_t)i[MDT_F_KV_LSTRIDE] * (o.p1.space == MDT_SP_ACT ? B : 1);
         a.eps_ln = o.f[MDT_FF_EPS_LN]; a.scale = o.f[MDT_FF_SCALE]; a.eps_gn = o.f[MDT_FF_EPS_GN];
         if (i[MDT_F_KV2]) {
-          const int per_wg = 64 / a.T;
+          const int per_wg = (wide ? 32 : 64) / a.T;
           if (!o.p1.space || B % 2 || (B / 2) % (per_wg > 0 ? per_wg : 1))
             return fail("mdt_program_run: a dual-batch fused transformer needs the shared K/V rows and B = 2 x (a multiple of the samples per workgroup)");
         }
-        if (!missing) e = mdt::launch_tf128(a, stream);
+        if (!missing) e = wide ? mdt::launch_tf256(a, stream) : mdt::launch_tf128(a, stream);
         break;
       }
       case MDT_OP_TIME_EMBED: {

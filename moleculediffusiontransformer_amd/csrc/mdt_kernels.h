@@ -152,6 +152,12 @@ struct TFArgs {
 };
 bool tf128_supported(int T, int Tk, int nvec, bool cross);
 hipError_t launch_tf128(const TFArgs& a, hipStream_t s);
+// MDT_OP_TF256 (k_tf256.hip): the same for a C = 256 level, 32-row workgroups.  Differences in the streams: tile
+// descriptors are kind (3 bits: 0 projection sub-tile, 1 output sub-tile, 2 K rows, 3 V rows, 4 scratch, 5 scratch + the next
+// sub-block's vectors) | aux << 3; every sub-block is followed by two scratch tiles; vectors are 768 floats per sub-block
+// ([bq 512 | bo 256], [b1 512 | b2 256], to_in: [bias 256]); npost = 8 sub-tiles.
+bool tf256_supported(int T, int Tk, int nheads, int nff, bool cross);
+hipError_t launch_tf256(const TFArgs& a, hipStream_t s);
 
 hipError_t launch_concat(const float* a, const float* b, float* out, int64_t rows, int ca, int cb, float scale_b,
                          hipStream_t s);

@@ -170,6 +170,8 @@ def run_program(ops, bufs: Buffers, B: int, n_shared_rows: int = 0) -> None:
             _tblock(op, bufs, B)
         elif op.kind == rt.OP_TF128:
             _tf128(op, bufs, B)
+        elif op.kind == rt.OP_TF256:
+            _tf256(op, bufs, B)
         else:
             raise ValueError(f"unknown op kind {op.kind}")
 
@@ -445,5 +447,118 @@ def _tf128(op, bufs: Buffers, B: int) -> None:
             x = hdn @ torch.cat(w2, dim=1).T + x @ wout.T + b2
         else:
             x = x + hdn @ torch.cat(w2, dim=1).T + b2
+    assert cur["t"] == NT, (cur["t"], NT)
+    bufs.view(op.out, B, B * T * C).view(B, T, C)[:] = x
+
+
+def _tf256(op, bufs: Buffers, B: int) -> None:
+    """MDT_OP_TF256 semantics (include/mdt_hip.h): as _tf128 for a 256-channel level; the stream holds 32 KB SUB-tiles (K
+    halves of projection tiles, row halves of output tiles), scratch descriptors close every sub-block, vectors are 768
+    floats per sub-block."""
+    i, f = op.i, op.f
+    C, T, NT, nvec = i[rt.F_C], i[rt.F_T], i[rt.F_NT], i[rt.F_NVEC]
+    Tk, bs, ldkv, H = i[rt.F_TK], i[rt.F_KV_BSTRIDE], i[rt.F_LDKV], i[rt.F_HEADS]
+    nblocks, nff, npost, cross = i[rt.F_NBLOCKS], i[rt.F_NFF], i[rt.F_NPOST], bool(i[rt.F_CROSS])
+    desc = bufs.view(op.p0, B, NT).contiguous().view(torch.int32).tolist()
+    nw = sum(1 for d in desc if (d & 7) < 2)
+    stream = bufs.view(op.w, B, nw * 64 * 128)
+    vec = bufs.view(op.bias, B, nvec)
+    accp = torch.tensor([16 * (2 * (k >> 5) + ((k & 7) >> 2)) + 4 * ((k >> 3) & 3) + (k & 3) for k in range(C)])
+    inv_acc = torch.empty(C, dtype=torch.long)
+    inv_acc[accp] = torch.arange(C)
+    inv_slot = torch.empty(64, dtype=torch.long)
+    inv_slot[torch.tensor(_SLOT_PERM)] = torch.arange(64)
+    cur = {"t": 0, "sb": 0}
+
+    def take(kind):
+        d = desc[cur["t"]]
+        cur["t"] += 1
+        assert d & 7 == kind, (cur["t"] - 1, d & 7, kind)
+        return d >> 3
+
+    def P():                       # projection tile = two K-half sub-tiles -> [64, C], natural K order
+        a_, b_ = take(0), take(0)
+        return torch.cat([_untile(stream, a_, 64, 128), _untile(stream, b_, 64, 128)], dim=1)[:, inv_acc]
+
+    def O(natural_from: Optional[int] = None):     # output tile = two row-half sub-tiles -> [C, 64]
+        a_, b_ = take(1), take(1)
+        t = torch.cat([_untile(stream, a_, 128, 64), _untile(stream, b_, 128, 64)], dim=0)
+        if natural_from is None:
+            return t[:, inv_slot]
+        cols = accp[natural_from: natural_from + 64] - natural_from
+        inv = torch.empty(64, dtype=torch.long)
+        inv[cols] = torch.arange(64)
+        return t[:, inv]
+
+    def end_subblock(last=False):
+        nxt = cur["sb"] + 1
+        d = desc[cur["t"]]
+        if last:
+            assert d & 7 == 4
+        else:
+            assert d & 7 == 5 and (d >> 3) == (((768 * nxt) // 256) << 1 | (nxt & 1)), "vector descriptor of the next sub-block"
+        assert desc[cur["t"] + 1] & 7 == 4
+        cur["t"] += 2
+        cur["sb"] = nxt
+
+    def V(off, n):
+        base = 768 * cur["sb"]
+        return vec[base + off: base + off + n]
+
+    x = bufs.view(op.a, B, B * T * C).view(B, T, C)
+    if i[rt.F_HAS_IN]:
+        xn = F.group_norm(x.transpose(1, 2), 32, None, None, eps=float(f[2])).transpose(1, 2)
+        w = torch.cat([P() for _ in range(C // 64)])
+        x = xn @ w.T + V(0, C)
+        end_subblock()
+    mid, D = 64 * H, 64
+    for blk in range(nblocks):
+        xn = F.layer_norm(x, (C,), None, None, eps=float(f[0]))
+        wq, wk, wv, wo = [], [], [], []
+        for h in range(H):
+            wq.append(P()), wk.append(P()), wv.append(P()), wo.append(O())
+        bq, bo = V(0, mid), V(mid, C)
+        q = (xn @ torch.cat(wq).T + bq).view(B, T, H, D).transpose(1, 2)
+        k = (xn @ torch.cat(wk).T).view(B, T, H, D).transpose(1, 2)
+        v = (xn @ torch.cat(wv).T).view(B, T, H, D).transpose(1, 2)
+        o = (((q @ k.transpose(-1, -2)) * float(f[1])).softmax(-1) @ v).transpose(1, 2).reshape(B, T, mid)
+        x = x + o @ torch.cat(wo, dim=1).T + bo
+        end_subblock()
+        if cross:
+            xn = F.layer_norm(x, (C,), None, None, eps=float(f[0]))
+            wq, wo = [], []
+            for h in range(H):
+                wq.append(P())
+                assert take(2) == (blk << 4 | h) and take(3) == (blk << 4 | h)
+                wo.append(O())
+            bq, bo = V(0, mid), V(mid, C)
+            lstride = i[rt.F_KV_LSTRIDE]
+            if bs == 0:
+                base = bufs.view(op.a2, B, (blk + 1) * lstride)[blk * lstride:]
+                kv = base[: Tk * ldkv].view(1, Tk, ldkv).expand(B, -1, -1)
+            else:
+                base = bufs.view(op.a2, B, (blk + 1) * lstride * B)[blk * lstride * B:]
+                kv = base.view(B, Tk, ldkv)
+            if i[rt.F_KV2]:
+                kvf = bufs.view(op.p1, B, (blk + 1) * lstride)[blk * lstride:][: Tk * ldkv].view(1, Tk, ldkv)
+                kv = torch.cat([kv[: B // 2], kvf.expand(B - B // 2, -1, -1)])
+            q = (xn @ torch.cat(wq).T + bq).view(B, T, H, D).transpose(1, 2)
+            k = kv[:, :, :mid].reshape(B, Tk, H, D).transpose(1, 2)
+            v = kv[:, :, mid: 2 * mid].reshape(B, Tk, H, D).transpose(1, 2)
+            o = (((q @ k.transpose(-1, -2)) * float(f[1])).softmax(-1) @ v).transpose(1, 2).reshape(B, T, mid)
+            x = x + o @ torch.cat(wo, dim=1).T + bo
+            end_subblock()
+        w1, w2 = [], []
+        for h in range(nff):
+            w1.append(P()), w2.append(O())
+        b1, b2 = V(0, 64 * nff), V(64 * nff, C)
+        hdn = F.gelu(x @ torch.cat(w1).T + b1)
+        last = blk == nblocks - 1
+        if last and npost:
+            wout = torch.cat([O(natural_from=64 * e) for e in range(npost // 2)], dim=1)
+            x = hdn @ torch.cat(w2, dim=1).T + x @ wout.T + b2
+        else:
+            x = x + hdn @ torch.cat(w2, dim=1).T + b2
+        end_subblock(last=last)
     assert cur["t"] == NT, (cur["t"], NT)
     bufs.view(op.out, B, B * T * C).view(B, T, C)[:] = x

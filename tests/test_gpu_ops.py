@@ -589,26 +589,28 @@ def _transformer_sd(p, C, layers, cross, ctx=128, mid=512, seed0=100):
     return sd
 
 
-@pytest.mark.parametrize("T,B,layers,cross,fixed", [(16, 5, 2, False, False), (16, 70, 4, True, False), (4, 16, 2, False, False),
-                                                    (16, 3, 2, True, True), (8, 9, 1, False, False), (2, 33, 1, False, False),
-                                                    (16, 1030, 1, True, False)])
-def test_fused_transformer_128(T, B, layers, cross, fixed):
-    """MDT_OP_TF128 (k_tf128.hip): a whole Transformer1d of a 128-channel level in one launch, against (i) the CPU
+@pytest.mark.parametrize("C,T,B,layers,cross,fixed", [
+    (128, 16, 5, 2, False, False), (128, 16, 70, 4, True, False), (128, 4, 16, 2, False, False), (128, 16, 3, 2, True, True),
+    (128, 8, 9, 1, False, False), (128, 2, 33, 1, False, False), (128, 16, 1030, 1, True, False),
+    (256, 4, 37, 2, True, False), (256, 4, 5, 2, False, False), (256, 4, 9, 4, True, True), (256, 16, 3, 1, False, False),
+    (256, 8, 11, 1, True, False), (256, 1, 70, 1, True, False), (256, 4, 1030, 1, True, False)])
+def test_fused_transformer(C, T, B, layers, cross, fixed):
+    """MDT_OP_TF128 / MDT_OP_TF256 (k_tf128.hip, k_tf256.hip): a whole Transformer1d in one launch, against (i) the CPU
     interpreter of the op (tile order, K-column permutation to the accumulator layout, vector layout) and (ii) the
     reference's module arithmetic written out with torch ops (modules.py:469-524, :401-410, :350-364, :314-320)."""
     from moleculediffusiontransformer_amd.compiler import Ten, UNetCompiler
     from moleculediffusiontransformer_amd.netspec import inverse_unet_config
     import torch.nn.functional as F
-    C, n_ctx, mid, H = 128, 12, 512, 8
+    n_ctx, mid, H = 12, 512, 8
     cfg = inverse_unet_config(16, 64, 128, n_ctx)
     p = "tf."
     sd = _transformer_sd(p, C, layers, cross)
     comp = UNetCompiler(cfg, 64, n_ctx, sd)
-    if not comp.tf128_ok(C, T, layers, cross):
-        pytest.skip("shape outside the fused transformer's envelope")
+    if not (comp.tf128_ok(C, T, layers, cross) or comp.tf256_ok(C, T, layers, cross)):
+        pytest.skip("shape outside the fused transformers' envelope")
     x = Ten(A, 0, T, C)
     y = comp.transformer(x, p, C, layers, cross, free_input=False)
-    assert [o.kind for o in comp.ops] == [rt.OP_TF128]
+    assert [o.kind for o in comp.ops] == [rt.OP_TF128 if C == 128 else rt.OP_TF256]
     op = comp.ops[0]
     kv_floats = n_ctx * 2 * mid
     act_x = rnd(B * T * C, seed=13) * 1.5 + 0.3
