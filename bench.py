@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--no-exact-f32", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--master-port", type=int, default=29511, help="rendezvous port when this script launches its own ranks")
     return ap.parse_args()
 
@@ -101,8 +102,19 @@ def op_flops(op, rt, B):
         if i[rt.B_MODE] == rt.TB_SELF:
             return B * (2.0 * t * c * 3 * mid + 4.0 * t * t * mid + 2.0 * t * mid * c)
         return B * (2.0 * t * c * mid + 4.0 * t * tk * mid + 2.0 * t * mid * c)
-    flops = getattr(op, "_flops", None)     # multi-sub-block ops carry their own count per sample
-    return float(flops) * B if flops else 0.0
+    if op.kind in (rt.OP_TF128, rt.OP_TF256):       # a whole Transformer1d: to_in + blocks (+ folded to_out)
+        c, t, tk = i[rt.F_C], i[rt.F_T], i[rt.F_TK]
+        mid, hid = 64 * i[rt.F_HEADS], 64 * i[rt.F_NFF]
+        blk = (2.0 * t * c * 3 * mid + 4.0 * t * t * mid + 2.0 * t * mid * c) + 4.0 * t * c * hid
+        if i[rt.F_CROSS]:
+            blk += 2.0 * t * c * mid + 4.0 * t * tk * mid + 2.0 * t * mid * c
+        return B * (i[rt.F_NBLOCKS] * blk + (2.0 * t * c * c if i[rt.F_HAS_IN] else 0.0) + (2.0 * t * c * c if i[rt.F_NPOST] else 0.0))
+    return 0.0
+
+
+# the fused transformer kernels (one sub-block per launch: k_tblock32 / k_tblock_lw; a whole Transformer1d per launch:
+# k_tf128 / k_tf256) are ONE kernel class for the roofline: same operator, same MFMA / LDS-ring structure
+KERNEL_CLASS = {7: "k_tblock", 11: "k_tblock", 12: "k_tblock"}
 
 
 def kernel_breakdown(eng, rt, B):
@@ -123,7 +135,7 @@ def kernel_breakdown(eng, rt, B):
             best = ms
     out = {}
     for op, t in zip(ops, best):
-        k = rt.OP_NAMES.get(op.kind, f"kind{op.kind}")
+        k = KERNEL_CLASS.get(op.kind) or rt.OP_NAMES.get(op.kind, f"kind{op.kind}")
         n, tot, fl = out.get(k, (0, 0.0, 0.0))
         out[k] = (n + 1, tot + t, fl + op_flops(op, rt, B))
     return out
@@ -149,10 +161,11 @@ def pmc_summary():
 def pmc_traffic(kernel_class):
     """HBM bytes per launch of one kernel class from the committed PMC summary, or (None, None)."""
     fname, rows = pmc_summary()
-    n = sum(r[1] for r in rows if r[0].startswith("mdt::" + kernel_class))
+    prefixes = ("mdt::k_tblock", "mdt::k_tf128", "mdt::k_tf256") if kernel_class == "k_tblock" else ("mdt::" + kernel_class,)
+    n = sum(r[1] for r in rows if r[0].startswith(prefixes))
     if not n:
         return None, None
-    mb = sum(r[1] * r[2] for r in rows if r[0].startswith("mdt::" + kernel_class))
+    mb = sum(r[1] * r[2] for r in rows if r[0].startswith(prefixes))
     return round(mb / n * 1e6), ("bytes per launch; profiles/" + fname +
                                  " (rocprofv3 PMC passes of this workload, recorded earlier, not collected live)")
 
@@ -251,7 +264,7 @@ def main():
     seq_of = lambda r: synth_normal(f"bench/seq/rank{r}", (B, n_cond))     # noqa: E731
     seq = seq_of(rank).to(device)
     if a.workload != "cfg1" or a.cond_scale != 1.0:
-        a.no_cpu_baseline = a.no_exact_f32 = True
+        a.no_cpu_baseline = a.no_exact_f32 = a.no_other_configs = True
     evals = 2 * (T - 1)
     eval_timer = rt.EventTimer(evals * (a.steps + a.warmup) + 8)
 
@@ -287,7 +300,7 @@ def main():
     eval_ms = eval_timer.collect()
     result = None
     if rank == 0:
-        eng = model.engine(device, n_cond)
+        eng = model._engine                               # the engine the timed calls ran on (kernel choice by batch)
         mols = world * B * a.steps
         value = mols / elapsed
         flops_exec = eng.c.flops_per_sample_eval           # executed per sample per eval (K/V + time mapping hoisted)
@@ -305,7 +318,8 @@ def main():
             dom = max((k for k in bd if bd[k][2] > 0), key=lambda k: bd[k][1])
             n_dom, ms_dom, fl_dom = bd[dom]
             alg = fl_dom / (ms_dom * 1e-3) / 1e12
-            roof.update({"kernel": dom + " (all instantiations of the dominant kernel class in one U-Net eval)",
+            roof.update({"kernel": dom + (" = fused transformer kernels k_tblock32 / k_tf128 / k_tf256" if dom == "k_tblock" else "")
+                                   + " (all launches of the dominant kernel class in one U-Net eval)",
                          "achieved": round(alg * mult, 2), "frac": round(alg * mult / peak, 4),
                          "algorithmic_tflops_fp32_equiv": round(alg, 2), "launches_per_eval": n_dom,
                          "avg_launch_us": round(1e3 * ms_dom / n_dom, 2), "flops_per_launch_avg": fl_dom / n_dom})
@@ -396,6 +410,30 @@ def main():
                                    "ms_per_step": round(1e3 * dt32 / f32_steps, 2), "dtype": "f32 (exact fp32 MFMA products)",
                                    "max_abs_vs_default_mode_same_noise": float((o32 - ref_step).abs().max())}
             del m32
+
+        if not a.no_other_configs and world == 1 and a.workload == "cfg1" and a.cond_scale == 1.0:
+            # the other single-GPU configurations of BASELINE.json with the same binary, few steps each (informational:
+            # the headline `value` above is configs[1])
+            def quick(tag, case, batch, tsteps, cscale, nsteps=2):
+                with contextlib.redirect_stdout(sys.stderr):
+                    mm = model if case == "cfg1" else make_synth_model(case, device)
+                sq = synth_normal(f"bench/other/{tag}", (batch, mm.unet.config.ctx_max_length)).to(device)
+                mm.sample(sq, device, cond_scale=cscale, timesteps=tsteps, noise=NoiseSource(seed=5, sample0=0))
+                torch.cuda.synchronize(device)
+                c0 = time.perf_counter()
+                for k in range(nsteps):
+                    o = mm.sample(sq, device, cond_scale=cscale, timesteps=tsteps, noise=NoiseSource(seed=6 + k, sample0=0))
+                torch.cuda.synchronize(device)
+                dt = (time.perf_counter() - c0) / nsteps
+                assert torch.isfinite(o).all()
+                return {"molecules_per_s": round(batch / dt, 1), "ms_per_step": round(1e3 * dt, 2), "batch": batch,
+                        "timesteps": tsteps, "cond_scale": cscale}
+            result["other_configs"] = {
+                "configs[2] QMDiffusionForward": quick("cfg3", "cfg3", 4096, 100, 1.0),
+                "configs[3] per-GPU shard (batch 8192)": quick("shard", "cfg1", 8192, 64, 1.0),
+                "configs[1] with guidance (cond_scale 7.5)": quick("cfg", "cfg1", 1024, 64, 7.5),
+                "configs[4] architecture (channels 256, fp32-class products)": quick("cfg5", "cfg5", 128, 16, 1.0, nsteps=1),
+            }
 
         if not a.no_cpu_baseline and world == 1:
             result["cpu_baseline"], result["parity"] = cpu_baseline_leg(torch, model, device, evals)

@@ -131,7 +131,7 @@ class CompiledUNet:
 
 class UNetCompiler:
     def __init__(self, cfg: UNetConfig, length: int, cond_len: int, sd: Dict[str, torch.Tensor],
-                 max_time_rows: int = 1024, gemm_mode: str = "bf16x3", fuse_blocks: bool = True):
+                 max_time_rows: int = 1024, gemm_mode: str = "bf16x3", fuse_blocks: bool = True, tf256: bool = False):
         self.fuse_blocks = fuse_blocks
         self.fuse_c256 = os.environ.get("MDT_FUSE_C256", "1") == "1"
         self.tb32 = os.environ.get("MDT_TB32", "1") == "1"           # C = 256 blocks on 32-row workgroups (k_tblock32)
@@ -154,7 +154,10 @@ class UNetCompiler:
         self.fuse_cross = os.environ.get("MDT_FUSE_CROSS", "1")
         self.use_gn_act = os.environ.get("MDT_GN_ACT", "1") == "1"
         self.tf128 = os.environ.get("MDT_TF128", "1") == "1"         # a whole C = 128 Transformer1d as ONE launch (k_tf128)
-        self.tf256 = os.environ.get("MDT_TF256", "1") == "1"         # ... and a whole C = 256 one (k_tf256, 32-row workgroups)
+        # ... and a whole C = 256 one (k_tf256, 32-row workgroups, no head split).  Measured at B = 1024 (128 workgroups): 1.38 ms
+        # for the five transformers against 1.25 ms as head-split launches (both bound by the per-CU weight stream); it wins
+        # once the batch fills the chip without the split, so it is a per-batch choice (engine: program "eval_wide")
+        self.tf256 = bool(tf256)
         if gemm_mode not in ("f32", "bf16x3"):
             raise ValueError("gemm_mode must be 'f32' (exact fp32 MFMA) or 'bf16x3' (split-bf16 MFMA)")
         self.gemm_mode = gemm_mode
@@ -1324,5 +1327,8 @@ def _prod(xs) -> int:
 
 
 def compile_unet(cfg: UNetConfig, length: int, cond_len: int, sd: Dict[str, torch.Tensor],
-                 max_time_rows: int = 1024, gemm_mode: str = "bf16x3", fuse_blocks: bool = True) -> CompiledUNet:
-    return UNetCompiler(cfg, length, cond_len, sd, max_time_rows, gemm_mode, fuse_blocks).build()
+                 max_time_rows: int = 1024, gemm_mode: str = "bf16x3", fuse_blocks: bool = True,
+                 tf256: bool = False) -> CompiledUNet:
+    """tf256: the 256-channel transformers as whole-transformer launches without the head split (k_tf256.hip; the better
+    form once the batch fills the chip by itself) instead of one head-split launch per sub-block (k_tblock32.hip)."""
+    return UNetCompiler(cfg, length, cond_len, sd, max_time_rows, gemm_mode, fuse_blocks, tf256).build()

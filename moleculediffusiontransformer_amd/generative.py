@@ -106,7 +106,8 @@ class _FusedLoop:
         o, emb = self.owner, self.kw["embedding"]
         if emb.shape[0] == 0:                       # nothing to generate (the reference returns an empty tensor too)
             return torch.empty(0, o.pred_dim, o.max_length, device=emb.device)
-        eng = o.engine(emb.device, emb.shape[1])
+        guided = self.kw.get("embedding_scale", 1.0) != 1.0
+        eng = o.engine(emb.device, emb.shape[1], emb.shape[0] * (2 if guided else 1))
         ns = o._noise_source(noise, emb.shape[0], emb.device)
         x = self.extra
         return run_adpm2(eng, emb, o.pred_dim, num_steps, ns, sigmas, sampler, o.diffusion.diffusion.sigma_data,
@@ -115,7 +116,8 @@ class _FusedLoop:
 
     def inpaint(self, source, mask, sampler, sigmas, num_steps, num_resamples):
         o, emb = self.owner, self.kw["embedding"]
-        eng = o.engine(emb.device, emb.shape[1])
+        guided = self.kw.get("embedding_scale", 1.0) != 1.0
+        eng = o.engine(emb.device, emb.shape[1], emb.shape[0] * (2 if guided else 1))
         draw, seed = self.extra.get("draw"), self.extra.get("seed")
         if draw is None and seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
@@ -160,6 +162,7 @@ class _QMBase(nn.Module):
         # 'bf16x3': split-bf16 MFMA GEMMs (fp32-class accuracy, ~5x the fp32-MFMA rate); 'f32': exact fp32 MFMA
         self.gemm_mode = os.environ.get("MDT_GEMM", "bf16x3")
         self._engine: Optional[UNetEngine] = None
+        self._engines = {}               # wide (bool) -> UNetEngine, for the current parameter values
         self._engine_key = None
         self.sampler_stats = {}
 
@@ -167,20 +170,42 @@ class _QMBase(nn.Module):
     def _param_key(self, device, n_ctx):
         return (str(device), n_ctx, self.gemm_mode, tuple((p.data_ptr(), p._version) for p in self.unet.parameters()))
 
-    def engine(self, device, n_ctx: Optional[int] = None) -> UNetEngine:
-        """Compiled-program engine for the current parameter values on `device` (rebuilt after an
-        optimiser step or load_state_dict) and `n_ctx` conditioning tokens."""
+    def _wide(self, batch: Optional[int]) -> bool:
+        """Which form of the 256-channel transformers to run (compiler.py: MDT_TF256).  One launch per sub-block with the
+        heads split over two workgroups fills the chip at small batches; from ~1536 samples (4 tokens per sample at that
+        level: 192 workgroups of 32 rows) the whole-transformer launch without the split is faster (measured: +10 % at 2048,
+        +7 % at 4096, -11 % at 1024)."""
+        env = os.environ.get("MDT_TF256", "auto")
+        if env in ("0", "1"):
+            return env == "1"
+        cfg = self.unet.config
+        t256 = None
+        length = self.max_length // cfg.patch_size
+        for lvl in range(cfg.num_layers + 1):
+            if cfg.level_channels(lvl) == 256:
+                t256 = length
+            if lvl < cfg.num_layers:
+                length //= cfg.factors[lvl]
+        return bool(batch) and t256 is not None and batch * t256 >= 6144
+
+    def engine(self, device, n_ctx: Optional[int] = None, batch: Optional[int] = None) -> UNetEngine:
+        """Compiled-program engine for the current parameter values on `device` (rebuilt after an optimiser step or
+        load_state_dict), `n_ctx` conditioning tokens and the kernel choice that fits `batch` U-Net rows (see _wide)."""
         device = torch.device(device)
         _require_gpu(device)
         n_ctx = self.unet.config.ctx_max_length if n_ctx is None else n_ctx
         if n_ctx > self.unet.config.ctx_max_length:
             raise AssertionError("Input sequence length must be <= max_length")   # FixedEmbedding, modules.py:1194
+        wide = self._wide(batch)
         key = self._param_key(device, n_ctx)
-        if self._engine is None or self._engine_key != key:
-            sd = {k: v.detach().float().cpu() for k, v in self.unet.state_dict().items()}
-            compiled = compile_unet(self.unet.config, self.max_length, n_ctx, sd, gemm_mode=self.gemm_mode)
-            self._engine = UNetEngine(compiled, device)
+        if self._engine_key != key:                  # parameters changed: every cached engine is stale
+            self._engines = {}
             self._engine_key = key
+        if wide not in self._engines:
+            sd = {k: v.detach().float().cpu() for k, v in self.unet.state_dict().items()}
+            compiled = compile_unet(self.unet.config, self.max_length, n_ctx, sd, gemm_mode=self.gemm_mode, tf256=wide)
+            self._engines[wide] = UNetEngine(compiled, device)
+        self._engine = self._engines[wide]
         return self._engine
 
     # ------------------------------------------------------------------ conditioning prelude
@@ -232,7 +257,7 @@ class _QMBase(nn.Module):
             return out
         lib = rt.load_library()
         device = x.device
-        eng = self.engine(device, embedding.shape[1])
+        eng = self.engine(device, embedding.shape[1], x.shape[0])
         B, C, L = x.shape
         Cp = eng.c.in_pad
         with torch.no_grad(), torch.cuda.device(device):
@@ -253,7 +278,7 @@ class _QMBase(nn.Module):
     def _denoise(self, x_noisy: Tensor, sigma, embedding: Tensor, embedding_scale: float = 1.0) -> Tensor:
         lib = rt.load_library()
         device = x_noisy.device
-        eng = self.engine(device, embedding.shape[1])
+        eng = self.engine(device, embedding.shape[1], x_noisy.shape[0])
         w = scale_weights(torch.as_tensor(sigma, dtype=torch.float32).cpu(), self.diffusion.diffusion.sigma_data)
         B, C, L = x_noisy.shape
         Cp = eng.c.in_pad

@@ -605,7 +605,7 @@ def test_fused_transformer(C, T, B, layers, cross, fixed):
     cfg = inverse_unet_config(16, 64, 128, n_ctx)
     p = "tf."
     sd = _transformer_sd(p, C, layers, cross)
-    comp = UNetCompiler(cfg, 64, n_ctx, sd)
+    comp = UNetCompiler(cfg, 64, n_ctx, sd, tf256=True)
     if not (comp.tf128_ok(C, T, layers, cross) or comp.tf256_ok(C, T, layers, cross)):
         pytest.skip("shape outside the fused transformers' envelope")
     x = Ten(A, 0, T, C)

@@ -71,6 +71,26 @@ def test_sample_matches_reference(models, name, case, want):
     assert (out.cpu() - out_ref).abs().max() < TOL
 
 
+def test_wide_batch_kernel_choice_matches_reference(monkeypatch):
+    """The 256-channel transformers run as head-split launches per sub-block at small batches and as whole-transformer
+    launches (k_tf256) from ~1536 samples on (generative.py::_wide).  Both forms against the reference's golden sample, and
+    the automatic choice by batch size."""
+    g = load_golden("cfg1_b2_t12_cfg7p5_sample.npz")
+    m = make_model("cfg1")
+    seq, T = to_t(g["seq"]), int(g["timesteps"])
+    init, step = noise_fns("cfg1_b2_t12_cfg7p5", tuple(g["out"].shape))
+    outs = {}
+    for wide in ("0", "1"):
+        monkeypatch.setenv("MDT_TF256", wide)
+        outs[wide] = m.sample(seq, DEV, cond_scale=7.5, timesteps=T, noise=NoiseSource(init=init, steps=lambda i: step(i, init))).cpu()
+        kinds = {op.kind for op in m._engine.c.programs["eval"]}
+        from moleculediffusiontransformer_amd import runtime as rt
+        assert (rt.OP_TF256 in kinds) == (wide == "1")
+        assert (outs[wide] - to_t(g["out"])).abs().max() < TOL
+    monkeypatch.delenv("MDT_TF256")
+    assert m._wide(1024) is False and m._wide(2048) is True and m._wide(None) is False
+
+
 def test_inpaint_matches_reference(models):
     g = load_golden("tiny_inpaint.npz")
     m = models("tiny")

@@ -172,7 +172,7 @@ def test_token_chain_between_the_two_models():
     assert tokens_to_forward_input(t, 3).tolist() == [[3.0, 5.0, 1.0], [2.0, 2.0, 0.0], [0.0, 0.0, 0.0]]
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "bf16x3-wide"])
 @pytest.mark.parametrize("case", ["tiny", "pd22", "cfg3", "cfg1", "sparse"])
 def test_lowering_matches_reference_golden(case, mode):
     """compiler.py's op program, executed by the CPU interpreter, reproduces the reference U-Net output."""
@@ -180,8 +180,14 @@ def test_lowering_matches_reference_golden(case, mode):
     mk = {"inverse": inverse_unet_config, "forward": forward_unet_config, "sparse": sparse_unet_config}[kind]
     ucfg = mk(kw["pred_dim"], kw["channels"], 128, kw["context_embedding_max_length"])
     usd = {k[5:]: v for k, v in synth_sd(case).items() if k.startswith("unet.")}
+    wide = mode.endswith("-wide")       # 256-channel transformers as whole-transformer launches (k_tf256)
+    mode = mode.split("-")[0]
+    if wide and case not in ("cfg1", "sparse"):
+        pytest.skip("no 256-channel fused transformer in this configuration")
     cu = compile_unet(ucfg, kw["max_length"], kw["context_embedding_max_length"], usd, max_time_rows=4,
-                      gemm_mode=mode)
+                      gemm_mode=mode, tf256=wide)
+    if wide:
+        assert any(op.kind == rt.OP_TF256 for op in cu.programs["eval"])
     tol = 1e-5 if mode == "f32" else 5e-5      # split weights carry ~2^-17 relative rounding
     g = load_golden(f"{case}_unet.npz")
     x, t, emb = (torch.from_numpy(g[k]) for k in ("x", "t", "emb"))
