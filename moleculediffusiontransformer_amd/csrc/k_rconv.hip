@@ -136,7 +136,7 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
   if (wave >= 4) {
     // ================= loader waves: the weight stream (k_tblock_lw.hip) =================
     const int iw = wave - 4;
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(MDT_LOADER_PRIO);
     const int lpP = lane >> 5;
     const int xP = (lane & 15) ^ lpP;
     const int baseP = ((lane >> 4) & 1) * (128 * CS) + lpP * (2 * CS);

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
   if (wave >= 4) {
     // ================= loader waves (see k_tblock_lw.hip) =================
     const int iw = wave - 4;
-    __builtin_amdgcn_s_setprio(3);   // few instructions, all on the critical path of the stream: issue ahead of the MFMA waves
+    __builtin_amdgcn_s_setprio(MDT_LOADER_PRIO);   // few instructions, all on the critical path of the stream: issue ahead of the MFMA waves
     const int lpP = lane >> 5;
     const int xP = (lane & 15) ^ lpP;
     const int baseP = ((lane >> 4) & 1) * (128 * CS) + lpP * (2 * CS);

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(512) void k_tf128(TFArgs a) {
   if (wave >= 4) {
     // ================= loader waves: the weight / K / V stream of every segment (k_tblock_lw.hip) =================
     const int iw = wave - 4;
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(MDT_LOADER_PRIO);
     const cu32p tiles = (cu32p)a.tiles;              // descriptors: kind (0 P, 1 O, 2 K, 3 V) | aux << 2, scalar loads
     const int lpP = lane >> 5;
     const int xP = (lane & 15) ^ lpP;

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
   if (wave >= 4) {
     // ================= loader waves (k_tblock32.hip, descriptor-driven as k_tf128.hip) =================
     const int iw = wave - 4;
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(MDT_LOADER_PRIO);
     const cu32p tiles = (cu32p)a.tiles;              // kind (3 bits) | aux << 3
     const int lpP = lane >> 5;
     const int xP = (lane & 15) ^ lpP;

@@ -4,6 +4,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// priority of the loader waves of the ring kernels (s_setprio): 3 = their few instructions issue ahead of the MFMA waves
+#ifndef MDT_LOADER_PRIO
+#define MDT_LOADER_PRIO 3
+#endif
+
 namespace mdt {
 
 struct GemmArgs {

@@ -6,20 +6,20 @@
 # 3. PMC passes, kernel-trace only, on a 4-timestep run: FETCH_SIZE, WRITE_SIZE (HBM traffic), SQ wave-state /
 #    MFMA-busy / LDS-conflict counters -> .../pmc_fetch, .../pmc_write, .../pmc_sq
 # tools/pmc_summary.py then folds 2+3 into the csv files committed under profiles/.
-tag=${1:-r1}
+tag=${1:-r2}
 root=$(pwd)
 out=$root/gpurun_out/prof_$tag
 rm -rf "$out"; mkdir -p "$out"
 export TMPDIR=/tmp
 python3 bench.py > "$out/bench.json" 2> "$out/bench.err"
 cd /tmp
-rocprofv3 --output-format csv --kernel-trace --stats -d "$out/trace" -o runc -- python3 "$root/bench.py" --no-cpu-baseline \
+rocprofv3 --output-format csv --kernel-trace --stats -d "$out/trace" -o runc -- python3 "$root/bench.py" --no-cpu-baseline --no-exact-f32 --no-other-configs \
     > "$out/bench_under_rocprof.json" 2> "$out/trace.log"
 rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d "$out/pmc_fetch" -o runc -- python3 "$root/bench.py" \
-    --no-cpu-baseline --no-breakdown --timesteps 4 --steps 1 --warmup 1 > "$out/pmc_fetch.json" 2> "$out/pmc_fetch.log"
+    --no-cpu-baseline --no-exact-f32 --no-other-configs --no-breakdown --timesteps 4 --steps 1 --warmup 1 > "$out/pmc_fetch.json" 2> "$out/pmc_fetch.log"
 rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d "$out/pmc_write" -o runc -- python3 "$root/bench.py" \
-    --no-cpu-baseline --no-breakdown --timesteps 4 --steps 1 --warmup 1 > "$out/pmc_write.json" 2> "$out/pmc_write.log"
+    --no-cpu-baseline --no-exact-f32 --no-other-configs --no-breakdown --timesteps 4 --steps 1 --warmup 1 > "$out/pmc_write.json" 2> "$out/pmc_write.log"
 rocprofv3 --output-format csv --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d "$out/pmc_sq" -o runc -- python3 "$root/bench.py" \
-    --no-cpu-baseline --no-breakdown --timesteps 4 --steps 1 --warmup 1 > "$out/pmc_sq.json" 2> "$out/pmc_sq.log"
+    --no-cpu-baseline --no-exact-f32 --no-other-configs --no-breakdown --timesteps 4 --steps 1 --warmup 1 > "$out/pmc_sq.json" 2> "$out/pmc_sq.log"
 cd "$root"
 # then, where profiles/ is tracked:  python3 tools/pmc_summary.py gpurun_out/prof_$tag $tag
