@@ -92,6 +92,10 @@ enum mdt_op_kind {
                           sub-block) | aux << 3, two scratch descriptors after every sub-block; vectors: 768 floats per
                           sub-block ([bias 256] / [bq 512 | bo 256] / [b1 512 | b2 256]); NPOST = 8 sub-tiles; ints and
                           floats as MDT_OP_TF128 with C = 256                                                     */
+  MDT_OP_ATTN_CTX = 13, /* cross-attention core against the NORMALISED CONTEXT itself (K = V = c, shared by all heads and layers;
+                          the per-layer key / value projections are folded into the query / output projections by the host):
+                          a = q' [B][T * heads][128] (rows (token, head)), a2 = c [B | 1][Tk <= 64][LDKV], out [B][T * heads][128]
+                          = softmax(q' c^T * scale) c; ints as MDT_OP_ATTN (LDQ / LDO unused)                              */
   MDT_OP_TBLOCK = 7    /* fused transformer sub-block, in place on x (TransformerBlock.forward, modules.py:456-461):
                           x += Attention(x) | x += Attention(x, context) | x += FeedForward(x); LayerNorm affine
                           folded into the projection weights, q/k/v/probabilities/hidden never leave registers */

@@ -153,6 +153,10 @@ class UNetCompiler:
         # "all" also the older kernels' shapes
         self.fuse_cross = os.environ.get("MDT_FUSE_CROSS", "1")
         self.use_gn_act = os.environ.get("MDT_GN_ACT", "1") == "1"
+        # cross-attention layers that run layer by layer over MANY keys (QMDiffusionForward: 64): fold the key / value
+        # projections into the query / output projections and attend to the normalised context itself
+        self.fold_ctx = os.environ.get("MDT_FOLD_CTX", "1") == "1"
+        self.has_chat = False                # some layer attends to the normalised context (ctx program emits it)
         self.tf128 = os.environ.get("MDT_TF128", "1") == "1"         # a whole C = 128 Transformer1d as ONE launch (k_tf128)
         # ... and a whole C = 256 one (k_tf256, 32-row workgroups, no head split).  Measured at B = 1024 (128 workgroups): 1.38 ms
         # for the five transformers against 1.25 ms as head-split launches (both bound by the per-CU weight stream); it wins
@@ -957,6 +961,48 @@ class UNetCompiler:
                   bias_off=self._vec(p + "attention.to_out.bias", c), res=t)
         self._free(ao)
 
+    def fold_ok(self) -> bool:
+        """Fold a layer-by-layer cross-attention onto the normalised context?  Worth it when the hoisted K / V rows are the
+        launch's main traffic (many keys); with few keys the doubled projections cost more than they save."""
+        return self.fold_ctx and self.n_ctx >= 32 and self.n_ctx <= 64 and self.cfg.ctx_features == 128
+
+    def attention_layer_folded(self, t: Ten, p: str) -> None:
+        """x = Attention(x, context) + x (modules.py:401-410, :350-364) WITHOUT materialised keys / values.  With
+        c = (ctx - mean) / std, LN_ctx(ctx) = c g + b, k_h = c A_h + a_h and v_h = c B_h + b_h (A_h = diag(g) Wk_h^T, ...):
+          S_h = q_h k_h^T = (q_h A_h^T) c^T + const per query  ->  q'_h = Mq_h LN(x),  Mq_h = diag(g) Wk_h^T Wq_h   [128 x C]
+          out = sum_h (P_h v_h) Wo_h^T + bo = sum_h (P_h c) N_h^T + bo',  N_h = Wo_h Wv_h diag(g),  bo' = bo + Wo (Wv b)
+        (the constant drops out of the softmax; rows of P sum to one).  Three ops: GEMM(LN) -> MDT_OP_ATTN_CTX -> GEMM."""
+        cfg, sd = self.cfg, self.sd
+        c, mid, F_ = t.ld, cfg.mid_features, cfg.ctx_features
+        H = cfg.heads
+        gq, bq = self._vec(p + "norm.weight", c), self._vec(p + "norm.bias", c)
+        g_c, b_c = sd[p + "norm_context.weight"].double(), sd[p + "norm_context.bias"].double()
+        wq = sd[p + "to_q.weight"].double()                                    # [mid, C]
+        wkv = sd[p + "to_kv.weight"].double()                                  # [2 mid, F]
+        wk, wv = wkv[:mid], wkv[mid:]
+        wo, bo = sd[p + "attention.to_out.weight"].double(), sd[p + "attention.to_out.bias"].double()   # [C, mid]
+        mq = torch.cat([(wk[64 * h: 64 * h + 64] * g_c.unsqueeze(0)).T @ wq[64 * h: 64 * h + 64] for h in range(H)])   # [H F, C]
+        nn_ = torch.cat([wo[:, 64 * h: 64 * h + 64] @ (wv[64 * h: 64 * h + 64] * g_c.unsqueeze(0)) for h in range(H)], dim=1)  # [C, H F]
+        bo2 = bo + wo @ (wv @ b_c)
+        qf = self._new(t.rows, H * F_)
+        self.gemm(t, (p + "folded.q", mq.float()), H * F_, qf, cin=c, pro=rt.PRO_LAYERNORM, gain=gq, nbias=bq, eps=1e-5)
+        r = self._new(t.rows, H * F_)
+        op = rt.MdtOp()
+        op.kind = rt.OP_ATTN_CTX
+        op.a, op.out = qf.ref(), r.ref()
+        op._kv = ("chat", 0)
+        op.a2 = _ref(rt.SP_ACT, 0)
+        i = op.i
+        i[rt.A_T], i[rt.A_TK], i[rt.A_HEADS] = t.rows, self.n_ctx, H
+        i[rt.A_LDQ], i[rt.A_LDKV], i[rt.A_LDO], i[rt.A_KV_BSTRIDE] = F_, F_, F_, self.n_ctx
+        op.f[0] = float(cfg.head_features) ** -0.5
+        self._emit(op)
+        self.flops += 2 * 2 * t.rows * H * self.n_ctx * F_
+        self._free(qf)
+        self.gemm(r, (p + "folded.out", nn_.float()), c, t, cin=H * F_, bias_off=self.W.add(p + "folded.out.bias", bo2.float()), res=t)
+        self._free(r)
+        self.has_chat = True
+
     def transformer(self, x: Ten, p: str, c: int, layers: int, cross: bool, free_input: bool = True) -> Ten:
         """Transformer1d.forward (modules.py:519-524)."""
         cfg = self.cfg
@@ -1031,6 +1077,9 @@ class UNetCompiler:
                     if (self.fuse_cross == "all" and keys16 <= 64) or (self.fuse_cross == "1" and ring_x):
                         self.tblock(t, rt.TB_CROSS, bp + "cross_attention.", len(self.cross_layers) - 1,
                                     variant=xv)
+                    elif self.fold_ok():
+                        self.cross_layers.pop()
+                        self.attention_layer_folded(t, bp + "cross_attention.")
                     else:
                         # q-GEMM + attention + out-GEMM (the pre-ring fused cross kernels measured slower than this:
                         # 78 us against ~62 us, their per-head K/V loads were not pipelined)
@@ -1044,7 +1093,9 @@ class UNetCompiler:
                     self.tblock(t, rt.TB_FF, bp + "feed_forward.", variant=ffv)
                 continue
             self.attention_layer(t, bp + "attention.", None)
-            if cross:
+            if cross and self.fold_ok():
+                self.attention_layer_folded(t, bp + "cross_attention.")
+            elif cross:
                 self.cross_layers.append(bp + "cross_attention.")
                 self.attention_layer(t, bp + "cross_attention.", len(self.cross_layers) - 1)
             h = self._new(t.rows, c * cfg.ff_mult)
@@ -1197,6 +1248,9 @@ class UNetCompiler:
         kv_base = self.arena.top
         self.kv_slots = [kv_base + i * self.n_ctx * mid2 for i in range(n_cross)]
         act_floats = kv_base + n_cross * self.n_ctx * mid2
+        chat_slot = act_floats                      # the normalised context c [n_ctx][ctx_features] per sample (folded layers)
+        if self.has_chat:
+            act_floats += (self.n_ctx * cfg.ctx_features + 63) // 64 * 64
 
         # ---- shared arena layout ----
         rows = self.max_time_rows
@@ -1211,6 +1265,7 @@ class UNetCompiler:
         ss_cur = self._shr_alloc("ss_cur", self.ss_total)
         kvf = self._shr_alloc("kv_fixed", n_cross * self.n_ctx * mid2)
         self.kv_fixed = [kvf + i * self.n_ctx * mid2 for i in range(n_cross)]
+        chat_fixed = self._shr_alloc("chat_fixed", self.n_ctx * cfg.ctx_features)
 
         # ---- resolve symbolic refs of the eval program; derive the fixed-embedding twin ----
         def resolve(ops, fixed: bool):
@@ -1220,7 +1275,13 @@ class UNetCompiler:
                 C_memmove(o, op)
                 if op.kind in (rt.OP_GEMM, rt.OP_GN_ACT, rt.OP_RCONV, rt.OP_RESBLOCK) and isinstance(getattr(op, "_film", None), tuple):
                     o.p3 = _ref(rt.SP_SHR, ss_cur + op._film[1])
-                if op.kind in (rt.OP_ATTN, rt.OP_TBLOCK, rt.OP_TF128, rt.OP_TF256) and isinstance(getattr(op, "_kv", None), tuple):
+                if op.kind == rt.OP_ATTN_CTX:
+                    if fixed:
+                        o.a2 = _ref(rt.SP_SHR, chat_fixed)
+                        o.i[rt.A_KV_BSTRIDE] = 0
+                    else:
+                        o.a2 = _ref(rt.SP_ACT, chat_slot)
+                elif op.kind in (rt.OP_ATTN, rt.OP_TBLOCK, rt.OP_TF128, rt.OP_TF256) and isinstance(getattr(op, "_kv", None), tuple):
                     idx = op._kv[1]
                     slot = {rt.OP_ATTN: rt.A_KV_BSTRIDE, rt.OP_TBLOCK: rt.B_KV_BSTRIDE, rt.OP_TF128: rt.F_KV_BSTRIDE,
                             rt.OP_TF256: rt.F_KV_BSTRIDE}[op.kind]
@@ -1238,7 +1299,7 @@ class UNetCompiler:
         # hoisted K/V, the second half to the FixedEmbedding's.  Needs every cross-attention block on a ring kernel (the
         # only ones that take the second K/V pointer); otherwise the engine falls back to two passes.
         tb_lw = os.environ.get("MDT_TB_LW", "1") != "0"
-        cross = [op for op in eval_ops if isinstance(getattr(op, "_kv", None), tuple)]
+        cross = [op for op in eval_ops if isinstance(getattr(op, "_kv", None), tuple)]      # (folded layers: never "ring")
         ring = all(op.kind in (rt.OP_TF128, rt.OP_TF256) or
                    (op.kind == rt.OP_TBLOCK and (op.i[rt.B_VARIANT] >= 2 or (op.i[rt.B_VARIANT] == 0 and tb_lw and op.i[rt.B_C] == 128
                                                                          and (16 // op.i[rt.B_T]) * op.i[rt.B_TK] <= 16)))
@@ -1304,6 +1365,18 @@ class UNetCompiler:
             self.ops = fixed_ops
             self.gemm(fixed, w, mid2, Ten(rt.SP_SHR, self.kv_fixed[idx], self.n_ctx, mid2), cin=cfg.ctx_features,
                       pro=rt.PRO_LAYERNORM, gain=gain, nbias=nb, eps=1e-5, m_mode=2, count_flops=False)
+        if self.has_chat:
+            # c = LayerNorm(ctx) without affine, once per call, shared by every folded layer: identity GEMM with the
+            # LayerNorm prologue (gain 1, bias 0)
+            F_ = cfg.ctx_features
+            eye = ("ctx_identity", torch.eye(F_))
+            ones, zeros = self.W.add("ctx_ones", torch.ones(F_)), self._zeros(F_)
+            self.ops = ctx_ops
+            self.gemm(ctx, eye, F_, Ten(rt.SP_ACT, chat_slot, self.n_ctx, F_), cin=F_, pro=rt.PRO_LAYERNORM, gain=ones,
+                      nbias=zeros, eps=1e-5)
+            self.ops = fixed_ops
+            self.gemm(fixed, eye, F_, Ten(rt.SP_SHR, chat_fixed, self.n_ctx, F_), cin=F_, pro=rt.PRO_LAYERNORM, gain=ones,
+                      nbias=zeros, eps=1e-5, m_mode=2, count_flops=False)
         programs["ctx"], programs["ctx_fixed"] = ctx_ops, fixed_ops
         flops_ctx = self.flops
 

@@ -137,4 +137,132 @@ hipError_t launch_attn(const AttnArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Cross-attention against the NORMALISED CONTEXT ITSELF (MDT_OP_ATTN_CTX): the per-layer key / value projections are
+// folded into the query and output projections on the host (compiler.py::attention_layer_folded),
+//   S_h = (LN(x) Mq_h^T) c^T,   out = sum_h (softmax(S_h) c) N_h^T,     c = (ctx - mean) / std  (no affine),
+// so every head of every layer attends to the same Tk x 128 matrix c instead of its own hoisted K / V rows
+// (QMDiffusionForward: 64 keys x 1024 floats per sample and layer = 1 GB per layer at B = 4096, the launch was HBM-bound).
+// K = V = c is shared by the heads, hence the (token, head) pairs of a sample are simply ROWS of one problem:
+//   Q' [R = T * heads rows][128]  x  c [Tk <= 64][128]   ->   out [R][128]
+// one wave per (sample, 16-row tile of R); both contractions in exact fp32 MFMA out of registers.  The MFMA contraction
+// index is free to permute, so both loads are laid out for coalescing instead of for the formula:
+//   S^T = c Q'^T : step s = 4 cc + e of lane quarter g contracts feature 16 cc + 4 g + e -> one dwordx4 per cc, the four
+//                  quarters of a row read 64 contiguous bytes;
+//   O^T = c^T P^T: output row i of tile dt is feature 4 i + dt -> the A operand of the four tiles is ONE dwordx4 of key
+//                  row 16 kt + 4 g + s at floats [64 half + 4 lo, +4), a full 256 B row segment per lane quarter, and
+//                  lane (query, g) ends with out[query][64 half + 16 g + 4 r .. +4) per r = one dwordx4 store.
+// ------------------------------------------------------------------------------------------------------------------
+template <int KT>
+__global__ __launch_bounds__(256) void k_attn_ctx(AttnArgs a) {
+  constexpr int D = 128;
+  const int R = a.T * a.heads;                         // rows per sample
+  const int QT = (R + 15) >> 4;
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wid >= a.batch * QT) return;
+  const int b = wid / QT, qt = wid % QT;
+  const int lane = threadIdx.x & 63;
+  const int lo = lane & 15, g = lane >> 4;
+  const float* q = a.q + (int64_t)b * R * D;           // rows (token, head) are contiguous 128-float vectors
+  const float* c = a.k + (int64_t)b * a.kv_bstride * a.ldkv;
+  float* o = a.out + (int64_t)b * R * D;
+
+  const int i = qt * 16 + lo;
+  float qr[32];
+  {
+    const float4* p = reinterpret_cast<const float4*>(q + (int64_t)(i < R ? i : 0) * D + 4 * g);
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) {
+      const float4 t = p[4 * cc];
+      qr[4 * cc] = t.x; qr[4 * cc + 1] = t.y; qr[4 * cc + 2] = t.z; qr[4 * cc + 3] = t.w;
+    }
+  }
+  f32x4 st[KT];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+    const int j = kt * 16 + lo;                        // A operand of S^T: key row j
+    const float4* p = reinterpret_cast<const float4*>(c + (int64_t)(j < a.Tk ? j : 0) * a.ldkv + 4 * g);
+    float kr[32];
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) {
+      const float4 t = p[4 * cc];
+      kr[4 * cc] = t.x; kr[4 * cc + 1] = t.y; kr[4 * cc + 2] = t.z; kr[4 * cc + 3] = t.w;
+    }
+    f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0;
+#pragma unroll
+    for (int s = 0; s < 32; s += 2) {
+      s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[s], qr[s], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[s + 1], qr[s + 1], s1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int jj = kt * 16 + 4 * g + r;
+      const float sv = jj < a.Tk ? (s0[r] + s1[r]) * a.scale : -INFINITY;
+      st[kt][r] = sv;
+      mx = fmaxf(mx, sv);
+    }
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float e = expf(st[kt][r] - mx);
+      st[kt][r] = e;
+      sum += e;
+    }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.0f / sum;
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) st[kt] *= inv;       // masked keys: exactly 0, times a finite (clamped) row below
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    f32x4 acc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      float4 vr[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int jj = kt * 16 + 4 * g + s;            // key row this lane quarter feeds at step s
+        vr[s] = *reinterpret_cast<const float4*>(c + (int64_t)(jj < a.Tk ? jj : 0) * a.ldkv + 64 * half + 4 * lo);
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float pr = st[kt][s];
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[s].x, pr, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[s].y, pr, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[s].z, pr, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[s].w, pr, acc[3], 0, 0, 0);
+      }
+    }
+    if (i < R) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        *reinterpret_cast<float4*>(o + (int64_t)i * D + 64 * half + 16 * g + 4 * r) =
+            make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+    }
+  }
+}
+
+hipError_t launch_attn_ctx(const AttnArgs& a, hipStream_t s) {
+  if (a.batch <= 0) return hipSuccess;
+  if (a.Tk <= 0 || a.Tk > 64 || a.ldkv % 4 || a.T <= 0 || a.heads <= 0) return hipErrorInvalidValue;
+  const int tiles = a.batch * ((a.T * a.heads + 15) / 16);
+  const dim3 grid((unsigned)((tiles + 3) / 4)), block(256);
+  switch ((a.Tk + 15) / 16) {
+    case 1: hipLaunchKernelGGL(k_attn_ctx<1>, grid, block, 0, s, a); break;
+    case 2: hipLaunchKernelGGL(k_attn_ctx<2>, grid, block, 0, s, a); break;
+    case 3: hipLaunchKernelGGL(k_attn_ctx<3>, grid, block, 0, s, a); break;
+    default: hipLaunchKernelGGL(k_attn_ctx<4>, grid, block, 0, s, a); break;
+  }
+  return hipGetLastError();
+}
+
 }  // namespace mdt

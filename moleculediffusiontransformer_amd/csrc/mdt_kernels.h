@@ -107,6 +107,8 @@ struct AttnArgs {
   float scale;
 };
 hipError_t launch_attn(const AttnArgs& a, hipStream_t s);
+// MDT_OP_ATTN_CTX: rows q [batch][T * heads][128] against the normalised context k [batch | 1][Tk][ldkv >= 128] (K = V)
+hipError_t launch_attn_ctx(const AttnArgs& a, hipStream_t s);
 
 struct TBlockArgs {
   float* x;            // [M][ldx] fp32, updated in place

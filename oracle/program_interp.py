@@ -168,6 +168,15 @@ def run_program(ops, bufs: Buffers, B: int, n_shared_rows: int = 0) -> None:
             out[:, 1 + half: 1 + 2 * half] = fr.cos()
         elif op.kind == rt.OP_TBLOCK:
             _tblock(op, bufs, B)
+        elif op.kind == rt.OP_ATTN_CTX:
+            T, Tk, H, ldkv, bs = i[rt.A_T], i[rt.A_TK], i[rt.A_HEADS], i[rt.A_LDKV], i[rt.A_KV_BSTRIDE]
+            q = bufs.view(op.a, B, B * T * H * 128).view(B, T * H, 128)
+            if bs == 0:
+                c = bufs.view(op.a2, B, Tk * ldkv).view(1, Tk, ldkv)[:, :, :128].expand(B, -1, -1)
+            else:
+                c = bufs.view(op.a2, B, B * Tk * ldkv).view(B, Tk, ldkv)[:, :, :128]
+            pr = ((q @ c.transpose(1, 2)) * float(f[0])).softmax(-1)
+            bufs.view(op.out, B, B * T * H * 128).view(B, T * H, 128)[:] = pr @ c
         elif op.kind == rt.OP_TF128:
             _tf128(op, bufs, B)
         elif op.kind == rt.OP_TF256:

@@ -156,6 +156,30 @@ def test_attention(B, T, Tk, shared):
     assert (ga - ca).abs().max() < 1e-5
 
 
+@pytest.mark.parametrize("B,T,Tk,shared", [(3, 16, 64, False), (2, 32, 64, True), (5, 4, 40, False), (2, 1, 33, False),
+                                           (1, 64, 64, False), (3, 8, 16, True)])
+def test_attention_on_normalised_context(B, T, Tk, shared):
+    """MDT_OP_ATTN_CTX: softmax(q' c^T scale) c with keys = values = the context rows, against the interpreter and torch."""
+    H, F_ = 8, 128
+    R = T * H
+    act = torch.cat([rnd(B * R * F_, seed=1) * 0.3, rnd(B * Tk * F_, seed=2), torch.zeros(B * R * F_)])
+    shr = rnd(Tk * F_, seed=3)
+    op = rt.MdtOp()
+    op.kind = rt.OP_ATTN_CTX
+    op.a, op.out = ref(A, 0), ref(A, R * F_ + Tk * F_)
+    op.a2 = ref(S, 0) if shared else ref(A, R * F_)
+    i = op.i
+    i[rt.A_T], i[rt.A_TK], i[rt.A_HEADS], i[rt.A_LDQ], i[rt.A_LDKV], i[rt.A_LDO] = T, Tk, H, F_, F_, F_
+    i[rt.A_KV_BSTRIDE] = 0 if shared else Tk
+    op.f[0] = 0.125
+    (ga, _, _), (ca, _, _) = run_both([op], torch.zeros(4), act, shr, {}, B)
+    assert (ga - ca).abs().max() < 1e-5
+    q = act[: B * R * F_].view(B, R, F_).double()
+    c = (shr.view(1, Tk, F_).expand(B, -1, -1) if shared else act[B * R * F_: B * (R + Tk) * F_].view(B, Tk, F_)).double()
+    want = ((q @ c.transpose(1, 2)) * 0.125).softmax(-1) @ c
+    assert (ga[B * (R + Tk) * F_:].view(B, R, F_).double() - want).abs().max() < 1e-5
+
+
 def test_concat_patch_time_embed():
     B, R, Ca, Cb = 3, 16, 128, 128
     act = torch.cat([rnd(B * R * Ca, seed=1), rnd(B * R * Cb, seed=2), torch.zeros(B * R * (Ca + Cb))])
