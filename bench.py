@@ -57,6 +57,9 @@ def parse():
                          "(configs[2]: --batch 4096 --timesteps 100); cfg5 = deep U-Net architecture of configs[4] "
                          "(channels 256, max_len 128).  Other workloads are informational: no CPU baseline / parity leg")
     ap.add_argument("--cond-scale", type=float, default=1.0, help="classifier-free guidance scale (2 U-Net passes if != 1)")
+    ap.add_argument("--gemm-mode", default=None, choices=("bf16x3", "f32", "bf16"),
+                    help="GEMM products: bf16x3 = split-bf16, fp32-class (default); f32 = exact fp32 MFMA; bf16 = plain bf16 "
+                         "products, the reduced-precision mode BASELINE configs[4] names (layer-by-layer GEMM program)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--no-exact-f32", action="store_true")
@@ -259,6 +262,8 @@ def main():
 
     with contextlib.redirect_stdout(sys.stderr):     # the class prints "Using unet type" like the reference does
         model = make_synth_model(a.workload, device)  # synthetic weights (no network for checkpoints)
+    if a.gemm_mode:
+        model.gemm_mode = a.gemm_mode
     B, T = a.batch, a.timesteps
     n_cond = model.unet.config.ctx_max_length
     seq_of = lambda r: synth_normal(f"bench/seq/rank{r}", (B, n_cond))     # noqa: E731
@@ -306,12 +311,15 @@ def main():
         flops_exec = eng.c.flops_per_sample_eval           # executed per sample per eval (K/V + time mapping hoisted)
         avg_eval_ms = sum(eval_ms) / len(eval_ms)
         split = eng.c.gemm_mode == "bf16x3"
+        plain = eng.c.gemm_mode == "bf16"
         # split-bf16 path: every fp32 product is 3 bf16 MFMAs, so the executed matrix-core work is 3x the
-        # algorithmic FLOPs and the roof is the dense bf16 MFMA peak; exact path: fp32 MFMA peak.
-        peak = BF16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
+        # algorithmic FLOPs and the roof is the dense bf16 MFMA peak; plain bf16: one MFMA per product, same roof;
+        # exact path: fp32 MFMA peak.
+        peak = BF16_MFMA_PEAK_TFLOPS if (split or plain) else FP32_MFMA_PEAK_TFLOPS
         mult = 3.0 if split else 1.0
         roof = {"bound": "mfma", "unit": "TFLOP/s", "peak": peak, "traffic": None,
-                "mfma_dtype": "bf16 (3 MFMAs per fp32 product, fp32 accumulate)" if split else "f32"}
+                "mfma_dtype": "bf16 (3 MFMAs per fp32 product, fp32 accumulate)" if split else
+                              ("bf16 (one MFMA per product, fp32 accumulate)" if plain else "f32")}
         extra = {}
         if not a.no_breakdown:
             bd = kernel_breakdown(eng, rt, B)
@@ -336,8 +344,8 @@ def main():
               "launches": len(eng.c.programs["eval"]),
               "flops_per_sample_executed": flops_exec,
               "tflops_executed_fp32_equiv": round(flops_exec * B / (avg_eval_ms * 1e-3) / 1e12, 2)}
-        if split:
-            ue["bf16_mfma_fraction_executed"] = round(3.0 * flops_exec * B / (avg_eval_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4)
+        if split or plain:
+            ue["bf16_mfma_fraction_executed"] = round(mult * flops_exec * B / (avg_eval_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4)
         else:
             ue["fp32_mfma_fraction_executed"] = round(flops_exec * B / (avg_eval_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)
         if a.workload == "cfg1":
@@ -368,10 +376,11 @@ def main():
             "unit": "molecules/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(1e3 * elapsed / a.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 storage/accumulate; GEMM products as split-bf16 (bf16x3) MFMA" if split else "f32",
+            "dtype": "f32 storage/accumulate; GEMM products as split-bf16 (bf16x3) MFMA" if split else
+                     ("f32 storage/accumulate; GEMM products in plain bf16 (reduced precision, see DESIGN.md)" if plain else "f32"),
             "data": "synthetic",
             "config": {"workload": WORKLOADS[a.workload]
-                                   + f"batch={B}/GPU, {T} timesteps ({evals} U-Net evals), cond_scale={a.cond_scale}, fp32",
+                                   + f"batch={B}/GPU, {T} timesteps ({evals} U-Net evals), cond_scale={a.cond_scale}, " + ("bf16 products" if plain else "fp32"),
                        "global_batch": world * B, "timesteps": T, "parallelism": f"batch-shard x{world}"},
             "roofline": roof,
         }
@@ -414,9 +423,11 @@ def main():
         if not a.no_other_configs and world == 1 and a.workload == "cfg1" and a.cond_scale == 1.0:
             # the other single-GPU configurations of BASELINE.json with the same binary, few steps each (informational:
             # the headline `value` above is configs[1])
-            def quick(tag, case, batch, tsteps, cscale, nsteps=2):
+            def quick(tag, case, batch, tsteps, cscale, nsteps=2, gemm_mode=None):
                 with contextlib.redirect_stdout(sys.stderr):
                     mm = model if case == "cfg1" else make_synth_model(case, device)
+                if gemm_mode:
+                    mm.gemm_mode = gemm_mode
                 sq = synth_normal(f"bench/other/{tag}", (batch, mm.unet.config.ctx_max_length)).to(device)
                 mm.sample(sq, device, cond_scale=cscale, timesteps=tsteps, noise=NoiseSource(seed=5, sample0=0))
                 torch.cuda.synchronize(device)
@@ -426,13 +437,22 @@ def main():
                 torch.cuda.synchronize(device)
                 dt = (time.perf_counter() - c0) / nsteps
                 assert torch.isfinite(o).all()
-                return {"molecules_per_s": round(batch / dt, 1), "ms_per_step": round(1e3 * dt, 2), "batch": batch,
-                        "timesteps": tsteps, "cond_scale": cscale}
+                r = {"molecules_per_s": round(batch / dt, 1), "ms_per_step": round(1e3 * dt, 2), "batch": batch,
+                     "timesteps": tsteps, "cond_scale": cscale}
+                if gemm_mode:
+                    # whole sample() call (sampler updates, conditioning prelude and hoisted programs included) over the
+                    # U-Net's executed FLOPs; bf16 mode: one MFMA per product
+                    fl = mm._engine.c.flops_per_sample_eval * batch * 2 * (tsteps - 1)
+                    r.update({"gemm_mode": gemm_mode, "tflops_executed": round(fl / dt / 1e12, 1),
+                              "bf16_mfma_fraction": round(fl / dt / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4)})
+                return r
             result["other_configs"] = {
                 "configs[2] QMDiffusionForward": quick("cfg3", "cfg3", 4096, 100, 1.0),
                 "configs[3] per-GPU shard (batch 8192)": quick("shard", "cfg1", 8192, 64, 1.0),
                 "configs[1] with guidance (cond_scale 7.5)": quick("cfg", "cfg1", 1024, 64, 7.5),
                 "configs[4] architecture (channels 256, fp32-class products)": quick("cfg5", "cfg5", 128, 16, 1.0, nsteps=1),
+                "configs[4] architecture in its bf16 mode (plain bf16 products, bf16 GEMM operands)":
+                    quick("cfg5b", "cfg5", 1024, 16, 1.0, nsteps=1, gemm_mode="bf16"),
             }
 
         if not a.no_cpu_baseline and world == 1:

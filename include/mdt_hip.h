@@ -92,6 +92,8 @@ enum mdt_op_kind {
                           sub-block) | aux << 3, two scratch descriptors after every sub-block; vectors: 768 floats per
                           sub-block ([bias 256] / [bq 512 | bo 256] / [b1 512 | b2 256]); NPOST = 8 sub-tiles; ints and
                           floats as MDT_OP_TF128 with C = 256                                                     */
+  MDT_OP_PREP16 = 14,  /* A operand of a bf16 x bf16 GEMM: out (bf16 [B][R_IN][CIN], CIN / 2 floats per row) = bf16(prologue(a[.., A_COL +
+                          c])); ints R_IN, LDA, CIN, A_COL, PRO, GROUPS, GSIZE, PRO_SILU and p0..p3 / eps as MDT_OP_GEMM          */
   MDT_OP_ATTN_CTX = 13, /* cross-attention core against the NORMALISED CONTEXT itself (K = V = c, shared by all heads and layers;
                           the per-layer key / value projections are folded into the query / output projections by the host):
                           a = q' [B][T * heads][128] (rows (token, head)), a2 = c [B | 1][Tk <= 64][LDKV], out [B][T * heads][128]
@@ -134,13 +136,21 @@ enum mdt_gemm_i {
   MDT_G_M_MODE = 19, /* 0: M = B * R_OUT; 1: M = n_shared_rows * R_OUT; 2: M = R_OUT               */
   MDT_G_A_COL = 20,  /* first channel of the A row to consume                                     */
   MDT_G_O_COL = 21,  /* first column of the output row to write                                   */
-  MDT_G_PHASES = 22  /* f > 1: ConvTranspose1d(k = 2f, stride f, padding f/2) as f output phases of 2 taps in ONE
+  MDT_G_PHASES = 22, /* f > 1: ConvTranspose1d(k = 2f, stride f, padding f/2) as f output phases of 2 taps in ONE
                         launch (modules.py:74-81): phase ph uses weights [ph][N][K], T_OFF = (ph < f/2),
                         O_OFF = f * T_OFF + ph - f/2, O_STRIDE = f; 0 / 1: a plain GEMM                 */
+  MDT_G_WFMT = 23    /* weight format: 0 = fp32 [N][K] (exact fp32 MFMA), or with a2 bound the hi (w) / lo (a2) bf16 planes of the
+                        split product; 1 = ONE bf16 plane [N][K] in w: plain bf16 products (A rounded to bf16 after the prologue,
+                        fp32 accumulation) -- the reduced-precision mode of the deep-UNet configuration;
+                        2 = as 1 with the A operand ALREADY bf16 (written by MDT_OP_PREP16; LDA / A_COL in bf16 elements): both
+                        operands stream through LDS-DMA; no prologue, stride, phases or output row mapping, cin % 64 == 0;
+                        6 = as 2 and the OUTPUT is bf16 too (LDC / O_COL in bf16 elements): a tensor whose only reader is the next
+                        bf16 x bf16 GEMM (feed-forward hidden layer)                                                          */
 };
 enum mdt_gemm_f { MDT_GF_EPS = 0 };
 
-enum mdt_gn_i { MDT_N_ROWS = 0, MDT_N_LD = 1, MDT_N_GROUPS = 2, MDT_N_GSIZE = 3, MDT_N_SILU = 4 };
+enum mdt_gn_i { MDT_N_ROWS = 0, MDT_N_LD = 1, MDT_N_GROUPS = 2, MDT_N_GSIZE = 3, MDT_N_SILU = 4,
+                MDT_N_OUT16 = 5 /* MDT_OP_GN_ACT: 1 = out is bf16 [rows][ld] (A operand of a bf16 x bf16 GEMM) */ };
 enum mdt_gn_f { MDT_NF_EPS = 0 };
 
 enum mdt_rconv_i { MDT_R_T = 0, MDT_R_C = 1, MDT_R_LDA = 2, MDT_R_LDC = 3, MDT_R_LDR = 4, MDT_R_TAPS = 5,
@@ -153,7 +163,8 @@ enum mdt_resblock_f { MDT_KF_EPS = 0 };
 
 enum mdt_attn_i {
   MDT_A_T = 0, MDT_A_TK = 1, MDT_A_HEADS = 2, MDT_A_LDQ = 3, MDT_A_LDKV = 4, MDT_A_LDO = 5,
-  MDT_A_KV_BSTRIDE = 6 /* rows between consecutive samples' K/V (TK, or 0 for a batch-invariant context) */
+  MDT_A_KV_BSTRIDE = 6, /* rows between consecutive samples' K/V (TK, or 0 for a batch-invariant context) */
+  MDT_A_OUT16 = 7       /* MDT_OP_ATTN: 1 = out is bf16 (LDO in bf16 elements), read by a bf16 x bf16 GEMM */
 };
 enum mdt_attn_f { MDT_AF_SCALE = 0 };
 

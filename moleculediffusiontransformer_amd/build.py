@@ -20,6 +20,7 @@ STAMP = os.path.join(CSRC, ".build_stamp")
 SOURCES = [
     ("k_gemm.hip", []),
     ("k_gemm_bf16x3.hip", []),
+    ("k_gemm_b16.hip", []),
     ("k_gemm_as.hip", []),
     # VGPR-form MFMA: keeps the persistent accumulators out of the AGPR shuttle (v_accvgpr_write + s_nop per MFMA)
     ("k_tblock.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),

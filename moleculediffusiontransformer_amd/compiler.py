@@ -42,6 +42,7 @@ class Ten:
     rows: int
     ld: int
     c: int = 0           # real (unpadded) channel count
+    b16: bool = False    # bf16 elements (ld counts ELEMENTS; the allocation is rows * ld / 2 floats): plain-bf16 mode only
 
     def ref(self) -> rt.MdtRef:
         return rt.MdtRef(self.space, 0, self.off)
@@ -155,6 +156,7 @@ class UNetCompiler:
         self.use_gn_act = os.environ.get("MDT_GN_ACT", "1") == "1"
         # cross-attention layers that run layer by layer over MANY keys (QMDiffusionForward: 64): fold the key / value
         # projections into the query / output projections and attend to the normalised context itself
+        self.b16 = os.environ.get("MDT_B16", "1") == "1"     # bf16 mode: regular layers as PREP16 + bf16 x bf16 GEMM
         self.fold_ctx = os.environ.get("MDT_FOLD_CTX", "1") == "1"
         self.has_chat = False                # some layer attends to the normalised context (ctx program emits it)
         self.tf128 = os.environ.get("MDT_TF128", "1") == "1"         # a whole C = 128 Transformer1d as ONE launch (k_tf128)
@@ -162,8 +164,9 @@ class UNetCompiler:
         # for the five transformers against 1.25 ms as head-split launches (both bound by the per-CU weight stream); it wins
         # once the batch fills the chip without the split, so it is a per-batch choice (engine: program "eval_wide")
         self.tf256 = bool(tf256)
-        if gemm_mode not in ("f32", "bf16x3"):
-            raise ValueError("gemm_mode must be 'f32' (exact fp32 MFMA) or 'bf16x3' (split-bf16 MFMA)")
+        if gemm_mode not in ("f32", "bf16x3", "bf16"):
+            raise ValueError("gemm_mode must be 'f32' (exact fp32 MFMA), 'bf16x3' (split-bf16 MFMA, fp32-class) or 'bf16' "
+                             "(plain bf16 products, reduced precision: layer-by-layer GEMMs only)")
         self.gemm_mode = gemm_mode
         self._packed: Dict = {}
         self._zeros_off, self._zeros_len = 0, 0
@@ -199,9 +202,17 @@ class UNetCompiler:
     def _new(self, rows: int, ld: int, c: int = 0) -> Ten:
         return Ten(rt.SP_ACT, self.arena.alloc(rows * ld), rows, ld, c or ld)
 
+    def _new16(self, rows: int, n: int) -> Ten:
+        """A bf16 tensor (the A operand of a bf16 x bf16 GEMM)."""
+        return Ten(rt.SP_ACT, self.arena.alloc(rows * n // 2), rows, n, n, True)
+
     def _free(self, t: Ten) -> None:
         if t.space == rt.SP_ACT:
-            self.arena.release(t.off, t.rows * t.ld)
+            self.arena.release(t.off, t.rows * t.ld // (2 if t.b16 else 1))
+
+    def b16_ok(self, cin: int) -> bool:
+        """Plain-bf16 mode: is a regular layer with `cin` input channels lowered to the bf16 x bf16 GEMM?"""
+        return self.gemm_mode == "bf16" and self.b16 and cin % 64 == 0
 
     def _zeros(self, n: int) -> int:
         if n > self._zeros_len:
@@ -234,9 +245,13 @@ class UNetCompiler:
         planes of the split-bf16 kernel (value rounded to nearest-even bf16, then its residual)."""
         name, w = wt
         split = self.gemm_mode == "bf16x3" and cin % 32 == 0
-        key = (name, split)
+        plain = self.gemm_mode == "bf16" and cin % 32 == 0
+        key = (name, split, plain)
         if key not in self._packed:
-            if split:
+            if plain:        # one bf16 plane; the third element marks the format (MDT_G_WFMT = 1)
+                hi = w.to(torch.bfloat16)
+                self._packed[key] = (self.W.add(name + "/bf16", hi.contiguous().view(-1).view(torch.float32)), None, 1)
+            elif split:
                 hi = w.to(torch.bfloat16)
                 lo = (w - hi.float()).to(torch.bfloat16)
                 self._packed[key] = (self.W.add(name + "/bf16_hi", hi.contiguous().view(-1).view(torch.float32)),
@@ -255,10 +270,42 @@ class UNetCompiler:
              film: Optional[rt.MdtRef] = None, groups: int = 0, gsize: int = 0, pro_silu: int = 0,
              act: int = 0, eps: float = 0.0, m_mode: int = 0, a_col: int = 0, o_col: int = 0,
              count_flops: bool = True, phases: int = 0) -> None:
+        r_out_ = a.rows if r_out is None else r_out
+        a16 = None
+        regular = (self.b16_ok(cin) and t_stride == 1 and phases <= 1 and o_stride == 1 and o_off == 0 and r_out_ == a.rows
+                   and out.rows == r_out_ and m_mode == 0)
+        assert not (a.b16 or out.b16) or (regular and (not a.b16 or (pro == rt.PRO_NONE and a_col == 0))), "bf16 operand"
+        if regular and not a.b16:
+            # plain-bf16 mode, regular layer: the prologue runs once per element in a pass of its own that writes the bf16 A
+            # operand (MDT_OP_PREP16), the GEMM streams both operands by LDS-DMA (k_gemm_b16.hip)
+            a16 = self._new16(a.rows, cin)
+            pre = rt.MdtOp()
+            pre.kind = rt.OP_PREP16
+            pre.a, pre.out = a.ref(), a16.ref()
+            if gain is not None:
+                pre.p0 = _ref(rt.SP_WEIGHT, gain)
+            if nbias is not None:
+                pre.p1 = _ref(rt.SP_WEIGHT, nbias)
+            if stats is not None:
+                pre.p2 = stats.ref()
+            if isinstance(film, tuple):
+                pre._film = film
+            elif film is not None:
+                pre.p3 = film
+            elif pro == rt.PRO_GROUPNORM:
+                pre.p3 = _ref(rt.SP_WEIGHT, self._zeros(2 * cin))
+            pi = pre.i
+            pi[rt.G_R_IN], pi[rt.G_LDA], pi[rt.G_CIN], pi[rt.G_A_COL] = a.rows, a.ld, cin, a_col
+            pi[rt.G_PRO], pi[rt.G_GROUPS], pi[rt.G_GSIZE], pi[rt.G_PRO_SILU] = pro, groups, gsize, pro_silu
+            pre.f[0] = eps
+            self._emit(pre)
+            a = a16
+            pro, gain, nbias, stats, film, groups, gsize, pro_silu, a_col = rt.PRO_NONE, None, None, None, None, 0, 0, 0, 0
         op = rt.MdtOp()
         op.kind = rt.OP_GEMM
-        w_off, wlo_off = self._pack_w(wt, cin)
+        w_off, wlo_off, *wfmt = self._pack_w(wt, cin)
         op.a, op.w, op.out = a.ref(), _ref(rt.SP_WEIGHT, w_off), out.ref()
+        op.i[rt.G_WFMT] = ((2 | (4 if out.b16 else 0)) if a.b16 else wfmt[0]) if wfmt else 0
         if wlo_off is not None:
             op.a2 = _ref(rt.SP_WEIGHT, wlo_off)
         if bias_off is not None:
@@ -290,6 +337,8 @@ class UNetCompiler:
         self._emit(op)
         if count_flops:
             self.flops += 2 * r_out * n * taps * cin * max(phases, 1)
+        if a16 is not None:
+            self._free(a16)
 
     def gn_stats(self, x: Ten, groups: int, gsize: int, eps: float) -> Ten:
         st = self._new(1, 2 * groups)
@@ -307,12 +356,13 @@ class UNetCompiler:
         if groups <= 0 or 256 % groups or gsize % 4 or groups * gsize != ld:
             return False
         tpg = 256 // groups
-        return (rows * (gsize // 4) + tpg - 1) // tpg <= 8
+        return (rows * (gsize // 4) + tpg - 1) // tpg <= 32
 
     def gn_act(self, x: Ten, groups: int, gsize: int, eps: float, gain: int, nbias: int, silu: bool,
                film=None) -> Ten:
-        """GroupNorm + FiLM + SiLU in one pass (MDT_OP_GN_ACT) -> new activated tensor."""
-        y = self._new(x.rows, x.ld, x.c)
+        """GroupNorm + FiLM + SiLU in one pass (MDT_OP_GN_ACT) -> new activated tensor (bf16 in the plain-bf16 mode: its
+        only reader is the convolution GEMM)."""
+        y = self._new16(x.rows, x.ld) if self.b16_ok(x.ld) else self._new(x.rows, x.ld, x.c)
         op = rt.MdtOp()
         op.kind = rt.OP_GN_ACT
         op.a, op.out = x.ref(), y.ref()
@@ -321,6 +371,7 @@ class UNetCompiler:
             op._film = film
         i = op.i
         i[rt.N_ROWS], i[rt.N_LD], i[rt.N_GROUPS], i[rt.N_GSIZE], i[rt.N_SILU] = x.rows, x.ld, groups, gsize, int(silu)
+        i[rt.N_OUT16] = int(y.b16)
         op.f[0] = eps
         self._emit(op)
         return y
@@ -338,6 +389,7 @@ class UNetCompiler:
         i = op.i
         i[rt.A_T], i[rt.A_TK], i[rt.A_HEADS] = q.rows, tk, cfg.heads
         i[rt.A_LDQ], i[rt.A_LDKV], i[rt.A_LDO], i[rt.A_KV_BSTRIDE] = q.ld, 2 * cfg.mid_features, out.ld, kv_bstride
+        i[rt.A_OUT16] = int(out.b16)
         op.f[0] = float(cfg.head_features) ** -0.5
         self._emit(op)
         self.flops += 2 * 2 * q.rows * tk * cfg.mid_features
@@ -946,7 +998,7 @@ class UNetCompiler:
         q = self._new(t.rows, mid)
         self.gemm(t, self._lin_w(p + "to_q.weight"), mid, q, cin=c, pro=rt.PRO_LAYERNORM,
                   gain=self._vec(p + "norm.weight", c), nbias=self._vec(p + "norm.bias", c), eps=1e-5)
-        ao = self._new(t.rows, mid)
+        ao = self._new16(t.rows, mid) if self.b16_ok(mid) else self._new(t.rows, mid)
         if cross_index is None:
             kv = self._new(t.rows, 2 * mid)
             self.gemm(t, self._lin_w(p + "to_kv.weight"), 2 * mid, kv, cin=c, pro=rt.PRO_LAYERNORM,
@@ -1098,7 +1150,8 @@ class UNetCompiler:
             elif cross:
                 self.cross_layers.append(bp + "cross_attention.")
                 self.attention_layer(t, bp + "cross_attention.", len(self.cross_layers) - 1)
-            h = self._new(t.rows, c * cfg.ff_mult)
+            hid = c * cfg.ff_mult
+            h = self._new16(t.rows, hid) if (self.b16_ok(c) and self.b16_ok(hid)) else self._new(t.rows, hid)
             self.gemm(t, self._lin_w(bp + "feed_forward.0.weight"), c * cfg.ff_mult, h, cin=c,
                       bias_off=self._vec(bp + "feed_forward.0.bias", c * cfg.ff_mult), act=1)
             self.gemm(h, self._lin_w(bp + "feed_forward.2.weight"), c, t, cin=c * cfg.ff_mult,
@@ -1273,7 +1326,7 @@ class UNetCompiler:
             for op in ops:
                 o = rt.MdtOp()
                 C_memmove(o, op)
-                if op.kind in (rt.OP_GEMM, rt.OP_GN_ACT, rt.OP_RCONV, rt.OP_RESBLOCK) and isinstance(getattr(op, "_film", None), tuple):
+                if op.kind in (rt.OP_GEMM, rt.OP_GN_ACT, rt.OP_RCONV, rt.OP_RESBLOCK, rt.OP_PREP16) and isinstance(getattr(op, "_film", None), tuple):
                     o.p3 = _ref(rt.SP_SHR, ss_cur + op._film[1])
                 if op.kind == rt.OP_ATTN_CTX:
                     if fixed:

@@ -117,7 +117,17 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
         }
       }
     }
-    if (i < a.T) {
+    if (i < a.T && a.out16) {
+      unsigned short* o16 = reinterpret_cast<unsigned short*>(a.out) + (int64_t)b * a.T * a.ldo + h * D;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        unsigned short hh[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hh[r] = __builtin_bit_cast(unsigned short, (__bf16)acc[dt][r]);
+        *reinterpret_cast<uint2*>(o16 + (int64_t)i * a.ldo + 16 * dt + 4 * g) =
+            make_uint2(hh[0] | ((unsigned)hh[1] << 16), hh[2] | ((unsigned)hh[3] << 16));
+      }
+    } else if (i < a.T) {
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
         *reinterpret_cast<float4*>(o + (int64_t)i * a.ldo + 16 * dt + 4 * g) =

@@ -44,15 +44,21 @@ __device__ __forceinline__ void split4(const float x[4], u16x4& hi, u16x4& lo) {
   }
 }
 
-template <int PRO, int TM, int TN, int BKT, int STAGES>
+// NPROD = 3: split products (above).  NPROD = 1: PLAIN bf16 products -- operands rounded to bf16 once, one MFMA per product,
+// fp32 accumulation; only the hi plane exists (in LDS and in the weight buffer).  This is the reduced-precision mode of
+// BASELINE configs[4] ("bf16"), selected per op by MDT_G_WFMT = 1; its error budget is stated in DESIGN.md / the bf16 tests.
+template <int PRO, int TM, int TN, int BKT, int STAGES, int NPROD = 3>
 __global__ __launch_bounds__(256) void k_gemm3(GemmArgs g) {
   constexpr int BM = 64 * TM, BN = 64 * TN, BK3 = 32 * BKT;
-  constexpr int ROWB = 4 * BK3 + 16;    // bytes per LDS row: hi plane | lo plane | pad
+  constexpr int PLANES = NPROD == 3 ? 2 : 1;
+  constexpr int ROWB = 2 * PLANES * BK3 + 16;    // bytes per LDS row: hi plane | [lo plane] | pad
   constexpr int C4 = BK3 / 4;           // float4 per A row chunk
   constexpr int AROWS = 256 / C4;       // A rows covered per pass of the 256 threads
   constexpr int RPT = BM / AROWS;       // A rows staged per thread
-  constexpr int WSEG = BK3 / 4;         // 16-byte W segments per row (hi and lo planes)
+  constexpr int HSEG = BK3 / 8;         // 16-byte W segments per row and plane
+  constexpr int WSEG = PLANES * HSEG;   // 16-byte W segments per row (hi [and lo] planes)
   constexpr int WPT = BN * WSEG / 256;  // W segments staged per thread
+  static_assert(WPT >= 1, "tile too small for 256 staging threads");
   constexpr int STAGE = (BM + BN) * ROWB;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -152,8 +158,7 @@ __global__ __launch_bounds__(256) void k_gemm3(GemmArgs g) {
       const int idx = tid + i * 256;
       const int row = idx / WSEG, seg = idx % WSEG;            // seg < WSEG/2: hi plane, else lo plane
       const int n = min(n0 + row, g.N - 1);
-      R.rw[i] = *reinterpret_cast<const uint4*>((seg < WSEG / 2 ? Whi : Wlo) + (int64_t)n * K + k0 +
-                                                (seg % (WSEG / 2)) * 8);
+      R.rw[i] = *reinterpret_cast<const uint4*>((seg < HSEG ? Whi : Wlo) + (int64_t)n * K + k0 + (seg % HSEG) * 8);
     }
   };
 
@@ -205,11 +210,18 @@ __global__ __launch_bounds__(256) void k_gemm3(GemmArgs g) {
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) x[e] = R.va[i] ? x[e] : 0.f;     // conv zero padding / rows past M
-      u16x4 hi, lo;
-      split4(x, hi, lo);
       unsigned char* rowp = stage + (r0 + i * AROWS) * ROWB + c4 * 8;
-      *reinterpret_cast<u16x4*>(rowp) = hi;
-      *reinterpret_cast<u16x4*>(rowp + 2 * BK3) = lo;
+      if constexpr (NPROD == 3) {
+        u16x4 hi, lo;
+        split4(x, hi, lo);
+        *reinterpret_cast<u16x4*>(rowp) = hi;
+        *reinterpret_cast<u16x4*>(rowp + 2 * BK3) = lo;
+      } else {
+        u16x4 hi;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hi[e] = __builtin_bit_cast(unsigned short, (__bf16)x[e]);
+        *reinterpret_cast<u16x4*>(rowp) = hi;
+      }
     }
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
@@ -230,20 +242,22 @@ __global__ __launch_bounds__(256) void k_gemm3(GemmArgs g) {
       for (int a = 0; a < TM; ++a) {
         const unsigned char* p = cur + (wr * 32 * TM + a * 32 + li) * ROWB + ks * 32 + lh * 16;
         ah[a] = *reinterpret_cast<const bf16x8*>(p);
-        al[a] = *reinterpret_cast<const bf16x8*>(p + 2 * BK3);
+        if constexpr (NPROD == 3) al[a] = *reinterpret_cast<const bf16x8*>(p + 2 * BK3);
       }
 #pragma unroll
       for (int b = 0; b < TN; ++b) {
         const unsigned char* p = cur + (BM + wc * 32 * TN + b * 32 + li) * ROWB + ks * 32 + lh * 16;
         bh[b] = *reinterpret_cast<const bf16x8*>(p);
-        bl[b] = *reinterpret_cast<const bf16x8*>(p + 2 * BK3);
+        if constexpr (NPROD == 3) bl[b] = *reinterpret_cast<const bf16x8*>(p + 2 * BK3);
       }
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+          if constexpr (NPROD == 3) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+          }
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
         }
     }
@@ -293,20 +307,20 @@ __global__ __launch_bounds__(256) void k_gemm3(GemmArgs g) {
   store_tile_coalesced<BM, BN>(Cs, g, m0, n0);
 }
 
-template <int PRO, int TM, int TN, int BKT, int STAGES>
+template <int PRO, int TM, int TN, int BKT, int STAGES, int NPROD = 3>
 static hipError_t launch3(const GemmArgs& g, hipStream_t s) {
-  constexpr int BM = 64 * TM, BN = 64 * TN, ROWB = 128 * BKT + 16;
+  constexpr int BM = 64 * TM, BN = 64 * TN, ROWB = (NPROD == 3 ? 128 : 64) * BKT + 16;
   const int mt = (g.M + BM - 1) / BM, nt = (g.N + BN - 1) / BN;
   size_t smem = STAGES * (size_t)(BM + BN) * ROWB + (PRO == 1 ? BM * 2 * sizeof(float) : 0);
   const size_t ctile = (size_t)BM * (BN + 4) * sizeof(float);     // epilogue staging reuses the same memory
   if (smem < ctile) smem = ctile;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm3<PRO, TM, TN, BKT, STAGES>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm3<PRO, TM, TN, BKT, STAGES, NPROD>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_gemm3<PRO, TM, TN, BKT, STAGES>), dim3((unsigned)(mt * nt), 1, (unsigned)(g.phases > 1 ? g.phases : 1)), dim3(256), smem, s, g);
+  hipLaunchKernelGGL((k_gemm3<PRO, TM, TN, BKT, STAGES, NPROD>), dim3((unsigned)(mt * nt), 1, (unsigned)(g.phases > 1 ? g.phases : 1)), dim3(256), smem, s, g);
   return hipGetLastError();
 }
 
@@ -350,6 +364,57 @@ static hipError_t launch3_pro(const GemmArgs& g, hipStream_t s) {
   stages = tiles(bm, bn) >= 512 ? 1 : 2;
   if (g_force_stages) stages = g_force_stages;
   return stages == 1 ? launch3_cfg<PRO, 1>(g, s, cfg) : launch3_cfg<PRO, 2>(g, s, cfg);
+}
+
+// Plain-bf16 products (NPROD = 1).  Tile choice: 128x128 tiles with a 64-deep chunk when they fill the chip, else as above.
+// MDT_TILE1="<cfg>,<stages>": cfg 0 = 128x128xBK64, 1 = 128x128xBK32, 2 = 128x64xBK64, 3 = 64x64xBK128, 4 = 64x64xBK64
+template <int PRO, int STAGES>
+static hipError_t launch1_cfg(const GemmArgs& g, hipStream_t s, int cfg) {
+  switch (cfg) {
+    case 0: return launch3<PRO, 2, 2, 2, STAGES, 1>(g, s);
+    case 1: return launch3<PRO, 2, 2, 1, STAGES, 1>(g, s);
+    case 2: return launch3<PRO, 2, 1, 2, STAGES, 1>(g, s);
+    case 3: return launch3<PRO, 1, 1, 4, STAGES, 1>(g, s);
+    case 4: return launch3<PRO, 1, 1, 2, STAGES, 1>(g, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+template <int PRO>
+static hipError_t launch1_pro(const GemmArgs& g, hipStream_t s) {
+  static int force_cfg = -2, force_stages = 0;
+  if (force_cfg == -2) {
+    force_cfg = -1;
+    if (const char* e = getenv("MDT_TILE1")) sscanf(e, "%d,%d", &force_cfg, &force_stages);
+  }
+  auto tiles = [&](int bm, int bn) {
+    return (int64_t)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * (g.phases > 1 ? g.phases : 1);
+  };
+  int cfg;
+  if (g.N > 64 && tiles(128, 128) >= 256) cfg = g.cin % 64 == 0 ? 0 : 1;
+  else if (g.cin % 64 == 0 && tiles(128, 64) >= 256) cfg = 2;
+  else if (g.cin % 128 == 0) cfg = 3;
+  else if (g.cin % 64 == 0) cfg = 4;
+  else cfg = 1;
+  if (force_cfg >= 0) {
+    const int need = force_cfg == 3 ? 128 : (force_cfg == 1 ? 32 : 64);
+    if (g.cin % need == 0) cfg = force_cfg;
+  }
+  int stages = 2;
+  if (force_stages) stages = force_stages;
+  return stages == 1 ? launch1_cfg<PRO, 1>(g, s, cfg) : launch1_cfg<PRO, 2>(g, s, cfg);
+}
+
+hipError_t launch_gemm_bf16(const GemmArgs& g, hipStream_t s) {
+  if (g.M <= 0) return hipSuccess;
+  if (g.cin % 32) return hipErrorInvalidValue;
+  switch (g.pro) {
+    case 0: return launch1_pro<0>(g, s);
+    case 1: return launch1_pro<1>(g, s);
+    case 2: return launch1_pro<2>(g, s);
+    case 3: return launch1_pro<3>(g, s);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 hipError_t launch_gemm_bf16x3(const GemmArgs& g, hipStream_t s) {

@@ -130,7 +130,16 @@ __global__ __launch_bounds__(256) void k_gn_act(GnActArgs a) {
         if (a.silu) t = t / (1.0f + expf(-t));
         x[j] = t;
       }
-      *reinterpret_cast<float4*>(yb + (int64_t)r * a.ld + 4 * q) = make_float4(x[0], x[1], x[2], x[3]);
+      if (a.out16) {
+        unsigned short hh[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) hh[j] = __builtin_bit_cast(unsigned short, (__bf16)x[j]);
+        unsigned short* y16 = reinterpret_cast<unsigned short*>(a.y) + (int64_t)b * a.rows * a.ld + grp * a.gsize;
+        *reinterpret_cast<uint2*>(y16 + (int64_t)r * a.ld + 4 * q) =
+            make_uint2(hh[0] | ((unsigned)hh[1] << 16), hh[2] | ((unsigned)hh[3] << 16));
+      } else {
+        *reinterpret_cast<float4*>(yb + (int64_t)r * a.ld + 4 * q) = make_float4(x[0], x[1], x[2], x[3]);
+      }
     }
   }
 }
@@ -138,7 +147,7 @@ __global__ __launch_bounds__(256) void k_gn_act(GnActArgs a) {
 bool gn_act_eligible(int rows, int ld, int groups, int gsize) {
   if (groups <= 0 || 256 % groups || gsize % 4 || groups * gsize != ld) return false;
   const int tpg = 256 / groups, nf4 = rows * (gsize / 4);
-  return (nf4 + tpg - 1) / tpg <= 8;
+  return (nf4 + tpg - 1) / tpg <= 32;      // <= 128 registers of elements per thread
 }
 
 hipError_t launch_gn_act(const GnActArgs& a, hipStream_t s) {
@@ -148,7 +157,9 @@ hipError_t launch_gn_act(const GnActArgs& a, hipStream_t s) {
   if (per <= 1) hipLaunchKernelGGL((k_gn_act<1>), dim3(a.batch), dim3(256), 0, s, a);
   else if (per <= 2) hipLaunchKernelGGL((k_gn_act<2>), dim3(a.batch), dim3(256), 0, s, a);
   else if (per <= 4) hipLaunchKernelGGL((k_gn_act<4>), dim3(a.batch), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((k_gn_act<8>), dim3(a.batch), dim3(256), 0, s, a);
+  else if (per <= 8) hipLaunchKernelGGL((k_gn_act<8>), dim3(a.batch), dim3(256), 0, s, a);
+  else if (per <= 16) hipLaunchKernelGGL((k_gn_act<16>), dim3(a.batch), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((k_gn_act<32>), dim3(a.batch), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 

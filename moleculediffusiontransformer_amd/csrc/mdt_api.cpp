@@ -70,6 +70,27 @@ static const char* validate(const mdt_op& o, int idx, char* buf, size_t nbuf) {
       if (i[MDT_G_M_MODE] < 0 || i[MDT_G_M_MODE] > 2) return bad("bad m_mode");
       if (o.res.space && i[MDT_G_LDR] <= 0) return bad("residual without ldr");
       if (o.a2.space && i[MDT_G_CIN] % 32) return bad("split-bf16 weights need cin % 32 == 0");
+      if (i[MDT_G_WFMT] < 0 || (i[MDT_G_WFMT] > 2 && i[MDT_G_WFMT] != 6)) return bad("bad weight format");
+      if (i[MDT_G_WFMT] & 2) {
+        if (!mdt::gemm_b16_supported(i[MDT_G_CIN], i[MDT_G_TAPS], i[MDT_G_LDA], i[MDT_G_A_COL]) || o.a2.space)
+          return bad("bf16 x bf16 GEMM needs cin % 64 == 0 and 16-byte aligned bf16 rows");
+        if (i[MDT_G_PRO] || i[MDT_G_T_STRIDE] != 1 || i[MDT_G_PHASES] > 1 || i[MDT_G_O_STRIDE] != 1 || i[MDT_G_O_OFF] ||
+            i[MDT_G_R_OUT] != i[MDT_G_R_IN] || i[MDT_G_O_ROWS] != i[MDT_G_R_OUT] || i[MDT_G_M_MODE])
+          return bad("bf16 x bf16 GEMM: no prologue / stride / phases / output row mapping (use MDT_OP_PREP16 + WFMT 1 forms)");
+      }
+      if (i[MDT_G_WFMT] == 1 && (i[MDT_G_CIN] % 32 || o.a2.space)) return bad("bf16 weights need cin % 32 == 0 and no lo plane");
+      break;
+    }
+    case MDT_OP_PREP16: {
+      const int32_t* i = o.i;
+      if (i[MDT_G_CIN] <= 0 || i[MDT_G_CIN] % 8 || i[MDT_G_R_IN] <= 0) return bad("bad dims");
+      if (i[MDT_G_LDA] % 4 || i[MDT_G_A_COL] % 4 || i[MDT_G_LDA] < i[MDT_G_A_COL] + i[MDT_G_CIN]) return bad("bad A rows");
+      if (i[MDT_G_PRO] < 0 || i[MDT_G_PRO] > 3) return bad("bad prologue");
+      if (!o.a.space || !o.out.space) return bad("missing operand");
+      if (i[MDT_G_PRO] == MDT_PRO_LAYERNORM && (!o.p0.space || !o.p1.space)) return bad("LayerNorm needs gain and bias");
+      if (i[MDT_G_PRO] == MDT_PRO_GROUPNORM &&
+          (!o.p0.space || !o.p1.space || !o.p2.space || !o.p3.space || i[MDT_G_GROUPS] <= 0 || i[MDT_G_GSIZE] <= 0))
+        return bad("GroupNorm needs gain, bias, stats, FiLM vector and groups");
       break;
     }
     case MDT_OP_GN_STATS:
@@ -226,13 +247,31 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
         g.N = i[MDT_G_N]; g.ldc = i[MDT_G_LDC]; g.o_rows = i[MDT_G_O_ROWS]; g.o_stride = i[MDT_G_O_STRIDE];
         g.o_off = i[MDT_G_O_OFF]; g.ldr = i[MDT_G_LDR]; g.pro = i[MDT_G_PRO]; g.groups = i[MDT_G_GROUPS];
         g.gsize = i[MDT_G_GSIZE]; g.pro_silu = i[MDT_G_PRO_SILU]; g.act = i[MDT_G_ACT]; g.a_col = i[MDT_G_A_COL];
-        g.o_col = i[MDT_G_O_COL]; g.eps = o.f[MDT_GF_EPS]; g.phases = i[MDT_G_PHASES];
-        if (!missing) {
+        g.o_col = i[MDT_G_O_COL]; g.eps = o.f[MDT_GF_EPS]; g.phases = i[MDT_G_PHASES]; g.wfmt = i[MDT_G_WFMT];
+        if (!missing && (i[MDT_G_WFMT] & 2)) {
+          mdt::Gemm16Args h;
+          h.A = reinterpret_cast<const unsigned short*>(g.A); h.W = reinterpret_cast<const unsigned short*>(g.W);
+          h.bias = g.bias; h.res = g.res; h.out = g.out; h.M = g.M; h.N = g.N; h.cin = g.cin; h.taps = g.taps; h.rows = g.r_in;
+          h.lda = g.lda; h.a_col = g.a_col; h.t_dj = g.t_dj; h.t_off = g.t_off; h.ldc = g.ldc; h.ldr = g.ldr; h.o_col = g.o_col;
+          h.act = g.act; h.out16 = (i[MDT_G_WFMT] & 4) ? 1 : 0;
+          e = mdt::launch_gemm_b16(h, stream);
+        } else if (!missing) {
           static const bool no_as = getenv("MDT_NO_AS") != nullptr;   // tuning aid: disable the A-stationary kernel
-          if (!g.W_lo) e = mdt::launch_gemm(g, stream);
+          if (i[MDT_G_WFMT] == 1) e = mdt::launch_gemm_bf16(g, stream);
+          else if (!g.W_lo) e = mdt::launch_gemm(g, stream);
           else if (!no_as && mdt::gemm_as_eligible(g)) e = mdt::launch_gemm_as(g, stream);
           else e = mdt::launch_gemm_bf16x3(g, stream);
         }
+        break;
+      }
+      case MDT_OP_PREP16: {
+        const int32_t* i = o.i;
+        mdt::Prep16Args g;
+        g.a = ptr(o.a); g.out = reinterpret_cast<unsigned short*>(ptr(o.out)); g.p0 = ptr(o.p0); g.p1 = ptr(o.p1);
+        g.p2 = ptr(o.p2); g.p3 = ptr(o.p3); g.rows = i[MDT_G_R_IN]; g.total_rows = B * g.rows; g.lda = i[MDT_G_LDA];
+        g.a_col = i[MDT_G_A_COL]; g.cin = i[MDT_G_CIN]; g.pro = i[MDT_G_PRO]; g.groups = i[MDT_G_GROUPS];
+        g.gsize = i[MDT_G_GSIZE]; g.pro_silu = i[MDT_G_PRO_SILU]; g.eps = o.f[MDT_GF_EPS];
+        if (!missing) e = mdt::launch_prep16(g, stream);
         break;
       }
       case MDT_OP_GN_STATS: {
@@ -246,7 +285,7 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
         mdt::GnActArgs a;
         a.x = ptr(o.a); a.y = ptr(o.out); a.gamma = ptr(o.p0); a.beta = ptr(o.p1); a.film = ptr(o.p3);
         a.batch = B; a.rows = o.i[MDT_N_ROWS]; a.ld = o.i[MDT_N_LD]; a.groups = o.i[MDT_N_GROUPS];
-        a.gsize = o.i[MDT_N_GSIZE]; a.silu = o.i[MDT_N_SILU]; a.eps = o.f[MDT_NF_EPS];
+        a.gsize = o.i[MDT_N_GSIZE]; a.silu = o.i[MDT_N_SILU]; a.eps = o.f[MDT_NF_EPS]; a.out16 = o.i[MDT_N_OUT16];
         if (!missing) e = mdt::launch_gn_act(a, stream);
         break;
       }
@@ -273,7 +312,7 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
         mdt::AttnArgs a;
         a.q = ptr(o.a); a.k = ptr(o.a2); a.out = ptr(o.out); a.batch = B; a.T = o.i[MDT_A_T]; a.Tk = o.i[MDT_A_TK];
         a.heads = o.i[MDT_A_HEADS]; a.ldq = o.i[MDT_A_LDQ]; a.ldkv = o.i[MDT_A_LDKV]; a.ldo = o.i[MDT_A_LDO];
-        a.kv_bstride = o.i[MDT_A_KV_BSTRIDE]; a.scale = o.f[MDT_AF_SCALE];
+        a.kv_bstride = o.i[MDT_A_KV_BSTRIDE]; a.scale = o.f[MDT_AF_SCALE]; a.out16 = o.i[MDT_A_OUT16];
         if (!missing) e = mdt::launch_attn(a, stream);
         break;
       }
@@ -281,7 +320,7 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
         mdt::AttnArgs a;
         a.q = ptr(o.a); a.k = ptr(o.a2); a.out = ptr(o.out); a.batch = B; a.T = o.i[MDT_A_T]; a.Tk = o.i[MDT_A_TK];
         a.heads = o.i[MDT_A_HEADS]; a.ldq = 128; a.ldkv = o.i[MDT_A_LDKV]; a.ldo = 128;
-        a.kv_bstride = o.i[MDT_A_KV_BSTRIDE]; a.scale = o.f[MDT_AF_SCALE];
+        a.kv_bstride = o.i[MDT_A_KV_BSTRIDE]; a.scale = o.f[MDT_AF_SCALE]; a.out16 = 0;
         if (!missing) e = mdt::launch_attn_ctx(a, stream);
         break;
       }

@@ -25,6 +25,7 @@ struct GemmArgs {
   int M, r_out, r_in, lda, cin, taps, t_stride, t_dj, t_off;
   int N, ldc, o_rows, o_stride, o_off, ldr;
   int pro, groups, gsize, pro_silu, act, a_col, o_col;
+  int wfmt;    // 1: W is ONE bf16 plane (plain bf16 products), else fp32 / hi + lo planes
   int phases;  // > 1: ConvTranspose1d(k = 2 f, stride f, padding f / 2) as f output phases of 2 taps each in ONE launch:
                // phase ph = blockIdx.z uses weights [ph][N][K], t_off = (ph < f/2), o_off = f t_off + ph - f/2
   float eps;
@@ -35,7 +36,7 @@ __device__ __forceinline__ void gemm_select_phase(GemmArgs& g) {
   if (g.phases > 1) {
     const int ph = blockIdx.z, f = g.phases;
     const int shift = ph < f / 2 ? 1 : 0;
-    const long wo = (long)ph * g.N * (g.taps * g.cin) / (g.W_lo ? 2 : 1);   // floats: bf16 planes hold 2 per float
+    const long wo = (long)ph * g.N * (g.taps * g.cin) / ((g.W_lo || g.wfmt == 1) ? 2 : 1);   // floats: bf16 planes hold 2 per float
     g.W += wo;
     if (g.W_lo) g.W_lo += wo;
     g.t_off = shift;
@@ -44,7 +45,31 @@ __device__ __forceinline__ void gemm_select_phase(GemmArgs& g) {
 }
 #endif
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t s);          // exact fp32 MFMA (k_gemm.hip)
-hipError_t launch_gemm_bf16x3(const GemmArgs& g, hipStream_t s);   // split-bf16 MFMA (k_gemm_bf16x3.hip)
+hipError_t launch_gemm_bf16x3(const GemmArgs& g, hipStream_t s);
+hipError_t launch_gemm_bf16(const GemmArgs& g, hipStream_t s);     // plain bf16 products: W = one bf16 plane   // split-bf16 MFMA (k_gemm_bf16x3.hip)
+
+// plain-bf16 GEMM with both operands in bf16 (k_gemm_b16.hip) and the pass that prepares its A operand
+struct Gemm16Args {
+  const unsigned short* A;   // bf16 [batches * rows][lda]
+  const unsigned short* W;   // bf16 [N][taps * cin]
+  const float* bias;
+  const float* res;
+  float* out;
+  int M, N, cin, taps, rows;  // rows per sample (taps stay inside a sample; source rows outside read as zero)
+  int lda, a_col;             // bf16 elements
+  int t_dj, t_off, ldc, ldr, o_col, act;
+  int out16;                  // 1: out is bf16 (ldc / o_col in bf16 elements)
+};
+bool gemm_b16_supported(int cin, int taps, int lda, int a_col);
+hipError_t launch_gemm_b16(const Gemm16Args& g, hipStream_t s);
+struct Prep16Args {
+  const float* a;
+  unsigned short* out;        // bf16 [total_rows][cin]
+  const float* p0; const float* p1; const float* p2; const float* p3;
+  int total_rows, rows, lda, a_col, cin, pro, groups, gsize, pro_silu;
+  float eps;
+};
+hipError_t launch_prep16(const Prep16Args& g, hipStream_t s);
 bool gemm_as_eligible(const GemmArgs& g);                           // wide-N / small-K layers
 hipError_t launch_gemm_as(const GemmArgs& g, hipStream_t s);       // A-stationary split-bf16 (k_gemm_as.hip)
 
@@ -64,6 +89,7 @@ struct GnActArgs {
   const float* film;   // [scale(ld) | shift(ld)] or nullptr
   int batch, rows, ld, groups, gsize, silu;
   float eps;
+  int out16;   // 1: y is bf16 [rows][ld] (the A operand of a bf16 x bf16 GEMM)
 };
 bool gn_act_eligible(int rows, int ld, int groups, int gsize);
 hipError_t launch_gn_act(const GnActArgs& a, hipStream_t s);
@@ -105,6 +131,7 @@ struct AttnArgs {
   float* out;
   int batch, T, Tk, heads, ldq, ldkv, ldo, kv_bstride;
   float scale;
+  int out16;   // MDT_OP_ATTN: 1 = out is bf16 (ldo in bf16 elements)
 };
 hipError_t launch_attn(const AttnArgs& a, hipStream_t s);
 // MDT_OP_ATTN_CTX: rows q [batch][T * heads][128] against the normalised context k [batch | 1][Tk][ldkv >= 128] (K = V)

@@ -19,17 +19,18 @@ OP_RESBLOCK = 10
 OP_TF128 = 11
 OP_TF256 = 12
 OP_ATTN_CTX = 13
+OP_PREP16 = 14
 OP_NAMES = {OP_GEMM: "k_gemm", OP_GN_STATS: "k_gn_stats", OP_ATTN: "k_attn", OP_CONCAT: "k_concat", OP_PATCH: "k_patch",
             OP_TIME_EMBED: "k_time_embed", OP_TBLOCK: "k_tblock", OP_GN_ACT: "k_gn_act", OP_RCONV: "k_rconv",
-            OP_RESBLOCK: "k_resblock", OP_TF128: "k_tf128", OP_TF256: "k_tf256", OP_ATTN_CTX: "k_attn_ctx"}
+            OP_RESBLOCK: "k_resblock", OP_TF128: "k_tf128", OP_TF256: "k_tf256", OP_ATTN_CTX: "k_attn_ctx", OP_PREP16: "k_prep16"}
 TB_SELF, TB_CROSS, TB_FF = 0, 1, 2
 PRO_NONE, PRO_LAYERNORM, PRO_GROUPNORM, PRO_SILU = 0, 1, 2, 3
 
 # integer slots (enum mdt_gemm_i etc. in mdt_hip.h)
 G_R_OUT, G_R_IN, G_LDA, G_CIN, G_TAPS, G_T_STRIDE, G_T_DJ, G_T_OFF, G_N, G_LDC, G_O_ROWS, G_O_STRIDE, \
-    G_O_OFF, G_LDR, G_PRO, G_GROUPS, G_GSIZE, G_PRO_SILU, G_ACT, G_M_MODE, G_A_COL, G_O_COL, G_PHASES = range(23)
-N_ROWS, N_LD, N_GROUPS, N_GSIZE, N_SILU = range(5)
-A_T, A_TK, A_HEADS, A_LDQ, A_LDKV, A_LDO, A_KV_BSTRIDE = range(7)
+    G_O_OFF, G_LDR, G_PRO, G_GROUPS, G_GSIZE, G_PRO_SILU, G_ACT, G_M_MODE, G_A_COL, G_O_COL, G_PHASES, G_WFMT = range(24)
+N_ROWS, N_LD, N_GROUPS, N_GSIZE, N_SILU, N_OUT16 = range(6)
+A_T, A_TK, A_HEADS, A_LDQ, A_LDKV, A_LDO, A_KV_BSTRIDE, A_OUT16 = range(8)
 C_ROWS, C_CA, C_CB = range(3)
 P_ROWS_IN, P_C_IN, P_LD_IN, P_LD_OUT, P_PATCH, P_INVERSE = range(6)
 T_HALF, T_LD = range(2)

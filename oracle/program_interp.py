@@ -43,11 +43,15 @@ def _silu(x):
 def run_program(ops, bufs: Buffers, B: int, n_shared_rows: int = 0) -> None:
     for op in ops:
         i, f = op.i, op.f
-        if op.kind == rt.OP_GEMM:
-            batches = B if i[rt.G_M_MODE] == 0 else (n_shared_rows if i[rt.G_M_MODE] == 1 else 1)
+        if op.kind in (rt.OP_GEMM, rt.OP_PREP16):
+            prep = op.kind == rt.OP_PREP16
+            batches = B if (prep or i[rt.G_M_MODE] == 0) else (n_shared_rows if i[rt.G_M_MODE] == 1 else 1)
             r_out, r_in, lda, cin, taps = i[rt.G_R_OUT], i[rt.G_R_IN], i[rt.G_LDA], i[rt.G_CIN], i[rt.G_TAPS]
             n, ldc, o_rows = i[rt.G_N], i[rt.G_LDC], i[rt.G_O_ROWS]
-            a = bufs.view(op.a, B, batches * r_in * lda).view(batches, r_in, lda)
+            if not prep and (i[rt.G_WFMT] & 2):      # A already bf16 (MDT_OP_PREP16): lda / a_col in bf16 elements
+                a = bufs.view(op.a, B, batches * r_in * lda // 2).view(torch.bfloat16).float().view(batches, r_in, lda)
+            else:
+                a = bufs.view(op.a, B, batches * r_in * lda).view(batches, r_in, lda)
             a = a[:, :, i[rt.G_A_COL]: i[rt.G_A_COL] + cin]
             pro = i[rt.G_PRO]
             if pro == rt.PRO_LAYERNORM:
@@ -67,8 +71,16 @@ def run_program(ops, bufs: Buffers, B: int, n_shared_rows: int = 0) -> None:
                     a = _silu(a)
             elif pro == rt.PRO_SILU:
                 a = _silu(a)
+            if prep:
+                dst = bufs.view(op.out, B, batches * r_in * cin // 2)
+                dst[:] = a.contiguous().to(torch.bfloat16).view(-1).view(torch.float32)
+                continue
             nph = max(int(i[rt.G_PHASES]), 1)         # > 1: ConvTranspose1d phases sharing one op (include/mdt_hip.h)
-            if op.a2.space != rt.SP_NONE:      # split-bf16 weights: two bf16 planes stored as raw bits
+            if i[rt.G_WFMT] in (1, 2, 6):              # plain bf16 products: one weight plane, A rounded to bf16 after the prologue
+                half = nph * n * taps * cin // 2
+                w_all = bufs.view(op.w, B, half).view(torch.bfloat16).float().view(nph, n, taps, cin)
+                a = a.to(torch.bfloat16).float()
+            elif op.a2.space != rt.SP_NONE:      # split-bf16 weights: two bf16 planes stored as raw bits
                 half = nph * n * taps * cin // 2
                 hi = bufs.view(op.w, B, half).view(torch.bfloat16).float()
                 lo = bufs.view(op.a2, B, half).view(torch.bfloat16).float()
@@ -76,7 +88,7 @@ def run_program(ops, bufs: Buffers, B: int, n_shared_rows: int = 0) -> None:
             else:
                 w_all = bufs.view(op.w, B, nph * n * taps * cin).view(nph, n, taps, cin)
             r = torch.arange(r_out)
-            out = bufs.view(op.out, B, batches * o_rows * ldc).view(batches, o_rows, ldc)
+            out = None if i[rt.G_WFMT] == 6 else bufs.view(op.out, B, batches * o_rows * ldc).view(batches, o_rows, ldc)
             for ph in range(nph):
                 w = w_all[ph]
                 t_off, o_off = i[rt.G_T_OFF], i[rt.G_O_OFF]
@@ -98,6 +110,10 @@ def run_program(ops, bufs: Buffers, B: int, n_shared_rows: int = 0) -> None:
                     ldr = i[rt.G_LDR]
                     res = bufs.view(op.res, B, batches * o_rows * ldr).view(batches, o_rows, ldr)
                     acc = acc + res[:, orow, :n]
+                if i[rt.G_WFMT] == 6:          # bf16 output (ldc in bf16 elements)
+                    assert ldc == n and nph == 1
+                    bufs.view(op.out, B, batches * o_rows * ldc // 2)[:] = acc.contiguous().to(torch.bfloat16).view(-1).view(torch.float32)
+                    continue
                 out[:, orow, i[rt.G_O_COL]: i[rt.G_O_COL] + n] = acc
         elif op.kind == rt.OP_GN_STATS:
             rows, ld, G, gs = i[rt.N_ROWS], i[rt.N_LD], i[rt.N_GROUPS], i[rt.N_GSIZE]
@@ -116,7 +132,10 @@ def run_program(ops, bufs: Buffers, B: int, n_shared_rows: int = 0) -> None:
                 y = y * (ss[:ld] + 1.0) + ss[ld:]
             if i[rt.N_SILU]:
                 y = _silu(y)
-            bufs.view(op.out, B, B * rows * ld).view(B, rows, ld)[:] = y
+            if i[rt.N_OUT16]:
+                bufs.view(op.out, B, B * rows * ld // 2)[:] = y.contiguous().to(torch.bfloat16).view(-1).view(torch.float32)
+            else:
+                bufs.view(op.out, B, B * rows * ld).view(B, rows, ld)[:] = y
         elif op.kind == rt.OP_RCONV:
             _rconv(op, bufs, B)
         elif op.kind == rt.OP_RESBLOCK:
@@ -135,8 +154,12 @@ def run_program(ops, bufs: Buffers, B: int, n_shared_rows: int = 0) -> None:
             v = kv[:, :, H * D: 2 * H * D].reshape(B, Tk, H, D).transpose(1, 2)
             sim = (q @ k.transpose(-1, -2)) * float(f[0])
             o = (sim.softmax(-1) @ v).transpose(1, 2).reshape(B, T, H * D)
-            out = bufs.view(op.out, B, B * T * ldo).view(B, T, ldo)
-            out[:, :, : H * D] = o
+            if i[rt.A_OUT16]:
+                assert ldo == H * D
+                bufs.view(op.out, B, B * T * ldo // 2)[:] = o.contiguous().to(torch.bfloat16).view(-1).view(torch.float32)
+            else:
+                out = bufs.view(op.out, B, B * T * ldo).view(B, T, ldo)
+                out[:, :, : H * D] = o
         elif op.kind == rt.OP_CONCAT:
             rows, ca, cb = i[rt.C_ROWS], i[rt.C_CA], i[rt.C_CB]
             a = bufs.view(op.a, B, B * rows * ca).view(B * rows, ca)

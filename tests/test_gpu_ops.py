@@ -344,6 +344,153 @@ def test_gemm_split_bf16(B, R, cin, N, taps, pro):
     assert (out_g - out_c).abs().max() < 4e-5 * max(scale, 1.0), ((out_g - out_c).abs().max().item(), scale)
 
 
+@pytest.mark.parametrize("B,R,cin,N,taps,pro", [
+    (64, 32, 512, 512, 3, rt.PRO_GROUPNORM),      # 128x128 tiles with 64-deep chunks, conv taps (deep-UNet level 1)
+    (96, 8, 1024, 2048, 1, rt.PRO_LAYERNORM),     # LayerNorm prologue over 1024 features
+    (3, 16, 128, 96, 3, rt.PRO_GROUPNORM),        # 64x64 tiles, ragged N and M
+    (40, 4, 512, 256, 1, rt.PRO_NONE),
+    (5, 64, 32, 64, 3, rt.PRO_NONE),              # 32 channels: 32-deep chunks
+    (33, 1, 256, 160, 1, rt.PRO_SILU),
+    (700, 16, 128, 384, 1, rt.PRO_NONE),
+])
+def test_gemm_plain_bf16(B, R, cin, N, taps, pro):
+    """The plain-bf16 mode of k_gemm3 (MDT_G_WFMT = 1: one bf16 weight plane, A rounded to bf16 after the prologue, fp32
+    accumulation) against the interpreter doing the same roundings, and its distance from the unrounded fp32 product
+    (the stated budget of the mode: 2^-8 relative per operand -> ~1e-2 of the output scale)."""
+    K = taps * cin
+    w = rnd(N, K, seed=1, scale=K ** -0.5)
+    hi = w.to(torch.bfloat16).contiguous().view(-1).view(torch.float32)
+    G = 8
+    gs = cin // G
+    weights = torch.cat([hi, rnd(N, seed=2), 1 + 0.1 * rnd(cin, seed=3), 0.1 * rnd(cin, seed=4)])
+    o_b, o_g, o_nb = hi.numel(), hi.numel() + N, hi.numel() + N + cin
+    xoff, stoff, ooff, roff = 0, R * cin, R * cin + 64, R * cin + 64 + R * N
+    act = torch.zeros(B * (roff + R * N))
+    act[: B * R * cin] = rnd(B * R * cin, seed=5) * 1.3 + 0.2
+    act[B * roff:] = rnd(B * R * N, seed=6)
+    shr = 0.3 * rnd(2 * cin, seed=7)
+    ops = []
+    if pro == rt.PRO_GROUPNORM:
+        st = rt.MdtOp()
+        st.kind = rt.OP_GN_STATS
+        st.a, st.out = ref(A, xoff), ref(A, stoff)
+        st.i[rt.N_ROWS], st.i[rt.N_LD], st.i[rt.N_GROUPS], st.i[rt.N_GSIZE] = R, cin, G, gs
+        st.f[0] = 1e-5
+        ops.append(st)
+    op = gemm_op(a=ref(A, xoff), w=ref(W, 0), bias=ref(W, o_b), out=ref(A, ooff), res=ref(A, roff),
+                 p0=ref(W, o_g), p1=ref(W, o_nb), p2=ref(A, stoff), p3=ref(S, 0), r_out=R, r_in=R, lda=cin, cin=cin,
+                 taps=taps, t_dj=1 if taps > 1 else 0, t_off=-(taps // 2), n=N, ldc=N, o_rows=R, ldr=N, pro=pro,
+                 groups=G, gsize=gs, pro_silu=1, act=0, eps=1e-5)
+    op.i[rt.G_WFMT] = 1
+    ops.append(op)
+    (ga, _, _), (ca, _, _) = run_both(ops, weights, act, shr, {}, B)
+    out_g, out_c = ga[B * ooff: B * roff], ca[B * ooff: B * roff]
+    scale = max(out_c.abs().max().item(), 1.0)
+    # same roundings on both sides; a prologue value that lands on a bf16 tie can round the other way (one bf16 ulp of one
+    # operand: ~2^-8 |a w|), hence not bitwise
+    assert (out_g - out_c).abs().max() < (2e-3 if pro != rt.PRO_NONE else 4e-5) * scale
+    # distance from the fp32 product (weights unrounded, activations unrounded)
+    full = torch.cat([w.view(-1), weights[o_b:]])
+    op32 = gemm_op(a=ref(A, xoff), w=ref(W, 0), bias=ref(W, N * K), out=ref(A, ooff), res=ref(A, roff),
+                   p0=ref(W, N * K + N), p1=ref(W, N * K + N + cin), p2=ref(A, stoff), p3=ref(S, 0), r_out=R, r_in=R, lda=cin,
+                   cin=cin, taps=taps, t_dj=1 if taps > 1 else 0, t_off=-(taps // 2), n=N, ldc=N, o_rows=R, ldr=N, pro=pro,
+                   groups=G, gsize=gs, pro_silu=1, act=0, eps=1e-5)
+    from oracle.program_interp import Buffers, run_program
+    cpu = Buffers(full, act.clone(), shr.clone(), {})
+    run_program(ops[:-1] + [op32], cpu, B, 0)
+    exact = cpu.act[B * ooff: B * roff]
+    assert (out_g - exact).abs().max() < 2e-2 * scale
+
+
+@pytest.mark.parametrize("tile", ["", "0", "1", "2"])
+@pytest.mark.parametrize("B,R,cin,N,taps,pro,act", [
+    (64, 32, 512, 512, 3, rt.PRO_GROUPNORM, 0),   # level-1 ResNet convolution of the deep U-Net
+    (70, 8, 1024, 2048, 1, rt.PRO_LAYERNORM, 1),  # feed-forward up-projection + GELU, ragged M
+    (33, 8, 1024, 1024, 3, rt.PRO_GROUPNORM, 0),
+    (5, 32, 64, 96, 3, rt.PRO_SILU, 0),           # ragged N
+    (3, 128, 256, 256, 1, rt.PRO_NONE, 0),
+])
+def test_gemm_bf16_streamed(B, R, cin, N, taps, pro, act, tile):
+    """MDT_OP_PREP16 + bf16 x bf16 GEMM (k_prep16 / k_gemm_b16: both operands by LDS-DMA) against the interpreter doing the
+    same roundings, in every tile configuration."""
+    import os
+    K = taps * cin
+    w = rnd(N, K, seed=1, scale=K ** -0.5)
+    hi = w.to(torch.bfloat16).contiguous().view(-1).view(torch.float32)
+    G = 8
+    gs = cin // G
+    weights = torch.cat([hi, rnd(N, seed=2), 1 + 0.1 * rnd(cin, seed=3), 0.1 * rnd(cin, seed=4)])
+    o_b, o_g, o_nb = hi.numel(), hi.numel() + N, hi.numel() + N + cin
+    xoff, stoff, a16off = 0, R * cin, R * cin + 64
+    ooff = a16off + R * cin // 2
+    roff = ooff + R * N
+    act_buf = torch.zeros(B * (roff + R * N))
+    act_buf[: B * R * cin] = rnd(B * R * cin, seed=5) * 1.3 + 0.2
+    act_buf[B * roff:] = rnd(B * R * N, seed=6)
+    shr = 0.3 * rnd(2 * cin, seed=7)
+    ops = []
+    if pro == rt.PRO_GROUPNORM:
+        st = rt.MdtOp()
+        st.kind = rt.OP_GN_STATS
+        st.a, st.out = ref(A, xoff), ref(A, stoff)
+        st.i[rt.N_ROWS], st.i[rt.N_LD], st.i[rt.N_GROUPS], st.i[rt.N_GSIZE] = R, cin, G, gs
+        st.f[0] = 1e-5
+        ops.append(st)
+    pre = rt.MdtOp()
+    pre.kind = rt.OP_PREP16
+    pre.a, pre.out, pre.p0, pre.p1, pre.p2, pre.p3 = ref(A, xoff), ref(A, a16off), ref(W, o_g), ref(W, o_nb), ref(A, stoff), ref(S, 0)
+    pi = pre.i
+    pi[rt.G_R_IN], pi[rt.G_LDA], pi[rt.G_CIN], pi[rt.G_PRO], pi[rt.G_GROUPS], pi[rt.G_GSIZE], pi[rt.G_PRO_SILU] = R, cin, cin, pro, G, gs, 1
+    pre.f[0] = 1e-5
+    ops.append(pre)
+    op = gemm_op(a=ref(A, a16off), w=ref(W, 0), bias=ref(W, o_b), out=ref(A, ooff), res=ref(A, roff), r_out=R, r_in=R, lda=cin,
+                 cin=cin, taps=taps, t_dj=1 if taps > 1 else 0, t_off=-(taps // 2), n=N, ldc=N, o_rows=R, ldr=N, act=act)
+    op.i[rt.G_WFMT] = 2
+    ops.append(op)
+    if tile:
+        os.environ["MDT_TILE16_LIVE"] = tile
+    try:
+        (ga, _, _), (ca, _, _) = run_both(ops, weights, act_buf, shr, {}, B)
+    finally:
+        os.environ.pop("MDT_TILE16_LIVE", None)
+    out_g, out_c = ga[B * ooff: B * roff], ca[B * ooff: B * roff]
+    scale = max(out_c.abs().max().item(), 1.0)
+    assert (out_g - out_c).abs().max() < (2e-3 if pro != rt.PRO_NONE else 4e-5) * scale
+    a16_g = ga[B * a16off: B * ooff].view(torch.bfloat16).float()
+    a16_c = ca[B * a16off: B * ooff].view(torch.bfloat16).float()
+    assert (a16_g - a16_c).abs().max() <= 2.0 ** -7 * max(a16_c.abs().max().item(), 1.0)     # at most one bf16 ulp (ties)
+
+
+def test_gemm_bf16_chain_with_bf16_intermediate():
+    """Feed-forward shape of the plain-bf16 mode: PREP16 -> GEMM (GELU, bf16 OUTPUT: MDT_G_WFMT 6) -> GEMM (+ residual),
+    against the interpreter."""
+    B, R, C, Hd = 37, 8, 1024, 2048
+    w1 = rnd(Hd, C, seed=1, scale=C ** -0.5).to(torch.bfloat16).contiguous().view(-1).view(torch.float32)
+    w2 = rnd(C, Hd, seed=2, scale=Hd ** -0.5).to(torch.bfloat16).contiguous().view(-1).view(torch.float32)
+    weights = torch.cat([w1, w2, rnd(Hd, seed=3), rnd(C, seed=4)])
+    o_w2, o_b1, o_b2 = w1.numel(), w1.numel() + w2.numel(), w1.numel() + w2.numel() + Hd
+    xoff, a16off, hoff = 0, R * C, R * C + R * C // 2
+    ooff = hoff + R * Hd // 2
+    act = torch.zeros(B * (ooff + R * C))
+    act[: B * R * C] = rnd(B * R * C, seed=5)
+    pre = rt.MdtOp()
+    pre.kind = rt.OP_PREP16
+    pre.a, pre.out = ref(A, xoff), ref(A, a16off)
+    pre.i[rt.G_R_IN], pre.i[rt.G_LDA], pre.i[rt.G_CIN] = R, C, C
+    g1 = gemm_op(a=ref(A, a16off), w=ref(W, 0), bias=ref(W, o_b1), out=ref(A, hoff), r_out=R, r_in=R, lda=C, cin=C, taps=1,
+                 n=Hd, ldc=Hd, o_rows=R, act=1)
+    g1.i[rt.G_WFMT] = 6
+    g2 = gemm_op(a=ref(A, hoff), w=ref(W, o_w2), bias=ref(W, o_b2), out=ref(A, ooff), res=ref(A, xoff), r_out=R, r_in=R,
+                 lda=Hd, cin=Hd, taps=1, n=C, ldc=C, o_rows=R, ldr=C)
+    g2.i[rt.G_WFMT] = 2
+    (ga, _, _), (ca, _, _) = run_both([pre, g1, g2], weights, act, torch.zeros(4), {}, B)
+    h_g = ga[B * hoff: B * ooff].view(torch.bfloat16).float()
+    h_c = ca[B * hoff: B * ooff].view(torch.bfloat16).float()
+    assert (h_g - h_c).abs().max() <= 2.0 ** -7 * max(h_c.abs().max().item(), 1.0)      # one bf16 ulp (rounding ties)
+    out_g, out_c = ga[B * ooff:], ca[B * ooff:]
+    assert (out_g - out_c).abs().max() < 3e-3 * max(out_c.abs().max().item(), 1.0)
+
+
 @pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("mode", [rt.TB_FF, rt.TB_SELF, rt.TB_CROSS])
 @pytest.mark.parametrize("C,T,B", [(128, 16, 5), (256, 4, 37), (128, 4, 16), (256, 16, 3), (128, 1, 70)])
