@@ -70,8 +70,10 @@ def main():
                     "GRBM_GUI_ACTIVE summed over the 8 XCDs (per-launch cycles = value / 8)\n")
             f.write("# mfma_util = MFMA_BUSY_CYCLES / (kernel duration of the same pass x 2.4 GHz nominal x 256 CUs x 4 SIMDs); "
                     "fractions are over ALL waves of a workgroup: the ring kernels' 4 loader waves (of 8) are parked by design\n")
+            f.write("# lds_active = SQ_LDS_IDX_ACTIVE / (duration x 2.4 GHz x 256 CUs): share of the time the CUs' LDS pipes are "
+                    "processing an instruction (fragment ds_reads + LDS-DMA writes; the fused kernels' actual roof, DESIGN 3.1)\n")
             f.write("kernel,dispatches,parked_frac,issue_stall_frac,issuing_frac,mfma_busy_cycles_per_dispatch,"
-                    "avg_duration_us,mfma_util,lds_conflict_frac\n")
+                    "avg_duration_us,mfma_util,lds_conflict_frac,lds_active\n")
             dur, dn = collections.Counter(), collections.Counter()
             for tf in glob.glob(os.path.join(src, "pmc_sq", "**", "*_kernel_trace.csv"), recursive=True):
                 for r in csv.DictReader(open(tf)):
@@ -92,7 +94,8 @@ def main():
                 lds = g("SQ_LDS_IDX_ACTIVE")
                 rows.append((wc, f"\"{k}\",{d},{g('SQ_WAIT_ANY') / wc:.3f},{g('SQ_WAIT_INST_ANY') / wc:.3f},"
                                  f"{g('SQ_ACTIVE_INST_ANY') / wc:.3f},{mf:.0f},{us:.1f},"
-                                 f"{mf / (gui * 1024) if gui else 0:.4f},{g('SQ_LDS_BANK_CONFLICT') / lds if lds else 0:.4f}\n"))
+                                 f"{mf / (gui * 1024) if gui else 0:.4f},{g('SQ_LDS_BANK_CONFLICT') / lds if lds else 0:.4f},"
+                                 f"{lds / d / (gui * 256) if gui else 0:.4f}\n"))
             for _, line in sorted(rows, key=lambda r: -r[0]):
                 f.write(line)
     print("profiles written for", tag)
