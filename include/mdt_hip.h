@@ -207,17 +207,30 @@ enum mdt_tf128_i {
   MDT_F_C = 0,           /* 128                                                                              */
   MDT_F_T = 1,           /* tokens per sample (divides 16)                                                    */
   MDT_F_NT = 2,          /* tiles in the stream (weight tiles + K / V tiles)                                  */
-  MDT_F_NVEC = 3,        /* floats of vectors (multiple of 256, <= 7168): [to_in bias 128] then per block
+  MDT_F_NVEC = 3,        /* floats of vectors (multiple of 256, <= 8192): [to_in bias 128] then per block
                             [bq 64 heads | bo 128] (self), the same (cross), [b1 64 nff | b2 128] (feed-forward)  */
   MDT_F_TK = 4, MDT_F_KV_BSTRIDE = 5, MDT_F_LDKV = 6, MDT_F_HEADS = 7,
   MDT_F_HAS_IN = 8,      /* 1: starts with to_in (two projection tiles, GroupNorm gain / bias folded into them)  */
-  MDT_F_NBLOCKS = 9, MDT_F_NFF = 10 /* hidden / 64 */,
+  MDT_F_NBLOCKS = 9 /* may be 0 (then HAS_IN = 0 too) when ResNet blocks are present */, MDT_F_NFF = 10 /* hidden / 64 */,
   MDT_F_NPOST = 11,      /* 2: to_out folded into the last feed-forward block (two extra output tiles), 0: none   */
   MDT_F_KV2 = 12,        /* 1: dual batch, as MDT_B_KV2 (first half = whole 64-row workgroups)                    */
   MDT_F_CROSS = 13,      /* 1: the blocks have a cross-attention sub-block                                        */
-  MDT_F_KV_LSTRIDE = 14  /* per-sample floats between consecutive cross layers' K|V rows                         */
+  MDT_F_KV_LSTRIDE = 14, /* per-sample floats between consecutive cross layers' K|V rows                         */
+  /* MDT_OP_TF128 only: ResnetBlock1d blocks (modules.py:145-205) of the level IN FRONT of the transformer, same launch */
+  MDT_F_RES_KIND = 15,   /* 0 none; 1: x = Block(x), N_RES times, every block's output ALSO stored as a skip tensor: block rb to
+                            res + rb * (B * T * C floats) (the up path reads them back); 2: x = Block(cat([x, s * skip[rb]])) with
+                            skip[rb] = res - rb * (B * T * C floats) (consumed in reverse order of production), s = f[SKIP_SCALE].
+                            Stream per block, kind 1: 6 + 6 projection tiles (convolution taps x output halves, K columns in
+                            accumulator order); kind 2: 2 to_out(x), [skip rows: descriptor 0 | (1 << 20 | rb) << 2], 2 to_out(skip),
+                            6 block1(x), [skip rows], 6 block1(skip), 6 block2.  Vectors per block ahead of the transformer's: kind 1
+                            [g1 | b1 | bias1 | g2 | b2 | bias2] (6 C), kind 2 [g1 (2C) | b1 (2C) | bias1 | bias_to_out | g2 | b2 | bias2]
+                            (9 C).  p3 = the blocks' FiLM rows [scale C | shift C] each, contiguous (NFILM floats)             */
+  MDT_F_N_RES = 16,
+  MDT_F_RES_PAIR1 = 17,  /* GroupNorm groups of block1: 1 = 32 channels, 0 = 16 channels (block2: RES_PAIR2)                */
+  MDT_F_RES_PAIR2 = 18,
+  MDT_F_NFILM = 19       /* FiLM floats staged behind the vectors (2 C per block, padded to a multiple of 256; NVEC + NFILM <= 8192) */
 };
-enum mdt_tf128_f { MDT_FF_EPS_LN = 0, MDT_FF_SCALE = 1, MDT_FF_EPS_GN = 2 };
+enum mdt_tf128_f { MDT_FF_EPS_LN = 0, MDT_FF_SCALE = 1, MDT_FF_EPS_GN = 2, MDT_FF_EPS_RES = 3, MDT_FF_SKIP_SCALE = 4 };
 
 typedef struct mdt_op {
   int32_t kind;

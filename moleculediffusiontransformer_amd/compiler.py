@@ -156,6 +156,8 @@ class UNetCompiler:
         self.use_gn_act = os.environ.get("MDT_GN_ACT", "1") == "1"
         # cross-attention layers that run layer by layer over MANY keys (QMDiffusionForward: 64): fold the key / value
         # projections into the query / output projections and attend to the normalised context itself
+        # ResNet blocks of a 128-channel level inside the transformer launch that follows them (k_tf128 RES = 1 / 2)
+        self.res128 = os.environ.get("MDT_RES128", "1") == "1"
         self.b16 = os.environ.get("MDT_B16", "1") == "1"     # bf16 mode: regular layers as PREP16 + bf16 x bf16 GEMM
         self.fold_ctx = os.environ.get("MDT_FOLD_CTX", "1") == "1"
         self.has_chat = False                # some layer attends to the normalised context (ctx program emits it)
@@ -753,24 +755,48 @@ class UNetCompiler:
     # 32 st + 8 g + e of the projection tile <-> feature 16 (2 st + (e >> 2)) + 4 g + (e & 3)
     _ACC_PERM = [16 * (2 * (k >> 5) + ((k & 7) >> 2)) + 4 * ((k >> 3) & 3) + (k & 3) for k in range(128)]
 
-    def tf128_ok(self, c: int, rows: int, layers: int, cross: bool) -> bool:
+    def tf128_ok(self, c: int, rows: int, layers: int, cross: bool, res_kind: int = 0, n_res: int = 0) -> bool:
         if not (self.tf128 and self.gemm_mode == "bf16x3" and self.fuse_blocks and self.fold_out):
             return False
-        if c != 128 or rows > 16 or 16 % rows or self.cfg.head_features != 64 or (c * self.cfg.ff_mult) % 64 or layers < 1:
+        if c != 128 or rows > 16 or 16 % rows or self.cfg.head_features != 64 or (c * self.cfg.ff_mult) % 64:
+            return False
+        if layers < 1 and n_res < 1:
             return False
         if cross and (16 // rows) * self.n_ctx > 16:
             return False
-        return self._tf128_nvec(c, layers, cross) <= 7168
+        nfilm = (2 * c * n_res + 255) // 256 * 256
+        return self._tf128_nvec(c, layers, cross, res_kind, n_res) + nfilm <= 8192      # 32 KB of LDS behind the 128 KB ring
 
-    def _tf128_nvec(self, c: int, layers: int, cross: bool) -> int:
+    def _tf128_nvec(self, c: int, layers: int, cross: bool, res_kind: int = 0, n_res: int = 0) -> int:
         mid, hid = self.cfg.mid_features, c * self.cfg.ff_mult
-        n = c + layers * ((mid + c) * (2 if cross else 1) + hid + c)
+        n = n_res * (6 * c if res_kind == 1 else 9 * c)
+        if layers > 0:
+            n += c + layers * ((mid + c) * (2 if cross else 1) + hid + c)
         return (n + 255) // 256 * 256
 
-    def transformer_fused128(self, x: Ten, p: str, c: int, layers: int, cross: bool, free_input: bool) -> Ten:
+    def res128_ok(self, p: str, c: int, rows: int, groups: int, two_source: bool) -> bool:
+        """Can the ResnetBlock1d at prefix p run inside a k_tf128 launch (csrc/k_tf128.hip, RES = 1 / 2)?  GroupNorm groups of 16
+        or 32 channels (statistics on whole 16-channel accumulator tiles), C -> C (single source) or 2C -> C with to_out."""
+        if not (self.res128 and self.tf128 and self.gemm_mode == "bf16x3" and self.fuse_blocks and self.fold_out):
+            return False
+        if c != 128 or rows > 16 or 16 % rows or groups <= 0:
+            return False
+        cin = 2 * c if two_source else c
+        if cin % groups or c % groups or cin // groups not in (16, 32) or c // groups not in (16, 32):
+            return False
+        w1 = self.sd.get(p + "block1.project.weight")
+        if w1 is None or tuple(w1.shape) != (c, cin, 3) or tuple(self.sd[p + "block2.project.weight"].shape) != (c, c, 3):
+            return False
+        return ((p + "to_out.weight") in self.sd) == two_source
+
+    def transformer_fused128(self, x: Ten, p: str, c: int, layers: int, cross: bool, free_input: bool, res=None,
+                             y: Optional[Ten] = None) -> Ten:
         """Transformer1d.forward (modules.py:519-524) as ONE MDT_OP_TF128: to_in, every block's sub-blocks and to_out (folded
         into the last feed-forward block), the residual stream kept in registers.  Weight tiles in consumption order; every
-        projection that consumes the residual stream has its K columns in accumulator order (_ACC_PERM)."""
+        projection that consumes the residual stream has its K columns in accumulator order (_ACC_PERM).
+        res = (kind, [block prefixes], groups, skip tensors, scale): ResnetBlock1d blocks of the level in front of the transformer
+        in the same launch -- kind 1: x = Block(x), outputs stored to skips[k]; kind 2: x = Block(cat([x, scale * skips[k]]))
+        (modules.py:193-205, :828-829); layers = 0: the blocks alone."""
         cfg, sd = self.cfg, self.sd
         rows, mid = x.rows, cfg.mid_features
         heads, nff = mid // 64, c * cfg.ff_mult // 64
@@ -784,14 +810,52 @@ class UNetCompiler:
             desc.append(kind | (len(tiles) << 2))
             tiles.append(self._tile(t))
 
-        # ---- to_in: GroupNorm(32, eps 1e-6) + Conv1d(k = 1); gain / bias folded: W (g xn + b) = (W g) xn + W b ----
-        g_in, b_in = sd[p + "to_in.0.weight"].double(), sd[p + "to_in.0.bias"].double()
-        w_in = sd[p + "to_in.1.weight"].reshape(c, c).double()
-        w_in_f = (w_in * g_in.unsqueeze(0)).float()
-        for half in range(c // 64):
-            wtile(w_in_f[64 * half: 64 * half + 64][:, acc], 0)
-        vec.append((w_in @ b_in + sd[p + "to_in.1.bias"].double()).float())
-        self.flops += 2 * rows * c * c
+        def conv3_tiles(w: torch.Tensor) -> None:                 # [c][c][3] -> (tap, output half) projection tiles
+            for tap in range(3):
+                for half in range(c // 64):
+                    wtile(w[64 * half: 64 * half + 64, :, tap][:, acc], 0)
+
+        res_kind, res_blocks, res_skips, film0 = 0, [], [], None
+        if res is not None:
+            res_kind, res_blocks, groups, res_skips, scale_b = res
+            assert len(res_skips) == len(res_blocks) and res_kind in (1, 2)
+            for rb, bp in enumerate(res_blocks):
+                ss_off = self.ss_total                              # FiLM vectors inside the shared (scale | shift) row
+                self.ss_offsets[bp] = ss_off
+                self.ss_total += 2 * c
+                film0 = ss_off if film0 is None else film0
+                w1, w2 = sd[bp + "block1.project.weight"].float(), sd[bp + "block2.project.weight"].float()
+                g1, b1 = sd[bp + "block1.groupnorm.weight"].float(), sd[bp + "block1.groupnorm.bias"].float()
+                g2, b2 = sd[bp + "block2.groupnorm.weight"].float(), sd[bp + "block2.groupnorm.bias"].float()
+                bias1, bias2 = sd[bp + "block1.project.bias"].float(), sd[bp + "block2.project.bias"].float()
+                if res_kind == 1:
+                    conv3_tiles(w1)
+                    conv3_tiles(w2)
+                    vec += [g1, b1, bias1, g2, b2, bias2]
+                    self.flops += 2 * rows * 3 * c * c * 2
+                else:
+                    wr, br = sd[bp + "to_out.weight"].float(), sd[bp + "to_out.bias"].float()      # [c, 2c, 1]
+                    skip_desc = 0 | (((1 << 20) | rb) << 2)
+                    for half in range(c // 64):
+                        wtile(wr[64 * half: 64 * half + 64, :c, 0][:, acc], 0)
+                    desc.append(skip_desc)
+                    for half in range(c // 64):
+                        wtile(wr[64 * half: 64 * half + 64, c:, 0][:, acc], 0)
+                    conv3_tiles(w1[:, :c])
+                    desc.append(skip_desc)
+                    conv3_tiles(w1[:, c:])
+                    conv3_tiles(w2)
+                    vec += [g1, b1, bias1, br, g2, b2, bias2]
+                    self.flops += 2 * rows * (3 * 2 * c * c + 3 * c * c + 2 * c * c)
+        if layers > 0:
+            # ---- to_in: GroupNorm(32, eps 1e-6) + Conv1d(k = 1); gain / bias folded: W (g xn + b) = (W g) xn + W b ----
+            g_in, b_in = sd[p + "to_in.0.weight"].double(), sd[p + "to_in.0.bias"].double()
+            w_in = sd[p + "to_in.1.weight"].reshape(c, c).double()
+            w_in_f = (w_in * g_in.unsqueeze(0)).float()
+            for half in range(c // 64):
+                wtile(w_in_f[64 * half: 64 * half + 64][:, acc], 0)
+            vec.append((w_in @ b_in + sd[p + "to_in.1.bias"].double()).float())
+            self.flops += 2 * rows * c * c
         cross0 = len(self.cross_layers)
         for li in range(layers):
             bp = p + f"blocks.{li}."
@@ -843,13 +907,25 @@ class UNetCompiler:
                 self.flops += 2 * rows * c * c
             vec += [b1, b2]
             self.flops += 2 * 2 * rows * c * w1.shape[0]
-        nvec = self._tf128_nvec(c, layers, cross)
+        nvec = self._tf128_nvec(c, layers, cross, res_kind, len(res_blocks))
         v = torch.cat([t.float().reshape(-1) for t in vec])
         assert v.numel() <= nvec, (v.numel(), nvec)
         v = torch.cat([v, torch.zeros(nvec - v.numel())])
-        y = self._new(rows, c)
+        if y is None:
+            y = self._new(rows, c)
         op = rt.MdtOp()
         op.kind = rt.OP_TF128
+        if res_kind:
+            op.res = res_skips[0].ref()
+            op._film = ("ss", film0)
+            op.i[rt.F_RES_KIND], op.i[rt.F_N_RES] = res_kind, len(res_blocks)
+            cin1 = (2 * c if res_kind == 2 else c)
+            op.i[rt.F_RES_PAIR1], op.i[rt.F_RES_PAIR2] = int(cin1 // groups == 32), int(c // groups == 32)
+            op.i[rt.F_NFILM] = (2 * c * len(res_blocks) + 255) // 256 * 256
+            op.f[rt.FF_EPS_RES], op.f[rt.FF_SKIP_SCALE] = 1e-5, float(scale_b if res_kind == 2 else 1.0)
+            for k in range(1, len(res_skips)):      # whole tensors apart, ascending (produced) / descending (consumed)
+                step = rows * c if res_kind == 1 else -rows * c
+                assert res_skips[k].off == res_skips[0].off + k * step and res_skips[k].space == rt.SP_ACT
         op.a, op.out = x.ref(), y.ref()
         op.w = _ref(rt.SP_WEIGHT, self.W.add(p + "tf128.tiles", torch.cat(tiles)))
         op.bias = _ref(rt.SP_WEIGHT, self.W.add(p + "tf128.vec", v))
@@ -857,7 +933,7 @@ class UNetCompiler:
         i = op.i
         i[rt.F_C], i[rt.F_T], i[rt.F_NT], i[rt.F_NVEC] = c, rows, len(desc), nvec
         i[rt.F_TK], i[rt.F_KV_BSTRIDE], i[rt.F_LDKV], i[rt.F_HEADS] = self.n_ctx, self.n_ctx, 2 * mid, heads
-        i[rt.F_HAS_IN], i[rt.F_NBLOCKS], i[rt.F_NFF], i[rt.F_NPOST] = 1, layers, nff, c // 64
+        i[rt.F_HAS_IN], i[rt.F_NBLOCKS], i[rt.F_NFF], i[rt.F_NPOST] = int(layers > 0), layers, nff, (c // 64 if layers > 0 else 0)
         i[rt.F_CROSS], i[rt.F_KV_LSTRIDE] = int(cross), self.n_ctx * 2 * mid
         op.f[0], op.f[1], op.f[2] = 1e-5, float(cfg.head_features) ** -0.5, 1e-6
         if cross:
@@ -1225,13 +1301,37 @@ class UNetCompiler:
                 y = self.transformer(x, dp + "pre_transformer_block.", co, cfg.pre_transformer, False)
                 skips.append(y)
                 x, x_is_skip = y, True
-            for j in range(cfg.num_blocks[i]):
-                x = self.resnet(x, dp + f"blocks.{j}.", co, co, g, free_input=not x_is_skip)
-                skips.append(x)
-                x_is_skip = True
-            if cfg.attentions[i] > 0:
-                x = self.transformer(x, dp + "transformer.", co, cfg.attentions[i], True, free_input=False)
-                skips.append(x)
+            nb, nat = cfg.num_blocks[i], cfg.attentions[i]
+            blocks = [dp + f"blocks.{j}." for j in range(nb)]
+            res_ok = nb > 0 and all(self.res128_ok(bp, co, x.rows, g, False) for bp in blocks)
+            together = res_ok and self.tf128_ok(co, x.rows, nat, nat > 0, 1, nb)
+            alone = res_ok and not together and self.tf128_ok(co, x.rows, 0, False, 1, nb) \
+                and (nat == 0 or self.tf128_ok(co, x.rows, nat, True))
+            if together or alone:
+                # the level's ResNet blocks in ONE launch, with the transformer that follows them when its vectors fit the LDS
+                # behind the ring as well; the outputs (all of them skips of the up path) are whole tensors apart in one
+                # allocation, so this launch and the up path's address them by index
+                n_out = nb + (1 if nat > 0 else 0)
+                base = self.arena.alloc(n_out * x.rows * co)
+                outs = [Ten(rt.SP_ACT, base + k * x.rows * co, x.rows, co, co) for k in range(n_out)]
+                if together:
+                    self.transformer_fused128(x, dp + "transformer.", co, nat, nat > 0, free_input=not x_is_skip,
+                                              res=(1, blocks, g, outs[:nb], 1.0), y=outs[-1])
+                else:
+                    self.transformer_fused128(x, "", co, 0, False, free_input=not x_is_skip,
+                                              res=(1, blocks, g, outs[:nb], 1.0), y=outs[nb - 1])
+                    if nat > 0:
+                        self.transformer_fused128(outs[nb - 1], dp + "transformer.", co, nat, True, False, y=outs[nb])
+                skips += outs
+                x = outs[-1]
+            else:
+                for bp in blocks:
+                    x = self.resnet(x, bp, co, co, g, free_input=not x_is_skip)
+                    skips.append(x)
+                    x_is_skip = True
+                if nat > 0:
+                    x = self.transformer(x, dp + "transformer.", co, nat, True, free_input=False)
+                    skips.append(x)
             skips_list.append(skips)
         cb = cfg.level_channels(cfg.num_layers)
         keep = x in skips_list[-1]
@@ -1244,15 +1344,33 @@ class UNetCompiler:
             ci, co, f = cfg.level_channels(i + 1), cfg.level_channels(i), cfg.factors[i]
             skips = skips_list.pop()
             n_res = cfg.num_blocks[i] + (1 if cfg.attentions[i] else 0)
-            for j in range(n_res):
-                s = skips.pop()
-                x = self.resnet_cat(x, s, 2 ** -0.5, up + f"blocks.{j}.", ci, g)
-            for s in skips:               # DownsampleBlock1d emits one more skip than is consumed (:702, :843-845)
-                self._free(s)
+            blocks = [up + f"blocks.{j}." for j in range(n_res)]
+            # the transformer that follows the blocks (it shares their launch when everything fits k_tf128)
+            tfs = []
             if cfg.pre_transformer > 0:
-                x = self.transformer(x, up + "pre_transformer_block.", ci, cfg.pre_transformer, False)
+                tfs.append((up + "pre_transformer_block.", cfg.pre_transformer, False))
             if cfg.attentions[i] > 0:
-                x = self.transformer(x, up + "transformer.", ci, cfg.attentions[i], True)
+                tfs.append((up + "transformer.", cfg.attentions[i], True))
+            cons = skips[len(skips) - n_res:][::-1] if 0 < n_res <= len(skips) else []       # in order of consumption
+            nxt = tfs[0] if tfs else ("", 0, False)
+            fused = (bool(cons) and x.ld == ci and all(self.res128_ok(bp, ci, x.rows, g, True) for bp in blocks)
+                     and all(sk.space == rt.SP_ACT and sk.rows == x.rows and sk.ld == ci
+                             and sk.off == cons[0].off - k * x.rows * ci for k, sk in enumerate(cons))
+                     and self.tf128_ok(ci, x.rows, nxt[1], nxt[2], 2, n_res))
+            if fused:
+                del skips[len(skips) - n_res:]
+                x = self.transformer_fused128(x, nxt[0], ci, nxt[1], nxt[2], True, res=(2, blocks, g, cons, 2 ** -0.5))
+                for sk in cons:
+                    self._free(sk)
+                tfs = tfs[1:]
+            else:
+                for bp in blocks:
+                    sk = skips.pop()
+                    x = self.resnet_cat(x, sk, 2 ** -0.5, bp, ci, g)
+            for sk in skips:              # DownsampleBlock1d emits one more skip than is consumed (:702, :843-845)
+                self._free(sk)
+            for tp, tl, tc in tfs:
+                x = self.transformer(x, tp, ci, tl, tc)
             # ConvTranspose1d k=2f s=f p=f/2 as f output phases of 2 taps each (modules.py:74-81)
             if f % 2:
                 raise ValueError("odd upsample factors are not supported")
@@ -1326,7 +1444,7 @@ class UNetCompiler:
             for op in ops:
                 o = rt.MdtOp()
                 C_memmove(o, op)
-                if op.kind in (rt.OP_GEMM, rt.OP_GN_ACT, rt.OP_RCONV, rt.OP_RESBLOCK, rt.OP_PREP16) and isinstance(getattr(op, "_film", None), tuple):
+                if op.kind in (rt.OP_GEMM, rt.OP_GN_ACT, rt.OP_RCONV, rt.OP_RESBLOCK, rt.OP_PREP16, rt.OP_TF128) and isinstance(getattr(op, "_film", None), tuple):
                     o.p3 = _ref(rt.SP_SHR, ss_cur + op._film[1])
                 if op.kind == rt.OP_ATTN_CTX:
                     if fixed:

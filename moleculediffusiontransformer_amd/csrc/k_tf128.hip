@@ -22,6 +22,18 @@
 //     loads; every sub-block's vectors (biases) are staged into LDS behind the ring once.
 //
 // Ring protocol, fragment layouts, attention core and GELU are those of k_tblock_lw.hip (read that file first).
+//
+// RES > 0: ResnetBlock1d blocks (modules.py:145-205) of the same level run IN FRONT of the transformer in the same launch --
+// a wave owns whole samples, so their GroupNorm statistics, FiLM, SiLU and the +-1 taps of the k = 3 convolutions (the
+// operand registers shifted by one lane inside the 16-lane row, k_rconv.hip) are wave-local as well:
+//   RES = 1 (down path):  x = Block(x), every block's output also stored as a skip tensor          (6 tiles / convolution pair 12)
+//   RES = 2 (up path):    x = Block(cat([x, s * skip]))  -- the 2C-channel input is never built: both sources are normalised
+//                         and convolved separately into the same accumulators, the 1x1 residual convolution to_out likewise
+//                         (24 tiles per block: 2 to_out on x, the skip rows themselves, 2 to_out on the skip, 6 block1 on x, the
+//                         skip rows again, 6 block1 on the skip, 6 block2)
+// The first convolution's output lives in a second accumulator set hT; the second convolution accumulates into the residual
+// stream.  Vectors per block: RES 1 [g1 | b1 | bias1 | g2 | b2 | bias2] (6 C), RES 2 [g1 (2C) | b1 (2C) | bias1 | bias_r | g2 | b2
+// | bias2] (9 C); the FiLM (scale | shift) rows of the blocks come from the shared time-mapping row (a.film, 2 C per block).
 #include <cstdlib>
 #include <type_traits>
 
@@ -107,8 +119,22 @@ constexpr int NU = 8;           // units (4 fragment reads + 6 MFMAs) per tile, 
 
 }  // namespace
 
+template <bool SHR>      // operand of the neighbouring token row (k_rconv.hip): lane i takes lane i - 1 (SHR) / i + 1, 0 at the ends
+__device__ __forceinline__ bf16x8 row_shift_tf(const bf16x8& v, bool keep) {
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  const i32x4 s = __builtin_bit_cast(i32x4, v);
+  i32x4 r;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int t = __builtin_amdgcn_update_dpp(0, s[k], SHR ? 0x111 : 0x101, 0xf, 0xf, true);
+    r[k] = keep ? t : 0;
+  }
+  return __builtin_bit_cast(bf16x8, r);
+}
+
 // NPW: LDS-DMA pieces per loader wave per K / V tile = ceil(context rows of the workgroup / 16); 0 = no cross segment
-template <int NPW>
+// RES: ResNet blocks in front of the transformer (0 none, 1 single source + skip stores, 2 two sources)
+template <int NPW, int RES>
 __global__ __launch_bounds__(512) void k_tf128(TFArgs a) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
 
@@ -150,6 +176,12 @@ __global__ __launch_bounds__(512) void k_tf128(TFArgs a) {
         voffKV[q] = (unsigned)(((sm * bstr + key) * a.ldkv + 4 * ((lane & 15) ^ (R & 15))) * 4);
       }
     }
+    // RES = 2: the skip rows of a block travel through the ring like a weight tile (kind 0, bit 20 of aux set, low bits = block):
+    // the workgroup's 64 rows x 512 B = one slot; 16-byte chunks XOR-swizzled with row & 15 inside each half row (conflict-free
+    // float4 reads of 16 rows).  A plain global load of these rows by the compute waves in the middle of the stream made hipcc
+    // spill ~390 registers per lane around it (incl. in-flight fragment registers).
+    const int rowb = blockIdx.x * 64;       // (offsets computed per piece: a third per-lane offset array next to voffP / voffO
+                                            // made hipcc index a merged array dynamically = scratch + vmcnt(0) per piece)
     auto pieces_of = [&](unsigned d) -> int { return (NPW > 0 && (d & 2u)) ? NPW : IPT; };
     auto issue_tile = [&](int tau, unsigned d) {
       unsigned char* slot = smem + (tau % NS) * SLOT + iw * 1024;
@@ -163,6 +195,18 @@ __global__ __launch_bounds__(512) void k_tf128(TFArgs a) {
 #pragma unroll
           for (int q = 0; q < NPW; ++q)
             __builtin_amdgcn_global_load_lds(base + voffKV[q], (__attribute__((address_space(3))) void*)(slot + q * 4096), 16, 0, 0);
+        }
+      } else if (RES == 2 && kind == 0u && (aux >> 20)) {
+        if constexpr (RES == 2) {
+          const unsigned char* base = reinterpret_cast<const unsigned char*>(
+              a.skip + (int64_t)(aux & 0xffu) * a.skip_stride + (int64_t)blockIdx.x * 64 * C);
+#pragma unroll
+          for (int q = 0; q < IPT; ++q) {
+            const int R = 2 * (iw + 4 * q) + (lane >> 5), pch = lane & 31;
+            const int c = (pch & 16) | ((pch & 15) ^ (R & 15));
+            const unsigned off = (unsigned)((min(rowb + R, a.M - 1) - rowb) * (C * 4) + c * 16);
+            __builtin_amdgcn_global_load_lds(base + off, (__attribute__((address_space(3))) void*)(slot + q * 4096), 16, 0, 0);
+          }
         }
       } else {
         const unsigned char* tile = wsrc + (int64_t)aux * SLOT;   // wave-uniform
@@ -194,6 +238,11 @@ __global__ __launch_bounds__(512) void k_tf128(TFArgs a) {
     for (int q = iw; q * 256 < a.nvec; q += 4)
       __builtin_amdgcn_global_load_lds(reinterpret_cast<const unsigned char*>(a.vec) + q * 1024 + lane * 16,
                                        (__attribute__((address_space(3))) void*)(smem + NS * SLOT + q * 1024), 16, 0, 0);
+    if constexpr (RES > 0) {                     // the ResNet blocks' FiLM rows (shared arena) behind the vectors
+      for (int q = iw; q * 256 < a.nfilm; q += 4)
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const unsigned char*>(a.film) + q * 1024 + lane * 16,
+                                         (__attribute__((address_space(3))) void*)(smem + NS * SLOT + a.nvec * 4 + q * 1024), 16, 0, 0);
+    }
     issue_tile(0, d0);
     if (NT > 1) issue_tile(1, d1);
     unsigned dn = d1;                                                    // descriptor of tile k + 1
@@ -242,7 +291,7 @@ __global__ __launch_bounds__(512) void k_tf128(TFArgs a) {
   for (int sp = 0; sp < 2; ++sp) aO[sp] = i * 128 + ((4 * sp + g) ^ ((i >> 1) & 7)) * 16;
 
   bf16x8 fh[3][2], fl[3][2];
-  auto frag_read = [&](auto kind, unsigned base, auto uc, int set, auto jc) {
+  auto frag_read = [&](auto kind, unsigned base, auto uc, int set, auto jc) __attribute__((always_inline)) {
     constexpr int KIND = decltype(kind)::value, u = decltype(uc)::value, j = decltype(jc)::value;
     constexpr int q = j >> 1, lo = j & 1;
     constexpr int off = (KIND == K_O) ? ((2 * (u % (NCT / 2)) + q) * 16 * 128 + lo * (C * 128))
@@ -253,7 +302,7 @@ __global__ __launch_bounds__(512) void k_tf128(TFArgs a) {
   using J1 = std::integral_constant<int, 1>;
   using J2 = std::integral_constant<int, 2>;
   using J3 = std::integral_constant<int, 3>;
-  auto prefetch2 = [&](auto kind, const unsigned char* slot, int off) {   // units 0 and 1 of a phase, as a burst
+  auto prefetch2 = [&](auto kind, const unsigned char* slot, int off) __attribute__((always_inline)) {   // units 0 and 1 of a phase, as a burst
     constexpr int KIND = decltype(kind)::value;
     const unsigned base = lds_addr(slot) + (KIND == K_O ? aO[0] : aP[0]);
     frag_read(kind, base, J0{}, off % 3, J0{}); frag_read(kind, base, J0{}, off % 3, J1{});
@@ -267,14 +316,14 @@ __global__ __launch_bounds__(512) void k_tf128(TFArgs a) {
 
   // One MFMA phase over the tile `tau` (k_tblock_lw.hip): 8 units; the reads of unit u+2 ride between the MFMAs of unit
   // u; for u+2 >= NU they belong to units 0/1 of the NEXT tile (kind NK), published by the barrier before unit NU-2.
-  auto phase = [&](auto kind, auto offc, auto nkind, bool has_next, f32x4* acc, const bf16x8* bh, const bf16x8* bl) {
+  auto phase = [&](auto kind, auto offc, auto nkind, bool has_next, f32x4* acc, const bf16x8* bh, const bf16x8* bl) __attribute__((always_inline)) {
     constexpr int KIND = decltype(kind)::value, OFF = decltype(offc)::value, NK = decltype(nkind)::value;
     const unsigned lc = lds_addr(slot_of(tau)), ln = lds_addr(slot_of(tau + 1));
     unsigned bc[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) bc[k] = lc + (KIND == K_O ? aO[k & 1] : aP[k]);
     const unsigned bn = ln + (NK == K_O ? aO[0] : aP[0]);
-    auto unit = [&](auto uc) {
+    auto unit = [&](auto uc) __attribute__((always_inline)) {
       constexpr int u = decltype(uc)::value;
       if (u == NU - 2 && has_next) {
         __builtin_amdgcn_sched_barrier(0);
@@ -288,7 +337,7 @@ __global__ __launch_bounds__(512) void k_tf128(TFArgs a) {
       if (later) lgkm_wait<4>(); else lgkm_wait<0>();
       constexpr int ia = (KIND == K_O) ? 2 * (u % (NCT / 2)) : 2 * (u & 1);
       constexpr int ib = (KIND == K_O) ? u / (NCT / 2) : (u >> 1);
-      auto rd = [&](auto jc) {
+      auto rd = [&](auto jc) __attribute__((always_inline)) {
         if (!pre) return;
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (in_phase) {
@@ -299,7 +348,7 @@ __global__ __launch_bounds__(512) void k_tf128(TFArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);
       };
-      auto mm = [&](const bf16x8& w, const bf16x8& x, int q) {
+      auto mm = [&](const bf16x8& w, const bf16x8& x, int q) __attribute__((always_inline)) {
         if constexpr (KIND == K_N) acc[ia + q] = MDT_MFMA_BF16(x, w, acc[ia + q], 0, 0, 0);
         else acc[ia + q] = MDT_MFMA_BF16(w, x, acc[ia + q], 0, 0, 0);
       };
@@ -324,29 +373,6 @@ __global__ __launch_bounds__(512) void k_tf128(TFArgs a) {
   const IC1 kN{};   // K_N
   const IC2 kO{};   // K_O
 
-  // loop-invariant softmax pieces (k_tblock_lw.hip)
-  const int samp_q = i / a.T;
-  float kmask[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) kmask[r] = ((4 * g + r) / a.T == samp_q) ? 0.f : -INFINITY;
-  const float scale2 = a.scale * 1.44269504088896340736f;
-  int aK = 0, xK = 0, aV[4] = {0, 0, 0, 0}, xV[4] = {0, 0, 0, 0};
-  bool kok[4] = {false, false, false, false};
-  if constexpr (NPW > 0) {
-    const int nkeys = (16 / a.T) * a.Tk;             // this wave's context rows
-    const int Rw = wave * nkeys;
-    const int Rk = Rw + min(i, nkeys - 1);
-    aK = Rk * 256;
-    xK = Rk & 15;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int jj = 4 * g + r;
-      const int Rv = Rw + min(jj, nkeys - 1);
-      aV[r] = Rv * 256 + (i & 3) * 4;
-      xV[r] = Rv & 15;
-      kok[r] = jj < nkeys && (jj / a.Tk) == samp_q;
-    }
-  }
   const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
   // GroupNorm of the to_in segment: token lanes of a sample by DPP inside the 16-lane row (k_rconv.hip)
   const float t1 = a.T > 1 ? 1.f : 0.f, t2 = a.T > 2 ? 1.f : 0.f, t4 = a.T > 4 ? 1.f : 0.f, t8 = a.T > 8 ? 1.f : 0.f;
@@ -354,7 +380,7 @@ __global__ __launch_bounds__(512) void k_tf128(TFArgs a) {
     const int mm_ = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xf, 0xf, true);
     return __builtin_fmaf(__builtin_bit_cast(float, mm_), f, v);
   };
-  auto token_sum = [&](float (&s)[NCT]) {            // stage-major: every stage is one batch of independent exchanges
+  auto token_sum = [&](float (&s)[NCT]) __attribute__((always_inline)) {            // stage-major: every stage is one batch of independent exchanges
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) s[ct] = dpp_fma(s[ct], t1, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
 #pragma unroll
@@ -372,7 +398,7 @@ __global__ __launch_bounds__(512) void k_tf128(TFArgs a) {
 
   bf16x8 xh[NST], xl[NST];
   // operands of the next projection from the residual stream: k-slot (st, g, e) <-> accT[2 st + (e >> 2)][e & 3]
-  auto make_operands = [&](bool layernorm) {
+  auto make_operands = [&](bool layernorm) __attribute__((always_inline)) {
     float mean = 0.f, rstd = 1.f;
     if (layernorm) {                                 // nn.LayerNorm statistics, two-pass; gain / bias folded into the weights
       float s = 0.f;
@@ -402,7 +428,7 @@ __global__ __launch_bounds__(512) void k_tf128(TFArgs a) {
     }
   };
   // accT += vec[off + 16 ct + 4 g + r] (the sub-block's output bias: accumulators start from residual + bias)
-  auto add_vec = [&](int off, bool replace) {
+  auto add_vec = [&](int off, bool replace) __attribute__((always_inline)) {
     const float* p = vec_s + off + 4 * g;
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
@@ -412,8 +438,218 @@ __global__ __launch_bounds__(512) void k_tf128(TFArgs a) {
     }
   };
 
-  int voff = 0;                                      // running offset into the vectors: [to_in bias] then per block
-                                                     // [bq | bo] (self), [bq | bo] (cross), [b1 | b2] (feed-forward)
+
+  int voff = 0;                                      // running offset into the vectors: [ResNet blocks] [to_in bias] then per
+                                                     // block [bq | bo] (self), [bq | bo] (cross), [b1 | b2] (feed-forward)
+  // ================= ResNet blocks in front of the transformer =================
+  if constexpr (RES > 0) {
+    const float* film_s = vec_s + a.nvec;
+    const bool keep_l = (i % a.T) != 0, keep_r = (i % a.T) != a.T - 1;
+    // GroupNorm statistics of groups of 16 (pair = false) or 32 (pair = true) channels over the sample's tokens, on the
+    // accumulator layout: a group is one / two 16-channel tiles ct -- 4 registers, the 4 lane groups, the sample's token lanes
+    auto gn_stats = [&](const f32x4* src, bool pair, float (&mu)[NCT], float (&rs)[NCT]) __attribute__((always_inline)) {
+      const float inv_n = 1.0f / (float)(a.T * (pair ? 32 : 16));
+      auto reduce = [&](float (&v)[NCT]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) v[ct] = xg16_add(v[ct]);
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) v[ct] = xg32_add(v[ct]);
+        token_sum(v);
+        if (pair) {
+#pragma unroll
+          for (int k = 0; k < NCT; k += 2) {
+            const float t = v[k] + v[k + 1];
+            v[k] = t;
+            v[k + 1] = t;
+          }
+        }
+      };
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) mu[ct] = (src[ct][0] + src[ct][1]) + (src[ct][2] + src[ct][3]);
+      reduce(mu);
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        mu[ct] *= inv_n;
+        float ss = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d = src[ct][r] - mu[ct];
+          ss += d * d;
+        }
+        rs[ct] = ss;
+      }
+      reduce(rs);
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) rs[ct] = __builtin_amdgcn_rsqf(rs[ct] * inv_n + a.eps_res);
+    };
+    // operands of a convolution: silu(GroupNorm(src) [* (scale + 1) + shift]) in k-slot order (make_operands' mapping)
+    auto gn_operands = [&](const f32x4* src, const float (&mu)[NCT], const float (&rs)[NCT], const float* gam, const float* bet,
+                           const float* film) __attribute__((always_inline)) {
+      // one k-step (two 16-channel tiles) at a time: a whole normalised copy of src next to src, two operand sets, the
+      // fragment sets and two more accumulator sets does not fit the register file
+#pragma unroll
+      for (int st = 0; st < NST; ++st) {
+        float v[8];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const int ct = 2 * st + hf;
+          const float4 gv = *reinterpret_cast<const float4*>(gam + 16 * ct + 4 * g);
+          const float4 bv = *reinterpret_cast<const float4*>(bet + 16 * ct + 4 * g);
+          const float g4[4] = {gv.x, gv.y, gv.z, gv.w}, b4[4] = {bv.x, bv.y, bv.z, bv.w};
+          float u[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float sc = rs[ct] * g4[r];
+            u[r] = src[ct][r] * sc + (b4[r] - sc * mu[ct]);
+          }
+          if (film) {
+            const float4 fv = *reinterpret_cast<const float4*>(film + 16 * ct + 4 * g);
+            const float4 hv = *reinterpret_cast<const float4*>(film + C + 16 * ct + 4 * g);
+            const float f4[4] = {fv.x, fv.y, fv.z, fv.w}, h4[4] = {hv.x, hv.y, hv.z, hv.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) u[r] = u[r] * f4[r] + (u[r] + h4[r]);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[4 * hf + r] = mvalid ? u[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-u[r])) : 0.f;
+        }
+        split8_tf(v, xh[st], xl[st]);
+      }
+    };
+    auto raw_operands = [&](const f32x4* src) __attribute__((always_inline)) {
+#pragma unroll
+      for (int st = 0; st < NST; ++st) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = mvalid ? src[2 * st + (e >> 2)][e & 3] : 0.f;
+        split8_tf(v, xh[st], xl[st]);
+      }
+    };
+    auto set_vec = [&](f32x4* acc, const float* p, bool add) __attribute__((always_inline)) {
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        const float4 b = *reinterpret_cast<const float4*>(p + 16 * ct + 4 * g);
+        const f32x4 bb = f32x4{b.x, b.y, b.z, b.w};
+        acc[ct] = add ? acc[ct] + bb : bb;
+      }
+    };
+    // Conv1d(k = 3) on the operands xh / xl into acc: tiles in order (tap, output half); the taps +-1 are the operands
+    // shifted by one lane.  O0 = fragment-set rotation at entry; six phases leave it unchanged.
+    auto conv3 = [&](auto o0, f32x4* acc, bool has_next) __attribute__((always_inline)) {
+      constexpr int O0 = decltype(o0)::value;
+      using A0 = std::integral_constant<int, O0 % 3>;
+      using A1 = std::integral_constant<int, (O0 + 2) % 3>;
+      using A2 = std::integral_constant<int, (O0 + 1) % 3>;
+      bf16x8 sh[NST], sl[NST];
+#pragma unroll
+      for (int st = 0; st < NST; ++st) { sh[st] = row_shift_tf<true>(xh[st], keep_l); sl[st] = row_shift_tf<true>(xl[st], keep_l); }
+      phase(kT, A0{}, kT, true, acc, sh, sl);
+      phase(kT, A1{}, kT, true, acc + 4, sh, sl);
+      phase(kT, A2{}, kT, true, acc, xh, xl);
+      phase(kT, A0{}, kT, true, acc + 4, xh, xl);
+#pragma unroll
+      for (int st = 0; st < NST; ++st) { sh[st] = row_shift_tf<false>(xh[st], keep_r); sl[st] = row_shift_tf<false>(xl[st], keep_r); }
+      phase(kT, A1{}, kT, true, acc, sh, sl);
+      phase(kT, A2{}, kT, has_next, acc + 4, sh, sl);
+    };
+    const bool tf_follows = a.has_in || a.nblocks > 0;
+    float mu[NCT], rs[NCT];
+    for (int rb = 0; rb < a.n_res; ++rb) {
+      const bool more = rb + 1 < a.n_res || tf_follows;
+      const float* pv = vec_s + voff;
+      f32x4 hT[NCT];
+      if constexpr (RES == 1) {
+        gn_stats(accT, a.res_pair1 != 0, mu, rs);
+        gn_operands(accT, mu, rs, pv, pv + C, nullptr);
+        set_vec(hT, pv + 2 * C, false);
+        conv3(IC0{}, hT, true);
+        gn_stats(hT, a.res_pair2 != 0, mu, rs);
+        gn_operands(hT, mu, rs, pv + 3 * C, pv + 4 * C, film_s + rb * 2 * C);
+        set_vec(accT, pv + 5 * C, true);                 // the stream is the block's residual
+        conv3(IC0{}, accT, more);
+        if (mvalid) {                                    // every block's output is a skip of the up path
+          float* so = a.skip + (int64_t)rb * a.skip_stride + (int64_t)m * C + 4 * g;
+#pragma unroll
+          for (int ct = 0; ct < NCT; ++ct)
+            store_nt(so + 16 * ct, make_float4(accT[ct][0], accT[ct][1], accT[ct][2], accT[ct][3]));
+        }
+        voff += 6 * C;
+      } else {
+        // Order chosen for the register budget (never more than three accumulator-sized sets next to two operand sets and the
+        // fragment sets): the skip rows arrive as a ring tile TWICE, once for the residual convolution, once for block1.
+        // Tiles: to_out_a (2), skip rows, to_out_b (2), conv1_a (6), skip rows, conv1_b (6), conv2 (6).
+        auto skip_rows = [&](f32x4* xbT) __attribute__((always_inline)) {
+          __builtin_amdgcn_s_barrier();                  // B(skip rows)
+          const unsigned char* ss_ = slot_of(tau) + (wave * 16 + i) * (C * 4);
+#pragma unroll
+          for (int ct = 0; ct < NCT; ++ct) {
+            const int ch = 4 * ct + g;
+            const float4 xr = *reinterpret_cast<const float4*>(ss_ + (((ch & 16) | ((ch & 15) ^ i)) << 4));
+            xbT[ct] = f32x4{xr.x, xr.y, xr.z, xr.w} * a.skip_scale;
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads are complete before the slot can be refilled
+          ++tau;
+          __builtin_amdgcn_s_barrier();                  // B(next weight tile)
+        };
+        f32x4 rT[NCT];
+        raw_operands(accT);                              // residual = to_out(cat) (k = 1)
+        set_vec(rT, pv + 5 * C, false);
+        phase(kT, IC0{}, kT, true, rT, xh, xl);
+        phase(kT, IC2{}, kT, false, rT + 4, xh, xl);
+        {
+          f32x4 xbT[NCT];
+          skip_rows(xbT);
+          prefetch2(kT, slot_of(tau), 0);
+          raw_operands(xbT);
+        }
+        phase(kT, IC0{}, kT, true, rT, xh, xl);
+        phase(kT, IC2{}, kT, true, rT + 4, xh, xl);      // rotation 1
+        // block1 over both sources (GroupNorm groups of the 2C-channel input never straddle the halves)
+        gn_stats(accT, a.res_pair1 != 0, mu, rs);
+        gn_operands(accT, mu, rs, pv, pv + 2 * C, nullptr);
+        set_vec(hT, pv + 4 * C, false);
+        conv3(IC1{}, hT, false);
+        {
+          f32x4 xbT[NCT];
+          skip_rows(xbT);
+          gn_stats(xbT, a.res_pair1 != 0, mu, rs);
+          gn_operands(xbT, mu, rs, pv + C, pv + 3 * C, nullptr);
+          prefetch2(kT, slot_of(tau), 0);
+        }
+        conv3(IC0{}, hT, true);
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) accT[ct] = rT[ct];
+        gn_stats(hT, a.res_pair2 != 0, mu, rs);
+        gn_operands(hT, mu, rs, pv + 6 * C, pv + 7 * C, film_s + rb * 2 * C);
+        set_vec(accT, pv + 8 * C, true);
+        conv3(IC0{}, accT, more);
+        voff += 9 * C;
+      }
+    }
+  }
+  // loop-invariant softmax pieces (k_tblock_lw.hip); computed behind the ResNet blocks, whose register demand would
+  // otherwise push them to scratch and back
+  const int samp_q = i / a.T;
+  float kmask[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) kmask[r] = ((4 * g + r) / a.T == samp_q) ? 0.f : -INFINITY;
+  const float scale2 = a.scale * 1.44269504088896340736f;
+  int aK = 0, xK = 0, aV[4] = {0, 0, 0, 0}, xV[4] = {0, 0, 0, 0};
+  bool kok[4] = {false, false, false, false};
+  if constexpr (NPW > 0) {
+    const int nkeys = (16 / a.T) * a.Tk;             // this wave's context rows
+    const int Rw = wave * nkeys;
+    const int Rk = Rw + min(i, nkeys - 1);
+    aK = Rk * 256;
+    xK = Rk & 15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int jj = 4 * g + r;
+      const int Rv = Rw + min(jj, nkeys - 1);
+      aV[r] = Rv * 256 + (i & 3) * 4;
+      xV[r] = Rv & 15;
+      kok[r] = jj < nkeys && (jj / a.Tk) == samp_q;
+    }
+  }
   // ---- Transformer1d.to_in: GroupNorm(32 groups of 4 channels, over the sample's tokens) + Conv1d(k = 1) ----
   if (a.has_in) {
     // the lane's float4 accT[ct] is exactly one group at one token; gain / bias are folded into the weights
@@ -441,12 +677,12 @@ __global__ __launch_bounds__(512) void k_tf128(TFArgs a) {
       for (int r = 0; r < 4; ++r) accT[ct][r] = (accT[ct][r] - gm[ct]) * rs;
     }
     make_operands(false);
-    add_vec(0, true);                                // accT = bias (the convolution REPLACES the stream)
+    add_vec(voff, true);                             // accT = bias (the convolution REPLACES the stream)
     phase(kT, IC0{}, kT, true, accT, xh, xl);        // output channels 0..63
     phase(kT, IC2{}, kT, false, accT + 4, xh, xl);   // output channels 64..127
     __builtin_amdgcn_s_barrier();                    // B(next tile); realigns the fragment-set rotation for the blocks
     prefetch2(kT, slot_of(tau), 0);
-    voff = C;
+    voff += C;
   }
 
   const int nheads = a.nheads, nff = a.nff;
@@ -661,38 +897,52 @@ __global__ __launch_bounds__(512) void k_tf128(TFArgs a) {
   }
 }
 
-template <int NPW>
+template <int NPW, int RES>
 static hipError_t launch_tf(const TFArgs& a, hipStream_t s) {
-  const size_t smem = (size_t)NS * SLOT + (size_t)a.nvec * sizeof(float);   // ring + every segment's vectors
+  const size_t smem = (size_t)NS * SLOT + (size_t)(a.nvec + (RES > 0 ? a.nfilm : 0)) * sizeof(float);   // ring + vectors [+ FiLM rows]
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tf128<NPW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tf128<NPW, RES>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_tf128<NPW>), dim3((unsigned)((a.M + 63) / 64)), dim3(512), smem, s, a);
+  hipLaunchKernelGGL((k_tf128<NPW, RES>), dim3((unsigned)((a.M + 63) / 64)), dim3(512), smem, s, a);
   return hipGetLastError();
 }
 
 bool tf128_supported(int T, int Tk, int nvec, bool cross) {
-  if (T <= 0 || 16 % T || nvec <= 0 || nvec % 256 || nvec > 7168) return false;     // 28 KB of vectors behind the 128 KB ring
+  if (T <= 0 || 16 % T || nvec <= 0 || nvec % 256 || nvec > 8192) return false;     // 32 KB of vectors behind the 128 KB ring
   if (cross && (Tk <= 0 || (16 / T) * Tk > 16)) return false;                         // one key tile per wave (k_tblock_lw.hip)
   return true;
+}
+
+template <int RES>
+static hipError_t launch_tf_res(const TFArgs& a, hipStream_t s, bool cross) {
+  if (!cross) return launch_tf<0, RES>(a, s);
+  switch (((64 / a.T) * a.Tk + 15) / 16) {
+    case 1: return launch_tf<1, RES>(a, s);
+    case 2: return launch_tf<2, RES>(a, s);
+    case 3: return launch_tf<3, RES>(a, s);
+    case 4: return launch_tf<4, RES>(a, s);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 hipError_t launch_tf128(const TFArgs& a, hipStream_t s) {
   if (a.M <= 0) return hipSuccess;
   const bool cross = a.kv != nullptr;
-  if (!tf128_supported(a.T, a.Tk, a.nvec, cross) || a.nblocks <= 0 || a.NT <= 0 || a.nheads <= 0 || a.nff <= 0)
+  if (!tf128_supported(a.T, a.Tk, a.nvec, cross) || a.nblocks < 0 || a.NT <= 0 || a.nheads <= 0 || a.nff <= 0)
     return hipErrorInvalidValue;
   if (a.npost != 0 && a.npost != 2) return hipErrorInvalidValue;
-  if (!cross) return launch_tf<0>(a, s);
-  switch (((64 / a.T) * a.Tk + 15) / 16) {
-    case 1: return launch_tf<1>(a, s);
-    case 2: return launch_tf<2>(a, s);
-    case 3: return launch_tf<3>(a, s);
-    case 4: return launch_tf<4>(a, s);
-    default: return hipErrorInvalidValue;
+  if (a.n_res < 0 || a.res_kind < 0 || a.res_kind > 2 || (a.res_kind == 0) != (a.n_res == 0)) return hipErrorInvalidValue;
+  if (a.n_res == 0 && a.nblocks == 0) return hipErrorInvalidValue;
+  if (a.n_res > 0 && (!a.skip || !a.film || a.nfilm % 256 || a.nfilm < 2 * C * a.n_res || a.nvec + a.nfilm > 8192))
+    return hipErrorInvalidValue;
+  if (a.nblocks == 0 && a.has_in) return hipErrorInvalidValue;
+  switch (a.res_kind) {
+    case 0: return launch_tf_res<0>(a, s, cross);
+    case 1: return launch_tf_res<1>(a, s, cross);
+    default: return launch_tf_res<2>(a, s, cross);
   }
 }
 

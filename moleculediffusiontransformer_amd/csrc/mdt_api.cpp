@@ -156,11 +156,19 @@ static const char* validate(const mdt_op& o, int idx, char* buf, size_t nbuf) {
       if (i[MDT_F_C] != 128) return bad("fused transformer needs C = 128");
       if (!mdt::tf128_supported(i[MDT_F_T], i[MDT_F_TK], i[MDT_F_NVEC], i[MDT_F_CROSS] != 0))
         return bad("shape not supported by the fused transformer (tokens per sample must divide 16, <= 16 context rows per 16 tokens, <= 7168 vector floats)");
-      if (i[MDT_F_NBLOCKS] <= 0 || i[MDT_F_NT] <= 0 || i[MDT_F_HEADS] <= 0 || i[MDT_F_HEADS] > 16 || i[MDT_F_NFF] <= 0)
+      if (i[MDT_F_NBLOCKS] < 0 || i[MDT_F_NT] <= 0 || i[MDT_F_HEADS] <= 0 || i[MDT_F_HEADS] > 16 || i[MDT_F_NFF] <= 0)
         return bad("bad block / tile / head counts");
       if (i[MDT_F_NPOST] != 0 && i[MDT_F_NPOST] != 2) return bad("npost must be 0 or 2");
       if (!o.a.space || !o.out.space || !o.w.space || !o.bias.space || !o.p0.space) return bad("missing operand");
       if (i[MDT_F_CROSS] && !o.a2.space) return bad("cross-attention blocks need the hoisted K/V rows");
+      if (i[MDT_F_RES_KIND] < 0 || i[MDT_F_RES_KIND] > 2 || (i[MDT_F_RES_KIND] == 0) != (i[MDT_F_N_RES] == 0) || i[MDT_F_N_RES] < 0 ||
+          i[MDT_F_N_RES] > 255)
+        return bad("bad ResNet block kind / count");
+      if (i[MDT_F_N_RES] == 0 && (i[MDT_F_NBLOCKS] == 0 || i[MDT_F_NFILM])) return bad("a transformer launch needs blocks");
+      if (i[MDT_F_NBLOCKS] == 0 && (i[MDT_F_HAS_IN] || i[MDT_F_NPOST])) return bad("to_in / to_out without transformer blocks");
+      if (i[MDT_F_N_RES] > 0 && (!o.res.space || !o.p3.space || i[MDT_F_NFILM] % 256 || i[MDT_F_NFILM] < 256 * i[MDT_F_N_RES] ||
+                                 i[MDT_F_NVEC] + i[MDT_F_NFILM] > 8192))
+        return bad("ResNet blocks need the skip tensors (res), the FiLM rows (p3) and NVEC + NFILM <= 8192");
       break;
     }
     case MDT_OP_TF256: {
@@ -384,6 +392,12 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
         a.kv_lstride = (int64_t)i[MDT_F_KV_LSTRIDE] * (o.a2.space == MDT_SP_ACT ? B : 1);
         a.kv2_lstride = (int64_t)i[MDT_F_KV_LSTRIDE] * (o.p1.space == MDT_SP_ACT ? B : 1);
         a.eps_ln = o.f[MDT_FF_EPS_LN]; a.scale = o.f[MDT_FF_SCALE]; a.eps_gn = o.f[MDT_FF_EPS_GN];
+        a.res_kind = wide ? 0 : i[MDT_F_RES_KIND]; a.n_res = wide ? 0 : i[MDT_F_N_RES];
+        a.res_pair1 = i[MDT_F_RES_PAIR1]; a.res_pair2 = i[MDT_F_RES_PAIR2]; a.nfilm = wide ? 0 : i[MDT_F_NFILM];
+        a.film = a.n_res ? ptr(o.p3) : nullptr; a.skip = a.n_res ? ptr(o.res) : nullptr;
+        // skip tensors of consecutive blocks: whole tensors apart (ascending where they are produced, descending where consumed)
+        a.skip_stride = (int64_t)B * a.T * i[MDT_F_C] * (a.res_kind == 2 ? -1 : 1);
+        a.skip_scale = o.f[MDT_FF_SKIP_SCALE]; a.eps_res = o.f[MDT_FF_EPS_RES];
         if (i[MDT_F_KV2]) {
           const int per_wg = (wide ? 32 : 64) / a.T;
           if (!o.p1.space || B % 2 || (B / 2) % (per_wg > 0 ? per_wg : 1))

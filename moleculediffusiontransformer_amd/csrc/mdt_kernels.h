@@ -183,6 +183,15 @@ struct TFArgs {
   int nff;               // hidden chunks of 64 of the feed-forward blocks
   int npost;             // 2: Transformer1d.to_out folded into the LAST feed-forward block (two extra output tiles), 0: none
   float eps_ln, eps_gn, scale;
+  // MDT_OP_TF128 only: ResnetBlock1d blocks in front of the transformer (k_tf128.hip)
+  int res_kind;          // 0 none; 1 single source, every block's output also stored to skip + rb * skip_stride;
+                         // 2 input cat([x, skip_scale * skip[rb]]) with skip[rb] = skip + rb * skip_stride
+  int n_res, res_pair1, res_pair2;   // blocks; GroupNorm groups of 32 (1) or 16 (0) channels in block1 / block2
+  int nfilm;             // FiLM floats staged from `film` (2 C per block, a multiple of 256)
+  const float* film;     // (scale | shift) rows of the blocks, contiguous (shared time-mapping row)
+  float* skip;
+  int64_t skip_stride;
+  float skip_scale, eps_res;
 };
 bool tf128_supported(int T, int Tk, int nvec, bool cross);
 hipError_t launch_tf128(const TFArgs& a, hipStream_t s);

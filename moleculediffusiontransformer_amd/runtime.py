@@ -40,7 +40,8 @@ B_MODE, B_C, B_T, B_NCHUNK, B_NBIAS, B_TK, B_KV_BSTRIDE, B_LDKV, B_HEADS, B_VARI
 B_KV2 = 11
 # MDT_OP_TF128 (enum mdt_tf128_i)
 (F_C, F_T, F_NT, F_NVEC, F_TK, F_KV_BSTRIDE, F_LDKV, F_HEADS, F_HAS_IN, F_NBLOCKS, F_NFF, F_NPOST, F_KV2, F_CROSS,
- F_KV_LSTRIDE) = range(15)
+ F_KV_LSTRIDE, F_RES_KIND, F_N_RES, F_RES_PAIR1, F_RES_PAIR2, F_NFILM) = range(20)
+FF_EPS_LN, FF_SCALE, FF_EPS_GN, FF_EPS_RES, FF_SKIP_SCALE = range(5)
 
 
 class MdtRef(C.Structure):

@@ -394,7 +394,7 @@ def _tf128(op, bufs: Buffers, B: int) -> None:
     Tk, bs, ldkv, H = i[rt.F_TK], i[rt.F_KV_BSTRIDE], i[rt.F_LDKV], i[rt.F_HEADS]
     nblocks, nff, npost, cross = i[rt.F_NBLOCKS], i[rt.F_NFF], i[rt.F_NPOST], bool(i[rt.F_CROSS])
     desc = bufs.view(op.p0, B, NT).contiguous().view(torch.int32).tolist()
-    nw = sum(1 for d in desc if (d & 3) < 2)
+    nw = sum(1 for d in desc if (d & 3) < 2 and not (d >> 22))          # (aux bit 20: the skip rows of a ResNet block)
     stream = bufs.view(op.w, B, nw * 64 * C)
     vec = bufs.view(op.bias, B, nvec)
     inv_acc = torch.empty(128, dtype=torch.long)
@@ -432,6 +432,57 @@ def _tf128(op, bufs: Buffers, B: int) -> None:
         return out
 
     x = bufs.view(op.a, B, B * T * C).view(B, T, C)
+    # ---- ResnetBlock1d blocks in front of the transformer (MDT_F_RES_KIND) ----
+    res_kind, n_res = i[rt.F_RES_KIND], i[rt.F_N_RES]
+    if res_kind:
+        film = bufs.view(op.p3, B, i[rt.F_NFILM])
+        eps_r, s_b = float(f[rt.FF_EPS_RES]), float(f[rt.FF_SKIP_SCALE])
+        gs1, gs2 = (32 if i[rt.F_RES_PAIR1] else 16), (32 if i[rt.F_RES_PAIR2] else 16)
+
+        def conv3_w():                       # 6 projection tiles (tap, output half) -> [C, C, 3]
+            w = torch.zeros(C, C, 3)
+            for tap in range(3):
+                for half in range(C // 64):
+                    w[64 * half: 64 * half + 64, :, tap] = P()
+            return w
+
+        def gn_silu(t, gsize, gam, bet, fl=None):      # t [B, T, c] -> silu(GroupNorm [* (scale + 1) + shift])
+            cc = t.shape[2]
+            y = F.group_norm(t.transpose(1, 2), cc // gsize, gam, bet, eps_r).transpose(1, 2)
+            if fl is not None:
+                y = y * (fl[:cc] + 1.0) + fl[cc:]
+            return _silu(y)
+
+        def conv3(t, w):                     # Conv1d(k = 3, padding 1) inside the sample
+            return F.conv1d(t.transpose(1, 2), w, None, padding=1).transpose(1, 2)
+
+        for rb in range(n_res):
+            fl = film[rb * 2 * C: (rb + 1) * 2 * C]
+            if res_kind == 1:
+                w1, w2 = conv3_w(), conv3_w()
+                g1, b1, bias1, g2, b2, bias2 = (V(C) for _ in range(6))
+                h = conv3(gn_silu(x, gs1, g1, b1), w1) + bias1
+                x = conv3(gn_silu(h, gs2, g2, b2, fl), w2) + bias2 + x
+                sk = rt.MdtRef(op.res.space, 0, op.res.off + rb * T * C)
+                bufs.view(sk, B, B * T * C).view(B, T, C)[:] = x
+            else:
+                def skip_desc():
+                    d = desc[cur["t"]]
+                    cur["t"] += 1
+                    assert d & 3 == 0 and (d >> 2) == ((1 << 20) | rb), "expected the skip rows of this block"
+                sk = rt.MdtRef(op.res.space, 0, op.res.off - rb * T * C)
+                xb = bufs.view(sk, B, B * T * C).view(B, T, C) * s_b
+                wra = torch.cat([P() for _ in range(C // 64)])
+                skip_desc()
+                wrb = torch.cat([P() for _ in range(C // 64)])
+                w1a = conv3_w()
+                skip_desc()
+                w1b, w2 = conv3_w(), conv3_w()
+                g1, b1, bias1, br, g2, b2, bias2 = V(2 * C), V(2 * C), V(C), V(C), V(C), V(C), V(C)
+                xc = gn_silu(torch.cat([x, xb], dim=2), gs1, g1, b1)
+                h = conv3(xc[:, :, :C], w1a) + conv3(xc[:, :, C:], w1b) + bias1
+                r = x @ wra.T + xb @ wrb.T + br
+                x = conv3(gn_silu(h, gs2, g2, b2, fl), w2) + bias2 + r
     if i[rt.F_HAS_IN]:
         xn = F.group_norm(x.transpose(1, 2), 32, None, None, eps=float(f[2])).transpose(1, 2)
         w = torch.cat([P() for _ in range(C // 64)])
@@ -538,6 +589,57 @@ def _tf256(op, bufs: Buffers, B: int) -> None:
         return vec[base + off: base + off + n]
 
     x = bufs.view(op.a, B, B * T * C).view(B, T, C)
+    # ---- ResnetBlock1d blocks in front of the transformer (MDT_F_RES_KIND) ----
+    res_kind, n_res = i[rt.F_RES_KIND], i[rt.F_N_RES]
+    if res_kind:
+        film = bufs.view(op.p3, B, i[rt.F_NFILM])
+        eps_r, s_b = float(f[rt.FF_EPS_RES]), float(f[rt.FF_SKIP_SCALE])
+        gs1, gs2 = (32 if i[rt.F_RES_PAIR1] else 16), (32 if i[rt.F_RES_PAIR2] else 16)
+
+        def conv3_w():                       # 6 projection tiles (tap, output half) -> [C, C, 3]
+            w = torch.zeros(C, C, 3)
+            for tap in range(3):
+                for half in range(C // 64):
+                    w[64 * half: 64 * half + 64, :, tap] = P()
+            return w
+
+        def gn_silu(t, gsize, gam, bet, fl=None):      # t [B, T, c] -> silu(GroupNorm [* (scale + 1) + shift])
+            cc = t.shape[2]
+            y = F.group_norm(t.transpose(1, 2), cc // gsize, gam, bet, eps_r).transpose(1, 2)
+            if fl is not None:
+                y = y * (fl[:cc] + 1.0) + fl[cc:]
+            return _silu(y)
+
+        def conv3(t, w):                     # Conv1d(k = 3, padding 1) inside the sample
+            return F.conv1d(t.transpose(1, 2), w, None, padding=1).transpose(1, 2)
+
+        for rb in range(n_res):
+            fl = film[rb * 2 * C: (rb + 1) * 2 * C]
+            if res_kind == 1:
+                w1, w2 = conv3_w(), conv3_w()
+                g1, b1, bias1, g2, b2, bias2 = (V(C) for _ in range(6))
+                h = conv3(gn_silu(x, gs1, g1, b1), w1) + bias1
+                x = conv3(gn_silu(h, gs2, g2, b2, fl), w2) + bias2 + x
+                sk = rt.MdtRef(op.res.space, 0, op.res.off + rb * T * C)
+                bufs.view(sk, B, B * T * C).view(B, T, C)[:] = x
+            else:
+                def skip_desc():
+                    d = desc[cur["t"]]
+                    cur["t"] += 1
+                    assert d & 3 == 0 and (d >> 2) == ((1 << 20) | rb), "expected the skip rows of this block"
+                sk = rt.MdtRef(op.res.space, 0, op.res.off - rb * T * C)
+                xb = bufs.view(sk, B, B * T * C).view(B, T, C) * s_b
+                wra = torch.cat([P() for _ in range(C // 64)])
+                skip_desc()
+                wrb = torch.cat([P() for _ in range(C // 64)])
+                w1a = conv3_w()
+                skip_desc()
+                w1b, w2 = conv3_w(), conv3_w()
+                g1, b1, bias1, br, g2, b2, bias2 = V(2 * C), V(2 * C), V(C), V(C), V(C), V(C), V(C)
+                xc = gn_silu(torch.cat([x, xb], dim=2), gs1, g1, b1)
+                h = conv3(xc[:, :, :C], w1a) + conv3(xc[:, :, C:], w1b) + bias1
+                r = x @ wra.T + xb @ wrb.T + br
+                x = conv3(gn_silu(h, gs2, g2, b2, fl), w2) + bias2 + r
     if i[rt.F_HAS_IN]:
         xn = F.group_norm(x.transpose(1, 2), 32, None, None, eps=float(f[2])).transpose(1, 2)
         w = torch.cat([P() for _ in range(C // 64)])

@@ -834,3 +834,92 @@ def test_fused_transformer(C, T, B, layers, cross, fixed):
     # same launch again from the same buffers: the ring protocol has no race that a second run would expose differently
     (ga2, _, _), _ = run_both([op], comp.W.pack(), act, shr, {}, B)
     assert torch.equal(ga2, ga)
+
+
+def _resnet_sd(p, c, cin, seed0):
+    r = lambda *sh, seed, scale=1.0: rnd(*sh, seed=seed0 + seed, scale=scale)   # noqa: E731
+    sd = {p + "block1.groupnorm.weight": 1 + 0.2 * r(cin, seed=1), p + "block1.groupnorm.bias": 0.2 * r(cin, seed=2),
+          p + "block1.project.weight": r(c, cin, 3, seed=3, scale=(3 * cin) ** -0.5), p + "block1.project.bias": 0.1 * r(c, seed=4),
+          p + "block2.groupnorm.weight": 1 + 0.2 * r(c, seed=5), p + "block2.groupnorm.bias": 0.2 * r(c, seed=6),
+          p + "block2.project.weight": r(c, c, 3, seed=7, scale=(3 * c) ** -0.5), p + "block2.project.bias": 0.1 * r(c, seed=8)}
+    if cin != c:
+        sd[p + "to_out.weight"] = r(c, cin, 1, seed=9, scale=cin ** -0.5)
+        sd[p + "to_out.bias"] = 0.1 * r(c, seed=10)
+    return sd
+
+
+@pytest.mark.parametrize("kind,T,B,n_res,layers,cross", [
+    (1, 16, 5, 3, 0, False),      # down path: the blocks alone, outputs stored as skips
+    (1, 16, 70, 1, 1, True),      # ... and in front of a transformer with cross-attention
+    (1, 4, 18, 2, 1, False),      # 4 tokens per sample: sample boundaries inside the 16-lane row
+    (2, 16, 5, 4, 2, False),      # up path: cat([x, skip / sqrt 2]) blocks + the pre-transformer (configs[1])
+    (2, 16, 1030, 1, 0, False),   # many workgroups, ragged last one
+    (2, 8, 9, 2, 1, False),
+    (2, 16, 33, 1, 1, True),
+])
+def test_resnet_blocks_inside_the_transformer_launch(kind, T, B, n_res, layers, cross):
+    """MDT_OP_TF128 with MDT_F_RES_KIND 1 / 2 (k_tf128.hip RES = 1 / 2): ResnetBlock1d blocks of the 128-channel level in front
+    of the transformer in one launch, against (i) the CPU interpreter of the op and (ii) the reference's module arithmetic
+    (modules.py:145-205: GroupNorm -> [FiLM] -> SiLU -> Conv1d(k = 3), twice, + to_out(x) | x; :828-829: cat with the scaled
+    skip).  Kind 1 also stores every block's output; kind 2 reads its skips in reverse order."""
+    from moleculediffusiontransformer_amd.compiler import Ten, UNetCompiler
+    from moleculediffusiontransformer_amd.netspec import inverse_unet_config
+    import torch.nn.functional as F
+    C, n_ctx, mid, G = 128, 12, 512, 8
+    cfg = inverse_unet_config(16, 64, 128, n_ctx)
+    p = "tf."
+    sd = _transformer_sd(p, C, max(layers, 1), cross)
+    blocks = [f"res{k}." for k in range(n_res)]
+    for k, bp in enumerate(blocks):
+        sd.update(_resnet_sd(bp, C, C if kind == 1 else 2 * C, 100 * (k + 1)))
+    comp = UNetCompiler(cfg, 64, n_ctx, sd)
+    assert all(comp.res128_ok(bp, C, T, G, kind == 2) for bp in blocks) and comp.tf128_ok(C, T, layers, cross, kind, n_res)
+    # per-sample arena: [x | y | skip 0 .. n_res-1 | K/V layers]
+    x, y = Ten(A, 0, T, C), Ten(A, T * C, T, C)
+    skips = [Ten(A, (2 + k) * T * C, T, C) for k in range(n_res)]
+    if kind == 2:
+        skips = skips[::-1]                  # consumed from the highest address downwards
+    comp.transformer_fused128(x, p, C, layers, cross, False, res=(kind, blocks, G, skips, 2 ** -0.5), y=y)
+    op = comp.ops[0]
+    assert op.kind == rt.OP_TF128 and len(comp.ops) == 1
+    film_off = 64
+    op.p3 = ref(S, film_off)
+    kv_floats = n_ctx * 2 * mid
+    if cross:
+        op.a2 = ref(A, (2 + n_res) * T * C)
+    act_x = rnd(B * T * C, seed=13) * 1.5 + 0.3
+    sk_in = rnd(n_res * B * T * C, seed=16) * 1.2 - 0.1 if kind == 2 else torch.zeros(n_res * B * T * C)
+    kv_all = rnd(layers * B * kv_floats, seed=14) if cross else torch.zeros(0)
+    act = torch.cat([act_x, torch.zeros(B * T * C), sk_in, kv_all])
+    shr = torch.cat([torch.zeros(film_off), 0.3 * rnd(n_res * 2 * C, seed=15), torch.zeros(256)])
+    (ga, _, _), (ca, _, _) = run_both([op], comp.W.pack(), act, shr, {}, B)
+    n = B * T * C
+    yg, yc = ga[n: 2 * n].view(B, T, C), ca[n: 2 * n].view(B, T, C)
+    assert torch.isfinite(yg).all()
+    tol = 2e-4 * max(1.0, yc.abs().max().item())
+    assert (yg - yc).abs().max() < tol, (yg - yc).abs().max().item()
+    assert torch.equal(ga[:n], act_x)
+    if kind == 1:                            # every block's output stored as a skip tensor
+        sg, sc = ga[2 * n: (2 + n_res) * n], ca[2 * n: (2 + n_res) * n]
+        assert (sg - sc).abs().max() < tol
+    else:
+        assert torch.equal(ga[2 * n: (2 + n_res) * n], sk_in)
+    # ---- the reference's arithmetic for the ResNet part (the transformer part is covered by test_fused_transformer) ----
+    if layers == 0:
+        h = act_x.view(B, T, C).transpose(1, 2).double()
+        for k, bp in enumerate(blocks):
+            fl = shr[film_off + k * 2 * C: film_off + (k + 1) * 2 * C].double()
+            xin = h
+            if kind == 2:
+                sk = sk_in.view(n_res, B, T, C)[n_res - 1 - k].transpose(1, 2).double() * 2 ** -0.5
+                xin = torch.cat([h, sk], dim=1)
+            g = lambda key: sd[bp + key].double()   # noqa: E731
+            t1 = F.conv1d(F.silu(F.group_norm(xin, G, g("block1.groupnorm.weight"), g("block1.groupnorm.bias"), 1e-5)),
+                          g("block1.project.weight"), g("block1.project.bias"), padding=1)
+            t2 = F.group_norm(t1, G, g("block2.groupnorm.weight"), g("block2.groupnorm.bias"), 1e-5)
+            t2 = F.silu(t2 * (fl[:C].view(1, C, 1) + 1) + fl[C:].view(1, C, 1))
+            t2 = F.conv1d(t2, g("block2.project.weight"), g("block2.project.bias"), padding=1)
+            h = t2 + (F.conv1d(xin, g("to_out.weight"), g("to_out.bias")) if kind == 2 else xin)
+            if kind == 1:
+                assert (ga[(2 + k) * n: (3 + k) * n].view(B, T, C).double() - h.transpose(1, 2)).abs().max() < tol
+        assert (yg.double() - h.transpose(1, 2)).abs().max() < tol
