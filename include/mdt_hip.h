@@ -145,7 +145,8 @@ enum mdt_gemm_i {
                         2 = as 1 with the A operand ALREADY bf16 (written by MDT_OP_PREP16; LDA / A_COL in bf16 elements): both
                         operands stream through LDS-DMA; no prologue, stride, phases or output row mapping, cin % 64 == 0;
                         6 = as 2 and the OUTPUT is bf16 too (LDC / O_COL in bf16 elements): a tensor whose only reader is the next
-                        bf16 x bf16 GEMM (feed-forward hidden layer)                                                          */
+                        bf16 x bf16 GEMM (feed-forward hidden layer); 10 = as 2 and ALSO a bf16 copy [rows][N] of the fp32 output
+                        into p0 (the residual stream as the A operand of the next GEMM, written where it is produced)        */
 };
 enum mdt_gemm_f { MDT_GF_EPS = 0 };
 
@@ -164,7 +165,9 @@ enum mdt_resblock_f { MDT_KF_EPS = 0 };
 enum mdt_attn_i {
   MDT_A_T = 0, MDT_A_TK = 1, MDT_A_HEADS = 2, MDT_A_LDQ = 3, MDT_A_LDKV = 4, MDT_A_LDO = 5,
   MDT_A_KV_BSTRIDE = 6, /* rows between consecutive samples' K/V (TK, or 0 for a batch-invariant context) */
-  MDT_A_OUT16 = 7       /* MDT_OP_ATTN: 1 = out is bf16 (LDO in bf16 elements), read by a bf16 x bf16 GEMM */
+  MDT_A_OUT16 = 7,      /* MDT_OP_ATTN: 1 = out is bf16 (LDO in bf16 elements), read by a bf16 x bf16 GEMM */
+  MDT_A_QCOL = 8,       /* MDT_OP_ATTN: first float of q inside its rows (q | k | v projected by ONE GEMM into one tensor) */
+  MDT_A_KCOL = 9        /* ... and of k inside the a2 rows (v follows heads * 64 floats later)                          */
 };
 enum mdt_attn_f { MDT_AF_SCALE = 0 };
 

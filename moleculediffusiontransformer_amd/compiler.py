@@ -158,7 +158,8 @@ class UNetCompiler:
         # projections into the query / output projections and attend to the normalised context itself
         # ResNet blocks of a 128-channel level inside the transformer launch that follows them (k_tf128 RES = 1 / 2)
         self.res128 = os.environ.get("MDT_RES128", "1") == "1"
-        self.b16 = os.environ.get("MDT_B16", "1") == "1"     # bf16 mode: regular layers as PREP16 + bf16 x bf16 GEMM
+        self.b16 = os.environ.get("MDT_B16", "1") == "1"
+        self.qkv_merge = os.environ.get("MDT_QKV_MERGE", "1") == "1"   # ... and self-attention's q | k | v as one GEMM     # bf16 mode: regular layers as PREP16 + bf16 x bf16 GEMM
         self.fold_ctx = os.environ.get("MDT_FOLD_CTX", "1") == "1"
         self.has_chat = False                # some layer attends to the normalised context (ctx program emits it)
         self.tf128 = os.environ.get("MDT_TF128", "1") == "1"         # a whole C = 128 Transformer1d as ONE launch (k_tf128)
@@ -183,6 +184,7 @@ class UNetCompiler:
         self.cfg, self.L, self.n_ctx, self.sd = cfg, length, cond_len, sd
         self.W = _Weights()
         self.arena = _Arena()
+        self._ones_off: Dict[int, int] = {}
         self.ops: List[rt.MdtOp] = []
         self.flops = 0
         self.max_time_rows = max_time_rows
@@ -215,6 +217,11 @@ class UNetCompiler:
     def b16_ok(self, cin: int) -> bool:
         """Plain-bf16 mode: is a regular layer with `cin` input channels lowered to the bf16 x bf16 GEMM?"""
         return self.gemm_mode == "bf16" and self.b16 and cin % 64 == 0
+
+    def _ones(self, n: int) -> int:
+        if n not in self._ones_off:
+            self._ones_off[n] = self.W.add(f"ones{n}", torch.ones(n))
+        return self._ones_off[n]
 
     def _zeros(self, n: int) -> int:
         if n > self._zeros_len:
@@ -271,7 +278,7 @@ class UNetCompiler:
              gain: Optional[int] = None, nbias: Optional[int] = None, stats: Optional[Ten] = None,
              film: Optional[rt.MdtRef] = None, groups: int = 0, gsize: int = 0, pro_silu: int = 0,
              act: int = 0, eps: float = 0.0, m_mode: int = 0, a_col: int = 0, o_col: int = 0,
-             count_flops: bool = True, phases: int = 0) -> None:
+             count_flops: bool = True, phases: int = 0, copy16: Optional[Ten] = None) -> None:
         r_out_ = a.rows if r_out is None else r_out
         a16 = None
         regular = (self.b16_ok(cin) and t_stride == 1 and phases <= 1 and o_stride == 1 and o_off == 0 and r_out_ == a.rows
@@ -307,7 +314,10 @@ class UNetCompiler:
         op.kind = rt.OP_GEMM
         w_off, wlo_off, *wfmt = self._pack_w(wt, cin)
         op.a, op.w, op.out = a.ref(), _ref(rt.SP_WEIGHT, w_off), out.ref()
-        op.i[rt.G_WFMT] = ((2 | (4 if out.b16 else 0)) if a.b16 else wfmt[0]) if wfmt else 0
+        op.i[rt.G_WFMT] = ((2 | (4 if out.b16 else 0) | (8 if copy16 is not None else 0)) if a.b16 else wfmt[0]) if wfmt else 0
+        if copy16 is not None:               # a bf16 copy of the fp32 output, written by the epilogue (MDT_G_WFMT 10)
+            assert a.b16 and copy16.b16 and not out.b16 and o_col == 0 and copy16.ld == n and copy16.rows == out.rows
+            op.p0 = copy16.ref()
         if wlo_off is not None:
             op.a2 = _ref(rt.SP_WEIGHT, wlo_off)
         if bias_off is not None:
@@ -378,7 +388,7 @@ class UNetCompiler:
         self._emit(op)
         return y
 
-    def attn(self, q: Ten, kv: rt.MdtRef, tk: int, kv_bstride: int, out: Ten) -> None:
+    def attn(self, q: Ten, kv: rt.MdtRef, tk: int, kv_bstride: int, out: Ten, ldkv: Optional[int] = None, kcol: int = 0) -> None:
         cfg = self.cfg
         op = rt.MdtOp()
         op.kind = rt.OP_ATTN
@@ -390,8 +400,8 @@ class UNetCompiler:
             op.a2 = kv
         i = op.i
         i[rt.A_T], i[rt.A_TK], i[rt.A_HEADS] = q.rows, tk, cfg.heads
-        i[rt.A_LDQ], i[rt.A_LDKV], i[rt.A_LDO], i[rt.A_KV_BSTRIDE] = q.ld, 2 * cfg.mid_features, out.ld, kv_bstride
-        i[rt.A_OUT16] = int(out.b16)
+        i[rt.A_LDQ], i[rt.A_LDKV], i[rt.A_LDO], i[rt.A_KV_BSTRIDE] = q.ld, ldkv or 2 * cfg.mid_features, out.ld, kv_bstride
+        i[rt.A_OUT16], i[rt.A_KCOL] = int(out.b16), kcol
         op.f[0] = float(cfg.head_features) ** -0.5
         self._emit(op)
         self.flops += 2 * 2 * q.rows * tk * cfg.mid_features
@@ -1067,10 +1077,31 @@ class UNetCompiler:
             self._free(x)
         return y
 
-    def attention_layer(self, t: Ten, p: str, cross_index: Optional[int]) -> None:
-        """x = Attention(x[, context]) + x, in place on t (modules.py:401-410, :457-459)."""
+    def attention_layer(self, t: Ten, p: str, cross_index: Optional[int], copy16: Optional[Ten] = None) -> None:
+        """x = Attention(x[, context]) + x, in place on t (modules.py:401-410, :457-459).  copy16 (plain-bf16 mode): the output
+        projection also writes a bf16 copy of the new x, the A operand of the feed-forward block that follows."""
         cfg = self.cfg
         c, mid = t.ld, cfg.mid_features
+        if cross_index is None and self.b16_ok(c) and self.b16_ok(mid) and self.qkv_merge:
+            # plain-bf16 mode: q | k | v as ONE GEMM over ONE normalised operand -- norm and norm_context differ only in their
+            # gains / biases, which fold into the weights (W (g xn + b) = (W g) xn + W b): one LayerNorm pass, one launch
+            sd = self.sd
+            wq, wkv = sd[p + "to_q.weight"].double(), sd[p + "to_kv.weight"].double()
+            gq, bq = sd[p + "norm.weight"].double(), sd[p + "norm.bias"].double()
+            gc, bc = sd[p + "norm_context.weight"].double(), sd[p + "norm_context.bias"].double()
+            w = torch.cat([wq * gq.unsqueeze(0), wkv * gc.unsqueeze(0)]).float()
+            bias = torch.cat([wq @ bq, wkv @ bc]).float()
+            qkv = self._new(t.rows, 3 * mid)
+            self.gemm(t, (p + "qkv.folded", w), 3 * mid, qkv, cin=c, pro=rt.PRO_LAYERNORM,
+                      gain=self._ones(c), nbias=self._zeros(c), eps=1e-5,
+                      bias_off=self.W.add(p + "qkv.folded.bias", bias))
+            ao = self._new16(t.rows, mid)
+            self.attn(qkv, qkv.ref(), t.rows, t.rows, ao, ldkv=3 * mid, kcol=mid)
+            self._free(qkv)
+            self.gemm(ao, self._lin_w(p + "attention.to_out.weight"), c, t, cin=mid,
+                      bias_off=self._vec(p + "attention.to_out.bias", c), res=t, copy16=copy16)
+            self._free(ao)
+            return
         q = self._new(t.rows, mid)
         self.gemm(t, self._lin_w(p + "to_q.weight"), mid, q, cin=c, pro=rt.PRO_LAYERNORM,
                   gain=self._vec(p + "norm.weight", c), nbias=self._vec(p + "norm.bias", c), eps=1e-5)
@@ -1086,7 +1117,7 @@ class UNetCompiler:
             self.attn(q, ("kv", cross_index), self.n_ctx, self.n_ctx, ao)
         self._free(q)
         self.gemm(ao, self._lin_w(p + "attention.to_out.weight"), c, t, cin=mid,
-                  bias_off=self._vec(p + "attention.to_out.bias", c), res=t)
+                  bias_off=self._vec(p + "attention.to_out.bias", c), res=t, copy16=copy16 if ao.b16 else None)
         self._free(ao)
 
     def fold_ok(self) -> bool:
@@ -1220,19 +1251,25 @@ class UNetCompiler:
                 else:
                     self.tblock(t, rt.TB_FF, bp + "feed_forward.", variant=ffv)
                 continue
-            self.attention_layer(t, bp + "attention.", None)
-            if cross and self.fold_ok():
+            hid = c * cfg.ff_mult
+            ff16 = self.b16_ok(c) and self.b16_ok(hid) and self.b16_ok(cfg.mid_features)
+            folded = cross and self.fold_ok()
+            # plain-bf16 mode: the attention block in front of the feed-forward block hands it x as bf16 (no conversion pass)
+            t16 = self._new16(t.rows, c) if (ff16 and not folded) else None
+            self.attention_layer(t, bp + "attention.", None, copy16=None if cross else t16)
+            if folded:
                 self.attention_layer_folded(t, bp + "cross_attention.")
             elif cross:
                 self.cross_layers.append(bp + "cross_attention.")
-                self.attention_layer(t, bp + "cross_attention.", len(self.cross_layers) - 1)
-            hid = c * cfg.ff_mult
+                self.attention_layer(t, bp + "cross_attention.", len(self.cross_layers) - 1, copy16=t16)
             h = self._new16(t.rows, hid) if (self.b16_ok(c) and self.b16_ok(hid)) else self._new(t.rows, hid)
-            self.gemm(t, self._lin_w(bp + "feed_forward.0.weight"), c * cfg.ff_mult, h, cin=c,
+            self.gemm(t16 if t16 is not None else t, self._lin_w(bp + "feed_forward.0.weight"), c * cfg.ff_mult, h, cin=c,
                       bias_off=self._vec(bp + "feed_forward.0.bias", c * cfg.ff_mult), act=1)
             self.gemm(h, self._lin_w(bp + "feed_forward.2.weight"), c, t, cin=c * cfg.ff_mult,
                       bias_off=self._vec(bp + "feed_forward.2.bias", c), res=t)
             self._free(h)
+            if t16 is not None:
+                self._free(t16)
         if y_fold is not None:                      # the last feed-forward block already produced to_out(t)
             if y_fold is not t:
                 self._free(t)

@@ -140,43 +140,38 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_b16(Gemm16Args g) {
     const int col = n0 + wc * 32 * TN + b * 32 + li;
     const bool cok = col < g.N;
     const float bias = (g.bias && cok) ? g.bias[col] : 0.f;
-    if (g.out16) {
-      // bf16 output (the only reader is another bf16 x bf16 GEMM; ldc in bf16 elements): neighbouring lanes swap one value of
-      // each register pair, so that a lane stores two consecutive columns of ONE row as 4 bytes
-      unsigned short* o16 = reinterpret_cast<unsigned short*>(g.out);
-      const bool odd = li & 1;
-#pragma unroll
-      for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const int mb = m0 + wr * 32 * TM + a * 32 + 8 * (r >> 2) + 4 * lh;
-          float v0 = acc[a][b][r] + bias, v1 = acc[a][b][r + 1] + bias;
-          if (g.act == 1) { v0 = gelu16(v0); v1 = gelu16(v1); }
-          if (g.res && cok) {
-            if (mb + (r & 3) < g.M) v0 += g.res[(int64_t)(mb + (r & 3)) * g.ldr + col];
-            if (mb + (r & 3) + 1 < g.M) v1 += g.res[(int64_t)(mb + (r & 3) + 1) * g.ldr + col];
-          }
-          const float recv = __shfl_xor(odd ? v0 : v1, 1, 64);
-          const float lo = odd ? recv : v0, hi = odd ? v1 : recv;
-          const int m = mb + (r & 3) + (odd ? 1 : 0);
-          if (cok && m < g.M) {
-            const unsigned pk = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)lo) |
-                                ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)hi) << 16);
-            *reinterpret_cast<unsigned*>(o16 + (int64_t)m * g.ldc + g.o_col + (col & ~1)) = pk;
-          }
-        }
-      continue;
-    }
+    // Register pairs (r, r + 1) are two consecutive rows of one column.  fp32 output: plain stores.  bf16 output (out16: the
+    // only reader is another bf16 x bf16 GEMM; ldc in bf16 elements) or bf16 COPY of the fp32 output (copy16: the residual
+    // stream as the next GEMM's A operand): neighbouring lanes swap one value of each pair, so that a lane stores two
+    // consecutive columns of ONE row as 4 bytes.
+    unsigned short* o16 = g.out16 ? reinterpret_cast<unsigned short*>(g.out) : g.copy16;
+    const int ld16 = g.out16 ? g.ldc : g.N, oc16 = g.out16 ? g.o_col : 0;
+    const bool odd = li & 1;
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wr * 32 * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (cok && m < g.M) {
-          float v = acc[a][b][r] + bias;
-          if (g.act == 1) v = gelu16(v);
-          if (g.res) v += g.res[(int64_t)m * g.ldr + col];
-          g.out[(int64_t)m * g.ldc + g.o_col + col] = v;
+      for (int r = 0; r < 16; r += 2) {
+        const int mb = m0 + wr * 32 * TM + a * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+        const bool ok0 = cok && mb < g.M, ok1 = cok && mb + 1 < g.M;
+        float v0 = acc[a][b][r] + bias, v1 = acc[a][b][r + 1] + bias;
+        if (g.act == 1) { v0 = gelu16(v0); v1 = gelu16(v1); }
+        if (g.res) {
+          if (ok0) v0 += g.res[(int64_t)mb * g.ldr + col];
+          if (ok1) v1 += g.res[(int64_t)(mb + 1) * g.ldr + col];
+        }
+        if (!g.out16) {
+          if (ok0) g.out[(int64_t)mb * g.ldc + g.o_col + col] = v0;
+          if (ok1) g.out[(int64_t)(mb + 1) * g.ldc + g.o_col + col] = v1;
+        }
+        if (o16) {
+          const float recv = __shfl_xor(odd ? v0 : v1, 1, 64);
+          const float lo = odd ? recv : v0, hi = odd ? v1 : recv;
+          const int m = mb + (odd ? 1 : 0);
+          if (cok && m < g.M) {
+            const unsigned pk = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)lo) |
+                                ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)hi) << 16);
+            *reinterpret_cast<unsigned*>(o16 + (int64_t)m * ld16 + oc16 + (col & ~1)) = pk;
+          }
         }
       }
   }

@@ -70,7 +70,8 @@ static const char* validate(const mdt_op& o, int idx, char* buf, size_t nbuf) {
       if (i[MDT_G_M_MODE] < 0 || i[MDT_G_M_MODE] > 2) return bad("bad m_mode");
       if (o.res.space && i[MDT_G_LDR] <= 0) return bad("residual without ldr");
       if (o.a2.space && i[MDT_G_CIN] % 32) return bad("split-bf16 weights need cin % 32 == 0");
-      if (i[MDT_G_WFMT] < 0 || (i[MDT_G_WFMT] > 2 && i[MDT_G_WFMT] != 6)) return bad("bad weight format");
+      if (i[MDT_G_WFMT] < 0 || (i[MDT_G_WFMT] > 2 && i[MDT_G_WFMT] != 6 && i[MDT_G_WFMT] != 10)) return bad("bad weight format");
+      if (i[MDT_G_WFMT] == 10 && (!o.p0.space || i[MDT_G_O_COL] || i[MDT_G_N] % 2)) return bad("bf16 copy needs its tensor (p0) and whole rows");
       if (i[MDT_G_WFMT] & 2) {
         if (!mdt::gemm_b16_supported(i[MDT_G_CIN], i[MDT_G_TAPS], i[MDT_G_LDA], i[MDT_G_A_COL]) || o.a2.space)
           return bad("bf16 x bf16 GEMM needs cin % 64 == 0 and 16-byte aligned bf16 rows");
@@ -116,6 +117,7 @@ static const char* validate(const mdt_op& o, int idx, char* buf, size_t nbuf) {
     case MDT_OP_ATTN:
       if (o.i[MDT_A_T] <= 0 || o.i[MDT_A_T] > 64 || o.i[MDT_A_TK] <= 0 || o.i[MDT_A_TK] > 64)
         return bad("attention supports 1..64 queries and keys per sample");
+      if (o.i[MDT_A_QCOL] < 0 || o.i[MDT_A_KCOL] < 0 || o.i[MDT_A_QCOL] % 4 || o.i[MDT_A_KCOL] % 4) return bad("bad q / k column offset");
       if (!o.a.space || !o.a2.space || !o.out.space) return bad("missing operand");
       break;
     case MDT_OP_ATTN_CTX:
@@ -262,6 +264,7 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
           h.bias = g.bias; h.res = g.res; h.out = g.out; h.M = g.M; h.N = g.N; h.cin = g.cin; h.taps = g.taps; h.rows = g.r_in;
           h.lda = g.lda; h.a_col = g.a_col; h.t_dj = g.t_dj; h.t_off = g.t_off; h.ldc = g.ldc; h.ldr = g.ldr; h.o_col = g.o_col;
           h.act = g.act; h.out16 = (i[MDT_G_WFMT] & 4) ? 1 : 0;
+          h.copy16 = (i[MDT_G_WFMT] & 8) ? reinterpret_cast<unsigned short*>(ptr(o.p0)) : nullptr;
           e = mdt::launch_gemm_b16(h, stream);
         } else if (!missing) {
           static const bool no_as = getenv("MDT_NO_AS") != nullptr;   // tuning aid: disable the A-stationary kernel
@@ -319,6 +322,8 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
       case MDT_OP_ATTN: {
         mdt::AttnArgs a;
         a.q = ptr(o.a); a.k = ptr(o.a2); a.out = ptr(o.out); a.batch = B; a.T = o.i[MDT_A_T]; a.Tk = o.i[MDT_A_TK];
+        if (a.q) a.q += o.i[MDT_A_QCOL];
+        if (a.k) a.k += o.i[MDT_A_KCOL];
         a.heads = o.i[MDT_A_HEADS]; a.ldq = o.i[MDT_A_LDQ]; a.ldkv = o.i[MDT_A_LDKV]; a.ldo = o.i[MDT_A_LDO];
         a.kv_bstride = o.i[MDT_A_KV_BSTRIDE]; a.scale = o.f[MDT_AF_SCALE]; a.out16 = o.i[MDT_A_OUT16];
         if (!missing) e = mdt::launch_attn(a, stream);

@@ -59,6 +59,7 @@ struct Gemm16Args {
   int lda, a_col;             // bf16 elements
   int t_dj, t_off, ldc, ldr, o_col, act;
   int out16;                  // 1: out is bf16 (ldc / o_col in bf16 elements)
+  unsigned short* copy16;     // fp32 output: also a bf16 copy [M][N] of it (the next GEMM's A operand), or nullptr
 };
 bool gemm_b16_supported(int cin, int taps, int lda, int a_col);
 hipError_t launch_gemm_b16(const Gemm16Args& g, hipStream_t s);

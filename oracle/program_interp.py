@@ -76,7 +76,7 @@ def run_program(ops, bufs: Buffers, B: int, n_shared_rows: int = 0) -> None:
                 dst[:] = a.contiguous().to(torch.bfloat16).view(-1).view(torch.float32)
                 continue
             nph = max(int(i[rt.G_PHASES]), 1)         # > 1: ConvTranspose1d phases sharing one op (include/mdt_hip.h)
-            if i[rt.G_WFMT] in (1, 2, 6):              # plain bf16 products: one weight plane, A rounded to bf16 after the prologue
+            if i[rt.G_WFMT] in (1, 2, 6, 10):              # plain bf16 products: one weight plane, A rounded to bf16 after the prologue
                 half = nph * n * taps * cin // 2
                 w_all = bufs.view(op.w, B, half).view(torch.bfloat16).float().view(nph, n, taps, cin)
                 a = a.to(torch.bfloat16).float()
@@ -115,6 +115,8 @@ def run_program(ops, bufs: Buffers, B: int, n_shared_rows: int = 0) -> None:
                     bufs.view(op.out, B, batches * o_rows * ldc // 2)[:] = acc.contiguous().to(torch.bfloat16).view(-1).view(torch.float32)
                     continue
                 out[:, orow, i[rt.G_O_COL]: i[rt.G_O_COL] + n] = acc
+                if i[rt.G_WFMT] == 10:         # ... and a bf16 copy of the fp32 output (the next GEMM's A operand)
+                    bufs.view(op.p0, B, batches * o_rows * n // 2)[:] = acc.contiguous().to(torch.bfloat16).view(-1).view(torch.float32)
         elif op.kind == rt.OP_GN_STATS:
             rows, ld, G, gs = i[rt.N_ROWS], i[rt.N_LD], i[rt.N_GROUPS], i[rt.N_GSIZE]
             x = bufs.view(op.a, B, B * rows * ld).view(B, rows, ld)[:, :, : G * gs].reshape(B, rows, G, gs)
@@ -144,14 +146,15 @@ def run_program(ops, bufs: Buffers, B: int, n_shared_rows: int = 0) -> None:
             T, Tk, H = i[rt.A_T], i[rt.A_TK], i[rt.A_HEADS]
             ldq, ldkv, ldo, bs = i[rt.A_LDQ], i[rt.A_LDKV], i[rt.A_LDO], i[rt.A_KV_BSTRIDE]
             D = 64
-            q = bufs.view(op.a, B, B * T * ldq).view(B, T, ldq)[:, :, : H * D].reshape(B, T, H, D).transpose(1, 2)
+            qc, kc = i[rt.A_QCOL], i[rt.A_KCOL]
+            q = bufs.view(op.a, B, B * T * ldq).view(B, T, ldq)[:, :, qc: qc + H * D].reshape(B, T, H, D).transpose(1, 2)
             if bs == 0:
                 kv = bufs.view(op.a2, B, Tk * ldkv).view(1, Tk, ldkv).expand(B, -1, -1)
             else:
                 assert bs == Tk
                 kv = bufs.view(op.a2, B, B * Tk * ldkv).view(B, Tk, ldkv)
-            k = kv[:, :, : H * D].reshape(B, Tk, H, D).transpose(1, 2)
-            v = kv[:, :, H * D: 2 * H * D].reshape(B, Tk, H, D).transpose(1, 2)
+            k = kv[:, :, kc: kc + H * D].reshape(B, Tk, H, D).transpose(1, 2)
+            v = kv[:, :, kc + H * D: kc + 2 * H * D].reshape(B, Tk, H, D).transpose(1, 2)
             sim = (q @ k.transpose(-1, -2)) * float(f[0])
             o = (sim.softmax(-1) @ v).transpose(1, 2).reshape(B, T, H * D)
             if i[rt.A_OUT16]:
