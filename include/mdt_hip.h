@@ -113,6 +113,9 @@ enum mdt_prologue {
 };
 
 /* integer / float parameter slots of mdt_op, per kind */
+/* common to the ring kernels' ops (MDT_OP_TBLOCK / RCONV / TF128 / TF256): size of the op's weight stream (w) in KB, 0 = unknown.
+   The launch BEFORE such an op pulls that stream into the L2s while it finishes (its loader waves are idle by then). */
+enum { MDT_W_KB = 23 };
 enum mdt_gemm_i {
   MDT_G_R_OUT = 0,   /* M rows per sample of this GEMM                                           */
   MDT_G_R_IN = 1,    /* rows per sample of the A tensor                                           */

@@ -430,6 +430,7 @@ class UNetCompiler:
         op.kind = rt.OP_RCONV
         op.a, op.out = x.ref(), out.ref()
         op.w = _ref(rt.SP_WEIGHT, self.W.add(name + "/rconv.tiles", torch.cat(tiles)))
+        op.i[rt.W_KB] = sum(t.numel() for t in tiles) * 4 // 1024
         if bias_off is not None:
             op.bias = _ref(rt.SP_WEIGHT, bias_off)
         if res is not None:
@@ -733,6 +734,7 @@ class UNetCompiler:
         op.kind = rt.OP_TBLOCK
         op.a = t.ref()
         op.w = _ref(rt.SP_WEIGHT, self.W.add(p + "tblock.tiles", torch.cat(tiles)))
+        op.i[rt.W_KB] = sum(t.numel() for t in tiles) * 4 // 1024
         op.bias = _ref(rt.SP_WEIGHT, self.W.add(p + "tblock.bias", bias))
         i = op.i
         i[rt.B_MODE], i[rt.B_C], i[rt.B_T], i[rt.B_NCHUNK], i[rt.B_NBIAS] = mode, c, rows, nchunk, bias.numel()
@@ -938,6 +940,7 @@ class UNetCompiler:
                 assert res_skips[k].off == res_skips[0].off + k * step and res_skips[k].space == rt.SP_ACT
         op.a, op.out = x.ref(), y.ref()
         op.w = _ref(rt.SP_WEIGHT, self.W.add(p + "tf128.tiles", torch.cat(tiles)))
+        op.i[rt.W_KB] = min(sum(t.numel() for t in tiles) * 4 // 1024, 4096)   # (at most an L2's worth: the head of the stream)
         op.bias = _ref(rt.SP_WEIGHT, self.W.add(p + "tf128.vec", v))
         op.p0 = _ref(rt.SP_WEIGHT, self.W.add(p + "tf128.desc", torch.tensor(desc, dtype=torch.int32).view(torch.float32)))
         i = op.i
@@ -1061,6 +1064,7 @@ class UNetCompiler:
         op.a, op.out = x.ref(), y.ref()
         v = torch.cat(vecs)
         op.w = _ref(rt.SP_WEIGHT, self.W.add(p + "tf256.tiles", torch.cat(tiles)))
+        op.i[rt.W_KB] = min(sum(t.numel() for t in tiles) * 4 // 1024, 4096)
         op.bias = _ref(rt.SP_WEIGHT, self.W.add(p + "tf256.vec", v))
         op.p0 = _ref(rt.SP_WEIGHT, self.W.add(p + "tf256.desc", torch.tensor(desc, dtype=torch.int32).view(torch.float32)))
         i = op.i

@@ -167,6 +167,7 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
       if (k + 2 < TT) issue_tile(k + 2);
       if (RTW == 2 && k == NT && nsrc == 2) __builtin_amdgcn_s_barrier();   // X of the second source (follows B(NT))
     }
+    prefetch_next_weights(a.pf_ptr, a.pf_lines, iw * 64 + lane);
     return;
   }
 

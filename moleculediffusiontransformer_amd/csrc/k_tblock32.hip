@@ -234,6 +234,7 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
       __builtin_amdgcn_s_barrier();                                      // B(k)
       if (k + 2 < NT) issue_tile(k + 2);
     }
+    prefetch_next_weights(a.pf_ptr, a.pf_lines, iw * 64 + lane);
     return;
   }
 

@@ -253,6 +253,7 @@ __global__ __launch_bounds__(512) void k_tf128(TFArgs a) {
       if (k + 2 < NT) issue_tile(k + 2, d2);
       dn = d2;
     }
+    prefetch_next_weights(a.pf_ptr, a.pf_lines, iw * 64 + lane);
     return;
   }
 

@@ -241,9 +241,22 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
     }
   };
 
+  static const bool no_prefetch = getenv("MDT_NO_PREFETCH") != nullptr;     // tuning aid: no next-launch weight prefetch
   for (int idx = first; idx < last; ++idx) {
     const mdt_op& o = p->ops[idx];
     hipError_t e = hipSuccess;
+    // the weight stream of the NEXT op, if it is a ring kernel's (MDT_W_KB: its size, set by the host compiler): the loader
+    // waves of this launch pull it into the L2s when they are done (mdt_kernels.h: prefetch_next_weights)
+    const void* pf_ptr = nullptr;
+    int pf_lines = 0;
+    if (!no_prefetch && idx + 1 < last) {
+      const mdt_op& nx = p->ops[idx + 1];
+      if ((nx.kind == MDT_OP_TBLOCK || nx.kind == MDT_OP_RCONV || nx.kind == MDT_OP_TF128 || nx.kind == MDT_OP_TF256) &&
+          nx.i[MDT_W_KB] > 0 && nx.w.space == MDT_SP_WEIGHT && bd->weights) {
+        pf_ptr = bd->weights + nx.w.off;
+        pf_lines = nx.i[MDT_W_KB] * 8;
+      }
+    }
     switch (o.kind) {
       case MDT_OP_GEMM: {
         const int32_t* i = o.i;
@@ -308,6 +321,7 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
         a.ldr = o.i[MDT_R_LDR]; a.taps = o.i[MDT_R_TAPS]; a.gsize = o.i[MDT_R_GSIZE]; a.silu = o.i[MDT_R_SILU];
         a.film_ld = o.i[MDT_R_FILM_LD]; a.eps = o.f[MDT_RF_EPS]; a.in_scale = o.f[MDT_RF_IN_SCALE];
         a.lda2 = o.i[MDT_R_LDA2]; a.in_scale2 = o.f[MDT_RF_IN_SCALE2];
+        a.pf_ptr = pf_ptr; a.pf_lines = pf_lines;
         if (!missing) e = mdt::launch_rconv(a, stream);
         break;
       }
@@ -359,6 +373,7 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
         a.kv_bstride = o.i[MDT_B_KV_BSTRIDE]; a.ldkv = o.i[MDT_B_LDKV]; a.nheads = o.i[MDT_B_HEADS]; a.nsamples = B;
         a.eps = o.f[MDT_BF_EPS]; a.scale = o.f[MDT_BF_SCALE];
         a.part = nullptr; a.nsplit = 1; a.xout = nullptr; a.pin = nullptr; a.pout = nullptr;
+        a.pf_ptr = pf_ptr; a.pf_lines = pf_lines;
         a.kv2 = o.i[MDT_B_KV2] ? ptr(o.p1) : nullptr;
         if (o.i[MDT_B_KV2]) {
           // the kernels pick conditional vs shared K/V per WORKGROUP (64 rows at C = 128, 32 rows in the C = 256 kernels):
@@ -403,6 +418,7 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
         // skip tensors of consecutive blocks: whole tensors apart (ascending where they are produced, descending where consumed)
         a.skip_stride = (int64_t)B * a.T * i[MDT_F_C] * (a.res_kind == 2 ? -1 : 1);
         a.skip_scale = o.f[MDT_FF_SKIP_SCALE]; a.eps_res = o.f[MDT_FF_EPS_RES];
+        a.pf_ptr = pf_ptr; a.pf_lines = pf_lines;
         if (i[MDT_F_KV2]) {
           const int per_wg = (wide ? 32 : 64) / a.T;
           if (!o.p1.space || B % 2 || (B / 2) % (per_wg > 0 ? per_wg : 1))
