@@ -59,11 +59,13 @@ __global__ __launch_bounds__(NT) void k_gn_stats(GnStatsArgs g) {
 // once, and the convolution becomes a plain GEMM on the activated tensor (zero padding is then exact).
 // One workgroup per sample; group g is owned by 256/G consecutive threads, which hold the group's
 // elements in registers (two-pass variance, shuffle reduction in a fixed order: deterministic).
-template <int NF4>
-__global__ __launch_bounds__(256) void k_gn_act(GnActArgs a) {
-  __shared__ float red[8];
+// TB threads per workgroup: 256, or 1024 for the large samples of the deep U-Net (16 K - 32 K elements: a quarter of the
+// registers per thread, four times the loads in flight per sample)
+template <int NF4, int TB = 256>
+__global__ __launch_bounds__(TB) void k_gn_act(GnActArgs a) {
+  __shared__ float red[TB / 64];
   const int b = blockIdx.x, tid = threadIdx.x;
-  const int tpg = 256 / a.groups;                  // threads per group (power of two)
+  const int tpg = TB / a.groups;                   // threads per group (power of two)
   const int grp = tid / tpg, u = tid % tpg;
   const int q4 = a.gsize / 4;                      // float4 per row of the group's channel span
   const int nf4 = a.rows * q4;                     // float4 per group
@@ -86,12 +88,21 @@ __global__ __launch_bounds__(256) void k_gn_act(GnActArgs a) {
       for (int off = tpg >> 1; off >= 1; off >>= 1) val += __shfl_xor(val, off, 64);
       return val;
     }
-    // one group = the whole workgroup (G = 1): wave shuffle + 4 partials through LDS
+    // a group spans several waves (G = 1 at 256 threads; G <= 8 at 1024): wave shuffle + the waves' partials through LDS,
+    // summed in a fixed order
     for (int off = 32; off >= 1; off >>= 1) val += __shfl_xor(val, off, 64);
     __syncthreads();
     if ((tid & 63) == 0) red[tid >> 6] = val;
     __syncthreads();
-    return (red[0] + red[1]) + (red[2] + red[3]);
+    const int nw = tpg / 64, w0 = (tid >> 6) / nw * nw;      // pairwise, in a fixed order: (r0 + r1) + (r2 + r3) ...
+    float v[TB / 64];
+#pragma unroll
+    for (int k = 0; k < TB / 64; ++k) v[k] = k < nw ? red[w0 + k] : 0.f;
+#pragma unroll
+    for (int st = 1; st < TB / 64; st *= 2)
+#pragma unroll
+      for (int k = 0; k + st < TB / 64; k += 2 * st) v[k] += v[k + st];
+    return v[0];
   };
   const float n = (float)(a.rows * a.gsize);
   const float mean = group_sum(s) / n;
@@ -158,6 +169,8 @@ hipError_t launch_gn_act(const GnActArgs& a, hipStream_t s) {
   else if (per <= 2) hipLaunchKernelGGL((k_gn_act<2>), dim3(a.batch), dim3(256), 0, s, a);
   else if (per <= 4) hipLaunchKernelGGL((k_gn_act<4>), dim3(a.batch), dim3(256), 0, s, a);
   else if (per <= 8) hipLaunchKernelGGL((k_gn_act<8>), dim3(a.batch), dim3(256), 0, s, a);
+  else if (1024 % a.groups == 0 && per <= 16) hipLaunchKernelGGL((k_gn_act<4, 1024>), dim3(a.batch), dim3(1024), 0, s, a);
+  else if (1024 % a.groups == 0) hipLaunchKernelGGL((k_gn_act<8, 1024>), dim3(a.batch), dim3(1024), 0, s, a);
   else if (per <= 16) hipLaunchKernelGGL((k_gn_act<16>), dim3(a.batch), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((k_gn_act<32>), dim3(a.batch), dim3(256), 0, s, a);
   return hipGetLastError();

@@ -538,7 +538,11 @@ def test_fused_transformer_sub_block(mode, C, T, B, variant):
 
 @pytest.mark.parametrize("B,R,C,G,film,silu,eps", [(5, 64, 64, 1, False, True, 1e-5), (3, 16, 128, 8, True, True, 1e-5),
                                                     (4, 4, 512, 8, True, True, 1e-5), (6, 16, 128, 32, False, False, 1e-6),
-                                                    (2, 4, 256, 32, False, False, 1e-6), (3, 64, 16, 1, False, True, 1e-5)])
+                                                    (2, 4, 256, 32, False, False, 1e-6), (3, 64, 16, 1, False, True, 1e-5),
+                                                    # deep-UNet samples (16 K - 32 K elements): the 1024-thread form
+                                                    (3, 32, 512, 8, True, True, 1e-5), (2, 32, 1024, 8, False, True, 1e-5),
+                                                    (2, 128, 256, 8, True, True, 1e-5), (3, 32, 512, 32, False, False, 1e-6),
+                                                    (2, 8, 2048, 8, False, True, 1e-5)])
 def test_gn_act(B, R, C, G, film, silu, eps):
     """k_gn_act (statistics + normalise + FiLM + SiLU in one pass) against torch's GroupNorm."""
     weights = torch.cat([1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)])
