@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Per-op HIP-event timing of one U-Net evaluation (GPU box).  Writes gpurun_out/op_profile_<case>_b<B>.txt."""
+"""Per-op HIP-event timing of one U-Net evaluation (GPU box): python tools/op_profile.py <case> <B> [gemm_mode].
+Writes gpurun_out/op_profile_<case>_b<B>.txt."""
 import os
 import sys
 
@@ -16,8 +17,10 @@ def main():
     case = sys.argv[1] if len(sys.argv) > 1 else "cfg1"
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
     m = make_model(case)
+    if len(sys.argv) > 3:
+        m.gemm_mode = sys.argv[3]            # bf16x3 (default) | f32 | bf16
     n_ctx = m.unet.config.ctx_max_length
-    eng = m.engine("cuda:0", n_ctx)
+    eng = m.engine("cuda:0", n_ctx, B)
     eng.reserve(B)
     emb = m._embed(synth_normal("prof/seq", (B, n_ctx)), "cuda:0")
     eng.prepare_context(emb)
