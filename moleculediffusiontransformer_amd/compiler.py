@@ -1166,12 +1166,14 @@ class UNetCompiler:
         self._free(r)
         self.has_chat = True
 
-    def transformer(self, x: Ten, p: str, c: int, layers: int, cross: bool, free_input: bool = True) -> Ten:
-        """Transformer1d.forward (modules.py:519-524)."""
+    def transformer(self, x: Ten, p: str, c: int, layers: int, cross: bool, free_input: bool = True,
+                    y_out: Optional[Ten] = None) -> Ten:
+        """Transformer1d.forward (modules.py:519-524).  y_out: where the result should be written (a tensor allocated by the
+        caller, e.g. next to the level's other skip tensors); the lowerings that cannot place their output return their own."""
         cfg = self.cfg
         assert x.ld == c and c % 32 == 0
         if self.tf128_ok(c, x.rows, layers, cross):
-            return self.transformer_fused128(x, p, c, layers, cross, free_input)
+            return self.transformer_fused128(x, p, c, layers, cross, free_input, y=y_out)
         if self.tf256_ok(c, x.rows, layers, cross):
             return self.transformer_fused256(x, p, c, layers, cross, free_input)
         t = self._new(x.rows, c)
@@ -1218,7 +1220,8 @@ class UNetCompiler:
                 # block, whose output leaves the chain (and may carry the folded closing convolution)
                 steps.append((rt.TB_FF, bp + "feed_forward.", None, self.ff_split and i + 1 < layers))
                 for mode, name, ci, two in steps:
-                    nxt = self._new(t.rows, c)
+                    last_ff = mode == rt.TB_FF and i == layers - 1 and self.fold_out
+                    nxt = y_out if (last_ff and y_out is not None) else self._new(t.rows, c)
                     po = self._new(t.rows, c) if two else None
                     if mode == rt.TB_FF and i == layers - 1 and self.fold_out:
                         # the transformer's closing 1x1 convolution rides on the last feed-forward block (below)
@@ -1249,7 +1252,7 @@ class UNetCompiler:
                         self.attention_layer(t, bp + "cross_attention.", len(self.cross_layers) - 1)
                 ffv = split if self.ff_split else variant
                 if i == layers - 1 and self.fold_out and ffv in (0, 2):
-                    y_fold = self._new(t.rows, c)
+                    y_fold = y_out if y_out is not None else self._new(t.rows, c)
                     self.tblock(t, rt.TB_FF, bp + "feed_forward.", variant=ffv,
                                 post=(self.sd[p + "to_out.1.weight"], self.sd[p + "to_out.1.bias"], y_fold))
                 else:
@@ -1278,7 +1281,7 @@ class UNetCompiler:
             if y_fold is not t:
                 self._free(t)
             return y_fold
-        y = self._new(t.rows, c)
+        y = y_out if y_out is not None else self._new(t.rows, c)
         if self.rconv_ok(t.rows, c, 1, 0):
             self.rconv(t, self.sd[p + "to_out.1.weight"], p + "to_out.1.weight", y, taps=1,
                        bias_off=self._vec(p + "to_out.1.bias", c))
@@ -1346,8 +1349,7 @@ class UNetCompiler:
             blocks = [dp + f"blocks.{j}." for j in range(nb)]
             res_ok = nb > 0 and all(self.res128_ok(bp, co, x.rows, g, False) for bp in blocks)
             together = res_ok and self.tf128_ok(co, x.rows, nat, nat > 0, 1, nb)
-            alone = res_ok and not together and self.tf128_ok(co, x.rows, 0, False, 1, nb) \
-                and (nat == 0 or self.tf128_ok(co, x.rows, nat, True))
+            alone = res_ok and not together and self.tf128_ok(co, x.rows, 0, False, 1, nb)
             if together or alone:
                 # the level's ResNet blocks in ONE launch, with the transformer that follows them when its vectors fit the LDS
                 # behind the ring as well; the outputs (all of them skips of the up path) are whole tensors apart in one
@@ -1362,7 +1364,10 @@ class UNetCompiler:
                     self.transformer_fused128(x, "", co, 0, False, free_input=not x_is_skip,
                                               res=(1, blocks, g, outs[:nb], 1.0), y=outs[nb - 1])
                     if nat > 0:
-                        self.transformer_fused128(outs[nb - 1], dp + "transformer.", co, nat, True, False, y=outs[nb])
+                        yy = self.transformer(outs[nb - 1], dp + "transformer.", co, nat, True, free_input=False, y_out=outs[nb])
+                        if yy is not outs[nb]:       # (a lowering that places its own output: the up path then finds its skips
+                            self._free(outs[nb])     # apart and runs its blocks as separate launches)
+                            outs[nb] = yy
                 skips += outs
                 x = outs[-1]
             else:
@@ -1394,16 +1399,20 @@ class UNetCompiler:
                 tfs.append((up + "transformer.", cfg.attentions[i], True))
             cons = skips[len(skips) - n_res:][::-1] if 0 < n_res <= len(skips) else []       # in order of consumption
             nxt = tfs[0] if tfs else ("", 0, False)
-            fused = (bool(cons) and x.ld == ci and all(self.res128_ok(bp, ci, x.rows, g, True) for bp in blocks)
-                     and all(sk.space == rt.SP_ACT and sk.rows == x.rows and sk.ld == ci
-                             and sk.off == cons[0].off - k * x.rows * ci for k, sk in enumerate(cons))
-                     and self.tf128_ok(ci, x.rows, nxt[1], nxt[2], 2, n_res))
+            res_ok = (bool(cons) and x.ld == ci and all(self.res128_ok(bp, ci, x.rows, g, True) for bp in blocks)
+                      and all(sk.space == rt.SP_ACT and sk.rows == x.rows and sk.ld == ci
+                              and sk.off == cons[0].off - k * x.rows * ci for k, sk in enumerate(cons)))
+            together = res_ok and nxt[1] > 0 and self.tf128_ok(ci, x.rows, nxt[1], nxt[2], 2, n_res)
+            fused = together or (res_ok and self.tf128_ok(ci, x.rows, 0, False, 2, n_res))
             if fused:
                 del skips[len(skips) - n_res:]
-                x = self.transformer_fused128(x, nxt[0], ci, nxt[1], nxt[2], True, res=(2, blocks, g, cons, 2 ** -0.5))
+                if together:
+                    x = self.transformer_fused128(x, nxt[0], ci, nxt[1], nxt[2], True, res=(2, blocks, g, cons, 2 ** -0.5))
+                    tfs = tfs[1:]
+                else:                     # the blocks alone (the transformer behind them is not a k_tf128 launch)
+                    x = self.transformer_fused128(x, "", ci, 0, False, True, res=(2, blocks, g, cons, 2 ** -0.5))
                 for sk in cons:
                     self._free(sk)
-                tfs = tfs[1:]
             else:
                 for bp in blocks:
                     sk = skips.pop()
