@@ -84,7 +84,10 @@ enum mdt_op_kind {
                           (projection tiles with their K columns permuted to the accumulator layout, see k_tf128.hip),
                           bias = every sub-block's vectors, p0 = tile descriptors (uint32 per tile: kind | aux << 2),
                           a2 = hoisted K|V rows of the FIRST cross-attention layer (layer l at + l * KV_LSTRIDE per-sample
-                          floats), p1 = batch-invariant K|V rows for the second half of a dual batch; ints: enum mdt_tf128_i */
+                          floats), p1 = batch-invariant K|V rows for the second half of a dual batch; ints: enum mdt_tf128_i.
+                          Optionally (MDT_F_RES_KIND) the level's ResnetBlock1d blocks (modules.py:145-205) run IN FRONT of the
+                          transformer in the same launch (or alone, NBLOCKS = 0): res = the blocks' skip tensors (stored by kind 1,
+                          read by kind 2), p3 = their FiLM rows                                                            */
   MDT_OP_TF256 = 12,   /* the same for a 256-channel level (32-row workgroups whose wave pairs split every chunk's features; the pair's
                           partial sums meet in scratch tiles of the ring).  Stream differences: 32 KB SUB-tiles (a [64][256]
                           projection tile = its two K halves, a [256][64] output tile = its two row halves), descriptors
