@@ -332,10 +332,10 @@ def main():
                          "algorithmic_tflops_fp32_equiv": round(alg, 2), "launches_per_eval": n_dom,
                          "avg_launch_us": round(1e3 * ms_dom / n_dom, 2), "flops_per_launch_avg": fl_dom / n_dom})
             if dom == "k_tblock":
-                # the contract's roofline is the MFMA fraction; what actually binds this kernel class is the CU's LDS pipe
-                # (every compute wave reads every weight fragment: 160 / 96 KB of LDS traffic per 32 KB tile)
-                roof["binding_resource"] = "LDS bandwidth of the CU (128 B/clk): weight tiles written once by LDS-DMA, read once " \
-                                           "per compute wave; k_tf128 at ~77 % of that roof (DESIGN.md section 3.5)"
+                # the contract's roofline is the MFMA fraction; what binds this kernel class is not a memory level
+                roof["binding_resource"] = "instruction issue of one wave per SIMD: MFMAs, the fragment ds_reads between them and the " \
+                                           "serial attention / softmax / GELU sections share one stream (bare streaming pipeline: 67 % " \
+                                           "MFMA-busy; LDS array ~26 % busy, L2 stream at half its measured rate)"
             if a.workload == "cfg1" and B == 1024:     # the committed PMC summary is of exactly this workload
                 roof["traffic"], roof["traffic_source"] = pmc_traffic(dom)
             extra["eval_breakdown_ms"] = {k: {"launches": n, "ms": round(t, 4),

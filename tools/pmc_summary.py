@@ -70,8 +70,8 @@ def main():
                     "GRBM_GUI_ACTIVE summed over the 8 XCDs (per-launch cycles = value / 8)\n")
             f.write("# mfma_util = MFMA_BUSY_CYCLES / (kernel duration of the same pass x 2.4 GHz nominal x 256 CUs x 4 SIMDs); "
                     "fractions are over ALL waves of a workgroup: the ring kernels' 4 loader waves (of 8) are parked by design\n")
-            f.write("# lds_active = SQ_LDS_IDX_ACTIVE / (duration x 2.4 GHz x 256 CUs): share of the time the CUs' LDS pipes are "
-                    "processing an instruction (fragment ds_reads + LDS-DMA writes; the fused kernels' actual roof, DESIGN 3.1)\n")
+            f.write("# lds_active = SQ_LDS_IDX_ACTIVE / (duration x 2.4 GHz x 256 CUs): share of the time the CUs' LDS arrays are "
+                    "busy (fragment ds_reads + LDS-DMA writes; 256 B/clk/CU for ds_read_b128 on gfx950 -- far from a limit, DESIGN 3.5)\n")
             f.write("kernel,dispatches,parked_frac,issue_stall_frac,issuing_frac,mfma_busy_cycles_per_dispatch,"
                     "avg_duration_us,mfma_util,lds_conflict_frac,lds_active\n")
             dur, dn = collections.Counter(), collections.Counter()

@@ -276,7 +276,9 @@ __global__ __launch_bounds__(LOADERS ? 512 : 256) void kpipe(const unsigned char
 // Ring-geometry sweep for the loader-wave pipeline: TILE bytes per tile, NSLOT slots, UPT units (4 reads + 6 MFMAs)
 // consumed per tile per wave, issue distance DIST tiles (tile k+DIST is issued after barrier B(k); needs
 // NSLOT >= DIST + 2).  The tile loop is unrolled by 3 so that the fragment-set rotation is static.
-template <int TILE, int NSLOT, int UPT, int DIST, int NODMA = 0, int RDPAT = 0>
+// STAGE = 1: the loader waves stage through REGISTERS (global_load_dwordx4 -> ds_write_b128, two tiles in flight in two register
+// sets) instead of LDS-DMA: tests whether the DMA's LDS write (vs a full-rate ds_write_b128) is what the LDS pipe pays for.
+template <int TILE, int NSLOT, int UPT, int DIST, int NODMA = 0, int RDPAT = 0, int STAGE = 0>
 __global__ __launch_bounds__(512) void kring(const unsigned char* w, float* out, unsigned long long* cyc,
                                              int ntiles, int wtiles, int unit_gap) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -300,6 +302,39 @@ __global__ __launch_bounds__(512) void kring(const unsigned char* w, float* out,
                                          (__attribute__((address_space(3))) void*)(slot + inst * 1024), 16, 0, 0);
       }
     };
+    if constexpr (STAGE == 1) {
+      static_assert(DIST == 2 && PIECES == 8, "register staging: two tiles of 8 pieces per wave in flight");
+      uint4 r0[PIECES], r1[PIECES];
+      auto load_tile = [&](int tau, uint4 (&r)[PIECES]) {
+        const unsigned char* tile = w + (int64_t)(tau % wtiles) * TILE;
+#pragma unroll
+        for (int q = 0; q < PIECES; ++q) r[q] = *reinterpret_cast<const uint4*>(tile + (iw + 4 * q) * 1024 + lane * 16);
+      };
+      auto write_tile = [&](int tau, const uint4 (&r)[PIECES]) {
+        unsigned char* slot = smem + (tau % NSLOT) * TILE;
+#pragma unroll
+        for (int q = 0; q < PIECES; ++q) *reinterpret_cast<uint4*>(slot + (iw + 4 * q) * 1024 + lane * 16) = r[q];
+      };
+      load_tile(0, r0);
+      load_tile(1, r1);
+      for (int k = 0; k < ntiles; k += 2) {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        write_tile(k, r0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        load_tile(k + 2, r0);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        write_tile(k + 1, r1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        load_tile(k + 3, r1);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 999) out[0] = (float)(r0[0].x + r1[0].x);
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+      if (tid == 0) cyc[blockIdx.x] = t1 - t0;
+      return;
+    }
     if (!NODMA) for (int t = 0; t < DIST; ++t) issue_tile(t);
     for (int k = 0; k < ntiles; ++k) {
       // tile k landed: at most (DIST - 1) newer tiles in flight
@@ -608,6 +643,8 @@ int main(int argc, char** argv) {
     report("D pure DMA  8KBx16, 4 loader waves", kdma<8192, 16, 4>, 512, blocks, 16 * 8192, 2048, 8192, 48);
     // 48 MFMAs per 32 KB per wave (k_tblock_lw: 64-row workgroups, every wave uses the whole tile)
     report("R 32KBx4 dist2, 8 units/tile   (k_tblock_lw now)", kring<32768, 4, 8, 2>, 512, blocks, 4 * 32768, 510, 32768, 48);
+    report("R 32KBx4 dist2, 8 units/tile, REGISTER-staged by the loaders", kring<32768, 4, 8, 2, 0, 0, 1>, 512, blocks, 4 * 32768, 510, 32768, 48);
+    report("R 32KBx4 dist2, 4 units/tile, REGISTER-staged by the loaders", kring<32768, 4, 4, 2, 0, 0, 1>, 512, blocks, 4 * 32768, 510, 32768, 24);
     report("R 32KBx4 dist2, 8 units/tile, NO DMA", kring<32768, 4, 8, 2, 1>, 512, blocks, 4 * 32768, 510, 32768, 48);
     report("R 32KBx4 dist2, 8 units/tile, NO DMA, k_tblock read pattern", kring<32768, 4, 8, 2, 1, 1>, 512, blocks, 4 * 32768, 510, 32768, 48);
     report("R 32KBx4 dist2, 8 units/tile, k_tblock read pattern", kring<32768, 4, 8, 2, 0, 1>, 512, blocks, 4 * 32768, 510, 32768, 48);
