@@ -655,6 +655,9 @@ int main(int argc, char** argv) {
     report("R 16KBx9 dist7, 4 units/tile", kring<16384, 9, 4, 7>, 512, blocks, 9 * 16384, 1020, 16384, 24);
     // 24 MFMAs per 32 KB per wave (k_tblock32: a wave uses half of each tile's features)
     report("R 32KBx4 dist2, 4 units/tile   (k_tblock32 now)", kring<32768, 4, 4, 2>, 512, blocks, 4 * 32768, 510, 32768, 24);
+    // 12 MFMAs per 32 KB per wave: a 16-row workgroup whose four waves take a quarter of every tile's features each
+    report("R 32KBx4 dist2, 2 units/tile   (16-row workgroups)", kring<32768, 4, 2, 2>, 512, blocks, 4 * 32768, 510, 32768, 12);
+    report("R 32KBx4 dist2, 2 units/tile, NO DMA", kring<32768, 4, 2, 2, 1>, 512, blocks, 4 * 32768, 510, 32768, 12);
     report("R 16KBx8 dist6, 2 units/tile", kring<16384, 8, 2, 6>, 512, blocks, 8 * 16384, 1020, 16384, 12);
     report("R 16KBx9 dist7, 2 units/tile", kring<16384, 9, 2, 7>, 512, blocks, 9 * 16384, 1020, 16384, 12);
     report("R  8KBx18 dist15, 1 unit/tile", kring<8192, 18, 1, 15>, 512, blocks, 18 * 8192, 2040, 8192, 6);
