@@ -939,10 +939,11 @@ class UNetCompiler:
                 step = rows * c if res_kind == 1 else -rows * c
                 assert res_skips[k].off == res_skips[0].off + k * step and res_skips[k].space == rt.SP_ACT
         op.a, op.out = x.ref(), y.ref()
-        op.w = _ref(rt.SP_WEIGHT, self.W.add(p + "tf128.tiles", torch.cat(tiles)))
+        wp = p or res_blocks[0]                    # (a launch of ResNet blocks alone is named after its first block)
+        op.w = _ref(rt.SP_WEIGHT, self.W.add(wp + "tf128.tiles", torch.cat(tiles)))
         op.i[rt.W_KB] = min(sum(t.numel() for t in tiles) * 4 // 1024, 4096)   # (at most an L2's worth: the head of the stream)
-        op.bias = _ref(rt.SP_WEIGHT, self.W.add(p + "tf128.vec", v))
-        op.p0 = _ref(rt.SP_WEIGHT, self.W.add(p + "tf128.desc", torch.tensor(desc, dtype=torch.int32).view(torch.float32)))
+        op.bias = _ref(rt.SP_WEIGHT, self.W.add(wp + "tf128.vec", v))
+        op.p0 = _ref(rt.SP_WEIGHT, self.W.add(wp + "tf128.desc", torch.tensor(desc, dtype=torch.int32).view(torch.float32)))
         i = op.i
         i[rt.F_C], i[rt.F_T], i[rt.F_NT], i[rt.F_NVEC] = c, rows, len(desc), nvec
         i[rt.F_TK], i[rt.F_KV_BSTRIDE], i[rt.F_LDKV], i[rt.F_HEADS] = self.n_ctx, self.n_ctx, 2 * mid, heads
