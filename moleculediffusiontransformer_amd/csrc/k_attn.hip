@@ -164,32 +164,39 @@ hipError_t launch_attn(const AttnArgs& a, hipStream_t s) {
 //                  row 16 kt + 4 g + s at floats [64 half + 4 lo, +4), a full 256 B row segment per lane quarter, and
 //                  lane (query, g) ends with out[query][64 half + 16 g + 4 r .. +4) per r = one dwordx4 store.
 // ------------------------------------------------------------------------------------------------------------------
-template <int KT>
+// RT row tiles of ONE sample per wave: the context rows (both operand layouts) are loaded once per wave, so with RT = 2 a
+// sample with 17..32 (token, head) rows reads its 2 x 32 KB of context once instead of twice -- the launch is bound by that
+// L2 -> CU traffic (4096 samples x 2 tiles x 72 KB = 590 MB per launch), not by its MFMAs.
+template <int KT, int RT>
 __global__ __launch_bounds__(256) void k_attn_ctx(AttnArgs a) {
   constexpr int D = 128;
   const int R = a.T * a.heads;                         // rows per sample
-  const int QT = (R + 15) >> 4;
+  const int QG = ((R + 15) / 16 + RT - 1) / RT;        // waves per sample
   const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (wid >= a.batch * QT) return;
-  const int b = wid / QT, qt = wid % QT;
+  if (wid >= a.batch * QG) return;
+  const int b = wid / QG, qg = wid % QG;
   const int lane = threadIdx.x & 63;
   const int lo = lane & 15, g = lane >> 4;
   const float* q = a.q + (int64_t)b * R * D;           // rows (token, head) are contiguous 128-float vectors
   const float* c = a.k + (int64_t)b * a.kv_bstride * a.ldkv;
   float* o = a.out + (int64_t)b * R * D;
 
-  const int i = qt * 16 + lo;
-  float qr[32];
-  {
-    const float4* p = reinterpret_cast<const float4*>(q + (int64_t)(i < R ? i : 0) * D + 4 * g);
+  int i[RT];
+  float qr[RT][32];
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+    i[t] = (qg * RT + t) * 16 + lo;
+    const float4* p = reinterpret_cast<const float4*>(q + (int64_t)(i[t] < R ? i[t] : 0) * D + 4 * g);
 #pragma unroll
     for (int cc = 0; cc < 8; ++cc) {
-      const float4 t = p[4 * cc];
-      qr[4 * cc] = t.x; qr[4 * cc + 1] = t.y; qr[4 * cc + 2] = t.z; qr[4 * cc + 3] = t.w;
+      const float4 v = p[4 * cc];
+      qr[t][4 * cc] = v.x; qr[t][4 * cc + 1] = v.y; qr[t][4 * cc + 2] = v.z; qr[t][4 * cc + 3] = v.w;
     }
   }
-  f32x4 st[KT];
-  float mx = -INFINITY;
+  f32x4 st[RT][KT];
+  float mx[RT];
+#pragma unroll
+  for (int t = 0; t < RT; ++t) mx[t] = -INFINITY;
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) {
     const int j = kt * 16 + lo;                        // A operand of S^T: key row j
@@ -197,81 +204,99 @@ __global__ __launch_bounds__(256) void k_attn_ctx(AttnArgs a) {
     float kr[32];
 #pragma unroll
     for (int cc = 0; cc < 8; ++cc) {
-      const float4 t = p[4 * cc];
-      kr[4 * cc] = t.x; kr[4 * cc + 1] = t.y; kr[4 * cc + 2] = t.z; kr[4 * cc + 3] = t.w;
-    }
-    f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0;
-#pragma unroll
-    for (int s = 0; s < 32; s += 2) {
-      s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[s], qr[s], s0, 0, 0, 0);
-      s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[s + 1], qr[s + 1], s1, 0, 0, 0);
+      const float4 v = p[4 * cc];
+      kr[4 * cc] = v.x; kr[4 * cc + 1] = v.y; kr[4 * cc + 2] = v.z; kr[4 * cc + 3] = v.w;
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int jj = kt * 16 + 4 * g + r;
-      const float sv = jj < a.Tk ? (s0[r] + s1[r]) * a.scale : -INFINITY;
-      st[kt][r] = sv;
-      mx = fmaxf(mx, sv);
+    for (int t = 0; t < RT; ++t) {
+      f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0;
+#pragma unroll
+      for (int s_ = 0; s_ < 32; s_ += 2) {
+        s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[s_], qr[t][s_], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[s_ + 1], qr[t][s_ + 1], s1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int jj = kt * 16 + 4 * g + r;
+        const float sv = jj < a.Tk ? (s0[r] + s1[r]) * a.scale : -INFINITY;
+        st[t][kt][r] = sv;
+        mx[t] = fmaxf(mx[t], sv);
+      }
     }
   }
-  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-  float sum = 0.f;
 #pragma unroll
-  for (int kt = 0; kt < KT; ++kt)
+  for (int t = 0; t < RT; ++t) {
+    mx[t] = fmaxf(mx[t], __shfl_xor(mx[t], 16, 64));
+    mx[t] = fmaxf(mx[t], __shfl_xor(mx[t], 32, 64));
+    float sum = 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float e = expf(st[kt][r] - mx);
-      st[kt][r] = e;
-      sum += e;
-    }
-  sum += __shfl_xor(sum, 16, 64);
-  sum += __shfl_xor(sum, 32, 64);
-  const float inv = 1.0f / sum;
+    for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-  for (int kt = 0; kt < KT; ++kt) st[kt] *= inv;       // masked keys: exactly 0, times a finite (clamped) row below
+      for (int r = 0; r < 4; ++r) {
+        const float e = expf(st[t][kt][r] - mx[t]);
+        st[t][kt][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) st[t][kt] *= inv;  // masked keys: exactly 0, times a finite (clamped) row below
+  }
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
-    f32x4 acc[4];
+    f32x4 acc[RT][4];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) acc[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
       float4 vr[4];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int jj = kt * 16 + 4 * g + s;            // key row this lane quarter feeds at step s
-        vr[s] = *reinterpret_cast<const float4*>(c + (int64_t)(jj < a.Tk ? jj : 0) * a.ldkv + 64 * half + 4 * lo);
+      for (int s_ = 0; s_ < 4; ++s_) {
+        const int jj = kt * 16 + 4 * g + s_;           // key row this lane quarter feeds at step s
+        vr[s_] = *reinterpret_cast<const float4*>(c + (int64_t)(jj < a.Tk ? jj : 0) * a.ldkv + 64 * half + 4 * lo);
       }
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const float pr = st[kt][s];
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[s].x, pr, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[s].y, pr, acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[s].z, pr, acc[2], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[s].w, pr, acc[3], 0, 0, 0);
-      }
-    }
-    if (i < R) {
+      for (int t = 0; t < RT; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        *reinterpret_cast<float4*>(o + (int64_t)i * D + 64 * half + 16 * g + 4 * r) =
-            make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+        for (int s_ = 0; s_ < 4; ++s_) {
+          const float pr = st[t][kt][s_];
+          acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[s_].x, pr, acc[t][0], 0, 0, 0);
+          acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[s_].y, pr, acc[t][1], 0, 0, 0);
+          acc[t][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[s_].z, pr, acc[t][2], 0, 0, 0);
+          acc[t][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[s_].w, pr, acc[t][3], 0, 0, 0);
+        }
     }
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+      if (i[t] < R) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          *reinterpret_cast<float4*>(o + (int64_t)i[t] * D + 64 * half + 16 * g + 4 * r) =
+              make_float4(acc[t][0][r], acc[t][1][r], acc[t][2][r], acc[t][3][r]);
+      }
+  }
+}
+
+template <int RT>
+static void launch_attn_ctx_rt(const AttnArgs& a, hipStream_t s) {
+  const int qg = ((a.T * a.heads + 15) / 16 + RT - 1) / RT;
+  const dim3 grid((unsigned)((a.batch * qg + 3) / 4)), block(256);
+  switch ((a.Tk + 15) / 16) {
+    case 1: hipLaunchKernelGGL((k_attn_ctx<1, RT>), grid, block, 0, s, a); break;
+    case 2: hipLaunchKernelGGL((k_attn_ctx<2, RT>), grid, block, 0, s, a); break;
+    case 3: hipLaunchKernelGGL((k_attn_ctx<3, RT>), grid, block, 0, s, a); break;
+    default: hipLaunchKernelGGL((k_attn_ctx<4, RT>), grid, block, 0, s, a); break;
   }
 }
 
 hipError_t launch_attn_ctx(const AttnArgs& a, hipStream_t s) {
   if (a.batch <= 0) return hipSuccess;
   if (a.Tk <= 0 || a.Tk > 64 || a.ldkv % 4 || a.T <= 0 || a.heads <= 0) return hipErrorInvalidValue;
-  const int tiles = a.batch * ((a.T * a.heads + 15) / 16);
-  const dim3 grid((unsigned)((tiles + 3) / 4)), block(256);
-  switch ((a.Tk + 15) / 16) {
-    case 1: hipLaunchKernelGGL(k_attn_ctx<1>, grid, block, 0, s, a); break;
-    case 2: hipLaunchKernelGGL(k_attn_ctx<2>, grid, block, 0, s, a); break;
-    case 3: hipLaunchKernelGGL(k_attn_ctx<3>, grid, block, 0, s, a); break;
-    default: hipLaunchKernelGGL(k_attn_ctx<4>, grid, block, 0, s, a); break;
-  }
+  if (a.T * a.heads > 16) launch_attn_ctx_rt<2>(a, s);     // two row tiles of a sample share the context loads
+  else launch_attn_ctx_rt<1>(a, s);
   return hipGetLastError();
 }
 

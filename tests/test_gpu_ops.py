@@ -157,7 +157,7 @@ def test_attention(B, T, Tk, shared):
 
 
 @pytest.mark.parametrize("B,T,Tk,shared", [(3, 16, 64, False), (2, 32, 64, True), (5, 4, 40, False), (2, 1, 33, False),
-                                           (1, 64, 64, False), (3, 8, 16, True)])
+                                           (1, 64, 64, False), (3, 8, 16, True), (2, 3, 20, False), (3, 5, 64, True)])
 def test_attention_on_normalised_context(B, T, Tk, shared):
     """MDT_OP_ATTN_CTX: softmax(q' c^T scale) c with keys = values = the context rows, against the interpreter and torch."""
     H, F_ = 8, 128

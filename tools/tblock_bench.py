@@ -18,7 +18,7 @@ for (C, T) in [(128, 16), (256, 4)]:
         variant = int(os.environ.get('VARIANT', '0'))
         if variant >= 2 and C != 256:
             continue
-        for B in (64 * 16 // T // 16, 1024):
+        for B in ([int(v) for v in os.environ['BS'].split(',')] if os.environ.get('BS') else (64 * 16 // T // 16, 1024)):
             n_ctx, mid, p = 12, 512, "blk."
             sd = {p + "norm.weight": torch.ones(C), p + "norm.bias": torch.zeros(C), p + "norm_context.weight": torch.ones(C),
                   p + "norm_context.bias": torch.zeros(C), p + "to_q.weight": rnd(mid, C, scale=C ** -0.5),
