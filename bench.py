@@ -333,9 +333,11 @@ def main():
                          "avg_launch_us": round(1e3 * ms_dom / n_dom, 2), "flops_per_launch_avg": fl_dom / n_dom})
             if dom == "k_tblock":
                 # the contract's roofline is the MFMA fraction; what binds this kernel class is not a memory level
-                roof["binding_resource"] = "instruction issue of one wave per SIMD: MFMAs, the fragment ds_reads between them and the " \
-                                           "serial attention / softmax / GELU sections share one stream (bare streaming pipeline: 67 % " \
-                                           "MFMA-busy; LDS array ~26 % busy, L2 stream at half its measured rate)"
+                roof["binding_resource"] = "per-launch latency, then instruction issue: in-kernel stamps of a 256-channel-level launch " \
+                                           "(DESIGN.md 3.5) show 26 % row round trip + LayerNorm / bf16 split before the first MFMA, 65 % " \
+                                           "streamed work at 58 % MFMA-busy (one wave per SIMD issues MFMAs, fragment ds_reads and the serial " \
+                                           "attention / softmax sections), 9 % drain; no memory level binds (LDS array ~26 % busy, weight " \
+                                           "stream at half its measured rate, same speed with 1 or 256 workgroups)"
             if a.workload == "cfg1" and B == 1024:     # the committed PMC summary is of exactly this workload
                 roof["traffic"], roof["traffic_source"] = pmc_traffic(dom)
             extra["eval_breakdown_ms"] = {k: {"launches": n, "ms": round(t, 4),

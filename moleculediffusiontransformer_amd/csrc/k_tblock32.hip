@@ -244,6 +244,22 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
   const int row0 = blockIdx.x * 32 + rt * 16;
   const int m = row0 + i;
   const bool mvalid = m < a.M;
+#ifdef MDT_STAMPS   // tuning build: wave 0 of workgroup 0 records the shader clock at phase boundaries into dbgbuf
+  unsigned long long* stamps = reinterpret_cast<unsigned long long*>(const_cast<float*>(a.dbgbuf));
+  int nstamp = 0;
+#define MDT_STAMP()                                                                   \
+  do {                                                                                \
+    if (stamps && blockIdx.x == 0 && wave == 0 && nstamp < 120) {                     \
+      unsigned long long t_;                                                          \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");      \
+      if (lane == 0) stamps[nstamp] = (t_ & 0xffffffffffffull) | ((unsigned long long)__LINE__ << 48);  \
+      ++nstamp;                                                                       \
+    }                                                                                 \
+  } while (0)
+#else
+#define MDT_STAMP() do {} while (0)
+#endif
+  MDT_STAMP();                                     // kernel entry
   const int mc = mvalid ? m : a.M - 1;
 
   bf16x8 xh[NST], xl[NST];
@@ -275,6 +291,11 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+#ifdef MDT_STAMPS
+    MDT_STAMP();                                     // past barrier P: row / bias loads issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MDT_STAMP();                                     // rows and biases arrived
+#endif
 #pragma unroll
     for (int st = 0; st < NST; ++st) {
       const float4 u = xu[st], w = xw[st];
@@ -351,21 +372,6 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
     frag_read(kind, b1, J1{}, (off + 1) % 3, J2{}); frag_read(kind, b1, J1{}, (off + 1) % 3, J3{});
   };
 
-#ifdef MDT_STAMPS   // tuning build: wave 0 of workgroup 0 records the shader clock at phase boundaries into dbgbuf
-  unsigned long long* stamps = reinterpret_cast<unsigned long long*>(const_cast<float*>(a.dbgbuf));
-  int nstamp = 0;
-#define MDT_STAMP()                                                                   \
-  do {                                                                                \
-    if (stamps && blockIdx.x == 0 && wave == 0 && nstamp < 120) {                     \
-      unsigned long long t_;                                                          \
-      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");      \
-      if (lane == 0) stamps[nstamp] = (t_ & 0xffffffffffffull) | ((unsigned long long)__LINE__ << 48);  \
-      ++nstamp;                                                                       \
-    }                                                                                 \
-  } while (0)
-#else
-#define MDT_STAMP() do {} while (0)
-#endif
   int tau = 0;
   auto slot_of = [&](int t) -> const unsigned char* { return smem + (t % NS) * SLOT; };
 
@@ -413,6 +419,8 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
       __builtin_amdgcn_sched_barrier(0);
 #ifdef MDT_STAMPS_UNITS
       MDT_STAMP();
+#elif defined(MDT_STAMPS)
+      if (tau == 0) MDT_STAMP();                     // the first sub-tile unit by unit: where the stream's start-up wait sits
 #endif
     };
     unit(std::integral_constant<int, 0>{}); unit(std::integral_constant<int, 1>{});
@@ -462,6 +470,7 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
   for (int k = 0; k < NBV; ++k)
     if (tid + 256 * k < 64 * (h1 - h0)) bias_s[tid + 256 * k] = bv[k];
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  MDT_STAMP();                                       // rows loaded, normalised and split
   __builtin_amdgcn_s_barrier();                      // B(0)
   prefetch2(kT, slot_of(0), 0);
   const unsigned bias_l = lds_addr(reinterpret_cast<const unsigned char*>(bias_s)) + 128 * fh + 16 * g;   // + 256 (h - h0)
@@ -674,15 +683,41 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
   // ---- sum the two feature halves' accumulators through LDS (the ring is idle now), add bias + residual ----
   // wave (rt, fh) finalises row tiles 8 fh .. 8 fh + 7 (read back from LDS: a register array cannot be indexed by fh)
   __builtin_amdgcn_s_barrier();                       // every wave is done with the last weight slot
+  // who writes what: in-place / chained head group 0 -> block output (partial + bias + input); every other head
+  // group -> its bare partial (variant 3: slot blockIdx.y of `part` for k_tb_reduce; chained: pout)
+  const bool bare = gridDim.y > 1 && !(CHAIN && blockIdx.y == 0);
+  const bool full = mvalid && !bare;
+  // The residual rows and the output bias are requested HERE, between the two halves of the accumulator exchange through LDS:
+  // their ~1 us round trip (in-kernel stamps: 3700 cycles from this barrier to the last store, ~2500 of them waiting
+  // for these loads behind the second barrier) overlaps the exchange.  Every load of the epilogue is requested before
+  // the first store: the output aliases the residual rows (in place), and with loads and stores alternating hipcc kept
+  // them in order -- eight exposed round trips.
   f32x4* part = reinterpret_cast<f32x4*>(smem);       // [4 waves][16][64 lanes] = 64 KB
 #pragma unroll
   for (int ct = 0; ct < NCT; ++ct) part[(wave * NCT + ct) * 64 + lane] = accT[ct];
+  __builtin_amdgcn_sched_barrier(0);
+  float4 bo[8], xr[8], pr[8];
+  {
+    if (full) {
+      const float* xi = a.x + (int64_t)m * a.ldx + 4 * g + 128 * fh;
+      const float* bi = bias + bo_off + 4 * g + 128 * fh;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) bo[c] = *reinterpret_cast<const float4*>(bi + 16 * c);
+      if (NX == 0) {                                         // folded closing convolution: Wout x is already in the sum
+#pragma unroll
+        for (int c = 0; c < 8; ++c) xr[c] = *reinterpret_cast<const float4*>(xi + 16 * c);
+      }
+      if (CHAIN && a.pin && NX == 0) {                       // chained form: the block input was x + pin
+        const float* pi = a.pin + (int64_t)m * C + 4 * g + 128 * fh;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) pr[c] = *reinterpret_cast<const float4*>(pi + 16 * c);
+      }
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (mvalid) {
-    // who writes what: in-place / chained head group 0 -> block output (partial + bias + input); every other head
-    // group -> its bare partial (variant 3: slot blockIdx.y of `part` for k_tb_reduce; chained: pout)
-    const bool bare = gridDim.y > 1 && !(CHAIN && blockIdx.y == 0);
     auto halves = [&](int c) -> f32x4 {                       // feature half 0 first
       const int ct = 8 * fh + c;
       return part[((2 * rt) * NCT + ct) * 64 + lane] + part[((2 * rt + 1) * NCT + ct) * 64 + lane];
@@ -695,28 +730,14 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
         store_nt(po + 16 * (8 * fh + c), make_float4(sum[0], sum[1], sum[2], sum[3]));
       }
     } else {
-      // every load of the epilogue is requested before the first store: the output aliases the residual rows (in
-      // place), and with loads and stores alternating hipcc kept them in order -- eight exposed round trips
-      const float* xi = a.x + (int64_t)m * a.ldx + 4 * g + 128 * fh;
-      const float* bi = bias + bo_off + 4 * g + 128 * fh;
       float* xo = ((CHAIN || NX > 0) ? a.xout : a.x) + (int64_t)m * a.ldx + 4 * g + 128 * fh;
-      float4 bo[8], xr[8];
-#pragma unroll
-      for (int c = 0; c < 8; ++c) bo[c] = *reinterpret_cast<const float4*>(bi + 16 * c);
-      if (NX == 0) {                                         // folded closing convolution: Wout x is already in the sum
-#pragma unroll
-        for (int c = 0; c < 8; ++c) xr[c] = *reinterpret_cast<const float4*>(xi + 16 * c);
-      } else {
+      if (NX != 0) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) xr[c] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      if (CHAIN && a.pin && NX == 0) {                       // chained form: the block input was x + pin
-        const float* pi = a.pin + (int64_t)m * C + 4 * g + 128 * fh;
+      if (CHAIN && a.pin && NX == 0) {
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          const float4 pr = *reinterpret_cast<const float4*>(pi + 16 * c);
-          xr[c].x += pr.x; xr[c].y += pr.y; xr[c].z += pr.z; xr[c].w += pr.w;
-        }
+        for (int c = 0; c < 8; ++c) { xr[c].x += pr[c].x; xr[c].y += pr[c].y; xr[c].z += pr[c].z; xr[c].w += pr[c].w; }
       }
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
@@ -726,6 +747,10 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
       }
     }
   }
+#ifdef MDT_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  MDT_STAMP();                                       // outputs stored
+#endif
 }
 
 template <int MODE, int NPW, bool CHAIN>
