@@ -26,6 +26,7 @@ import json
 import os
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -230,6 +231,55 @@ def cpu_baseline_leg(torch, model, device, evals):
     return base, parity
 
 
+class PowerSampler(threading.Thread):
+    """Socket power and the SMU's shader-clock reading of THIS rank's GPU during the timed region (amdgpu hwmon sysfs,
+    world-readable: a file read every 50 ms on a host thread).  Context for the roofline, not a metric: the fused kernels
+    run the package at ~1.2 kW of its 1.4 kW cap, and in-kernel clock stamps (profiles/r2_launch_timeline.txt)
+    show the shader clock the waves actually see dropping to 1.8-2.0 GHz in the streamed phases."""
+
+    def __init__(self, device_index):
+        super().__init__(daemon=True)
+        self.dir, self.stop_flag, self.w, self.mhz = None, threading.Event(), [], []
+        try:
+            import glob
+            import torch
+            pr = torch.cuda.get_device_properties(device_index)
+            bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            for d in glob.glob("/sys/class/drm/card*/device"):
+                if os.path.basename(os.path.realpath(d)) == bdf:
+                    hw = glob.glob(os.path.join(d, "hwmon", "hwmon*"))
+                    if hw and os.path.exists(os.path.join(hw[0], "power1_input")):
+                        self.dir = hw[0]
+        except Exception:
+            self.dir = None
+
+    def _read(self, name):
+        with open(os.path.join(self.dir, name)) as f:
+            return float(f.read().strip())
+
+    def run(self):
+        while self.dir and not self.stop_flag.is_set():
+            try:
+                self.w.append(self._read("power1_input") * 1e-6)
+                self.mhz.append(self._read("freq1_input") * 1e-6)
+            except Exception:
+                break
+            self.stop_flag.wait(0.05)
+
+    def summary(self):
+        self.stop_flag.set()
+        if not self.w:
+            return None
+        cap = None
+        try:
+            cap = self._read("power1_cap") * 1e-6
+        except Exception:
+            pass
+        return {"socket_w_avg": round(sum(self.w) / len(self.w), 1), "socket_w_max": round(max(self.w), 1), "cap_w": cap,
+                "sclk_mhz_smu_avg": round(sum(self.mhz) / len(self.mhz), 0), "samples": len(self.w),
+                "source": "amdgpu hwmon power1_input / freq1_input of this GPU, sampled every 50 ms over the timed steps"}
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "RANK" not in os.environ:
@@ -291,11 +341,15 @@ def main():
             torch.cuda.synchronize(device)
 
     fence()
+    sampler = PowerSampler(device.index if device.index is not None else 0) if rank == 0 else None
+    if sampler:
+        sampler.start()
     t0 = time.perf_counter()
     for k in range(a.steps):
         out = one_step(a.warmup + k, True)
     fence()
     elapsed = time.perf_counter() - t0
+    power = sampler.summary() if sampler else None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -377,6 +431,7 @@ def main():
                     ue["hbm_measured_source"] = f"profiles/{fname}: PMC bytes (FETCH_SIZE x2 + WRITE_SIZE) of the profiled run " \
                                                 f"/ its U-Net evaluations, over THIS run's evaluation time"
         extra["unet_eval"] = ue
+        extra["power"] = power
         result = {
             "metric": "molecules/sec @64 diffusion steps (QM9 max_len=64)" if a.workload == "cfg1"
                       else f"molecules/sec @{T} diffusion steps ({a.workload})", "value": round(value, 2),

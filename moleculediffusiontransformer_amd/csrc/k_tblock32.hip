@@ -260,6 +260,23 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
 #define MDT_STAMP() do {} while (0)
 #endif
   MDT_STAMP();                                     // kernel entry
+#ifdef MDT_STAMPS   // every workgroup: 100 MHz real-time clock at 8 points (dispatch spread, where the slow workgroups lose
+                    // their time, tail) -> dbgbuf[256 + 8 id + k]
+#define MDT_RSTAMP(K)                                                                                   \
+  do {                                                                                                  \
+    if (stamps && wave == 0) {                                                                          \
+      unsigned long long t_, c_;                                                                        \
+      asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "=s"(c_)::"memory"); \
+      if (lane == 0) {                                                                                  \
+        stamps[256 + 8 * (blockIdx.x + gridDim.x * blockIdx.y) + (K)] = t_;                             \
+        stamps[256 + 8 * 1024 + 8 * (blockIdx.x + gridDim.x * blockIdx.y) + (K)] = c_;                  \
+      }                                                                                                 \
+    }                                                                                                   \
+  } while (0)
+#else
+#define MDT_RSTAMP(K) do {} while (0)
+#endif
+  MDT_RSTAMP(0);
   const int mc = mvalid ? m : a.M - 1;
 
   bf16x8 xh[NST], xl[NST];
@@ -295,6 +312,7 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
     MDT_STAMP();                                     // past barrier P: row / bias loads issued
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     MDT_STAMP();                                     // rows and biases arrived
+    MDT_RSTAMP(1);
 #endif
 #pragma unroll
     for (int st = 0; st < NST; ++st) {
@@ -471,6 +489,7 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
     if (tid + 256 * k < 64 * (h1 - h0)) bias_s[tid + 256 * k] = bv[k];
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   MDT_STAMP();                                       // rows loaded, normalised and split
+  MDT_RSTAMP(2);
   __builtin_amdgcn_s_barrier();                      // B(0)
   prefetch2(kT, slot_of(0), 0);
   const unsigned bias_l = lds_addr(reinterpret_cast<const unsigned char*>(bias_s)) + 128 * fh + 16 * g;   // + 256 (h - h0)
@@ -658,6 +677,7 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
     phase(kO, IC1{}, kO, true, accT, oh, ol);               // output rows 0..127
     if (NX > 0 && !more) phase(kO, IC2{}, kO, true, accT + 8, oh, ol);   // the folded convolution's sub-tiles follow
     else phase(kO, IC2{}, kT, more, accT + 8, oh, ol);      // output rows 128..255
+    if (h - h0 < 4) MDT_RSTAMP(3 + (h - h0));
   }
   if constexpr (MODE == TB_FF) {
     if (NX > 0) {
@@ -750,6 +770,7 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
 #ifdef MDT_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   MDT_STAMP();                                       // outputs stored
+  MDT_RSTAMP(7);
 #endif
 }
 

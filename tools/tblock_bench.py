@@ -30,7 +30,7 @@ for (C, T) in [(128, 16), (256, 4)]:
             op = comp.ops[0]
             if mode == rt.TB_CROSS:
                 op.a2 = ref(A, T * C)
-            dbg = torch.zeros(1024, device=dev)
+            dbg = torch.zeros(2 * (256 + 16 * 1024) + 64, device=dev)
             if os.environ.get('MDT_DBG', '0') == '8':
                 op.p0 = ref(rt.SP_EXT0, 0)
             W = comp.W.pack().to(dev)
@@ -55,4 +55,25 @@ for (C, T) in [(128, 16), (256, 4)]:
                 ls = dbg.cpu().view(torch.int64)[128:248].tolist()
                 if ls[0] > 0:
                     print("   loader (wait-landed, barrier, issue+loop) x tiles:", [(ls[3*k+1]-ls[3*k], ls[3*k+2]-ls[3*k+1], ls[3*k+3]-ls[3*k+2]) for k in range(12) if ls[3*k+3] > 0])
+            if os.environ.get('MDT_DBG', '0') == '8':
+                nwg = min(1024, ((B * T + 31) // 32) * 2)
+                rt_ = dbg.cpu().view(torch.int64)[256:256 + 8 * nwg].view(-1, 8)
+                rt_ = rt_[rt_[:, 0] > 0]
+                if len(rt_):
+                    t0 = int(rt_[:, 0].min())
+                    us = (rt_ - t0).double() / 100.0       # us since the first workgroup entered
+                    names = ["entry", "rows arrived", "normalised", "head 1", "head 2", "head 3", "head 4", "exit"]
+                    print(f"   {len(rt_)} workgroups, 100 MHz clock, us since the first entry (min / mean / max over workgroups), then per-workgroup phase lengths:")
+                    for k in range(8):
+                        if (rt_[:, k] > 0).all():
+                            d = us[:, k] - (us[:, k - 1] if k else 0)
+                            print(f"     {names[k]:13s} at {us[:, k].min():6.2f} / {us[:, k].mean():6.2f} / {us[:, k].max():6.2f}   phase {d.min():5.2f} / {d.mean():5.2f} / {d.max():5.2f}")
+                    cy = dbg.cpu().view(torch.int64)[256 + 8 * 1024:256 + 8 * 1024 + 8 * nwg].view(-1, 8)[:len(rt_)]
+                    for k0, k1, nm in ((0, 7, "whole kernel"), (3, 6, "heads 2-4")):
+                        mhz = (cy[:, k1] - cy[:, k0]).double() / (rt_[:, k1] - rt_[:, k0]).double() * 100.0
+                        print(f"     shader clock over {nm}: {mhz.min():.0f} / {mhz.mean():.0f} / {mhz.max():.0f} MHz; cycles {float((cy[:, k1] - cy[:, k0]).double().mean()):.0f}")
+                    tot = us[:, 7] - us[:, 0]
+                    slow = int(tot.argmax()); fast = int(tot.argmin())
+                    print(f"     slowest workgroup #{slow}: phases", [round(float(us[slow, k] - (us[slow, k - 1] if k else 0)), 2) for k in range(8)],
+                          f"fastest #{fast}:", [round(float(us[fast, k] - (us[fast, k - 1] if k else 0)), 2) for k in range(8)])
             print(f"C={C} T={T} {name:5s} B={B:5d} blocks={(B * T + 63) // 64:4d}: {ms * 1e3:7.1f} us  weights {W.numel() * 4 / 1e6:.2f} MB", flush=True)
