@@ -106,6 +106,11 @@ constexpr int IPT = CS / 16;    // DMA pieces per sub-tile per loader wave
 constexpr int NST = C / 32;     // k-steps of a full projection
 constexpr int NCT = C / 16;     // 16-row tiles of the output projection
 constexpr int NU = 4;           // units (4 fragment reads + 6 MFMAs) per sub-tile per wave
+#ifdef MDT_TB32_PLAIN_PROLOGUE   // tuning build: every wave loads / normalises / splits whole rows (A/B of the shared prologue)
+constexpr bool SHARED_PROLOGUE = false;
+#else
+constexpr bool SHARED_PROLOGUE = true;
+#endif
 
 }  // namespace
 
@@ -229,6 +234,10 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
     __builtin_amdgcn_s_barrier();   // P: the compute waves' row and bias loads are queued ahead of the stream
     issue_tile(0);
     if (NT > 1) issue_tile(1);
+    if constexpr (MODE != TB_FF && SHARED_PROLOGUE) {
+      __builtin_amdgcn_s_barrier();   // S1: LayerNorm statistics pooled between the two waves of a row tile
+      __builtin_amdgcn_s_barrier();   // S2: operand planes exchanged (compute waves' prologue; the feed-forward kernel keeps the plain one)
+    }
     for (int k = 0; k < NT; ++k) {
       wait_vm(k + 1 < NT ? (is_kv(k + 1) ? NPW : IPT) : 0);              // tile k landed; tile k+1 may be in flight
       __builtin_amdgcn_s_barrier();                                      // B(k)
@@ -282,6 +291,7 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
   bf16x8 xh[NST], xl[NST];
   constexpr int NBV = 4;                 // per-chunk bias vectors: 64 (h1 - h0) floats over 256 lanes, nchunk <= 16
   float bv[NBV];
+  if constexpr (MODE == TB_FF || !SHARED_PROLOGUE)
   {
     float xr[NST][8];
     const float* xp = a.x + (int64_t)mc * a.ldx + 8 * g;
@@ -356,7 +366,108 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
       split8_32(v, xh[st], xl[st]);
     }
   }
-
+  else
+  {
+    // The two waves of a row tile need the same 16 normalised rows as MFMA operands.  Each of them loads, normalises and
+    // splits only HALF of every row (channels 128 fh .. 128 fh + 127 = k-steps 4 fh .. 4 fh + 3) and hands the bf16 planes to
+    // the other through ring slot 2 (free until B(0)); the LayerNorm statistics of the two halves are pooled exactly
+    // (mean and sum of squared deviations per half, Chan et al.) through the head of slot 3.  Before, both waves did
+    // all of it: 128 KB of row requests per workgroup through a 64 B/clk path and ~500 VALU instructions per lane ahead
+    // of the first MFMA (launch timeline).
+    constexpr int NH = NST / 2;
+    float xr[NH][8];
+    const float* xp = a.x + (int64_t)mc * a.ldx + 8 * g + 128 * fh;
+    float4 xu[NH], xw[NH], pu[NH], pw[NH];
+#pragma unroll
+    for (int st = 0; st < NH; ++st) {
+      xu[st] = *reinterpret_cast<const float4*>(xp + 32 * st);
+      xw[st] = *reinterpret_cast<const float4*>(xp + 32 * st + 4);
+    }
+    if (CHAIN && a.pin) {                            // chained form (variant 4): block input = x + pin
+      const float* pp = a.pin + (int64_t)mc * C + 8 * g + 128 * fh;
+#pragma unroll
+      for (int st = 0; st < NH; ++st) {
+        pu[st] = *reinterpret_cast<const float4*>(pp + 32 * st);
+        pw[st] = *reinterpret_cast<const float4*>(pp + 32 * st + 4);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NBV; ++k) bv[k] = (tid + 256 * k < 64 * (h1 - h0)) ? a.bias[64 * h0 + tid + 256 * k] : 0.f;
+    // P: the loader waves start the weight stream only now, behind this wave's requests (queued behind the stream's
+    // first two tiles the rows came back ~1500 cycles later).  sched_barrier: without it hipcc moves the rows' first
+    // uses (and with them the wait for the loads) in front of the barrier, i.e. the stream starts a round trip late
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#ifdef MDT_STAMPS
+    MDT_STAMP();                                     // past barrier P: row / bias loads issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MDT_STAMP();                                     // rows and biases arrived
+    MDT_RSTAMP(1);
+#endif
+#pragma unroll
+    for (int st = 0; st < NH; ++st) {
+      const float4 u = xu[st], w = xw[st];
+      xr[st][0] = u.x; xr[st][1] = u.y; xr[st][2] = u.z; xr[st][3] = u.w;
+      xr[st][4] = w.x; xr[st][5] = w.y; xr[st][6] = w.z; xr[st][7] = w.w;
+    }
+    if (CHAIN && a.pin) {
+#pragma unroll
+      for (int st = 0; st < NH; ++st) {
+        xr[st][0] += pu[st].x; xr[st][1] += pu[st].y; xr[st][2] += pu[st].z; xr[st][3] += pu[st].w;
+        xr[st][4] += pw[st].x; xr[st][5] += pw[st].y; xr[st][6] += pw[st].z; xr[st][7] += pw[st].w;
+      }
+    }
+    float mean = 0.f, rstd = 1.f;
+    {
+      float s = 0.f;
+#pragma unroll
+      for (int st = 0; st < NH; ++st)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += xr[st][e];
+      s = xg16_add(s);
+      s = xg32_add(s);
+      const float mean_h = s / (float)(C / 2);
+      float m2 = 0.f;
+#pragma unroll
+      for (int st = 0; st < NH; ++st)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = xr[st][e] - mean_h;
+          m2 += d * d;
+        }
+      m2 = xg16_add(m2);
+      m2 = xg32_add(m2);
+      float2* stat = reinterpret_cast<float2*>(smem + 3 * SLOT);      // [wave][row]
+      if (g == 0) stat[wave * 16 + i] = make_float2(mean_h, m2);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                  // S1 (the loader waves take part)
+      const float2 other = stat[(wave ^ 1) * 16 + i];
+      const float dm = mean_h - other.x;
+      mean = 0.5f * (mean_h + other.x);
+      const float ss = m2 + other.y + (float)(C / 4) * dm * dm;
+      rstd = 1.0f / sqrtf(ss / (float)C + a.eps);
+    }
+    unsigned char* xch = smem + 2 * SLOT + rt * (NST * 2048) + lane * 16;     // [row tile][k-step][plane][lane] 16-byte operands
+    const float rs = mvalid ? rstd : 0.f;            // rows past M: zero operands (their inputs are a real row's, finite)
+#pragma unroll
+    for (int st = 0; st < NH; ++st) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (xr[st][e] - mean) * rs;
+      bf16x8 hh, ll;
+      split8_32(v, hh, ll);
+      *reinterpret_cast<bf16x8*>(xch + (NH * fh + st) * 2048) = hh;
+      *reinterpret_cast<bf16x8*>(xch + (NH * fh + st) * 2048 + 1024) = ll;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                    // S2
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+      xh[st] = *reinterpret_cast<const bf16x8*>(xch + st * 2048);
+      xl[st] = *reinterpret_cast<const bf16x8*>(xch + st * 2048 + 1024);
+    }
+  }
   // fragment addressing inside a sub-tile (C = 128 tile format), this wave's feature half folded in:
   //   projection sub-tile: row = 32 fh + 16 q + i, chunk = 4 st + g ; output sub-tile: row = 16 ct + i, chunk = 4 fh + g
   int aP[4];
