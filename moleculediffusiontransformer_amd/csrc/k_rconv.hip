@@ -314,6 +314,11 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
     __builtin_amdgcn_sched_barrier(0);               // the loads' first uses (and their waits) stay behind the barrier
     if (src == 0) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+#ifdef MDT_STAMPS
+    MDT_STAMP();                                     // loads issued, past barrier P
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MDT_STAMP();                                     // rows and per-channel parameters arrived
+#endif
     if (src == 0) {
       if (a.bias) {
 #pragma unroll
@@ -411,6 +416,7 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
           rstd[st][hf] = ss;
         }
       group_sum(rstd);
+      MDT_STAMP();                                   // group statistics
 #pragma unroll
       for (int st = 0; st < NSTW; ++st)
 #pragma unroll
@@ -453,6 +459,7 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
           }
       }
     }
+    MDT_STAMP();                                     // normalised, FiLM, SiLU
     if constexpr (RTW == 2) {
       // exchange: [wave][k-step][hi | lo][lane] 16-byte entries; every wave reads back all NST k-steps of its row tile
       unsigned char* ex = smem + NS * SLOT;            // 32 KB behind the ring
