@@ -172,10 +172,12 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
     }
     // MODE_CROSS: sub-tiles 2 and 3 of a head are the K and V rows (row = (sample, key), 256 B, chunks swizzled with
     // the row index) of the workgroup's samples -- layout and padding as in k_tblock_lw.hip
-    const int kv_rows = (MODE == TB_CROSS) ? (32 / a.T) * a.Tk : 0;
+    const int ltl = 31 - __builtin_clz((unsigned)a.T);   // T is a power of two (host check)
+    const int kv_rows = (MODE == TB_CROSS) ? (32 >> ltl) * a.Tk : 0;
     unsigned voffKV[8];                              // NPW <= 8 used (fixed bound, see k_tblock_lw.hip)
     if constexpr (MODE == TB_CROSS) {
-      const int sample0 = blockIdx.x * (32 / a.T);
+      const int sample0 = blockIdx.x * (32 >> ltl);
+      const float inv_tk = 1.0f / (float)a.Tk;
       // dual batch (classifier-free guidance, both passes in one launch): the samples of the second half read the
       // batch-invariant K / V rows a.kv2 (a workgroup never straddles the halves: the host checks B % 16 == 0)
       const int bstr = (a.kv2 && sample0 >= a.nsamples / 2) ? 0 : a.kv_bstride;
@@ -183,7 +185,8 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
       for (int q = 0; q < NPW; ++q) {
         const int R = 4 * (iw + 4 * q) + (lane >> 4);
         const int Rc = min(R, kv_rows - 1);
-        const int sm = min(Rc / a.Tk, a.nsamples - 1 - sample0), key = Rc % a.Tk;
+        const int smq = (int)(((float)Rc + 0.5f) * inv_tk);       // Rc / Tk for Rc < 96: (Rc + 0.5) / Tk is >= 0.5 / Tk from an integer
+        const int sm = min(smq, a.nsamples - 1 - sample0), key = Rc - smq * a.Tk;
         voffKV[q] = (unsigned)(((sm * bstr + key) * a.ldkv + 4 * ((lane & 15) ^ (R & 15))) * 4);
       }
     }
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
     auto issue_kv = [&](int tau) {
       if constexpr (MODE == TB_CROSS) {
         unsigned char* slot = smem + (tau % NS) * SLOT + iw * 1024;
-        const int sample0 = blockIdx.x * (32 / a.T);
+        const int sample0 = blockIdx.x * (32 >> ltl);
         const bool second = a.kv2 && sample0 >= a.nsamples / 2;
         const unsigned char* base = reinterpret_cast<const unsigned char*>(
             (second ? a.kv2 : a.kv + (int64_t)sample0 * a.kv_bstride * a.ldkv) + 64 * (h0 + tau / SPC) + ((tau % SPC) == 3 ? 64 * a.nheads : 0));
@@ -570,10 +573,12 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
 
   const float* bias = a.bias;
   const int bo_off = (MODE == TB_SELF) ? 3 * 64 * a.nchunk : 64 * a.nchunk;   // [bq | bk | bv | bo] / [bq | bo] / [b1 | b2]
-  const int samp_q = i / a.T;                        // loop-invariant softmax pieces, see k_tblock_lw.hip
+  const int lt = 31 - __builtin_clz((unsigned)a.T);  // 16 % T == 0 (host check): T is a power of two, x / T = x >> lt.  A run-time
+                                                     // integer division is ~35 VALU instructions; the 17 of this section cost ~2500 cycles
+  const int samp_q = i >> lt;                        // loop-invariant softmax pieces, see k_tblock_lw.hip
   float kmask[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) kmask[r] = ((4 * g + r) / a.T == samp_q) ? 0.f : -INFINITY;
+  for (int r = 0; r < 4; ++r) kmask[r] = (((4 * g + r) >> lt) == samp_q) ? 0.f : -INFINITY;
   const float scale2 = a.scale * 1.44269504088896340736f;
   // MODE_CROSS: this row tile's context rows inside a K / V tile start at row rt * nkeys; lane (i, g) reads K row
   // 16 kt + i and V rows 16 kt + 4 g + r (clamped to a real row past the end: masked scores, zero probabilities).
@@ -581,14 +586,14 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
   int nkeys = 0, Rw = 0;
   unsigned okbits = 0;
   if constexpr (MODE == TB_CROSS) {
-    nkeys = (16 / a.T) * a.Tk;
+    nkeys = (16 >> lt) * a.Tk;
     Rw = rt * nkeys;
 #pragma unroll
     for (int kt = 0; kt < KTM; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int jj = 16 * kt + 4 * g + r;
-        if (jj < nkeys && (jj / a.Tk) == samp_q) okbits |= 1u << (4 * kt + r);
+        if (jj < nkeys && jj >= samp_q * a.Tk && jj < (samp_q + 1) * a.Tk) okbits |= 1u << (4 * kt + r);   // jj / Tk == samp_q
       }
   }
   const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
