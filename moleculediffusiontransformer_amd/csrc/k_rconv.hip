@@ -196,7 +196,8 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
   const int mc = mvalid ? m : a.M - 1;
 
   // neighbours inside the sample: row i - 1 exists unless i starts a sample, row i + 1 unless i ends one
-  const bool has_prev = (i % a.T) != 0, has_next_row = (i % a.T) != a.T - 1;
+  const int it = i & (a.T - 1);                      // i % T: 16 % T == 0 (host check), T is a power of two
+  const bool has_prev = it != 0, has_next_row = it != a.T - 1;
 
   // fragment addressing inside a tile: row = 16 ft + i, chunk = 4 st + g (C = 128 tile format, k_tblock_lw.hip)
   int aP[4];

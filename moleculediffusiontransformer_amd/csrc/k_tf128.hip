@@ -445,7 +445,7 @@ __global__ __launch_bounds__(512) void k_tf128(TFArgs a) {
   // ================= ResNet blocks in front of the transformer =================
   if constexpr (RES > 0) {
     const float* film_s = vec_s + a.nvec;
-    const bool keep_l = (i % a.T) != 0, keep_r = (i % a.T) != a.T - 1;
+    const bool keep_l = (i & (a.T - 1)) != 0, keep_r = (i & (a.T - 1)) != a.T - 1;   // i % T, T a power of two (16 % T == 0)
     // GroupNorm statistics of groups of 16 (pair = false) or 32 (pair = true) channels over the sample's tokens, on the
     // accumulator layout: a group is one / two 16-channel tiles ct -- 4 registers, the 4 lane groups, the sample's token lanes
     auto gn_stats = [&](const f32x4* src, bool pair, float (&mu)[NCT], float (&rs)[NCT]) __attribute__((always_inline)) {
