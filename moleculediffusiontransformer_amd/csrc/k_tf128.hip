@@ -712,6 +712,10 @@ __global__ __launch_bounds__(512) void k_tf128(TFArgs a) {
 #pragma unroll
           for (int ft = 0; ft < 4; ++ft) qT[ft] += bq[ft];
         }
+#ifdef MDT_ABL_ATTN   // timing experiment only (wrong results): the attention core of self-attention (S, softmax, P V) skipped
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) oT[dt] = qT[dt] + kTt[dt] + vT[dt];
+#else
         f32x4 s0 = zero4, s1 = zero4;
 #pragma unroll
         for (int ft = 0; ft < 4; ++ft) {
@@ -748,6 +752,7 @@ __global__ __launch_bounds__(512) void k_tf128(TFArgs a) {
 #pragma unroll
           for (int dt = 0; dt < 4; ++dt) oT[dt] = MDT_MFMA_F32(vT[dt][r], p, oT[dt], 0, 0, 0);
         }
+#endif
         bf16x8 oh[2], ol[2];
 #pragma unroll
         for (int sp = 0; sp < 2; ++sp) {
@@ -868,7 +873,11 @@ __global__ __launch_bounds__(512) void k_tf128(TFArgs a) {
 #pragma unroll
           for (int ft = 0; ft < 4; ++ft)
 #pragma unroll
+#ifdef MDT_ABL_GELU   // timing experiment only (wrong results): what the serial GELU costs
+            for (int r = 0; r < 4; ++r) oT[ft][r] = oT[ft][r] + b1[ft][r];
+#else
             for (int r = 0; r < 4; ++r) oT[ft][r] = gelu_tf(oT[ft][r] + b1[ft][r]);
+#endif
         }
         bf16x8 oh[2], ol[2];
 #pragma unroll
