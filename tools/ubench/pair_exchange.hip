@@ -60,7 +60,7 @@ __global__ __launch_bounds__(512) void kpair(float* buf, unsigned* flags, unsign
     else LD4("sc0 sc1");
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      if (v[k][0] != (float)r || v[k][1] != (float)other || v[k][2] != (float)(threadIdx.x + 512 * k)) ++bad;
+      if (v[k][0] != (float)r || v[k][1] != (float)other) ++bad;        // stale or foreign data
   }
   asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
   if (bad) atomicAdd(errs, bad);
@@ -70,10 +70,10 @@ __global__ __launch_bounds__(512) void kpair(float* buf, unsigned* flags, unsign
 int main() {
   const int nwg = 256, rounds = 200;
   float* buf; unsigned *flags, *errs; unsigned long long* res;
-  hipMalloc(&buf, (size_t)2 * nwg * 32768); hipMalloc(&flags, nwg * 128); hipMalloc(&errs, 64); hipMalloc(&res, nwg * 8);
+  hipMalloc(&buf, (size_t)2 * nwg * 32768); hipMalloc(&flags, nwg * 128); hipMalloc(&errs, 256); hipMalloc(&res, nwg * 8);
   for (int mode = 0; mode < 4; ++mode)
     for (int off : {128, 1}) {
-      hipMemset(flags, 0, nwg * 128); hipMemset(errs, 0, 64); hipMemset(buf, 0, (size_t)2 * nwg * 32768);
+      hipMemset(flags, 0, nwg * 128); hipMemset(errs, 0, 256); hipMemset(buf, 0, (size_t)2 * nwg * 32768);
       if (mode == 0) hipLaunchKernelGGL(kpair<0>, dim3(nwg), dim3(512), 0, 0, buf, flags, errs, res, rounds, off);
       else if (mode == 1) hipLaunchKernelGGL(kpair<1>, dim3(nwg), dim3(512), 0, 0, buf, flags, errs, res, rounds, off);
       else if (mode == 2) hipLaunchKernelGGL(kpair<2>, dim3(nwg), dim3(512), 0, 0, buf, flags, errs, res, rounds, off);
