@@ -453,6 +453,9 @@ def main():
             # last rank's first rows must equal, bit for bit, a 1-rank run of those global indices with the same seed
             probe = min(64, B)
             r_last = world - 1
+            # same kernels as the timed run (the 256-channel transformers' form depends on the batch in 'auto'; the two
+            # forms agree to rounding only): pin the model to the choice the timed engine was compiled with
+            model.kernel_choice = "wide" if eng.c.tf256 else "narrow"
             alone = model.sample(seq_of(r_last)[:probe].to(device), device, cond_scale=a.cond_scale, timesteps=T, clamp=False,
                                  noise=NoiseSource(seed=1234 + a.warmup + a.steps - 1, sample0=r_last * B))
             rows = out[r_last * B: r_last * B + probe]

@@ -26,10 +26,15 @@
 extern "C" {
 #endif
 
-#define MDT_ABI_VERSION 2
+#define MDT_ABI_VERSION 3
 
 int mdt_abi_version(void);
 const char *mdt_last_error(void);
+/* Process-wide tuning / test hooks (not needed for correct results): "pair_stride" = v > 0 places the two workgroups of
+ * every pair-split MDT_OP_TF256 v workgroup ids apart whatever the op says (1: neighbours, i.e. different XCDs; 0: back to
+ * the ops' own value); "tile16" = 0 | 1 | 2 forces a tile of the bf16 x bf16 GEMM (-1: automatic).  Returns 0, or 1 for an
+ * unknown key. */
+int mdt_set_tuning(const char *key, int32_t value);
 
 /* ------------------------------------------------------------------ */
 /* U-Net evaluation as an op program                                   */
@@ -94,7 +99,16 @@ enum mdt_op_kind {
                           kind (3 bits: 0 projection, 1 output, 2 K rows, 3 V rows, 4 scratch, 5 scratch + vectors of the next
                           sub-block) | aux << 3, two scratch descriptors after every sub-block; vectors: 768 floats per
                           sub-block ([bias 256] / [bq 512 | bo 256] / [b1 512 | b2 256]); NPOST = 8 sub-tiles; ints and
-                          floats as MDT_OP_TF128 with C = 256                                                     */
+                          floats as MDT_OP_TF128 with C = 256.
+                          MDT_F_NSPLIT = 2 (batches whose 32-row blocks do not fill the chip): every row block is served by a
+                          PAIR of workgroups, half hh = 0 | 1 taking heads / hidden chunks / to_in output chunks / folded
+                          to_out k chunks [hh n/2, (hh + 1) n/2); p0 then holds TWO descriptor tables of NT entries (half 0,
+                          half 1; each sub-block's two scratch descriptors are followed by two more, kind 4, for the hand-off),
+                          and the two workgroups hand each other their 32 x 256 partial sums inside the launch after every
+                          sub-block: p3 = hand-off blocks, 2 * ceil(B T / 32) * 2 * 8192 floats; p2 = flag words (uint32):
+                          64 diagnostic words (bit 0 of word 0 is raised if a poll timed out), then one 128-byte line per
+                          (row block, half), counting hand-offs monotonically across launches -- zero them once, never between
+                          launches.  The result does not depend on where the two workgroups run (k_tf256.hip)          */
   MDT_OP_PREP16 = 14,  /* A operand of a bf16 x bf16 GEMM: out (bf16 [B][R_IN][CIN], CIN / 2 floats per row) = bf16(prologue(a[.., A_COL +
                           c])); ints R_IN, LDA, CIN, A_COL, PRO, GROUPS, GSIZE, PRO_SILU and p0..p3 / eps as MDT_OP_GEMM          */
   MDT_OP_ATTN_CTX = 13, /* cross-attention core against the NORMALISED CONTEXT itself (K = V = c, shared by all heads and layers;
@@ -237,7 +251,11 @@ enum mdt_tf128_i {
   MDT_F_N_RES = 16,
   MDT_F_RES_PAIR1 = 17,  /* GroupNorm groups of block1: 1 = 32 channels, 0 = 16 channels (block2: RES_PAIR2)                */
   MDT_F_RES_PAIR2 = 18,
-  MDT_F_NFILM = 19       /* FiLM floats staged behind the vectors (2 C per block, padded to a multiple of 256; NVEC + NFILM <= 8192) */
+  MDT_F_NFILM = 19,      /* FiLM floats staged behind the vectors (2 C per block, padded to a multiple of 256; NVEC + NFILM <= 8192) */
+  /* MDT_OP_TF256 only */
+  MDT_F_NSPLIT = 20,     /* 0 / 1: one workgroup per 32-row block; 2: a pair of workgroups per block (see MDT_OP_TF256)      */
+  MDT_F_PAIR_STRIDE = 21 /* NSPLIT = 2: workgroup ids of a pair are this far apart (0 = 8: one XCD under the observed round-robin
+                            placement; 1 = neighbours on different XCDs) -- speed only                                       */
 };
 enum mdt_tf128_f { MDT_FF_EPS_LN = 0, MDT_FF_SCALE = 1, MDT_FF_EPS_GN = 2, MDT_FF_EPS_RES = 3, MDT_FF_SKIP_SCALE = 4 };
 

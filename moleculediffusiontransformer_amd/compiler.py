@@ -28,6 +28,7 @@ from . import runtime as rt
 from .netspec import UNetConfig
 
 EXT_XIN, EXT_CTX, EXT_OUT = 0, 1, 2      # bindings.ext slots used by the programs
+EXT_XFLAGS, EXT_XBUF = 3, 4              # pair-split MDT_OP_TF256: hand-off flags / blocks (engine.py sizes them per batch)
 
 
 def pad16(c: int) -> int:
@@ -128,6 +129,8 @@ class CompiledUNet:
     # or 32 / T (C = 256) samples and picks conditional vs fixed K/V per WORKGROUP, so the number of samples must be a
     # multiple of the largest such group or a workgroup would straddle the two halves
     dual_multiple: int = 1
+    tf256: bool = False              # compiled with the whole-transformer form of the 256-channel level (generative._wide)
+    xchg_tokens: int = 0             # > 0: pair-split MDT_OP_TF256 ops present; tokens per sample of the largest (engine.py)
 
 
 class UNetCompiler:
@@ -167,6 +170,12 @@ class UNetCompiler:
         # for the five transformers against 1.25 ms as head-split launches (both bound by the per-CU weight stream); it wins
         # once the batch fills the chip without the split, so it is a per-batch choice (engine: program "eval_wide")
         self.tf256 = bool(tf256)
+        # ... and where the batch does NOT fill the chip that way: the same launch with every row block's heads split over a
+        # PAIR of workgroups that hand each other their partial sums inside the launch (k_tf256 NSPLIT = 2; MDT_TF256_PAIR=0:
+        # one head-split launch per sub-block, k_tblock32, as in rounds 1-2)
+        self.tf256_pair = os.environ.get("MDT_TF256_PAIR", "1") == "1"
+        self.pair_stride = int(os.environ.get("MDT_PAIR_STRIDE", "8"))
+        self.xchg_tokens = 0                 # max tokens per sample over the pair-split ops (sizes the hand-off buffers)
         if gemm_mode not in ("f32", "bf16x3", "bf16"):
             raise ValueError("gemm_mode must be 'f32' (exact fp32 MFMA), 'bf16x3' (split-bf16 MFMA, fp32-class) or 'bf16' "
                              "(plain bf16 products, reduced precision: layer-by-layer GEMMs only)")
@@ -959,7 +968,7 @@ class UNetCompiler:
         return y
 
     def tf256_ok(self, c: int, rows: int, layers: int, cross: bool) -> bool:
-        if not (self.tf256 and self.gemm_mode == "bf16x3" and self.fuse_blocks and self.fold_out):
+        if not ((self.tf256 or self.tf256_pair) and self.gemm_mode == "bf16x3" and self.fuse_blocks and self.fold_out):
             return False
         if c != 256 or rows > 16 or 16 % rows or self.cfg.head_features != 64 or layers < 1:
             return False
@@ -971,43 +980,52 @@ class UNetCompiler:
         """Transformer1d.forward (modules.py:519-524) of a 256-channel level as ONE MDT_OP_TF256 (csrc/k_tf256.hip): 32 KB
         sub-tiles in consumption order, two scratch descriptors behind every sub-block (the wave pairs' partial sums meet
         there; the first one carries the next sub-block's vectors), K columns of residual-stream consumers in accumulator
-        order."""
+        order.  Pair-split form (self.tf256 False): TWO descriptor tables over one tile pool -- half hh lists only its heads /
+        hidden chunks / to_in output chunks / folded to_out k chunks -- and two more barrier-only descriptors per sub-block for
+        the hand-off between the two workgroups."""
         cfg, sd = self.cfg, self.sd
         rows, mid = x.rows, cfg.mid_features
         heads, nff = mid // 64, c * cfg.ff_mult // 64
+        nsplit = 1 if self.tf256 else 2
         acc = torch.tensor([16 * (2 * (k >> 5) + ((k & 7) >> 2)) + 4 * ((k >> 3) & 3) + (k & 3) for k in range(c)])
         slot = torch.tensor(self._SLOT_PERM)
         P, O, K, V, SCR, SCRV = 0, 1, 2, 3, 4, 5
         tiles: List[torch.Tensor] = []
-        desc: List[int] = []
+        descs: List[List[int]] = [[] for _ in range(nsplit)]
         vecs: List[torch.Tensor] = []
 
-        def sub(t: torch.Tensor, kind: int) -> None:
-            desc.append(kind | (len(tiles) << 3))
+        def half_of(index: int, count: int) -> int:          # which workgroup of the pair takes item `index` of `count`
+            return index * nsplit // count
+
+        def sub(t: torch.Tensor, kind: int, hh: int) -> None:
+            descs[hh].append(kind | (len(tiles) << 3))
             tiles.append(self._tile(t))
 
-        def ptile(w: torch.Tensor) -> None:                  # [64][256] projection tile -> its two K halves
+        def ptile(w: torch.Tensor, hh: int) -> None:         # [64][256] projection tile -> its two K halves
             wp = w[:, acc]
-            sub(wp[:, :128], P)
-            sub(wp[:, 128:], P)
+            sub(wp[:, :128], P, hh)
+            sub(wp[:, 128:], P, hh)
 
-        def otile(w: torch.Tensor) -> None:                  # [256][64] output tile -> its two row halves
-            sub(w[:128], O)
-            sub(w[128:], O)
+        def otile(w: torch.Tensor, hh: int) -> None:         # [256][64] output tile -> its two row halves
+            sub(w[:128], O, hh)
+            sub(w[128:], O, hh)
 
         def end_subblock(v: List[torch.Tensor], last: bool = False) -> None:
             flat = torch.cat([t.float().reshape(-1) for t in v])
             assert flat.numel() <= 768
             vecs.append(torch.cat([flat, torch.zeros(768 - flat.numel())]))
             nxt = len(vecs)                                  # index of the next sub-block's vectors
-            desc.append(SCR if last else (SCRV | ((((768 * nxt) // 256) << 1 | (nxt & 1)) << 3)))
-            desc.append(SCR)
+            for d in descs:
+                d.append(SCR if last else (SCRV | ((((768 * nxt) // 256) << 1 | (nxt & 1)) << 3)))
+                d.append(SCR)
+                if nsplit == 2:
+                    d += [SCR, SCR]                          # the hand-off's two barriers
 
         g_in, b_in = sd[p + "to_in.0.weight"].double(), sd[p + "to_in.0.bias"].double()
         w_in = sd[p + "to_in.1.weight"].reshape(c, c).double()
         w_in_f = (w_in * g_in.unsqueeze(0)).float()
         for ch in range(c // 64):
-            ptile(w_in_f[64 * ch: 64 * ch + 64])
+            ptile(w_in_f[64 * ch: 64 * ch + 64], half_of(ch, c // 64))
         end_subblock([(w_in @ b_in + sd[p + "to_in.1.bias"].double()).float()])
         self.flops += 2 * rows * c * c
         cross0 = len(self.cross_layers)
@@ -1021,10 +1039,11 @@ class UNetCompiler:
             wq_f, bq_f = wq * g_q.unsqueeze(0), wq @ b_q
             wkv_f, bkv_f = wkv * g_c.unsqueeze(0), wkv @ b_c
             for h in range(heads):
-                ptile(wq_f[64 * h: 64 * h + 64])
-                ptile(wkv_f[64 * h: 64 * h + 64])
-                ptile(wkv_f[mid + 64 * h: mid + 64 * h + 64])
-                otile(wo[:, 64 * h: 64 * h + 64][:, slot])
+                hh = half_of(h, heads)
+                ptile(wq_f[64 * h: 64 * h + 64], hh)
+                ptile(wkv_f[64 * h: 64 * h + 64], hh)
+                ptile(wkv_f[mid + 64 * h: mid + 64 * h + 64], hh)
+                otile(wo[:, 64 * h: 64 * h + 64][:, slot], hh)
             end_subblock([bq_f, bo + wo @ bkv_f[mid:]])
             self.flops += 2 * rows * c * 3 * mid + 4 * rows * rows * mid + 2 * rows * mid * c
             if cross:
@@ -1036,10 +1055,11 @@ class UNetCompiler:
                 wo, bo = sd[cp + "attention.to_out.weight"], sd[cp + "attention.to_out.bias"]
                 wq_f, bq_f = wq * g_q.unsqueeze(0), wq @ b_q
                 for h in range(heads):
-                    ptile(wq_f[64 * h: 64 * h + 64])
-                    desc.append(K | ((layer << 4 | h) << 3))
-                    desc.append(V | ((layer << 4 | h) << 3))
-                    otile(wo[:, 64 * h: 64 * h + 64][:, slot])
+                    hh = half_of(h, heads)
+                    ptile(wq_f[64 * h: 64 * h + 64], hh)
+                    descs[hh].append(K | ((layer << 4 | h) << 3))
+                    descs[hh].append(V | ((layer << 4 | h) << 3))
+                    otile(wo[:, 64 * h: 64 * h + 64][:, slot], hh)
                 end_subblock([bq_f, bo])
                 self.flops += 2 * rows * c * mid + 4 * rows * self.n_ctx * mid + 2 * rows * mid * c
             fp = bp + "feed_forward."
@@ -1050,15 +1070,18 @@ class UNetCompiler:
                 wout, bout = sd[p + "to_out.1.weight"].reshape(c, c).double(), sd[p + "to_out.1.bias"].double()
                 w2, b2 = (wout @ w2.double()).float(), (wout @ b2.double() + bout).float()
             for h in range(nff):
-                ptile(w1[64 * h: 64 * h + 64])
-                otile(w2[:, 64 * h: 64 * h + 64][:, slot])
+                hh = half_of(h, nff)
+                ptile(w1[64 * h: 64 * h + 64], hh)
+                otile(w2[:, 64 * h: 64 * h + 64][:, slot], hh)
             if last:
                 wout_f = sd[p + "to_out.1.weight"].reshape(c, c)
                 for e in range(c // 64):
-                    otile(wout_f[:, acc[64 * e: 64 * e + 64]])
+                    otile(wout_f[:, acc[64 * e: 64 * e + 64]], half_of(e, c // 64))
                 self.flops += 2 * rows * c * c
             end_subblock([b1, b2], last=last)
             self.flops += 2 * 2 * rows * c * w1.shape[0]
+        assert all(len(d) == len(descs[0]) for d in descs)
+        desc = [v for d in descs for v in d]
         y = self._new(rows, c)
         op = rt.MdtOp()
         op.kind = rt.OP_TF256
@@ -1069,7 +1092,11 @@ class UNetCompiler:
         op.bias = _ref(rt.SP_WEIGHT, self.W.add(p + "tf256.vec", v))
         op.p0 = _ref(rt.SP_WEIGHT, self.W.add(p + "tf256.desc", torch.tensor(desc, dtype=torch.int32).view(torch.float32)))
         i = op.i
-        i[rt.F_C], i[rt.F_T], i[rt.F_NT], i[rt.F_NVEC] = c, rows, len(desc), v.numel()
+        i[rt.F_C], i[rt.F_T], i[rt.F_NT], i[rt.F_NVEC] = c, rows, len(descs[0]), v.numel()
+        i[rt.F_NSPLIT], i[rt.F_PAIR_STRIDE] = nsplit, self.pair_stride
+        if nsplit == 2:
+            op.p2, op.p3 = _ref(rt.SP_EXT0 + EXT_XFLAGS, 0), _ref(rt.SP_EXT0 + EXT_XBUF, 0)
+            self.xchg_tokens = max(self.xchg_tokens, rows)
         i[rt.F_TK], i[rt.F_KV_BSTRIDE], i[rt.F_LDKV], i[rt.F_HEADS] = self.n_ctx, self.n_ctx, 2 * mid, heads
         i[rt.F_HAS_IN], i[rt.F_NBLOCKS], i[rt.F_NFF], i[rt.F_NPOST] = 1, layers, nff, 2 * (c // 64)
         i[rt.F_CROSS], i[rt.F_KV_LSTRIDE] = int(cross), self.n_ctx * 2 * mid
@@ -1606,7 +1633,8 @@ class UNetCompiler:
                             programs=programs, act_floats=act_floats, shr_floats=self.shr_top,
                             max_time_rows=rows, shr=dict(self.shr), ss_total=self.ss_total, n_cross=n_cross,
                             flops_per_sample_eval=flops_eval, flops_ctx_per_sample=flops_ctx, gemm_mode=self.gemm_mode,
-                            weight_index=dict(self.W.index), dual_multiple=dual_multiple)
+                            weight_index=dict(self.W.index), dual_multiple=dual_multiple, tf256=self.tf256,
+                            xchg_tokens=self.xchg_tokens)
 
 
 def C_memmove(dst: rt.MdtOp, src: rt.MdtOp) -> None:

@@ -196,8 +196,10 @@ bool gemm_b16_supported(int cin, int taps, int lda, int a_col) {
   return cin > 0 && cin % 64 == 0 && taps >= 1 && lda % 8 == 0 && a_col % 8 == 0;
 }
 
-// MDT_TILE16 = 0 (256 x 256), 1 (256 x 128), 2 (128 x 128) forces a tile (tuning aid, read once);
-// MDT_TILE16_LIVE: the same, read at every launch (tests walk the configurations in one process)
+// MDT_TILE16 = 0 (256 x 256), 1 (256 x 128), 2 (128 x 128) forces a tile (tuning aid, read once); mdt_set_tuning("tile16", v)
+// does the same at run time (tests walk the configurations in one process; -1 = automatic)
+static int g_force_tile16 = -1;
+void set_tile16(int v) { g_force_tile16 = v; }
 hipError_t launch_gemm_b16(const Gemm16Args& g, hipStream_t s) {
   if (g.M <= 0) return hipSuccess;
   if (!gemm_b16_supported(g.cin, g.taps, g.lda, g.a_col)) return hipErrorInvalidValue;
@@ -206,8 +208,7 @@ hipError_t launch_gemm_b16(const Gemm16Args& g, hipStream_t s) {
     force0 = -1;
     if (const char* e = getenv("MDT_TILE16")) force0 = atoi(e);
   }
-  int force = force0;
-  if (const char* e = getenv("MDT_TILE16_LIVE")) if (*e) force = atoi(e);
+  const int force = g_force_tile16 >= 0 ? g_force_tile16 : force0;
   auto tiles = [&](int bm, int bn) { return (int64_t)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn); };
   int cfg = tiles(256, 256) >= 256 ? 0 : (tiles(256, 128) >= 256 ? 1 : 2);     // the largest tile that still fills 256 CUs
   if (force >= 0) cfg = force;

@@ -23,6 +23,23 @@
 //     LDS-DMA with the scratch tile in front of the sub-block.
 //
 // Ring protocol, sub-tile formats and the attention core are those of k_tblock32.hip / k_tblock_lw.hip.
+//
+// NSPLIT = 2 (the form for batches that do not fill the chip with 32-row workgroups, e.g. 128 row blocks at B = 1024): the
+// heads / hidden chunks / to_in output chunks of a row block are split over a PAIR of workgroups, each with its own tile
+// descriptor table (tiles + hh * NT) over the shared weight stream.  Both keep the whole residual row; at the end of every
+// sub-block, behind the wave pairs' exchange, the two workgroups HAND their 32 x 256 partial sums TO EACH OTHER inside the
+// launch and add them in a fixed order (half 0 + half 1), so both hold bitwise identical rows -- no partial-sum tensors between
+// launches, one launch per Transformer1d instead of one per sub-block.  The hand-off is the form MI355X_MICROARCH.md lists as
+// measured-valid for any placement of the two workgroups ("Hand-offs measured with sc1 loads", first row): 16-byte sc1 stores of
+// whole 128-byte lines, every storing wave s_waitcnt vmcnt(0), workgroup barrier, ONE lane's sc1 flag store; ONE wave polls the
+// partner's flag with sc1 loads, workgroup barrier, 16-byte sc1 loads.  tools/ubench/pair_handoff.hip: 2.2 us per 32 KB round
+// for partners on one XCD (workgroup ids 8 apart), 3.8 us on different XCDs, 0 stale pieces in 2 x 10^8 checks either way under
+// uneven load; correctness never depends on the placement, PAIR_STRIDE only picks the fast one.  The buffers are double-
+// buffered by the hand-off count of the launch, the flags count hand-offs monotonically across launches (both partners always
+// make the same number), a poll gives up after ~0.3 s and raises xflags[0] instead of hanging the GPU.  The stores / loads go
+// through __builtin_amdgcn_raw_buffer_* (aux = sc1): hipcc tracks their waits and the store-data hazard (an inline-asm
+// global_store_dwordx4 followed within two wait states by a VALU write to its data registers stores garbage: first version of
+// the probe).
 #include <cstdlib>
 #include <type_traits>
 
@@ -112,11 +129,16 @@ constexpr int KTM = 3;          // key tiles per wave (cross): at most 48 contex
 constexpr int RED_BYTES = KTM * 4 * 64 * 16;   // partial S^T exchange [key tile][4 waves][64 lanes] f32x4
 constexpr int VEC_FLOATS = 768;                // vectors of one sub-block: [bq 512 | bo 256], [b1 512 | b2 256], [b_in 256]
 constexpr int VEC_BYTES = VEC_FLOATS * 4;
+constexpr int AUX_SC1 = 16;                        // raw_buffer_* cache policy: sc1 (agent scope)
+constexpr int AUX_SC1_VOLATILE = 16 | (1 << 31);   // ... and not to be hoisted / merged (the flag poll)
+constexpr unsigned XBLOCK = 32 * C * 4;            // bytes one workgroup hands over per round
+constexpr unsigned long long POLL_TIMEOUT = 30000000ull;   // s_memrealtime ticks (100 MHz): 0.3 s
 
 }  // namespace
 
 // NPW: LDS-DMA pieces per loader wave per K / V tile = ceil(context rows of the workgroup / 16); 0 = no cross-attention
-template <int NPW>
+// NSPLIT: 1 = one workgroup per 32-row block; 2 = a pair of workgroups per block (see the head of the file)
+template <int NPW, int NSPLIT>
 __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   unsigned char* red_b = smem + NS * SLOT;
@@ -126,12 +148,23 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int NT = a.NT;
   const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(a.w);
+  // row block and half of this workgroup: linear id = (group, half, member) with PAIR_STRIDE members per group, so partners are
+  // PAIR_STRIDE ids apart (8: same XCD under the observed round-robin placement; 1: neighbours on different XCDs)
+  int rb = blockIdx.x, hh = 0;
+  const int nrb = (a.M + 31) / 32;
+  if constexpr (NSPLIT == 2) {
+    const int S = a.pair_stride, id = blockIdx.x;
+    const int grp = id / (2 * S), w = id - grp * 2 * S;
+    hh = w / S;
+    rb = grp * S + (w - hh * S);
+    if (rb >= nrb) return;                          // padding of the last group: both partners leave
+  }
 
   if (wave >= 4) {
     // ================= loader waves (k_tblock32.hip, descriptor-driven as k_tf128.hip) =================
     const int iw = wave - 4;
     __builtin_amdgcn_s_setprio(MDT_LOADER_PRIO);
-    const cu32p tiles = (cu32p)a.tiles;              // kind (3 bits) | aux << 3
+    const cu32p tiles = (cu32p)(a.tiles + (NSPLIT == 2 ? hh * NT : 0));   // kind (3 bits) | aux << 3
     const int lpP = lane >> 5;
     const int xP = (lane & 15) ^ lpP;
     const int baseP = ((lane >> 4) & 1) * (128 * CS) + lpP * (2 * CS);
@@ -145,7 +178,7 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
       voffP[q] = (unsigned)(U * (2 * CS) + ((xP ^ (U & 15)) << 4) + baseP);
       voffO[q] = (unsigned)(((inst * 8) / CS) * (128 * CS) + ((inst * 8) % CS) * 128 + ((xO ^ (4 * (inst & 1))) << 4) + baseO);
     }
-    const int sample0 = blockIdx.x * (32 / a.T);
+    const int sample0 = rb * (32 / a.T);
     const bool second = a.kv2 && sample0 >= a.nsamples / 2;      // dual batch: shared K / V rows for the second half
     unsigned voffKV[8];
     if constexpr (NPW > 0) {
@@ -230,7 +263,7 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
   // ================= compute waves =================
   const int i = lane & 15, g = lane >> 4;
   const int rt = wave >> 1, fh = wave & 1;
-  const int row0 = blockIdx.x * 32 + rt * 16;
+  const int row0 = rb * 32 + rt * 16;
   const int m = row0 + i;
   const bool mvalid = m < a.M;
   const int mc = mvalid ? m : a.M - 1;
@@ -238,6 +271,34 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
 
   // the residual stream: accT[ct][r] = x[row i][16 ct + 4 g + r]; both waves of a row tile hold the whole row
   f32x4 accT[NCT];
+#ifdef MDT_STAMPS   // tuning build: wave 0 of the two workgroups of row block 0 record (source line << 48 | shader clock) at phase
+                    // boundaries behind the flag lines: xflags[64 + 64 nrb + 512 hh ...] (tools/tf256_bench.py allocates the room)
+  unsigned long long* stamps = reinterpret_cast<unsigned long long*>(a.xflags + 64 + 64 * nrb + 512 * hh);
+  int nstamp = 0;
+#define MDT_STAMP()                                                                                           \
+  do {                                                                                                        \
+    if (NSPLIT == 2 && rb == 0 && wave == 0 && nstamp < 250) {                                                \
+      unsigned long long t_;                                                                                  \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                              \
+      if (lane == 0) stamps[nstamp] = (t_ & 0xffffffffffffull) | ((unsigned long long)__LINE__ << 48);        \
+      ++nstamp;                                                                                               \
+    }                                                                                                         \
+  } while (0)
+#else
+#define MDT_STAMP() do {} while (0)
+#endif
+  // pair hand-off state (NSPLIT == 2): flag words xflags[64 + 32 * (2 rb + hh)] (one 128-byte line each; xflags[0..63] are
+  // diagnostics), hand-off blocks xbuf[parity][rb][hh][row tile][accumulator tile][lane] f32x4
+  unsigned xround = 0;                               // my flag's value = hand-offs I have completed, ever
+  int xn = 0;                                        // hand-offs of this launch (buffer parity)
+  __amdgpu_buffer_rsrc_t xres, fres;
+  const unsigned fown = (64u + 32u * (unsigned)(2 * rb + hh)) * 4u;
+  if constexpr (NSPLIT == 2) {
+    xres = __builtin_amdgcn_make_buffer_rsrc(a.xbuf, 0, 0x7fffffff, 0x00020000);
+    fres = __builtin_amdgcn_make_buffer_rsrc(a.xflags, 0, 0x7fffffff, 0x00020000);
+    xround = (unsigned)__builtin_amdgcn_readfirstlane(
+        __builtin_amdgcn_raw_buffer_load_b32(fres, 0, fown, AUX_SC1_VOLATILE));                      // written by an earlier LAUNCH
+  }
   {
     const float* xp = a.x + (int64_t)mc * C + 4 * g;
     float4 xr[NCT];
@@ -251,12 +312,10 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
   }
 
   // fragment addressing inside a sub-tile (k_tblock32.hip), this wave's feature half folded in
-  int aP[4];
-#pragma unroll
-  for (int st = 0; st < 4; ++st) {
-    const int lc = 4 * st + g;
-    aP[st] = fh * (2 * 16 * 4 * CS) + i * (4 * CS) + ((lc & ~15) | ((lc & 15) ^ i)) * 16;
-  }
+  // aP(st) = fh * 16384 + i * 512 + ((4 st + g) ^ i) * 16 = aP0 ^ (64 st): ONE register instead of four (4 st only touches bits 6-7 of
+  // the address, which nothing else carries into)
+  const int aP0 = fh * (2 * 16 * 4 * CS) + i * (4 * CS) + ((g ^ i) & 15) * 16;
+  auto aP = [&](int st) -> int { return aP0 ^ (64 * st); };
   const int aO = i * 128 + ((4 * fh + g) ^ ((i >> 1) & 7)) * 16;
 
   bf16x8 frh[3][2], frl[3][2];
@@ -273,7 +332,7 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
   auto prefetch2 = [&](auto kind, const unsigned char* slot, int off) {
     constexpr int KIND = decltype(kind)::value;
     const unsigned l = lds_addr(slot);
-    const unsigned b0 = l + (KIND == K_O ? aO : aP[0]), b1 = l + (KIND == K_O ? aO : aP[1]);
+    const unsigned b0 = l + (KIND == K_O ? aO : aP(0)), b1 = l + (KIND == K_O ? aO : aP(1));
     frag_read(kind, b0, J0{}, off % 3, J0{}); frag_read(kind, b0, J0{}, off % 3, J1{});
     frag_read(kind, b0, J0{}, off % 3, J2{}); frag_read(kind, b0, J0{}, off % 3, J3{});
     frag_read(kind, b1, J1{}, (off + 1) % 3, J0{}); frag_read(kind, b1, J1{}, (off + 1) % 3, J1{});
@@ -289,9 +348,9 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
     const unsigned lc = lds_addr(slot_of(tau)), ln = lds_addr(slot_of(tau + 1));
     unsigned bc[4], bn[2];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) bc[k] = lc + (KIND == K_O ? aO : aP[k]);
+    for (int k = 0; k < 4; ++k) bc[k] = lc + (KIND == K_O ? aO : aP(k));
 #pragma unroll
-    for (int k = 0; k < 2; ++k) bn[k] = ln + (NK == K_O ? aO : aP[k]);
+    for (int k = 0; k < 2; ++k) bn[k] = ln + (NK == K_O ? aO : aP(k));
     auto unit = [&](auto uc) {
       constexpr int u = decltype(uc)::value;
       if (u == NU - 2 && has_next) {
@@ -336,15 +395,27 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
   const IC2 kO{};
 
   const int samp_q = i / a.T;
-  float kmask[4];
+  unsigned kbits = 0;                                // bit r: key 4 g + r belongs to this lane's sample (self-attention mask)
 #pragma unroll
-  for (int r = 0; r < 4; ++r) kmask[r] = ((4 * g + r) / a.T == samp_q) ? 0.f : -INFINITY;
+  for (int r = 0; r < 4; ++r) kbits |= ((4 * g + r) / a.T == samp_q) ? (1u << r) : 0u;
   const float scale2 = a.scale * 1.44269504088896340736f;
   int nkeys = 0, Rw = 0;
   unsigned okbits = 0;
+  // K / V rows of this wave inside a K / V tile: row R = Rw + 16 kt + (i | 4 g + r), 256 bytes, 16-byte chunks XOR-swizzled with
+  // R & 15 (independent of kt): ONE base per operand, the key tile kt is an immediate offset of 4096 bytes and the second
+  // 16-feature half is the base ^ 64.  Rows past the wave's keys (up to row 95 of the 128-row slot) hold other samples' rows or
+  // older tiles -- finite fp32 bit patterns in either case (every slot is filled by weight sub-tiles before the first K / V
+  // tile: bf16 pairs whose upper half is a finite bf16) -- and meet a probability of exactly 0.
+  unsigned kb0 = 0, vb0[4] = {0, 0, 0, 0};
   if constexpr (NPW > 0) {
     nkeys = (16 / a.T) * a.Tk;
     Rw = rt * nkeys;
+    kb0 = (unsigned)((Rw + i) * 256 + (((8 * fh + g) ^ ((Rw + i) & 15)) << 4));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int R = Rw + 4 * g + r;
+      vb0[r] = (unsigned)(R * 256 + (i & 3) * 4 + (((8 * fh + (i >> 2)) ^ (R & 15)) << 4));
+    }
 #pragma unroll
     for (int kt = 0; kt < KTM; ++kt)
 #pragma unroll
@@ -370,7 +441,9 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
     for (int ct = 0; ct < NCT; ++ct) s[ct] = dpp_fma(s[ct], t8, std::integral_constant<int, 0x140>{});
   };
 
+  MDT_STAMP();                                       // entry -> row loads issued, lane constants
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  MDT_STAMP();                                       // rows arrived
   __builtin_amdgcn_s_barrier();                      // B(0)
   prefetch2(kT, slot_of(0), 0);
   const unsigned vec_l0 = lds_addr(vec_b);
@@ -414,7 +487,7 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
       const float4 b = *reinterpret_cast<const float4*>(p + 16 * ct);
       const f32x4 bb = f32x4{b.x, b.y, b.z, b.w};
       const f32x4 mine = keep_residual ? accT[ct] + bb : bb;
-      accT[ct] = fh ? zero4 : mine;
+      accT[ct] = (fh | hh) ? zero4 : mine;
     }
   };
   // end of a sub-block: the two feature-half waves of a row tile add their partial accumulators through the two scratch
@@ -436,14 +509,71 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // read before the slot can be refilled (two barriers later)
     ++tau;
   };
+  // NSPLIT == 2: the two workgroups of the pair hand each other their 32 x 256 partial sums (head of the file); two
+  // barrier-only tiles of the stream (descriptor kind 4) keep the loader waves in step.  Every wave holds its row tile's 16
+  // accumulator tiles after the wave pairs' exchange; wave (rt, fh) publishes tiles 8 fh .. 8 fh + 7 and reads all 16 of the
+  // partner's.
+  auto pair_handoff = [&]() {
+    if constexpr (NSPLIT == 2) {
+      // wave-uniform part of the addresses in the scalar offset (an SGPR), the lane's 16 bytes in the vector offset
+      const unsigned sbase = __builtin_amdgcn_readfirstlane(
+          (((unsigned)(xn & 1) * (unsigned)nrb + (unsigned)rb) * 2u + (unsigned)hh) * XBLOCK + (unsigned)rt * (16u * 1024u));
+      const unsigned vlane = (unsigned)lane * 16u;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const f32x4 lo_ = accT[c], hi_ = accT[8 + c];
+        const f32x4 v = f32x4{fh ? hi_[0] : lo_[0], fh ? hi_[1] : lo_[1], fh ? hi_[2] : lo_[2], fh ? hi_[3] : lo_[3]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), xres, vlane, sbase + (unsigned)(8 * fh + c) * 1024u, AUX_SC1);
+      }
+      MDT_STAMP();                                       // hand-off: stores issued
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave, in front of the barrier the flag store follows
+      MDT_STAMP();                                       // ... drained
+      __builtin_amdgcn_s_barrier();                      // B(first hand-off tile)
+      MDT_STAMP();                                       // ... every wave of the workgroup drained
+      ++xround;
+      if (wave == 0) {
+        __builtin_amdgcn_raw_buffer_store_b32((int)xround, fres, 0, fown, AUX_SC1);
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (;;) {
+          const unsigned got = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(fres, 0, fown ^ 128u, AUX_SC1_VOLATILE);
+          if ((int)(got - xround) >= 0) break;
+          __builtin_amdgcn_s_sleep(2);
+          if (__builtin_amdgcn_s_memrealtime() - t0 > POLL_TIMEOUT) {   // never hang the GPU: flag the launch and go on
+            if (lane == 0) atomicOr(a.xflags, 1u);
+            break;
+          }
+        }
+      }
+      MDT_STAMP();                                       // ... partner's flag seen
+      __builtin_amdgcn_s_barrier();                      // B(second hand-off tile): the partner's block is complete
+      const unsigned sother = sbase ^ XBLOCK;            // the same block of half hh ^ 1
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        f32x4 o[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+          o[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, vlane, sother + (unsigned)(8 * half + c) * 1024u,
+                                                                                 AUX_SC1_VOLATILE));
+#pragma unroll
+        for (int c = 0; c < 8; ++c) accT[8 * half + c] = hh ? (o[c] + accT[8 * half + c]) : (accT[8 * half + c] + o[c]);
+      }
+      ++xn;
+      tau += 2;
+      MDT_STAMP();                                       // ... partner's block added
+    }
+  };
   auto exchange = [&]() {
+    MDT_STAMP();                                         // sub-block streamed
     exchange_half(std::integral_constant<int, 0>{});
     exchange_half(std::integral_constant<int, 1>{});
     vpar ^= 1;
+    MDT_STAMP();                                         // wave pairs exchanged
+    pair_handoff();
   };
   auto next_subblock = [&]() {                       // first tile of the next sub-block: always a projection sub-tile
     __builtin_amdgcn_s_barrier();                    // B(tau)
     prefetch2(kT, slot_of(tau), 0);
+    MDT_STAMP();                                     // next sub-block's first tile there
   };
 
   // ---- Transformer1d.to_in: GroupNorm(32 groups of 8 channels, over the sample's tokens) + Conv1d(k = 1) ----
@@ -473,50 +603,86 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
     }
     make_operands(false);
     // this wave produces output channels 64 c + 32 fh + 16 q + (4 g + r), i.e. accumulator tiles 4 c + 2 fh + q, complete
-    // sums (both K halves); the other half of the tiles stays zero and arrives through the exchange; bias on wave 0 only
+    // sums (both K halves); the other tiles stay zero and arrive through the exchanges; bias on wave 0 (of half 0) only
     const float* bp = reinterpret_cast<const float*>(vec_b + vpar * VEC_BYTES) + 4 * g;
-    auto in_chunk = [&](auto cc, auto o0, auto o1, bool more) {
-      constexpr int c = decltype(cc)::value;
-      f32x4 t[2] = {zero4, zero4};
-      phase(kT, o0, kT, true, t, xh, xl);            // K half 0
-      phase(kT, o1, kT, more, t, xh + 4, xl + 4);    // K half 1
+    if constexpr (NSPLIT == 1) {
+      auto in_chunk = [&](auto cc, auto o0, auto o1, bool more) {
+        constexpr int c = decltype(cc)::value;
+        f32x4 t[2] = {zero4, zero4};
+        phase(kT, o0, kT, true, t, xh, xl);            // K half 0
+        phase(kT, o1, kT, more, t, xh + 4, xl + 4);    // K half 1
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 b = *reinterpret_cast<const float4*>(bp + 16 * (4 * c + q));
-        const f32x4 bb = fh ? zero4 : f32x4{b.x, b.y, b.z, b.w};
-        const f32x4 mine = (q >> 1) == 0 ? (fh ? zero4 : t[q & 1]) : (fh ? t[q & 1] : zero4);
-        accT[4 * c + q] = mine + bb;
+        for (int q = 0; q < 4; ++q) {
+          const float4 b = *reinterpret_cast<const float4*>(bp + 16 * (4 * c + q));
+          const f32x4 bb = fh ? zero4 : f32x4{b.x, b.y, b.z, b.w};
+          const f32x4 mine = (q >> 1) == 0 ? (fh ? zero4 : t[q & 1]) : (fh ? t[q & 1] : zero4);
+          accT[4 * c + q] = mine + bb;
+        }
+      };
+      in_chunk(IC0{}, IC0{}, IC1{}, true);
+      in_chunk(IC1{}, IC2{}, IC0{}, true);
+      in_chunk(IC2{}, IC1{}, IC2{}, true);
+      in_chunk(std::integral_constant<int, 3>{}, IC0{}, IC1{}, false);
+    } else {
+      // half hh owns output chunks 2 hh and 2 hh + 1 (its table holds only their sub-tiles): tiles 8 hh + 4 j + 2 fh + q
+      f32x4 t0[2] = {zero4, zero4}, t1[2] = {zero4, zero4};
+      phase(kT, IC0{}, kT, true, t0, xh, xl);
+      phase(kT, IC1{}, kT, true, t0, xh + 4, xl + 4);
+      phase(kT, IC2{}, kT, true, t1, xh, xl);
+      phase(kT, IC0{}, kT, false, t1, xh + 4, xl + 4);
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        const int hv = ct >> 3, j = (ct >> 2) & 1, fv = (ct >> 1) & 1, q = ct & 1;     // compile-time after unrolling
+        const float4 b = *reinterpret_cast<const float4*>(bp + 16 * ct);
+        const bool own = (hh == hv) && (fh == fv);
+        const f32x4 tv = j ? t1[q] : t0[q];
+        const bool first = (hh | fh) == 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float bias_r = r == 0 ? b.x : (r == 1 ? b.y : (r == 2 ? b.z : b.w));
+          accT[ct][r] = (own ? tv[r] : 0.f) + (first ? bias_r : 0.f);
+        }
       }
-    };
-    in_chunk(IC0{}, IC0{}, IC1{}, true);
-    in_chunk(IC1{}, IC2{}, IC0{}, true);
-    in_chunk(IC2{}, IC1{}, IC2{}, true);
-    in_chunk(std::integral_constant<int, 3>{}, IC0{}, IC1{}, false);
+    }
     exchange();
     next_subblock();
   }
 
-  const int nheads = a.nheads, nff = a.nff;
+  // this workgroup's heads / hidden chunks: h0 .. h0 + nheads - 1 of the module's a.nheads (biases are indexed globally)
+  const int nheads = a.nheads / NSPLIT, nff = a.nff / NSPLIT;
+  const int h0 = hh * nheads, f0 = hh * nff;
   for (int blk = 0; blk < a.nblocks; ++blk) {
     const bool last_blk = blk + 1 == a.nblocks;
-    const unsigned bias_l = 128u * (unsigned)fh + 16u * (unsigned)g;     // + parity base + 256 h
+    const unsigned bias_l = 128u * (unsigned)fh + 16u * (unsigned)g;     // + parity base + 256 (global head / chunk)
     // ================= x += Attention(x) =================
     {
       make_operands(true);
-      start_acc(64 * nheads, true);
-      const unsigned bl = vec_l0 + vpar * VEC_BYTES + bias_l;
+      start_acc(64 * a.nheads, true);
+      MDT_STAMP();                                     // LayerNorm + operand split done
+      const unsigned bl = vec_l0 + vpar * VEC_BYTES + bias_l + 256u * (unsigned)h0;
       for (int h = 0; h < nheads; ++h) {
         const bool more = h + 1 < nheads;
         f32x4 oT[2];
         f32x4 qT[2], kTt[2], vT[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) { kTt[q] = zero4; vT[q] = zero4; qT[q] = zero4; }
+#ifdef MDT_STAMPS_HEAD
+#define MDT_HSTAMP() do { if (blk == 0) MDT_STAMP(); } while (0)
+#else
+#define MDT_HSTAMP() do {} while (0)
+#endif
         phase(kT, IC0{}, kT, true, qT, xh, xl);
+        MDT_HSTAMP();
         phase(kT, IC1{}, kT, true, qT, xh + 4, xl + 4);
+        MDT_HSTAMP();
         phase(kT, IC2{}, kT, true, kTt, xh, xl);
+        MDT_HSTAMP();
         phase(kT, IC0{}, kN, true, kTt, xh + 4, xl + 4);
+        MDT_HSTAMP();
         phase(kN, IC1{}, kN, true, vT, xh, xl);
+        MDT_HSTAMP();
         phase(kN, IC2{}, kN, false, vT, xh + 4, xl + 4);
+        MDT_HSTAMP();
         {
           f32x4 bq[2];
           lds_read_f4_off<0>(bq[0], bl + 256 * h); lds_read_f4_off<64>(bq[1], bl + 256 * h);
@@ -541,7 +707,7 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
         float mx = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float sv = s01[r] * scale2 + kmask[r];
+          const float sv = ((kbits >> r) & 1u) ? s01[r] * scale2 : -INFINITY;
           st[r] = sv;
           mx = fmaxf(mx, sv);
         }
@@ -571,8 +737,11 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
           for (int e = 0; e < 8; ++e) v[e] = oT[e >> 2][e & 3];
           split8_tf(v, oh[0], ol[0]);
         }
+        MDT_HSTAMP();                                           // attention core done
         phase(kO, IC1{}, kO, true, accT, oh, ol);               // output rows 0..127
+        MDT_HSTAMP();
         phase(kO, IC2{}, kT, more, accT + 8, oh, ol);           // output rows 128..255
+        MDT_HSTAMP();
       }
       exchange();
       next_subblock();
@@ -580,8 +749,9 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
     // ================= x += Attention(x, context) =================
     if constexpr (NPW > 0) {
       make_operands(true);
-      start_acc(64 * nheads, true);
-      const unsigned bl = vec_l0 + vpar * VEC_BYTES + bias_l;
+      start_acc(64 * a.nheads, true);
+      MDT_STAMP();                                     // LayerNorm + operand split done
+      const unsigned bl = vec_l0 + vpar * VEC_BYTES + bias_l + 256u * (unsigned)h0;
       for (int h = 0; h < nheads; ++h) {
         const bool more = h + 1 < nheads;
         f32x4 oT[2];
@@ -602,10 +772,8 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
         float4 k0[KTM], k1[KTM];
 #pragma unroll
         for (int kt = 0; kt < KTM; ++kt) {
-          const int R = Rw + min(16 * kt + i, nkeys - 1);
-          const unsigned char* kp = sk + R * 256;
-          k0[kt] = *reinterpret_cast<const float4*>(kp + (((8 * fh + g) ^ (R & 15)) << 4));
-          k1[kt] = *reinterpret_cast<const float4*>(kp + (((8 * fh + 4 + g) ^ (R & 15)) << 4));
+          k0[kt] = *reinterpret_cast<const float4*>(sk + kb0 + 4096 * kt);
+          k1[kt] = *reinterpret_cast<const float4*>(sk + (kb0 ^ 64u) + 4096 * kt);
         }
         f32x4 sp0[KTM], sp1[KTM];
 #pragma unroll
@@ -659,10 +827,8 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
         for (int kt = 0; kt < KTM; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int R = Rw + min(16 * kt + 4 * g + r, nkeys - 1);
-            const unsigned char* vp = sv + R * 256 + (i & 3) * 4;
-            v0[kt][r] = *reinterpret_cast<const float*>(vp + (((8 * fh + (i >> 2)) ^ (R & 15)) << 4));
-            v1[kt][r] = *reinterpret_cast<const float*>(vp + (((8 * fh + 4 + (i >> 2)) ^ (R & 15)) << 4));
+            v0[kt][r] = *reinterpret_cast<const float*>(sv + vb0[r] + 4096 * kt);
+            v1[kt][r] = *reinterpret_cast<const float*>(sv + (vb0[r] ^ 64u) + 4096 * kt);
           }
 #pragma unroll
         for (int kt = 0; kt < KTM; ++kt)
@@ -693,8 +859,9 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
     {
       const int npost = last_blk ? a.npost : 0;
       make_operands(false);
-      start_acc(64 * nff, npost == 0);               // folded closing convolution: no residual (Wout x rides as tiles)
-      const unsigned bl = vec_l0 + vpar * VEC_BYTES + bias_l;
+      start_acc(64 * a.nff, npost == 0);             // folded closing convolution: no residual (Wout x rides as tiles)
+      MDT_STAMP();                                     // LayerNorm + operand split done
+      const unsigned bl = vec_l0 + vpar * VEC_BYTES + bias_l + 256u * (unsigned)f0;
       for (int h = 0; h < nff; ++h) {
         const bool more = h + 1 < nff;
         f32x4 oT[2];
@@ -736,39 +903,76 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
           oxh[0] = __builtin_bit_cast(bf16x8, hv);
           oxl[0] = __builtin_bit_cast(bf16x8, lv);
         };
-        pick(0); phase(kO, IC0{}, kO, true, accT, oxh, oxl); phase(kO, IC1{}, kO, true, accT + 8, oxh, oxl);
-        pick(1); phase(kO, IC2{}, kO, true, accT, oxh, oxl); phase(kO, IC0{}, kO, true, accT + 8, oxh, oxl);
-        pick(2); phase(kO, IC1{}, kO, true, accT, oxh, oxl); phase(kO, IC2{}, kO, true, accT + 8, oxh, oxl);
-        pick(3); phase(kO, IC0{}, kO, true, accT, oxh, oxl); phase(kO, IC1{}, kT, false, accT + 8, oxh, oxl);
+        if constexpr (NSPLIT == 1) {
+          pick(0); phase(kO, IC0{}, kO, true, accT, oxh, oxl); phase(kO, IC1{}, kO, true, accT + 8, oxh, oxl);
+          pick(1); phase(kO, IC2{}, kO, true, accT, oxh, oxl); phase(kO, IC0{}, kO, true, accT + 8, oxh, oxl);
+          pick(2); phase(kO, IC1{}, kO, true, accT, oxh, oxl); phase(kO, IC2{}, kO, true, accT + 8, oxh, oxl);
+          pick(3); phase(kO, IC0{}, kO, true, accT, oxh, oxl); phase(kO, IC1{}, kT, false, accT + 8, oxh, oxl);
+        } else {
+          // half hh takes the k chunks 2 hh and 2 hh + 1 of Wout x (register selects: hh and fh are not compile-time)
+          auto pick2 = [&](int j) {
+            const i32x4 a0 = __builtin_bit_cast(i32x4, xh[2 * j]), a1 = __builtin_bit_cast(i32x4, xh[2 * j + 1]);
+            const i32x4 a2 = __builtin_bit_cast(i32x4, xh[4 + 2 * j]), a3 = __builtin_bit_cast(i32x4, xh[5 + 2 * j]);
+            const i32x4 b0 = __builtin_bit_cast(i32x4, xl[2 * j]), b1 = __builtin_bit_cast(i32x4, xl[2 * j + 1]);
+            const i32x4 b2 = __builtin_bit_cast(i32x4, xl[4 + 2 * j]), b3 = __builtin_bit_cast(i32x4, xl[5 + 2 * j]);
+            i32x4 hv, lv;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              hv[k] = hh ? (fh ? a3[k] : a2[k]) : (fh ? a1[k] : a0[k]);
+              lv[k] = hh ? (fh ? b3[k] : b2[k]) : (fh ? b1[k] : b0[k]);
+            }
+            oxh[0] = __builtin_bit_cast(bf16x8, hv);
+            oxl[0] = __builtin_bit_cast(bf16x8, lv);
+          };
+          pick2(0); phase(kO, IC0{}, kO, true, accT, oxh, oxl); phase(kO, IC1{}, kO, true, accT + 8, oxh, oxl);
+          pick2(1); phase(kO, IC2{}, kO, true, accT, oxh, oxl); phase(kO, IC0{}, kT, false, accT + 8, oxh, oxl);
+        }
       }
       exchange();
       if (!last_blk) next_subblock();
     }
   }
 
-  // ---- the residual stream leaves the kernel once: wave (rt, fh) stores channels 128 fh .. 128 fh + 127 of its rows ----
+  // ---- the residual stream leaves the kernel once: wave (rt, fh) stores channels 128 fh .. 128 fh + 127 of its rows (NSPLIT
+  // == 2: both workgroups hold the same rows; half hh stores channels 128 fh + 64 hh .. + 63) ----
+  MDT_STAMP();
   if (mvalid) {
-    float* xo = a.out + (int64_t)m * C + 4 * g + 128 * fh;
+    if constexpr (NSPLIT == 1) {
+      float* xo = a.out + (int64_t)m * C + 4 * g + 128 * fh;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      // (component-wise value selects: a select between the two array ELEMENTS becomes a select of their addresses and
-      //  keeps the whole accumulator array in scratch memory)
-      const f32x4 lo_ = accT[c], hi_ = accT[8 + c];
-      store_nt(xo + 16 * c, make_float4(fh ? hi_[0] : lo_[0], fh ? hi_[1] : lo_[1], fh ? hi_[2] : lo_[2], fh ? hi_[3] : lo_[3]));
+      for (int c = 0; c < 8; ++c) {
+        // (component-wise value selects: a select between the two array ELEMENTS becomes a select of their addresses and
+        //  keeps the whole accumulator array in scratch memory)
+        const f32x4 lo_ = accT[c], hi_ = accT[8 + c];
+        store_nt(xo + 16 * c, make_float4(fh ? hi_[0] : lo_[0], fh ? hi_[1] : lo_[1], fh ? hi_[2] : lo_[2], fh ? hi_[3] : lo_[3]));
+      }
+    } else {
+      float* xo = a.out + (int64_t)m * C + 4 * g + 128 * fh + 64 * hh;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const f32x4 q0 = accT[c], q1 = accT[4 + c], q2 = accT[8 + c], q3 = accT[12 + c];
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fh ? (hh ? q3[r] : q2[r]) : (hh ? q1[r] : q0[r]);
+        store_nt(xo + 16 * c, make_float4(v[0], v[1], v[2], v[3]));
+      }
     }
   }
 }
 
-template <int NPW>
+template <int NPW, int NSPLIT>
 static hipError_t launch_tf2(const TFArgs& a, hipStream_t s) {
   const size_t smem = (size_t)NS * SLOT + RED_BYTES + 2 * VEC_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tf256<NPW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tf256<NPW, NSPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_tf256<NPW>), dim3((unsigned)((a.M + 31) / 32)), dim3(512), smem, s, a);
+  const int nrb = (a.M + 31) / 32;
+  unsigned grid = (unsigned)nrb;
+  if (NSPLIT == 2) grid = 2u * (unsigned)a.pair_stride * (unsigned)((nrb + a.pair_stride - 1) / a.pair_stride);
+  hipLaunchKernelGGL((k_tf256<NPW, NSPLIT>), dim3(grid), dim3(512), smem, s, a);
   return hipGetLastError();
 }
 
@@ -778,21 +982,31 @@ bool tf256_supported(int T, int Tk, int nheads, int nff, bool cross) {
   return true;
 }
 
+template <int NSPLIT>
+static hipError_t launch_tf256_n(const TFArgs& a, hipStream_t s) {
+  const bool cross = a.kv != nullptr;
+  if (!cross) return launch_tf2<0, NSPLIT>(a, s);
+  switch (((32 / a.T) * a.Tk + 15) / 16) {
+    case 1: return launch_tf2<1, NSPLIT>(a, s);
+    case 2: return launch_tf2<2, NSPLIT>(a, s);
+    case 3: return launch_tf2<3, NSPLIT>(a, s);
+    case 4: return launch_tf2<4, NSPLIT>(a, s);
+    case 5: return launch_tf2<5, NSPLIT>(a, s);
+    case 6: return launch_tf2<6, NSPLIT>(a, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 hipError_t launch_tf256(const TFArgs& a, hipStream_t s) {
   if (a.M <= 0) return hipSuccess;
   const bool cross = a.kv != nullptr;
   if (!tf256_supported(a.T, a.Tk, a.nheads, a.nff, cross) || a.nblocks <= 0 || a.NT <= 0) return hipErrorInvalidValue;
   if (a.npost != 0 && a.npost != 8) return hipErrorInvalidValue;
-  if (!cross) return launch_tf2<0>(a, s);
-  switch (((32 / a.T) * a.Tk + 15) / 16) {
-    case 1: return launch_tf2<1>(a, s);
-    case 2: return launch_tf2<2>(a, s);
-    case 3: return launch_tf2<3>(a, s);
-    case 4: return launch_tf2<4>(a, s);
-    case 5: return launch_tf2<5>(a, s);
-    case 6: return launch_tf2<6>(a, s);
-    default: return hipErrorInvalidValue;
+  if (a.nsplit == 2) {
+    if (!a.xbuf || !a.xflags || a.pair_stride <= 0 || a.pair_stride > 64) return hipErrorInvalidValue;
+    return launch_tf256_n<2>(a, s);
   }
+  return launch_tf256_n<1>(a, s);
 }
 
 }  // namespace mdt

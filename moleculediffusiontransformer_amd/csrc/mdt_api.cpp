@@ -36,7 +36,16 @@ struct mdt_timer {
 
 extern "C" {
 
+static int g_pair_stride = 0;    // mdt_set_tuning("pair_stride", v): overrides MDT_F_PAIR_STRIDE of every pair-split op (tests)
+
 void mdt_set_error(const char* msg) { g_err = msg ? msg : ""; }
+int mdt_set_tuning(const char* key, int32_t value) {
+  const std::string k = key ? key : "";
+  if (k == "pair_stride") { g_pair_stride = value; return 0; }
+  if (k == "tile16") { mdt::set_tile16(value); return 0; }
+  g_err = "mdt_set_tuning: unknown key '" + k + "'";
+  return 1;
+}
 const char* mdt_last_error(void) { return g_err.c_str(); }
 int mdt_abi_version(void) { return MDT_ABI_VERSION; }
 
@@ -157,7 +166,7 @@ static const char* validate(const mdt_op& o, int idx, char* buf, size_t nbuf) {
       const int32_t* i = o.i;
       if (i[MDT_F_C] != 128) return bad("fused transformer needs C = 128");
       if (!mdt::tf128_supported(i[MDT_F_T], i[MDT_F_TK], i[MDT_F_NVEC], i[MDT_F_CROSS] != 0))
-        return bad("shape not supported by the fused transformer (tokens per sample must divide 16, <= 16 context rows per 16 tokens, <= 7168 vector floats)");
+        return bad("shape not supported by the fused transformer (tokens per sample must divide 16, <= 16 context rows per 16 tokens, <= 8192 vector floats)");
       if (i[MDT_F_NBLOCKS] < 0 || i[MDT_F_NT] <= 0 || i[MDT_F_HEADS] <= 0 || i[MDT_F_HEADS] > 16 || i[MDT_F_NFF] <= 0)
         return bad("bad block / tile / head counts");
       if (i[MDT_F_NPOST] != 0 && i[MDT_F_NPOST] != 2) return bad("npost must be 0 or 2");
@@ -182,6 +191,9 @@ static const char* validate(const mdt_op& o, int idx, char* buf, size_t nbuf) {
       if (i[MDT_F_NPOST] != 0 && i[MDT_F_NPOST] != 8) return bad("npost must be 0 or 8");
       if (!o.a.space || !o.out.space || !o.w.space || !o.bias.space || !o.p0.space) return bad("missing operand");
       if (i[MDT_F_CROSS] && !o.a2.space) return bad("cross-attention blocks need the hoisted K/V rows");
+      if (i[MDT_F_NSPLIT] != 0 && i[MDT_F_NSPLIT] != 1 && i[MDT_F_NSPLIT] != 2) return bad("NSPLIT must be 1 or 2");
+      if (i[MDT_F_NSPLIT] == 2 && (!o.p2.space || !o.p3.space || i[MDT_F_PAIR_STRIDE] < 0 || i[MDT_F_PAIR_STRIDE] > 64))
+        return bad("the pair-split form needs the hand-off flags (p2), the hand-off blocks (p3) and a pair stride of 1..64");
       break;
     }
     default:
@@ -419,6 +431,10 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
         a.skip_stride = (int64_t)B * a.T * i[MDT_F_C] * (a.res_kind == 2 ? -1 : 1);
         a.skip_scale = o.f[MDT_FF_SKIP_SCALE]; a.eps_res = o.f[MDT_FF_EPS_RES];
         a.pf_ptr = pf_ptr; a.pf_lines = pf_lines;
+        a.nsplit = wide && i[MDT_F_NSPLIT] == 2 ? 2 : 1;
+        a.pair_stride = g_pair_stride > 0 ? g_pair_stride : (i[MDT_F_PAIR_STRIDE] > 0 ? i[MDT_F_PAIR_STRIDE] : 8);
+        a.xflags = a.nsplit == 2 ? reinterpret_cast<unsigned*>(const_cast<float*>(ptr(o.p2))) : nullptr;
+        a.xbuf = a.nsplit == 2 ? const_cast<float*>(ptr(o.p3)) : nullptr;
         if (i[MDT_F_KV2]) {
           const int per_wg = (wide ? 32 : 64) / a.T;
           if (!o.p1.space || B % 2 || (B / 2) % (per_wg > 0 ? per_wg : 1))

@@ -63,6 +63,7 @@ struct Gemm16Args {
 };
 bool gemm_b16_supported(int cin, int taps, int lda, int a_col);
 hipError_t launch_gemm_b16(const Gemm16Args& g, hipStream_t s);
+void set_tile16(int v);          // tuning hook behind mdt_set_tuning("tile16", v)
 struct Prep16Args {
   const float* a;
   unsigned short* out;        // bf16 [total_rows][cin]
@@ -86,11 +87,12 @@ __device__ __forceinline__ void prefetch_next_weights(const void* p, int lines, 
   const int per = (lines + nx - 1) / nx;
   const int lo = xw * per, hi = lo + per < lines ? lo + per : lines;
   const unsigned char* b = reinterpret_cast<const unsigned char*>(p);
-  for (int l = lo + lane256; l < hi; l += 256) {
-    unsigned v;
-    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(b + (int64_t)l * 128) : "memory");
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // volatile loads through the compiler: it tracks the landing registers and places the waits itself (an inline-asm load with a
+  // bare "=v" output may have its register reused while the load is still in flight); the values are folded into a sink the
+  // optimiser cannot drop
+  unsigned acc = 0;
+  for (int l = lo + lane256; l < hi; l += 256) acc |= *reinterpret_cast<const volatile unsigned*>(b + (int64_t)l * 128);
+  asm volatile("" :: "v"(acc));
 }
 #endif
 
@@ -219,6 +221,11 @@ struct TFArgs {
   float skip_scale, eps_res;
   const void* pf_ptr;    // weight stream of the NEXT launch (pulled into the L2s by the loader waves), or nullptr
   int pf_lines;
+  // MDT_OP_TF256 with the row blocks' heads split over workgroup PAIRS (k_tf256.hip, NSPLIT = 2)
+  int nsplit;            // 1 | 2; 2: `tiles` holds two descriptor tables of NT entries (half 0, half 1)
+  int pair_stride;       // workgroup ids of a pair are this far apart (8: same XCD as observed; 1: neighbours)
+  float* xbuf;           // hand-off blocks [2 parities][row blocks][2 halves][32 x 256] fp32
+  unsigned* xflags;      // [0..63] diagnostics (bit 0 of word 0: a poll timed out); from word 64: one 128-byte line per (row block, half)
 };
 bool tf128_supported(int T, int Tk, int nvec, bool cross);
 hipError_t launch_tf128(const TFArgs& a, hipStream_t s);

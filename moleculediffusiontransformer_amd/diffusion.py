@@ -119,7 +119,7 @@ class ADPM2Sampler(Sampler):
 
     def forward(self, noise, fn: Callable, sigmas: Tensor, num_steps: int) -> Tensor:
         """diffusion.py:517-524.  ``noise`` is the initial draw (B, C, L) or, on the fused path, a NoiseSource."""
-        fused = getattr(fn, "fused", None)
+        fused = getattr(fn, "fused", None) if type(self).step is ADPM2Sampler.step else None   # a subclass's step() is honoured
         if fused is not None:
             return fused.sample(noise, self, sigmas, num_steps)
         if isinstance(noise, NoiseSource):
@@ -132,7 +132,7 @@ class ADPM2Sampler(Sampler):
     def inpaint(self, source: Tensor, mask: Tensor, fn: Callable, sigmas: Tensor, num_steps: int,
                 num_resamples: int) -> Tensor:
         """diffusion.py:526-549."""
-        fused = getattr(fn, "fused", None)
+        fused = getattr(fn, "fused", None) if type(self).step is ADPM2Sampler.step else None
         if fused is not None:
             return fused.inpaint(source, mask, self, sigmas, num_steps, num_resamples)
         x = float(sigmas[0]) * torch.randn_like(source)
@@ -222,9 +222,23 @@ class BoundDenoise:
     ADPM2Sampler.forward / inpaint take the whole loop instead of calling back per step."""
 
     def __init__(self, denoise_fn: Callable, kwargs: dict, extra: Optional[dict] = None):
-        self.denoise_fn, self.kwargs = denoise_fn, dict(kwargs)
-        owner = getattr(getattr(denoise_fn, "__self__", None), "_owner", None)
-        self.fused = owner._fused_adapter(self.kwargs, extra or {}) if owner is not None else None
+        self.denoise_fn, self.kwargs, self._extra = denoise_fn, dict(kwargs), dict(extra or {})
+        self._owner = getattr(getattr(denoise_fn, "__self__", None), "_owner", None)
+        self._fused = False            # not built yet
+
+    @property
+    def fused(self):
+        """Built on first use (a custom Sampler that only calls back per step never needs it); None when the denoiser is
+        not a QMDiffusion* model's, or when the call carries kwargs the fused loop does not take (they then reach
+        denoise_fn through the per-step path, which raises or accepts them exactly as the callable does)."""
+        if self._fused is False:
+            self._fused = None
+            if self._owner is not None:
+                try:
+                    self._fused = self._owner._fused_adapter(self.kwargs, self._extra)
+                except TypeError:
+                    self._fused = None
+        return self._fused
 
     def __call__(self, *a, **ka):
         return self.denoise_fn(*a, **{**ka, **self.kwargs})
@@ -247,10 +261,13 @@ class DiffusionSampler(nn.Module):
     def forward(self, noise, num_steps: Optional[int] = None, *, trace=None, timer=None, tokens=None, **kwargs) -> Tensor:
         num_steps = self.num_steps if num_steps is None else num_steps
         assert num_steps is not None, "Parameter `num_steps` must be provided"
-        sigmas = self.sigma_schedule(num_steps)
+        device = kwargs["embedding"].device if isinstance(kwargs.get("embedding"), torch.Tensor) else None
+        sigmas = self.sigma_schedule(num_steps, device)             # diffusion.py:585: (num_steps, device)
         fn = BoundDenoise(self.denoise_fn, kwargs, dict(trace=trace, timer=timer, tokens=tokens, clamp=self.clamp))
         x = self.sampler(noise, fn=fn, sigmas=sigmas, num_steps=num_steps)
-        if fn.fused is None and self.clamp:          # the fused loop applies the final clamp itself (mdt_clamp)
+        took_fused = (fn.fused is not None and isinstance(self.sampler, ADPM2Sampler)
+                      and type(self.sampler).step is ADPM2Sampler.step)
+        if not took_fused and self.clamp:            # the fused loop applies the final clamp itself (mdt_clamp)
             x = x.clamp(-1.0, 1.0)
         return x
 
@@ -269,7 +286,7 @@ class DiffusionInpainter(nn.Module):
     @torch.no_grad()
     def forward(self, inpaint: Tensor, inpaint_mask: Tensor, *, draw=None, seed=None, **kwargs) -> Tensor:
         fn = BoundDenoise(self.denoise_fn, kwargs, dict(draw=draw, seed=seed))
-        return self.inpaint_fn(source=inpaint, mask=inpaint_mask, fn=fn, sigmas=self.sigma_schedule(self.num_steps),
+        return self.inpaint_fn(source=inpaint, mask=inpaint_mask, fn=fn, sigmas=self.sigma_schedule(self.num_steps, inpaint.device),
                                num_steps=self.num_steps, num_resamples=self.num_resamples)
 
 

@@ -2,7 +2,11 @@
 collective inside the step loop, ONE all-gather of the generated samples per call (RCCL over xGMI;
 backend "nccl" is RCCL on ROCm).  No cross-sample op exists on the path, so sharding
 the batch axis is exact: with the counter-based noise keyed by the GLOBAL sample index an N-rank run
-returns the same samples as a 1-rank run.
+returns the same samples as a 1-rank run -- bit for bit as long as both run the same kernels.  The one
+batch-dependent kernel choice of the package (the form of the 256-channel transformers,
+generative._QMBase._wide) is therefore PINNED for a sharded call: sample_sharded(..., model=m) resolves it
+once from the largest shard, on every rank alike, and a later 1-rank run of any sub-batch on the same model
+reproduces the rows exactly (m.kernel_choice stays pinned until pin_kernel_choice(None)).
 """
 from __future__ import annotations
 
@@ -40,11 +44,25 @@ def all_gather_samples(local: Tensor, total: int, group=None) -> Tensor:
     return torch.cat([out[r * mx: r * mx + s] for r, s in enumerate(sizes)])
 
 
-def sample_sharded(local_sample: Callable[[Tensor, int], Tensor], sequences: Tensor, group=None) -> Tensor:
+def pin_for_shards(model, total: int, world: int, guided: bool = False) -> Optional[str]:
+    """Pin ``model``'s batch-dependent kernel choice from the LARGEST shard of ``total`` samples over ``world`` ranks (the
+    same value on every rank), unless it is pinned already.  Returns the choice in force (None without a model)."""
+    if model is None:
+        return None
+    if getattr(model, "kernel_choice", "auto") == "auto":
+        lo, hi = shard_bounds(total, world, 0)
+        model.pin_kernel_choice((hi - lo) * (2 if guided else 1))
+    return model.kernel_choice
+
+
+def sample_sharded(local_sample: Callable[[Tensor, int], Tensor], sequences: Tensor, group=None, model=None,
+                   guided: bool = False) -> Tensor:
     """Every rank passes the same global `sequences` (B, n); rank r generates samples for its contiguous
-    slice via ``local_sample(seq_slice, first_global_index)`` and all ranks receive the full result."""
+    slice via ``local_sample(seq_slice, first_global_index)`` and all ranks receive the full result.  ``model``: the
+    QMDiffusion* object ``local_sample`` calls, so that its kernel choice is pinned shard-independently (module docstring)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
+    pin_for_shards(model, sequences.shape[0], world, guided)
     lo, hi = shard_bounds(sequences.shape[0], world, rank)
     local = local_sample(sequences[lo:hi], lo)
     if world == 1:
@@ -60,10 +78,11 @@ def all_gather_tokens(local: Tensor, total: int, vocab: int, group=None) -> Tens
 
 
 def sample_tokens_sharded(local_sample_tokens: Callable[[Tensor, int], Tensor], sequences: Tensor, vocab: int,
-                          group=None) -> Tensor:
+                          group=None, model=None, guided: bool = False) -> Tensor:
     """As sample_sharded, for ``local_sample_tokens(seq_slice, first_global_index) -> (b_r, L)`` token ids."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
+    pin_for_shards(model, sequences.shape[0], world, guided)
     lo, hi = shard_bounds(sequences.shape[0], world, rank)
     local = local_sample_tokens(sequences[lo:hi], lo)
     if world == 1:

@@ -13,7 +13,7 @@ from typing import Dict, Optional
 import torch
 
 from . import runtime as rt
-from .compiler import EXT_CTX, EXT_OUT, EXT_XIN, CompiledUNet
+from .compiler import EXT_CTX, EXT_OUT, EXT_XBUF, EXT_XFLAGS, EXT_XIN, CompiledUNet
 
 
 def _require_gpu(device: torch.device) -> None:
@@ -38,6 +38,8 @@ class UNetEngine:
             try:
                 self.programs: Dict[str, rt.Program] = {k: rt.Program(v) for k, v in compiled.programs.items()}
             except RuntimeError as e:
+                if "mdt_program_create" not in str(e):      # only validation errors mean "outside the envelope"
+                    raise
                 raise RuntimeError(
                     f"U-Net configuration outside the envelope of the MI355X kernels (max_length={compiled.length}, "
                     f"channels={compiled.cfg.channels}, patch_size={compiled.cfg.patch_size}): {e}.  Supported: self-attention "
@@ -56,6 +58,7 @@ class UNetEngine:
         self.xin = None           # (B, L, Cp) token-major U-Net input
         self.pred = None          # (B, L, Cp) token-major U-Net output
         self.pred_fixed = None
+        self.xflags = self.xbuf = None
         self._graphs: Dict[str, torch.cuda.CUDAGraph] = {}
         self._time_rows = 0
         self._fixed_ready = False
@@ -72,13 +75,29 @@ class UNetEngine:
         self.xin = torch.zeros(B, c.length, c.in_pad, device=self.device)
         self.pred = torch.zeros(B, c.length, c.in_pad, device=self.device)
         self.pred_fixed = torch.zeros(B, c.length, c.in_pad, device=self.device)
+        self.xflags = self.xbuf = None
+        if c.xchg_tokens:
+            # pair-split MDT_OP_TF256 (k_tf256.hip): per 32-row block two hand-off blocks of 32 x 256 fp32 in two parities, and
+            # one 128-byte flag line per (row block, half) behind 64 diagnostic words.  The flags count hand-offs monotonically
+            # over the life of the buffer: zeroed here, never between launches.
+            nrb = (B * c.xchg_tokens + 31) // 32
+            self.xflags = torch.zeros(64 + 64 * nrb, dtype=torch.int32, device=self.device)
+            self.xbuf = torch.empty(2 * nrb * 2 * 32 * 256, device=self.device)
         self.B = B
 
     def _bind(self, xin=None, ctx=None, out=None) -> rt.MdtBindings:
         b = rt.MdtBindings()
         b.weights, b.act, b.shr = rt.ptr(self.weights), rt.ptr(self.act), rt.ptr(self.shr)
         b.ext[EXT_XIN], b.ext[EXT_CTX], b.ext[EXT_OUT] = rt.ptr(xin), rt.ptr(ctx), rt.ptr(out)
+        b.ext[EXT_XFLAGS], b.ext[EXT_XBUF] = rt.ptr(getattr(self, "xflags", None)), rt.ptr(getattr(self, "xbuf", None))
         return b
+
+    def handoff_status(self) -> int:
+        """Diagnostic word of the pair hand-offs (synchronises): 0 = fine; bit 0 = some poll ran into its time-out, i.e. the
+        results of that launch are garbage (a partner workgroup never arrived).  0 when the program has no pair-split op."""
+        if getattr(self, "xflags", None) is None:
+            return 0
+        return int(self.xflags[0].item())
 
     # ------------------------------------------------------------------ per-call preparation
     def prepare_times(self, c_noise: torch.Tensor) -> None:

@@ -13,7 +13,7 @@ from typing import Callable, Optional
 import torch
 import torch.nn as nn
 
-from . import runtime as rt
+from . import ops, runtime as rt
 from .compiler import compile_unet
 from .diffusion import (ADPM2Sampler, DiffusionInpainter, DiffusionSampler, KarrasSchedule, LogNormalDistribution,
                         NoiseSource, run_adpm2, run_adpm2_inpaint, scale_weights)
@@ -110,9 +110,20 @@ class _FusedLoop:
         eng = o.engine(emb.device, emb.shape[1], emb.shape[0] * (2 if guided else 1))
         ns = o._noise_source(noise, emb.shape[0], emb.device)
         x = self.extra
-        return run_adpm2(eng, emb, o.pred_dim, num_steps, ns, sigmas, sampler, o.diffusion.diffusion.sigma_data,
-                         self.kw.get("embedding_scale", 1.0), bool(x.get("clamp", False)), x.get("trace"), x.get("timer"),
-                         x.get("tokens"))
+        sigma_data = o.diffusion.diffusion.sigma_data
+        scale = self.kw.get("embedding_scale", 1.0)
+        if ns.steps is None and x.get("trace") is None and x.get("timer") is None and type(sampler) is ADPM2Sampler:
+            # the plain call (counter-based step noise, nothing to record): the whole loop as ONE custom op
+            tok = x.get("tokens")
+            init = None if ns.init is None else ns.init.to(device=emb.device, dtype=torch.float32)
+            out, t = torch.ops.mdt.sample(emb, init, None, torch.as_tensor(sigmas, dtype=torch.float32).cpu(),
+                                          ops.register_engine(eng), o.pred_dim, float(sampler.rho), float(sigma_data), float(scale),
+                                          bool(x.get("clamp", False)), int(ns.seed or 0), int(ns.sample0), tok is not None)
+            if tok is not None:
+                tok.copy_(t)
+            return out
+        return run_adpm2(eng, emb, o.pred_dim, num_steps, ns, sigmas, sampler, sigma_data, scale, bool(x.get("clamp", False)),
+                         x.get("trace"), x.get("timer"), x.get("tokens"))
 
     def inpaint(self, source, mask, sampler, sigmas, num_steps, num_resamples):
         o, emb = self.owner, self.kw["embedding"]
@@ -161,6 +172,8 @@ class _QMBase(nn.Module):
         self.unet._evaluator = self._unet_call
         # 'bf16x3': split-bf16 MFMA GEMMs (fp32-class accuracy, ~5x the fp32-MFMA rate); 'f32': exact fp32 MFMA
         self.gemm_mode = os.environ.get("MDT_GEMM", "bf16x3")
+        # form of the 256-channel transformers: 'auto' (by the batch of each call), 'wide', 'narrow' (see _wide)
+        self.kernel_choice = {"1": "wide", "0": "narrow"}.get(os.environ.get("MDT_TF256", "auto"), "auto")
         self._engine: Optional[UNetEngine] = None
         self._engines = {}               # wide (bool) -> UNetEngine, for the current parameter values
         self._engine_key = None
@@ -174,10 +187,11 @@ class _QMBase(nn.Module):
         """Which form of the 256-channel transformers to run (compiler.py: MDT_TF256).  One launch per sub-block with the
         heads split over two workgroups fills the chip at small batches; from ~1536 samples (4 tokens per sample at that
         level: 192 workgroups of 32 rows) the whole-transformer launch without the split is faster (measured: +10 % at 2048,
-        +7 % at 4096, -11 % at 1024)."""
-        env = os.environ.get("MDT_TF256", "auto")
-        if env in ("0", "1"):
-            return env == "1"
+        +7 % at 4096, -11 % at 1024).  The two forms add the heads' partial sums in different orders, so they agree to
+        rounding (1e-6 class), not bit for bit: ``kernel_choice`` = 'wide' / 'narrow' pins one of them for every batch size
+        (what a sharded run does, distributed.sample_sharded / pin_kernel_choice); 'auto' decides per call."""
+        if self.kernel_choice in ("wide", "narrow"):
+            return self.kernel_choice == "wide"
         cfg = self.unet.config
         t256 = None
         length = self.max_length // cfg.patch_size
@@ -187,6 +201,17 @@ class _QMBase(nn.Module):
             if lvl < cfg.num_layers:
                 length //= cfg.factors[lvl]
         return bool(batch) and t256 is not None and batch * t256 >= 6144
+
+    def pin_kernel_choice(self, batch: Optional[int]) -> str:
+        """Resolve 'auto' for a batch of ``batch`` U-Net rows (samples, doubled under guidance) and keep that choice for every
+        later call, whatever its batch: per-sample results then do not depend on how a batch is split over calls or ranks.
+        ``batch`` None releases the pin.  Returns the choice now in force."""
+        if batch is None:
+            self.kernel_choice = "auto"
+        else:
+            self.kernel_choice = "auto"
+            self.kernel_choice = "wide" if self._wide(batch) else "narrow"
+        return self.kernel_choice
 
     def engine(self, device, n_ctx: Optional[int] = None, batch: Optional[int] = None) -> UNetEngine:
         """Compiled-program engine for the current parameter values on `device` (rebuilt after an optimiser step or
@@ -210,22 +235,13 @@ class _QMBase(nn.Module):
 
     # ------------------------------------------------------------------ conditioning prelude
     def _embed(self, sequences: Tensor, device) -> Tensor:
-        """generative.py:838-850 / :149-161 on the device (mdt_cond_embed)."""
+        """generative.py:838-850 / :149-161 on the device (torch.ops.mdt.cond_embed -> mdt_cond_embed)."""
         device = torch.device(device)
         _require_gpu(device)
-        lib = rt.load_library()
-        seq = sequences.detach().float().to(device).contiguous()
-        B, n = seq.shape
-        out = torch.empty(B, n, self._text_dim + self._pos_dim, device=device)
-        if B == 0:
-            return out
-        w = self.fc1.weight.detach().float().to(device).contiguous().view(-1)
-        b = self.fc1.bias.detach().float().to(device).contiguous()
-        inv = self.p_enc_1d.inv_freq.detach().float().to(device).contiguous() if self._pos_dim else w
-        with torch.cuda.device(device):
-            rt.check(lib.mdt_cond_embed(rt.ptr(seq), rt.ptr(w), rt.ptr(b), rt.ptr(inv), rt.ptr(out), B, n,
-                                        self._text_dim, self._pos_dim, rt.current_stream()))
-        return out
+        seq = sequences.detach().float().to(device)
+        inv = self.p_enc_1d.inv_freq.detach().float().to(device) if self._pos_dim else None
+        return torch.ops.mdt.cond_embed(seq, self.fc1.weight.detach().to(device), self.fc1.bias.detach().to(device), inv,
+                                        self._pos_dim)
 
     # ------------------------------------------------------------------ seams used by the wrappers above
     def _noise_source(self, noise, B, device, sample0=0):
@@ -255,49 +271,26 @@ class _QMBase(nn.Module):
                 rows = (t == v).nonzero().flatten().to(x.device)
                 out[rows] = self._unet_call(x[rows], v, embedding[rows], embedding_scale)
             return out
-        lib = rt.load_library()
         device = x.device
+        _require_gpu(device)
         eng = self.engine(device, embedding.shape[1], x.shape[0])
-        B, C, L = x.shape
-        Cp = eng.c.in_pad
-        with torch.no_grad(), torch.cuda.device(device):
-            st = rt.current_stream()
-            eng.reserve(B)
-            eng.prepare_context(embedding)
-            eng.prepare_times(t[:1])
-            eng.select_time(0)
-            xc = x.detach().float().contiguous()
-            rt.check(lib.mdt_precond_in(rt.ptr(xc), rt.ptr(eng.xin), 1.0, B, C, L, Cp, st))
-            pred = eng.eval(False)
-            if embedding_scale != 1.0:
-                um = eng.eval(True)
-                rt.check(lib.mdt_cfg_mix(rt.ptr(pred), rt.ptr(um), rt.ptr(pred), float(embedding_scale),
-                                         pred.numel(), st))
+        C = x.shape[1]
+        with torch.no_grad():
+            xin = torch.ops.mdt.precond_in(x, 1.0, eng.c.in_pad)
+            pred = torch.ops.mdt.unet_eval(xin, embedding, float(t[0]), float(embedding_scale), ops.register_engine(eng))
             return pred[:, :, :C].transpose(1, 2).contiguous()
 
     def _denoise(self, x_noisy: Tensor, sigma, embedding: Tensor, embedding_scale: float = 1.0) -> Tensor:
-        lib = rt.load_library()
+        """KDiffusion_mod.denoise_fn for a scalar sigma (diffusion.py:798-814) as three ops: input scaling, the network,
+        output mix + clip."""
         device = x_noisy.device
+        _require_gpu(device)
         eng = self.engine(device, embedding.shape[1], x_noisy.shape[0])
         w = scale_weights(torch.as_tensor(sigma, dtype=torch.float32).cpu(), self.diffusion.diffusion.sigma_data)
-        B, C, L = x_noisy.shape
-        Cp = eng.c.in_pad
-        with torch.no_grad(), torch.cuda.device(device):
-            st = rt.current_stream()
-            eng.reserve(B)
-            eng.prepare_context(embedding)
-            eng.prepare_times(torch.tensor([w.c_noise]))
-            eng.select_time(0)
-            xc = x_noisy.detach().float().contiguous()
-            rt.check(lib.mdt_precond_in(rt.ptr(xc), rt.ptr(eng.xin), w.c_in, B, C, L, Cp, st))
-            pred = eng.eval(False)
-            if embedding_scale != 1.0:
-                um = eng.eval(True)
-                rt.check(lib.mdt_cfg_mix(rt.ptr(pred), rt.ptr(um), rt.ptr(pred), float(embedding_scale),
-                                         pred.numel(), st))
-            out = torch.empty_like(xc)
-            rt.check(lib.mdt_precond_out(rt.ptr(xc), rt.ptr(pred), rt.ptr(out), w.c_skip, w.c_out, B, C, L, Cp, st))
-            return out
+        with torch.no_grad():
+            xin = torch.ops.mdt.precond_in(x_noisy, w.c_in, eng.c.in_pad)
+            pred = torch.ops.mdt.unet_eval(xin, embedding, w.c_noise, float(embedding_scale), ops.register_engine(eng))
+            return torch.ops.mdt.precond_out(x_noisy, pred, w.c_skip, w.c_out)
 
     # ------------------------------------------------------------------ public API (reference signatures)
     def forward(self, sequences, output):

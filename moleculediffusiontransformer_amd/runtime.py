@@ -12,7 +12,7 @@ from typing import Optional
 from . import build as _build
 
 N_EXT = 8
-ABI_VERSION = 2        # MDT_ABI_VERSION of include/mdt_hip.h this binding was written against
+ABI_VERSION = 3        # MDT_ABI_VERSION of include/mdt_hip.h this binding was written against
 SP_NONE, SP_WEIGHT, SP_ACT, SP_SHR, SP_EXT0 = 0, 1, 2, 3, 4
 OP_GEMM, OP_GN_STATS, OP_ATTN, OP_CONCAT, OP_PATCH, OP_TIME_EMBED, OP_TBLOCK, OP_GN_ACT, OP_RCONV = 1, 2, 3, 4, 5, 6, 7, 8, 9
 OP_RESBLOCK = 10
@@ -41,7 +41,7 @@ B_MODE, B_C, B_T, B_NCHUNK, B_NBIAS, B_TK, B_KV_BSTRIDE, B_LDKV, B_HEADS, B_VARI
 B_KV2 = 11
 # MDT_OP_TF128 (enum mdt_tf128_i)
 (F_C, F_T, F_NT, F_NVEC, F_TK, F_KV_BSTRIDE, F_LDKV, F_HEADS, F_HAS_IN, F_NBLOCKS, F_NFF, F_NPOST, F_KV2, F_CROSS,
- F_KV_LSTRIDE, F_RES_KIND, F_N_RES, F_RES_PAIR1, F_RES_PAIR2, F_NFILM) = range(20)
+ F_KV_LSTRIDE, F_RES_KIND, F_N_RES, F_RES_PAIR1, F_RES_PAIR2, F_NFILM, F_NSPLIT, F_PAIR_STRIDE) = range(22)
 FF_EPS_LN, FF_SCALE, FF_EPS_GN, FF_EPS_RES, FF_SKIP_SCALE = range(5)
 
 
@@ -66,6 +66,7 @@ _F, _P, _I, _L, _U64, _U32 = C.c_float, C.c_void_p, C.c_int32, C.c_int64, C.c_ui
 SYMBOLS = {
     "mdt_abi_version": (_I, []),
     "mdt_last_error": (C.c_char_p, []),
+    "mdt_set_tuning": (_I, [C.c_char_p, _I]),
     "mdt_program_create": (_P, [C.POINTER(MdtOp), _I]),
     "mdt_program_destroy": (None, [_P]),
     "mdt_program_num_ops": (_I, [_P]),

@@ -540,13 +540,16 @@ def _tf128(op, bufs: Buffers, B: int) -> None:
 def _tf256(op, bufs: Buffers, B: int) -> None:
     """MDT_OP_TF256 semantics (include/mdt_hip.h): as _tf128 for a 256-channel level; the stream holds 32 KB SUB-tiles (K
     halves of projection tiles, row halves of output tiles), scratch descriptors close every sub-block, vectors are 768
-    floats per sub-block."""
+    floats per sub-block.  MDT_F_NSPLIT = 2: two descriptor tables, half hh listing heads / hidden chunks / to_in output
+    chunks / folded to_out k chunks [hh n/2, (hh + 1) n/2) and two more scratch descriptors per sub-block (the hand-off)."""
     i, f = op.i, op.f
     C, T, NT, nvec = i[rt.F_C], i[rt.F_T], i[rt.F_NT], i[rt.F_NVEC]
     Tk, bs, ldkv, H = i[rt.F_TK], i[rt.F_KV_BSTRIDE], i[rt.F_LDKV], i[rt.F_HEADS]
     nblocks, nff, npost, cross = i[rt.F_NBLOCKS], i[rt.F_NFF], i[rt.F_NPOST], bool(i[rt.F_CROSS])
-    desc = bufs.view(op.p0, B, NT).contiguous().view(torch.int32).tolist()
-    nw = sum(1 for d in desc if (d & 7) < 2)
+    nsplit = 2 if i[rt.F_NSPLIT] == 2 else 1
+    desc_all = bufs.view(op.p0, B, nsplit * NT).contiguous().view(torch.int32).tolist()
+    tabs = [desc_all[h * NT: (h + 1) * NT] for h in range(nsplit)]
+    nw = 1 + max(d >> 3 for d in desc_all if (d & 7) < 2)
     stream = bufs.view(op.w, B, nw * 64 * 128)
     vec = bufs.view(op.bias, B, nvec)
     accp = torch.tensor([16 * (2 * (k >> 5) + ((k & 7) >> 2)) + 4 * ((k >> 3) & 3) + (k & 3) for k in range(C)])
@@ -554,20 +557,23 @@ def _tf256(op, bufs: Buffers, B: int) -> None:
     inv_acc[accp] = torch.arange(C)
     inv_slot = torch.empty(64, dtype=torch.long)
     inv_slot[torch.tensor(_SLOT_PERM)] = torch.arange(64)
-    cur = {"t": 0, "sb": 0}
+    cur = {"t": [0] * nsplit, "sb": 0}
 
-    def take(kind):
-        d = desc[cur["t"]]
-        cur["t"] += 1
-        assert d & 7 == kind, (cur["t"] - 1, d & 7, kind)
+    def tab(index, count):         # which table lists item `index` of `count`
+        return index * nsplit // count
+
+    def take(kind, hh=0):
+        d = tabs[hh][cur["t"][hh]]
+        cur["t"][hh] += 1
+        assert d & 7 == kind, (hh, cur["t"][hh] - 1, d & 7, kind)
         return d >> 3
 
-    def P():                       # projection tile = two K-half sub-tiles -> [64, C], natural K order
-        a_, b_ = take(0), take(0)
+    def P(hh=0):                   # projection tile = two K-half sub-tiles -> [64, C], natural K order
+        a_, b_ = take(0, hh), take(0, hh)
         return torch.cat([_untile(stream, a_, 64, 128), _untile(stream, b_, 64, 128)], dim=1)[:, inv_acc]
 
-    def O(natural_from: Optional[int] = None):     # output tile = two row-half sub-tiles -> [C, 64]
-        a_, b_ = take(1), take(1)
+    def O(hh=0, natural_from: Optional[int] = None):     # output tile = two row-half sub-tiles -> [C, 64]
+        a_, b_ = take(1, hh), take(1, hh)
         t = torch.cat([_untile(stream, a_, 128, 64), _untile(stream, b_, 128, 64)], dim=0)
         if natural_from is None:
             return t[:, inv_slot]
@@ -578,13 +584,16 @@ def _tf256(op, bufs: Buffers, B: int) -> None:
 
     def end_subblock(last=False):
         nxt = cur["sb"] + 1
-        d = desc[cur["t"]]
-        if last:
-            assert d & 7 == 4
-        else:
-            assert d & 7 == 5 and (d >> 3) == (((768 * nxt) // 256) << 1 | (nxt & 1)), "vector descriptor of the next sub-block"
-        assert desc[cur["t"] + 1] & 7 == 4
-        cur["t"] += 2
+        for hh in range(nsplit):
+            t0 = cur["t"][hh]
+            d = tabs[hh][t0]
+            if last:
+                assert d & 7 == 4
+            else:
+                assert d & 7 == 5 and (d >> 3) == (((768 * nxt) // 256) << 1 | (nxt & 1)), "vector descriptor of the next sub-block"
+            n_scr = 2 * nsplit                                   # wave-pair exchange (+ the hand-off's two barriers)
+            assert all(tabs[hh][t0 + k] & 7 == 4 for k in range(1, n_scr))
+            cur["t"][hh] += n_scr
         cur["sb"] = nxt
 
     def V(off, n):
@@ -592,60 +601,9 @@ def _tf256(op, bufs: Buffers, B: int) -> None:
         return vec[base + off: base + off + n]
 
     x = bufs.view(op.a, B, B * T * C).view(B, T, C)
-    # ---- ResnetBlock1d blocks in front of the transformer (MDT_F_RES_KIND) ----
-    res_kind, n_res = i[rt.F_RES_KIND], i[rt.F_N_RES]
-    if res_kind:
-        film = bufs.view(op.p3, B, i[rt.F_NFILM])
-        eps_r, s_b = float(f[rt.FF_EPS_RES]), float(f[rt.FF_SKIP_SCALE])
-        gs1, gs2 = (32 if i[rt.F_RES_PAIR1] else 16), (32 if i[rt.F_RES_PAIR2] else 16)
-
-        def conv3_w():                       # 6 projection tiles (tap, output half) -> [C, C, 3]
-            w = torch.zeros(C, C, 3)
-            for tap in range(3):
-                for half in range(C // 64):
-                    w[64 * half: 64 * half + 64, :, tap] = P()
-            return w
-
-        def gn_silu(t, gsize, gam, bet, fl=None):      # t [B, T, c] -> silu(GroupNorm [* (scale + 1) + shift])
-            cc = t.shape[2]
-            y = F.group_norm(t.transpose(1, 2), cc // gsize, gam, bet, eps_r).transpose(1, 2)
-            if fl is not None:
-                y = y * (fl[:cc] + 1.0) + fl[cc:]
-            return _silu(y)
-
-        def conv3(t, w):                     # Conv1d(k = 3, padding 1) inside the sample
-            return F.conv1d(t.transpose(1, 2), w, None, padding=1).transpose(1, 2)
-
-        for rb in range(n_res):
-            fl = film[rb * 2 * C: (rb + 1) * 2 * C]
-            if res_kind == 1:
-                w1, w2 = conv3_w(), conv3_w()
-                g1, b1, bias1, g2, b2, bias2 = (V(C) for _ in range(6))
-                h = conv3(gn_silu(x, gs1, g1, b1), w1) + bias1
-                x = conv3(gn_silu(h, gs2, g2, b2, fl), w2) + bias2 + x
-                sk = rt.MdtRef(op.res.space, 0, op.res.off + rb * T * C)
-                bufs.view(sk, B, B * T * C).view(B, T, C)[:] = x
-            else:
-                def skip_desc():
-                    d = desc[cur["t"]]
-                    cur["t"] += 1
-                    assert d & 3 == 0 and (d >> 2) == ((1 << 20) | rb), "expected the skip rows of this block"
-                sk = rt.MdtRef(op.res.space, 0, op.res.off - rb * T * C)
-                xb = bufs.view(sk, B, B * T * C).view(B, T, C) * s_b
-                wra = torch.cat([P() for _ in range(C // 64)])
-                skip_desc()
-                wrb = torch.cat([P() for _ in range(C // 64)])
-                w1a = conv3_w()
-                skip_desc()
-                w1b, w2 = conv3_w(), conv3_w()
-                g1, b1, bias1, br, g2, b2, bias2 = V(2 * C), V(2 * C), V(C), V(C), V(C), V(C), V(C)
-                xc = gn_silu(torch.cat([x, xb], dim=2), gs1, g1, b1)
-                h = conv3(xc[:, :, :C], w1a) + conv3(xc[:, :, C:], w1b) + bias1
-                r = x @ wra.T + xb @ wrb.T + br
-                x = conv3(gn_silu(h, gs2, g2, b2, fl), w2) + bias2 + r
     if i[rt.F_HAS_IN]:
         xn = F.group_norm(x.transpose(1, 2), 32, None, None, eps=float(f[2])).transpose(1, 2)
-        w = torch.cat([P() for _ in range(C // 64)])
+        w = torch.cat([P(tab(ch, C // 64)) for ch in range(C // 64)])
         x = xn @ w.T + V(0, C)
         end_subblock()
     mid, D = 64 * H, 64
@@ -653,7 +611,8 @@ def _tf256(op, bufs: Buffers, B: int) -> None:
         xn = F.layer_norm(x, (C,), None, None, eps=float(f[0]))
         wq, wk, wv, wo = [], [], [], []
         for h in range(H):
-            wq.append(P()), wk.append(P()), wv.append(P()), wo.append(O())
+            hh = tab(h, H)
+            wq.append(P(hh)), wk.append(P(hh)), wv.append(P(hh)), wo.append(O(hh))
         bq, bo = V(0, mid), V(mid, C)
         q = (xn @ torch.cat(wq).T + bq).view(B, T, H, D).transpose(1, 2)
         k = (xn @ torch.cat(wk).T).view(B, T, H, D).transpose(1, 2)
@@ -665,9 +624,10 @@ def _tf256(op, bufs: Buffers, B: int) -> None:
             xn = F.layer_norm(x, (C,), None, None, eps=float(f[0]))
             wq, wo = [], []
             for h in range(H):
-                wq.append(P())
-                assert take(2) == (blk << 4 | h) and take(3) == (blk << 4 | h)
-                wo.append(O())
+                hh = tab(h, H)
+                wq.append(P(hh))
+                assert take(2, hh) == (blk << 4 | h) and take(3, hh) == (blk << 4 | h)
+                wo.append(O(hh))
             bq, bo = V(0, mid), V(mid, C)
             lstride = i[rt.F_KV_LSTRIDE]
             if bs == 0:
@@ -687,15 +647,15 @@ def _tf256(op, bufs: Buffers, B: int) -> None:
             end_subblock()
         w1, w2 = [], []
         for h in range(nff):
-            w1.append(P()), w2.append(O())
+            w1.append(P(tab(h, nff))), w2.append(O(tab(h, nff)))
         b1, b2 = V(0, 64 * nff), V(64 * nff, C)
         hdn = F.gelu(x @ torch.cat(w1).T + b1)
         last = blk == nblocks - 1
         if last and npost:
-            wout = torch.cat([O(natural_from=64 * e) for e in range(npost // 2)], dim=1)
+            wout = torch.cat([O(tab(e, npost // 2), natural_from=64 * e) for e in range(npost // 2)], dim=1)
             x = hdn @ torch.cat(w2, dim=1).T + x @ wout.T + b2
         else:
             x = x + hdn @ torch.cat(w2, dim=1).T + b2
         end_subblock(last=last)
-    assert cur["t"] == NT, (cur["t"], NT)
+    assert all(t == NT for t in cur["t"]), (cur["t"], NT)
     bufs.view(op.out, B, B * T * C).view(B, T, C)[:] = x

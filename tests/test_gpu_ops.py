@@ -448,11 +448,11 @@ def test_gemm_bf16_streamed(B, R, cin, N, taps, pro, act, tile):
     op.i[rt.G_WFMT] = 2
     ops.append(op)
     if tile:
-        os.environ["MDT_TILE16_LIVE"] = tile
+        rt.load_library().mdt_set_tuning(b"tile16", int(tile))
     try:
         (ga, _, _), (ca, _, _) = run_both(ops, weights, act_buf, shr, {}, B)
     finally:
-        os.environ.pop("MDT_TILE16_LIVE", None)
+        rt.load_library().mdt_set_tuning(b"tile16", -1)
     out_g, out_c = ga[B * ooff: B * roff], ca[B * ooff: B * roff]
     scale = max(out_c.abs().max().item(), 1.0)
     assert (out_g - out_c).abs().max() < (2e-3 if pro != rt.PRO_NONE else 4e-5) * scale
@@ -764,29 +764,44 @@ def _transformer_sd(p, C, layers, cross, ctx=128, mid=512, seed0=100):
     return sd
 
 
+def _handoff_ext(B, T):
+    """bindings.ext[3] / [4] of a pair-split MDT_OP_TF256: zeroed flag words, hand-off blocks (engine.py sizes them alike)."""
+    nrb = (B * T + 31) // 32
+    return {3: torch.zeros(64 + 64 * nrb), 4: torch.zeros(2 * nrb * 2 * 32 * 256)}
+
+
+@pytest.mark.parametrize("form", ["whole", "pair8", "pair1"])
 @pytest.mark.parametrize("C,T,B,layers,cross,fixed", [
     (128, 16, 5, 2, False, False), (128, 16, 70, 4, True, False), (128, 4, 16, 2, False, False), (128, 16, 3, 2, True, True),
     (128, 8, 9, 1, False, False), (128, 2, 33, 1, False, False), (128, 16, 1030, 1, True, False),
     (256, 4, 37, 2, True, False), (256, 4, 5, 2, False, False), (256, 4, 9, 4, True, True), (256, 16, 3, 1, False, False),
     (256, 8, 11, 1, True, False), (256, 1, 70, 1, True, False), (256, 4, 1030, 1, True, False)])
-def test_fused_transformer(C, T, B, layers, cross, fixed):
+def test_fused_transformer(C, T, B, layers, cross, fixed, form):
     """MDT_OP_TF128 / MDT_OP_TF256 (k_tf128.hip, k_tf256.hip): a whole Transformer1d in one launch, against (i) the CPU
     interpreter of the op (tile order, K-column permutation to the accumulator layout, vector layout) and (ii) the
-    reference's module arithmetic written out with torch ops (modules.py:469-524, :401-410, :350-364, :314-320)."""
+    reference's module arithmetic written out with torch ops (modules.py:469-524, :401-410, :350-364, :314-320).
+    form: 'whole' = one workgroup per 32-row block; 'pair8' / 'pair1' = the pair-split form of the 256-channel level (two
+    descriptor tables, hand-off between the two workgroups inside the launch) with the partners 8 workgroup ids apart (one XCD
+    under the observed placement) or neighbours (different XCDs): the result must not depend on it."""
     from moleculediffusiontransformer_amd.compiler import Ten, UNetCompiler
     from moleculediffusiontransformer_amd.netspec import inverse_unet_config
     import torch.nn.functional as F
+    if C == 128 and form != "whole":
+        pytest.skip("the pair split exists for the 256-channel level only")
     n_ctx, mid, H = 12, 512, 8
     cfg = inverse_unet_config(16, 64, 128, n_ctx)
     p = "tf."
     sd = _transformer_sd(p, C, layers, cross)
-    comp = UNetCompiler(cfg, 64, n_ctx, sd, tf256=True)
+    comp = UNetCompiler(cfg, 64, n_ctx, sd, tf256=(form == "whole"))
+    comp.pair_stride = 1 if form == "pair1" else 8
     if not (comp.tf128_ok(C, T, layers, cross) or comp.tf256_ok(C, T, layers, cross)):
         pytest.skip("shape outside the fused transformers' envelope")
     x = Ten(A, 0, T, C)
     y = comp.transformer(x, p, C, layers, cross, free_input=False)
     assert [o.kind for o in comp.ops] == [rt.OP_TF128 if C == 128 else rt.OP_TF256]
     op = comp.ops[0]
+    assert op.i[rt.F_NSPLIT] == (2 if (C == 256 and form != "whole") else (1 if C == 256 else 0))
+    ext = _handoff_ext(B, T) if form != "whole" else {}
     kv_floats = n_ctx * 2 * mid
     act_x = rnd(B * T * C, seed=13) * 1.5 + 0.3
     kv_all = rnd(layers * B * kv_floats, seed=14) if cross else torch.zeros(0)
@@ -800,9 +815,14 @@ def test_fused_transformer(C, T, B, layers, cross, fixed):
         else:
             op.a2 = ref(A, 2 * T * C)
     act = torch.cat([act_x, torch.zeros(B * T * C), kv_all])
-    (ga, _, _), (ca, _, _) = run_both([op], comp.W.pack(), act, shr, {}, B)
+    (ga, _, ge), (ca, _, _) = run_both([op], comp.W.pack(), act, shr, ext, B)
     yg, yc = ga[B * T * C: 2 * B * T * C].view(B, T, C), ca[B * T * C: 2 * B * T * C].view(B, T, C)
     assert torch.isfinite(yg).all()
+    if ext:
+        flags = ge[3].view(torch.int32)
+        nsub = 1 + layers * (3 if cross else 2)
+        assert int(flags[0]) == 0, "a hand-off poll timed out"
+        assert bool((flags[64::32] == nsub).all()), "every (row block, half) counts one hand-off per sub-block"
     tol = 2e-4 * max(1.0, yc.abs().max().item())
     assert (yg - yc).abs().max() < tol, (yg - yc).abs().max().item()
     assert torch.equal(ga[: B * T * C], act_x) and torch.equal(ga[2 * B * T * C:], kv_all)     # inputs untouched
@@ -836,8 +856,71 @@ def test_fused_transformer(C, T, B, layers, cross, fixed):
     want = F.conv1d(h.transpose(1, 2), sd[p + "to_out.1.weight"], sd[p + "to_out.1.bias"]).transpose(1, 2)
     assert (yg - want).abs().max() < tol, (yg - want).abs().max().item()
     # same launch again from the same buffers: the ring protocol has no race that a second run would expose differently
-    (ga2, _, _), _ = run_both([op], comp.W.pack(), act, shr, {}, B)
+    (ga2, _, _), _ = run_both([op], comp.W.pack(), act, shr, ext, B)
     assert torch.equal(ga2, ga)
+
+
+@pytest.mark.parametrize("T,B,layers,cross", [(4, 1024, 2, True), (4, 37, 1, True), (16, 9, 1, False)])
+def test_pair_handoff_is_placement_independent_and_repeatable(T, B, layers, cross):
+    """The pair-split MDT_OP_TF256 hands 32 x 256 partial sums between two workgroups inside the launch (sc1 stores, drained,
+    workgroup barrier, flag; poll, barrier, sc1 loads: the placement-independent form of MI355X_MICROARCH.md).  120 launches
+    on ONE set of flag words (they count monotonically across launches), partners alternately on one XCD (ids 8 apart) and on
+    different XCDs (neighbouring ids, forced through mdt_set_tuning): every launch returns the same bits, which agree with the
+    CPU interpreter and, to rounding (different summation order of the heads), with the whole-workgroup form."""
+    from moleculediffusiontransformer_amd.compiler import Ten, UNetCompiler
+    from moleculediffusiontransformer_amd.netspec import inverse_unet_config
+    from oracle.program_interp import Buffers, run_program
+    n_ctx, mid, C = 12, 512, 256
+    cfg = inverse_unet_config(16, 64, 128, n_ctx)
+    p = "tf."
+    sd = _transformer_sd(p, C, layers, cross)
+    lib = rt.load_library()
+
+    def build(whole):
+        comp = UNetCompiler(cfg, 64, n_ctx, sd, tf256=whole)
+        comp.transformer(Ten(A, 0, T, C), p, C, layers, cross, free_input=False)
+        op = comp.ops[0]
+        op.out = ref(A, T * C)
+        if cross:
+            op.a2 = ref(A, 2 * T * C)
+        return op, comp.W.pack()
+    kv_floats = n_ctx * 2 * mid
+    act0 = torch.cat([rnd(B * T * C, seed=21) * 1.5 + 0.3, torch.zeros(B * T * C), rnd(layers * B * kv_floats, seed=22) if cross else torch.zeros(0)])
+    op, weights = build(False)
+    cpu = Buffers(weights.clone(), act0.clone(), torch.zeros(4), {})
+    run_program([op], cpu, B, 0)
+    want = cpu.act[B * T * C: 2 * B * T * C]
+    gw, ga, gs = weights.to(DEV), act0.to(DEV), torch.zeros(4, device=DEV)
+    ext = {k: v.to(DEV) for k, v in _handoff_ext(B, T).items()}
+    b = rt.MdtBindings()
+    b.weights, b.act, b.shr = rt.ptr(gw), rt.ptr(ga), rt.ptr(gs)
+    b.ext[3], b.ext[4] = rt.ptr(ext[3]), rt.ptr(ext[4])
+    prog = rt.Program([op])
+    outs = []
+    try:
+        with torch.cuda.device(DEV):
+            for rep in range(120):
+                lib.mdt_set_tuning(b"pair_stride", 1 if rep % 2 else 8)
+                ga[B * T * C: 2 * B * T * C].zero_()
+                prog.run(b, B, 0)
+                if rep < 4 or rep % 10 == 0:
+                    outs.append(ga[B * T * C: 2 * B * T * C].clone())
+                else:
+                    assert torch.equal(ga[B * T * C: 2 * B * T * C], outs[0]), rep
+            torch.cuda.synchronize()
+    finally:
+        lib.mdt_set_tuning(b"pair_stride", 0)
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    flags = ext[3].view(torch.int32).cpu()
+    nsub = 1 + layers * (3 if cross else 2)
+    assert int(flags[0]) == 0 and bool((flags[64::32] == 120 * nsub).all())
+    tol = 2e-4 * max(1.0, want.abs().max().item())
+    assert (outs[0].cpu() - want).abs().max() < tol
+    # the whole-workgroup form of the same transformer (other summation order of the heads' partial sums)
+    opw, ww = build(True)
+    (gaw, _, _), _ = run_both([opw], ww, act0, torch.zeros(4), {}, B)
+    assert (gaw[B * T * C: 2 * B * T * C] - outs[0].cpu()).abs().max() < tol
 
 
 def _resnet_sd(p, c, cin, seed0):

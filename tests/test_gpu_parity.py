@@ -71,24 +71,48 @@ def test_sample_matches_reference(models, name, case, want):
     assert (out.cpu() - out_ref).abs().max() < TOL
 
 
-def test_wide_batch_kernel_choice_matches_reference(monkeypatch):
-    """The 256-channel transformers run as head-split launches per sub-block at small batches and as whole-transformer
-    launches (k_tf256) from ~1536 samples on (generative.py::_wide).  Both forms against the reference's golden sample, and
-    the automatic choice by batch size."""
+def test_wide_batch_kernel_choice_matches_reference():
+    """The 256-channel transformers run pair-split at small batches and as whole-transformer launches without the split
+    (k_tf256) from ~1536 samples on (generative.py::_wide).  Both forms against the reference's golden sample, the automatic
+    choice by batch size, and the pin that makes per-sample results independent of how a batch is sharded."""
+    from moleculediffusiontransformer_amd import runtime as rt
     g = load_golden("cfg1_b2_t12_cfg7p5_sample.npz")
     m = make_model("cfg1")
     seq, T = to_t(g["seq"]), int(g["timesteps"])
     init, step = noise_fns("cfg1_b2_t12_cfg7p5", tuple(g["out"].shape))
     outs = {}
-    for wide in ("0", "1"):
-        monkeypatch.setenv("MDT_TF256", wide)
-        outs[wide] = m.sample(seq, DEV, cond_scale=7.5, timesteps=T, noise=NoiseSource(init=init, steps=lambda i: step(i, init))).cpu()
-        kinds = {op.kind for op in m._engine.c.programs["eval"]}
-        from moleculediffusiontransformer_amd import runtime as rt
-        assert (rt.OP_TF256 in kinds) == (wide == "1")
-        assert (outs[wide] - to_t(g["out"])).abs().max() < TOL
-    monkeypatch.delenv("MDT_TF256")
+    for choice in ("narrow", "wide"):
+        m.kernel_choice = choice
+        outs[choice] = m.sample(seq, DEV, cond_scale=7.5, timesteps=T, noise=NoiseSource(init=init, steps=lambda i: step(i, init))).cpu()
+        forms = {op.i[rt.F_NSPLIT] for op in m._engine.c.programs["eval"] if op.kind == rt.OP_TF256}
+        assert forms == ({1} if choice == "wide" else {2}) and m._engine.c.tf256 == (choice == "wide")
+        assert m._engine.handoff_status() == 0
+        assert (outs[choice] - to_t(g["out"])).abs().max() < TOL
+    m.kernel_choice = "auto"
     assert m._wide(1024) is False and m._wide(2048) is True and m._wide(None) is False
+
+
+def test_kernel_choice_pin_makes_shards_bitwise_equal_across_the_threshold():
+    """2048 samples on one rank take the wide form, 2 x 1024 on two ranks the narrow one, and the two forms agree
+    to rounding only.  With the choice pinned from the largest shard (distributed.pin_for_shards, what sample_sharded(model=)
+    does) a 1-rank run of any sub-batch reproduces the sharded rows bit for bit; unpinned ('auto') it is tolerance only."""
+    from moleculediffusiontransformer_amd.distributed import pin_for_shards
+    m = make_model("cfg1")
+    B, T = 2048, 3
+    seq = synth_normal("straddle/seq", (B, 12))
+    run = lambda s, first: m.sample(s, DEV, cond_scale=1.0, timesteps=T, noise=NoiseSource(seed=77, sample0=first))   # noqa: E731
+    assert m.kernel_choice == "auto"
+    whole_auto = run(seq, 0)                       # 2048 rows: wide
+    assert m._engine.c.tf256
+    assert pin_for_shards(m, B, 2) == "narrow"     # two shards of 1024
+    halves = torch.cat([run(seq[:1024], 0), run(seq[1024:], 1024)])
+    assert not m._engine.c.tf256
+    whole_pinned = run(seq, 0)                     # the 1-rank run with the same pin: same kernels at 2048 rows
+    assert not m._engine.c.tf256
+    assert torch.equal(whole_pinned, halves)
+    assert (whole_auto - halves).abs().max() < 1e-4
+    m.pin_kernel_choice(None)
+    assert m.kernel_choice == "auto"
 
 
 def test_inpaint_matches_reference(models):

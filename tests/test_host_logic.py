@@ -2,6 +2,7 @@
 import ctypes
 import re
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -25,7 +26,7 @@ def test_c_abi_exports_every_declared_symbol():
     assert declared == set(rt.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.mdt_abi_version() == rt.ABI_VERSION == 2
+    assert lib.mdt_abi_version() == rt.ABI_VERSION == 3
     assert ctypes.sizeof(rt.MdtOp) == 8 + 10 * 16 + 24 * 4 + 8 * 4
     bad = rt.MdtOp()
     bad.kind = 1   # GEMM with cin == 0
@@ -224,27 +225,39 @@ def test_lowering_matches_reference_golden(case, mode):
     assert abs(cu.flops_per_sample_eval - {"cfg1": 388.7e6}.get(case, cu.flops_per_sample_eval)) < 1e6
 
 
-def test_ring_kernels_keep_their_arrays_in_registers():
+_RING_UNITS = ("k_tblock32", "k_rconv", "k_tf128", "k_tf256")
+
+
+@pytest.fixture(scope="module")
+def ring_kernel_reports():
+    """One hipcc run per ring-kernel translation unit (build.py's flags): resource remarks + the ISA lint, in parallel."""
+    import shutil
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not available")
+    import isa_lint
+    import kernel_resources
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        res = list(ex.map(kernel_resources.resources, _RING_UNITS))
+        lint = list(ex.map(isa_lint.lint_unit, _RING_UNITS))
+    return dict(zip(_RING_UNITS, res)), dict(zip(_RING_UNITS, lint))
+
+
+def test_ring_kernels_keep_their_arrays_in_registers(ring_kernel_reports):
     """A register array that hipcc decides to index dynamically moves to scratch; in a loader wave every scratch load is
     then waited for with vmcnt(0) and the whole LDS-DMA stream serialises (seen twice: 2-5x slower kernels, all tests
-    green).  Compile the ring kernels with resource remarks and bound their scratch use."""
+    green), and a spill next to an in-flight inline-asm ds_read stores a register that has not landed yet.  Compile the ring
+    kernels with resource remarks and bound their scratch use: 0 for k_tf128 (all 15 instantiations) and the k_rconv forms on
+    the default path; k_tf256 sits at the 256-register limit of two waves per SIMD (accumulators 64 + operands 64 + three
+    fragment sets 48 + per-head tiles) and keeps a few dozen bytes of compiler-managed spills of scalars OUTSIDE the
+    fragment registers (the ISA lint below checks that none of them touches an in-flight read)."""
     import re
-    import shutil
-    import subprocess
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    if not os.path.exists(hipcc):
-        pytest.skip("hipcc not available")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    csrc = os.path.join(root, "moleculediffusiontransformer_amd", "csrc")
-    limits = {"k_tblock_lw": 0, "k_tblock32": 24, "k_rconv": 0}          # bytes per lane (a few spilled scalars at most)
+    res, _ = ring_kernel_reports
+    limits = {"k_tblock32": 24, "k_rconv": 0, "k_tf128": 0, "k_tf256": 100}     # bytes per lane
     for name, limit in limits.items():
-        r = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-mllvm", "-amdgpu-mfma-vgpr-form=1",
-                            "-I", os.path.join(root, "include"), "-c", os.path.join(csrc, name + ".hip"), "-o", os.devnull,
-                            "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
-        assert r.returncode == 0, r.stderr[-2000:]
-        kernels = re.findall(r"Function Name: (\S+).*?ScratchSize \[bytes/lane\]: (\d+)", r.stderr, flags=re.S)
-        assert kernels, r.stderr[-500:]
-        for fn, scratch in kernels:
+        assert res[name], name
+        for fn, v in res[name]:
             if name == "k_rconv" and re.search(r"ELi2ELi[01]EEEvNS_9RConvArgsE$", fn):
                 # two-source instantiations <..., NSRC = 2, PRO>: only the 1x1 form without a prologue (PRO = 0) is on the
                 # default path (the concatenated inputs' residual convolution; C = 128, or C = 256 with the output channels
@@ -252,7 +265,29 @@ def test_ring_kernels_keep_their_arrays_in_registers():
                 if not (fn.endswith("ELi4ELi128ELi1ELi1ELi2ELi0EEEvNS_9RConvArgsE") or
                         fn.endswith("ELi2ELi256ELi1ELi2ELi2ELi0EEEvNS_9RConvArgsE")):
                     continue
-            assert int(scratch) <= limit, (fn, scratch)
+            assert 0 <= v["scratch"] <= limit, (fn, v)
+
+
+def test_no_instruction_touches_an_in_flight_fragment_read(ring_kernel_reports):
+    """tools/isa_lint.py on the compiler's assembly of every ring kernel: inside every basic block, no instruction reads or
+    writes the destination registers of a ds_read before an s_waitcnt lgkmcnt that covers it (hipcc treats the inline-asm
+    fragment reads as complete where they are issued, so a copy / spill / re-use placed right behind one would move a
+    register that has not landed)."""
+    import isa_lint
+    # the lint itself: a copy right behind a read is caught, the same copy behind a covering wait is not, and a counted wait
+    # retires exactly the reads with enough younger LDS operations
+    rd = "ds_read_b128 v[4:7], v1 offset:0"
+    assert len(isa_lint.lint_kernel([rd, "v_mov_b32_e32 v8, v5", "s_waitcnt lgkmcnt(0)"])) == 1
+    assert isa_lint.lint_kernel([rd, "s_waitcnt lgkmcnt(0)", "v_mov_b32_e32 v8, v5"]) == []
+    two = [rd, "ds_read_b128 v[8:11], v1 offset:256", "s_waitcnt lgkmcnt(1)"]
+    assert isa_lint.lint_kernel(two + ["v_mfma_f32_16x16x32_bf16 v[20:23], v[4:7], v[12:15], v[20:23]"]) == []
+    assert len(isa_lint.lint_kernel(two + ["v_mfma_f32_16x16x32_bf16 v[20:23], v[8:11], v[12:15], v[20:23]"])) == 1
+    assert len(isa_lint.lint_kernel([rd, "scratch_store_dword off, v6, off offset:4", "s_waitcnt lgkmcnt(0)"])) == 1
+    _, lint = ring_kernel_reports
+    for name, (report, n_reads) in lint.items():
+        assert n_reads > 100, (name, n_reads)
+        for kernel, violations in report.items():
+            assert not violations, (name, kernel, violations[:3])
 
 
 @pytest.mark.parametrize("cin,cout", [(16, 64), (64, 16)])
@@ -306,3 +341,27 @@ def test_bench_power_sampler_is_optional():
     s.start()
     s.join(timeout=2)
     assert s.summary() is None
+
+
+def test_torch_library_ops_are_registered_and_refuse_cpu_tensors():
+    """SURVEY section 8(b), last row: the native boundary as a torch.library namespace.  Every op of torch.ops.mdt has a
+    schema and shape inference (meta tensors, no GPU needed) and raises RuntimeError for non-HIP tensors (TORCH_CHECK
+    convention; there is no CPU implementation behind the ops)."""
+    import moleculediffusiontransformer_amd.ops as ops  # noqa: F401  (registers the namespace)
+    names = ["cond_embed", "precond_in", "precond_out", "cfg_mix", "adpm2_mid", "adpm2_next", "adpm2_euler", "argmax_tokens",
+             "unet_eval", "sample", "all_gather_samples"]
+    for n in names:
+        assert hasattr(torch.ops.mdt, n), n
+    m = lambda *s, dt=torch.float32: torch.empty(*s, device="meta", dtype=dt)   # noqa: E731
+    assert torch.ops.mdt.cond_embed(m(3, 12), m(64, 1), m(64), m(32), 64).shape == (3, 12, 128)
+    assert torch.ops.mdt.precond_in(m(3, 16, 64), 0.5, 16).shape == (3, 64, 16)
+    assert torch.ops.mdt.precond_out(m(3, 16, 64), m(3, 64, 16), 0.1, 0.2).shape == (3, 16, 64)
+    xm, xin = torch.ops.mdt.adpm2_mid(m(3, 22, 32), m(3, 32, 32), 0.1, 0.2, 1.0, -0.1, 0.3)
+    assert xm.shape == (3, 22, 32) and xin.shape == (3, 32, 32)
+    assert torch.ops.mdt.argmax_tokens(m(3, 16, 64)).dtype == torch.int32
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        torch.ops.mdt.cond_embed(torch.zeros(3, 12), torch.zeros(64, 1), torch.zeros(64), torch.zeros(32), 64)
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        torch.ops.mdt.precond_in(torch.zeros(3, 16, 64), 0.5, 16)
+    with pytest.raises(RuntimeError):
+        torch.ops.mdt.unet_eval(torch.zeros(1, 64, 16), torch.zeros(1, 12, 128), 0.0, 1.0, 987654)
