@@ -300,11 +300,16 @@ def main():
     dev_index = 0 if share else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1:
+    # a rank environment (torch.distributed.run, or RANK=0 WORLD_SIZE=1 by hand) brings the process group up even for one
+    # rank: the RCCL all-gather of the samples then runs at N = 1 too (smoke test of the collective path on a one-GPU box)
+    grouped = world > 1 or "RANK" in os.environ
+    if grouped:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(a.master_port))
         if share:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from moleculediffusiontransformer_amd import NoiseSource, runtime as rt
     from moleculediffusiontransformer_amd.distributed import all_gather_samples
@@ -327,8 +332,8 @@ def main():
         out = model.sample(seq, device, cond_scale=a.cond_scale, timesteps=T, clamp=False,
                            noise=NoiseSource(seed=1234 + step_idx, sample0=rank * B),
                            timer=eval_timer if timed else None)
-        if world > 1:
-            out = all_gather_samples(out, world * B)
+        if grouped:
+            out = all_gather_samples(out, world * B, force_collective=True)
         return out
 
     for w in range(a.warmup):
@@ -336,7 +341,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if grouped:
             dist.barrier()
             torch.cuda.synchronize(device)
 
@@ -350,7 +355,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     power = sampler.summary() if sampler else None
-    if world > 1:
+    if grouped:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -416,20 +421,19 @@ def main():
                 REF_OPGRAPH_BYTES_PER_SAMPLE_EVAL * B / (avg_eval_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
             if B == 1024:
                 fname, rows = pmc_summary()
-                evals_profiled = None
-                for nm, n, mb in rows:                      # launches per eval are known for the sampler-update kernels
-                    if "k_adpm2_mid" in nm:
-                        evals_profiled = 2 * n
+                # kernels of the EVAL program only (not the hoisted time / context programs' k_gemm_as / k_gemm / k_time_embed,
+                # the sampler's own kernels or torch's fills), evaluations counted from a kernel that runs once per evaluation
+                eval_kernels = ("mdt::k_tf128", "mdt::k_tf256", "mdt::k_tblock", "mdt::k_tb_reduce", "mdt::k_rconv", "mdt::k_gemm3",
+                                "mdt::k_resblock", "mdt::k_attn", "mdt::k_gn_", "mdt::k_concat", "mdt::k_patch")
+                evals_profiled = sum(n for nm, n, mb in rows if nm.startswith("mdt::k_resblock<16, 64>")) or None
                 if rows and evals_profiled:
-                    # every kernel of the profiled run that belongs to a U-Net evaluation (not the sampler / setup kernels)
-                    unet_mb = sum(n * mb for nm, n, mb in rows
-                                  if not any(s in nm for s in ("k_adpm2", "k_precond", "k_init_noise", "k_cond_embed",
-                                                               "k_time_embed", "k_argmax", "k_clamp")))
+                    unet_mb = sum(n * mb for nm, n, mb in rows if nm.startswith(eval_kernels))
                     per_eval = unet_mb / evals_profiled
                     ue["hbm_measured_mb_per_eval"] = round(per_eval, 1)
                     ue["hbm_measured_frac"] = round(per_eval * 1e6 / (avg_eval_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-                    ue["hbm_measured_source"] = f"profiles/{fname}: PMC bytes (FETCH_SIZE x2 + WRITE_SIZE) of the profiled run " \
-                                                f"/ its U-Net evaluations, over THIS run's evaluation time"
+                    ue["hbm_measured_source"] = f"profiles/{fname}: PMC bytes (FETCH_SIZE x2 + WRITE_SIZE) of the eval program's kernels " \
+                                                f"over the {evals_profiled} evaluations of the profiled run (counted from k_resblock<16, 64>, " \
+                                                f"one launch per evaluation), over THIS run's evaluation time"
         extra["unet_eval"] = ue
         extra["power"] = power
         result = {
@@ -448,7 +452,7 @@ def main():
         }
         result.update(extra)
 
-        if world > 1:
+        if grouped:
             # the gathered tensor holds every rank's rows; counter-based noise is keyed by the GLOBAL sample index, so the
             # last rank's first rows must equal, bit for bit, a 1-rank run of those global indices with the same seed
             probe = min(64, B)
@@ -488,13 +492,13 @@ def main():
         if not a.no_other_configs and world == 1 and a.workload == "cfg1" and a.cond_scale == 1.0:
             # the other single-GPU configurations of BASELINE.json with the same binary, few steps each (informational:
             # the headline `value` above is configs[1])
-            def quick(tag, case, batch, tsteps, cscale, nsteps=2, gemm_mode=None):
+            def quick(tag, case, batch, tsteps, cscale, nsteps=2, gemm_mode=None, warm_timesteps=None):
                 with contextlib.redirect_stdout(sys.stderr):
                     mm = model if case == "cfg1" else make_synth_model(case, device)
                 if gemm_mode:
                     mm.gemm_mode = gemm_mode
                 sq = synth_normal(f"bench/other/{tag}", (batch, mm.unet.config.ctx_max_length)).to(device)
-                mm.sample(sq, device, cond_scale=cscale, timesteps=tsteps, noise=NoiseSource(seed=5, sample0=0))
+                mm.sample(sq, device, cond_scale=cscale, timesteps=warm_timesteps or tsteps, noise=NoiseSource(seed=5, sample0=0))
                 torch.cuda.synchronize(device)
                 c0 = time.perf_counter()
                 for k in range(nsteps):
@@ -511,6 +515,34 @@ def main():
                     r.update({"gemm_mode": gemm_mode, "tflops_executed": round(fl / dt / 1e12, 1),
                               "bf16_mfma_fraction": round(fl / dt / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4)})
                 return r
+            def sampler_update_rate(batch):
+                """The genuinely HBM-bound kernel class: the two halves of the ADPM2 update at the configs[3] shard
+                size, HIP-event timed over 50 launches each; algorithmic bytes = every tensor read or written once."""
+                lib = rt.load_library()
+                C_, L_, Cp_ = 16, 64, 16
+                x = torch.randn(batch, C_, L_, device=device)
+                xm, pred, xin = torch.empty_like(x), torch.randn(batch, L_, Cp_, device=device), torch.empty(batch, L_, Cp_, device=device)
+                st = rt.current_stream()
+                res = {}
+                for name, nbuf, call in (
+                        ("k_adpm2_mid", 4, lambda: lib.mdt_adpm2_mid(rt.ptr(x), rt.ptr(pred), rt.ptr(xm), rt.ptr(xin), 0.5, 0.5, 1.0, -0.1,
+                                                                     0.7, batch, C_, L_, Cp_, st)),
+                        ("k_adpm2_next", 5, lambda: lib.mdt_adpm2_next(rt.ptr(x), rt.ptr(xm), rt.ptr(pred), 0, rt.ptr(xin), 0.5, 0.5, 1.0,
+                                                                       -0.1, 0.01, 0.7, 9, 1, 0, batch, C_, L_, Cp_, 0, st))):
+                    for _ in range(5):
+                        rt.check(call())
+                    tm = rt.EventTimer(1)
+                    tm.start()
+                    for _ in range(50):
+                        rt.check(call())
+                    tm.stop()
+                    us = tm.collect()[0] * 1e3 / 50
+                    nbytes = nbuf * batch * C_ * L_ * 4
+                    res[name] = {"us_per_launch": round(us, 2), "algorithmic_mb": round(nbytes / 1e6, 1),
+                                 "gb_per_s": round(nbytes / (us * 1e-6) / 1e9, 0),
+                                 "hbm_peak_frac": round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 3)}
+                res["batch"] = batch
+                return res
             result["other_configs"] = {
                 "configs[2] QMDiffusionForward": quick("cfg3", "cfg3", 4096, 100, 1.0),
                 "configs[3] per-GPU shard (batch 8192)": quick("shard", "cfg1", 8192, 64, 1.0),
@@ -518,12 +550,15 @@ def main():
                 "configs[4] architecture (channels 256, fp32-class products)": quick("cfg5", "cfg5", 128, 16, 1.0, nsteps=1),
                 "configs[4] architecture in its bf16 mode (plain bf16 products, bf16 GEMM operands)":
                     quick("cfg5b", "cfg5", 1024, 16, 1.0, nsteps=1, gemm_mode="bf16"),
+                "configs[4] in its bf16 mode at its stated length (256 timesteps = 510 U-Net evaluations)":
+                    quick("cfg5c", "cfg5", 512, 256, 1.0, nsteps=1, gemm_mode="bf16", warm_timesteps=4),
+                "sampler update kernels at the configs[3] shard size (HBM-bound class)": sampler_update_rate(8192),
             }
 
         if not a.no_cpu_baseline and world == 1:
             result["cpu_baseline"], result["parity"] = cpu_baseline_leg(torch, model, device, evals)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -129,8 +129,13 @@ constexpr int KTM = 3;          // key tiles per wave (cross): at most 48 contex
 constexpr int RED_BYTES = KTM * 4 * 64 * 16;   // partial S^T exchange [key tile][4 waves][64 lanes] f32x4
 constexpr int VEC_FLOATS = 768;                // vectors of one sub-block: [bq 512 | bo 256], [b1 512 | b2 256], [b_in 256]
 constexpr int VEC_BYTES = VEC_FLOATS * 4;
-constexpr int AUX_SC1 = 16;                        // raw_buffer_* cache policy: sc1 (agent scope)
-constexpr int AUX_SC1_VOLATILE = 16 | (1 << 31);   // ... and not to be hoisted / merged (the flag poll)
+// raw_buffer_* cache policies of the hand-off.  MDT_XH_MODE (tuning builds): 0 = sc1 stores, sc1 loads (the guide's measured row);
+// 1 = sc0 sc1 (system scope) both sides; 2 = sc1 stores, sc0 sc1 loads (what the volatile bit gives)
+#ifndef MDT_XH_MODE
+#define MDT_XH_MODE 0
+#endif
+constexpr int AUX_ST = MDT_XH_MODE == 1 ? 17 : 16;
+constexpr int AUX_LD = MDT_XH_MODE == 0 ? 16 : 17;
 constexpr unsigned XBLOCK = 32 * C * 4;            // bytes one workgroup hands over per round
 constexpr unsigned long long POLL_TIMEOUT = 30000000ull;   // s_memrealtime ticks (100 MHz): 0.3 s
 
@@ -289,6 +294,9 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
 #endif
   // pair hand-off state (NSPLIT == 2): flag words xflags[64 + 32 * (2 rb + hh)] (one 128-byte line each; xflags[0..63] are
   // diagnostics), hand-off blocks xbuf[parity][rb][hh][row tile][accumulator tile][lane] f32x4
+#ifdef MDT_XH_LOG
+  unsigned xlog_first = 0, xlog_last = 0, xlog_got = 0, xlog_epoch = 0;
+#endif
   unsigned xround = 0;                               // my flag's value = hand-offs I have completed, ever
   int xn = 0;                                        // hand-offs of this launch (buffer parity)
   __amdgpu_buffer_rsrc_t xres, fres;
@@ -296,9 +304,11 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
   if constexpr (NSPLIT == 2) {
     xres = __builtin_amdgcn_make_buffer_rsrc(a.xbuf, 0, 0x7fffffff, 0x00020000);
     fres = __builtin_amdgcn_make_buffer_rsrc(a.xflags, 0, 0x7fffffff, 0x00020000);
-    xround = (unsigned)__builtin_amdgcn_readfirstlane(
-        __builtin_amdgcn_raw_buffer_load_b32(fres, 0, fown, AUX_SC1_VOLATILE));                      // written by an earlier LAUNCH
+    xround = (unsigned)__builtin_amdgcn_readfirstlane(__builtin_amdgcn_raw_buffer_load_b32(fres, 0, fown, AUX_LD));   // written by an earlier LAUNCH
   }
+#ifdef MDT_XH_LOG
+  xlog_epoch = xround;
+#endif
   {
     const float* xp = a.x + (int64_t)mc * C + 4 * g;
     float4 xr[NCT];
@@ -523,20 +533,52 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
       for (int c = 0; c < 8; ++c) {
         const f32x4 lo_ = accT[c], hi_ = accT[8 + c];
         const f32x4 v = f32x4{fh ? hi_[0] : lo_[0], fh ? hi_[1] : lo_[1], fh ? hi_[2] : lo_[2], fh ? hi_[3] : lo_[3]};
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), xres, vlane, sbase + (unsigned)(8 * fh + c) * 1024u, AUX_SC1);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), xres, vlane, sbase + (unsigned)(8 * fh + c) * 1024u, AUX_ST);
       }
       MDT_STAMP();                                       // hand-off: stores issued
+#ifdef MDT_XH_FENCE
+      __threadfence();
+#endif
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave, in front of the barrier the flag store follows
       MDT_STAMP();                                       // ... drained
       __builtin_amdgcn_s_barrier();                      // B(first hand-off tile)
       MDT_STAMP();                                       // ... every wave of the workgroup drained
       ++xround;
+#ifdef MDT_XH_RB      // experiment: read my own block back through the L2 before the flag goes out
+      {
+        f32x4 rbk[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+          rbk[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, vlane, sbase + (unsigned)(8 * fh + c) * 1024u, AUX_LD));
+        float sink = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) sink += rbk[c][0];
+        asm volatile("" :: "v"(sink) : "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+#endif
       if (wave == 0) {
-        __builtin_amdgcn_raw_buffer_store_b32((int)xround, fres, 0, fown, AUX_SC1);
+#ifdef MDT_XH_D1
+        for (int d = 0; d < 40; ++d) __builtin_amdgcn_s_sleep(127);
+#endif
+        __builtin_amdgcn_raw_buffer_store_b32((int)xround, fres, 0, fown, AUX_ST);
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+#ifdef MDT_XH_LOG
+        int xtries = 0;
+#endif
         for (;;) {
-          const unsigned got = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(fres, 0, fown ^ 128u, AUX_SC1_VOLATILE);
-          if ((int)(got - xround) >= 0) break;
+#ifdef MDT_XH_LOG
+          ++xtries;
+#endif
+          asm volatile("" ::: "memory");           // a fresh load every turn (the builtin is not volatile: that bit would make it sc0 sc1)
+          const unsigned got = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(fres, 0, fown ^ 128u, AUX_LD);
+          if ((int)(got - xround) >= 0) {
+#ifdef MDT_XH_LOG
+            if (xtries == 1) ++xlog_first;
+            xlog_got = got;
+#endif
+            break;
+          }
           __builtin_amdgcn_s_sleep(2);
           if (__builtin_amdgcn_s_memrealtime() - t0 > POLL_TIMEOUT) {   // never hang the GPU: flag the launch and go on
             if (lane == 0) atomicOr(a.xflags, 1u);
@@ -545,7 +587,14 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
         }
       }
       MDT_STAMP();                                       // ... partner's flag seen
+#ifdef MDT_XH_D2
+      if (wave == 0) for (int d = 0; d < 40; ++d) __builtin_amdgcn_s_sleep(127);
+#endif
       __builtin_amdgcn_s_barrier();                      // B(second hand-off tile): the partner's block is complete
+      asm volatile("" ::: "memory");
+#ifdef MDT_XH_FENCE
+      __threadfence();
+#endif
       const unsigned sother = sbase ^ XBLOCK;            // the same block of half hh ^ 1
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
@@ -553,12 +602,15 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
 #pragma unroll
         for (int c = 0; c < 8; ++c)
           o[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, vlane, sother + (unsigned)(8 * half + c) * 1024u,
-                                                                                 AUX_SC1_VOLATILE));
+                                                                                 AUX_LD));
 #pragma unroll
         for (int c = 0; c < 8; ++c) accT[8 * half + c] = hh ? (o[c] + accT[8 * half + c]) : (accT[8 * half + c] + o[c]);
       }
       ++xn;
       tau += 2;
+#ifdef MDT_XH_LOG
+      xlog_last = xround;
+#endif
       MDT_STAMP();                                       // ... partner's block added
     }
   };
@@ -936,6 +988,19 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
   // ---- the residual stream leaves the kernel once: wave (rt, fh) stores channels 128 fh .. 128 fh + 127 of its rows (NSPLIT
   // == 2: both workgroups hold the same rows; half hh stores channels 128 fh + 64 hh .. + 63) ----
   MDT_STAMP();
+#ifdef MDT_XH_LOG   // one record per launch and role (row blocks 0..3): [epoch read at entry, XCC id, polls that passed at the first
+                    // try, last flag value seen, my last flag value] behind the flag lines (tools/_dbg5.py allocates the room)
+  if (NSPLIT == 2 && wave == 0 && lane == 0 && rb < 4) {
+    unsigned* lg = a.xflags + 64 + 64 * nrb + 4096 * (2 * rb + hh);
+    const unsigned slot = atomicAdd(lg, 1u);
+    if (slot < 500) {
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      unsigned* e = lg + 8 + 8 * slot;
+      e[0] = xlog_epoch; e[1] = xcc & 15u; e[2] = xlog_first; e[3] = xlog_got; e[4] = xlog_last; e[5] = blockIdx.x;
+    }
+  }
+#endif
   if (mvalid) {
     if constexpr (NSPLIT == 1) {
       float* xo = a.out + (int64_t)m * C + 4 * g + 128 * fh;

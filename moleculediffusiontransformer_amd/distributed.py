@@ -25,10 +25,11 @@ def shard_bounds(total: int, world: int, rank: int) -> Tuple[int, int]:
     return start, start + q + (1 if rank < r else 0)
 
 
-def all_gather_samples(local: Tensor, total: int, group=None) -> Tensor:
-    """All-gather per-rank (b_r, C, L) results into the global (total, C, L) tensor on every rank."""
+def all_gather_samples(local: Tensor, total: int, group=None, force_collective: bool = False) -> Tensor:
+    """All-gather per-rank (b_r, C, L) results into the global (total, C, L) tensor on every rank.  A one-rank group returns
+    ``local`` as is unless ``force_collective`` (the RCCL smoke test on a one-GPU box: the same all_gather_into_tensor call)."""
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not force_collective:
         return local
     rank = dist.get_rank(group)
     sizes = [shard_bounds(total, world, r)[1] - shard_bounds(total, world, r)[0] for r in range(world)]
@@ -70,11 +71,11 @@ def sample_sharded(local_sample: Callable[[Tensor, int], Tensor], sequences: Ten
     return all_gather_samples(local, sequences.shape[0], group)
 
 
-def all_gather_tokens(local: Tensor, total: int, vocab: int, group=None) -> Tensor:
+def all_gather_tokens(local: Tensor, total: int, vocab: int, group=None, force_collective: bool = False) -> Tensor:
     """All-gather decoded token ids (b_r, L) -> (total, L) int64 on every rank.  Ids below 256 travel as ONE byte each
     (L bytes per molecule instead of the 4 * C * L bytes of the fp32 sample: 64 B instead of 4 KB for BASELINE configs[1])."""
     wire = local.to(torch.uint8 if vocab <= 256 else torch.int32)
-    return all_gather_samples(wire, total, group).long()
+    return all_gather_samples(wire, total, group, force_collective).long()
 
 
 def sample_tokens_sharded(local_sample_tokens: Callable[[Tensor, int], Tensor], sequences: Tensor, vocab: int,

@@ -318,7 +318,7 @@ def _(embedding, init_noise, step_noise, sigmas, handle, pred_dim, rho, sigma_da
 def all_gather_samples(local: Tensor, total: int) -> Tensor:
     """(b_r, ...) per rank -> (total, ...) on every rank over the default process group (RCCL on HIP tensors)."""
     from .distributed import all_gather_samples as gather
-    return gather(local, int(total)).clone()
+    return gather(local, int(total), force_collective=True)
 
 
 @all_gather_samples.register_fake

@@ -257,3 +257,41 @@ def test_bench_two_rank_logic_on_one_gpu():
     mg = d["multi_gpu"]
     assert mg["rccl_ranks_seen"] == 2 and mg["gathered_rows"] == 128 and mg["collectives_per_step"] == 1
     assert mg["shard_invariance"]["bitwise_equal_to_1_rank_run"] is True and mg["shard_invariance"]["rank"] == 1
+
+
+def test_rccl_all_gather_runs_on_one_gpu():
+    """the RCCL path had never executed anywhere.  On a one-GPU box: (i) backend "nccl" (= RCCL) at world size 1
+    with all_gather_into_tensor FORCED through all_gather_samples / all_gather_tokens on device tensors; (ii) bench.py as one
+    rank of a rank environment (RANK=0 WORLD_SIZE=1): process group up, gather per step, barrier + max-over-ranks timing,
+    `multi_gpu` in the line with the shard-invariance probe."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import os, torch, torch.distributed as dist\\n"
+        "from moleculediffusiontransformer_amd.distributed import all_gather_samples, all_gather_tokens\\n"
+        "dev = torch.device('cuda', 0); torch.cuda.set_device(dev)\\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)\\n"
+        "x = torch.randn(5, 16, 64, device=dev)\\n"
+        "y = all_gather_samples(x, 5, force_collective=True)\\n"
+        "assert y.data_ptr() != x.data_ptr() and torch.equal(y, x)\\n"
+        "t = torch.randint(0, 16, (5, 64), device=dev)\\n"
+        "assert torch.equal(all_gather_tokens(t, 5, 16, force_collective=True), t)\\n"
+        "z = torch.ops.mdt.all_gather_samples(x, 5)\\n"
+        "assert torch.equal(z, x)\\n"
+        "dist.barrier(); torch.cuda.synchronize(); dist.destroy_process_group(); print('RCCL_OK', dist.Backend.NCCL)\\n")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=root)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+    env.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_PORT="29542")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--batch", "64",
+                        "--timesteps", "4", "--no-breakdown", "--no-cpu-baseline", "--no-exact-f32", "--no-other-configs"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    mg = d["multi_gpu"]
+    assert d["n_gpus"] == 1 and mg["backend"].startswith("nccl") and mg["rccl_ranks_seen"] == 1 and mg["gathered_rows"] == 64
+    assert mg["shard_invariance"]["bitwise_equal_to_1_rank_run"] is True

@@ -1,6 +1,6 @@
 """Folds the rocprofv3 outputs of tools/profile_round.sh into the small csv summaries kept under profiles/.
 
-usage: python tools/pmc_summary.py gpurun_out/prof_r1 r1
+usage: python tools/pmc_summary.py gpurun_out/prof_r1 r1 [destination directory, default profiles/]
 
 FETCH_SIZE is reported in KB and, on gfx950, counts exactly half of the bytes of wide coalesced reads
 (MI355X_MICROARCH.md, HBM section) -> corrected = 2 x raw.  WRITE_SIZE (KB) is exact.
@@ -31,8 +31,10 @@ def counters(d: str, counter: str):
 
 def main():
     src, tag = sys.argv[1], sys.argv[2]
-    dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
     os.makedirs(dst, exist_ok=True)
+    what = open(os.path.join(src, "args.txt")).read().strip() if os.path.exists(os.path.join(src, "args.txt")) else \
+        "bench.py --batch 1024 --timesteps 4"
     for kind in ("kernel_stats", "domain_stats"):
         fs = glob.glob(os.path.join(src, "trace", "**", f"*_{kind}.csv"), recursive=True)
         if fs:
@@ -43,8 +45,7 @@ def main():
     fr, fn = counters(os.path.join(src, "pmc_fetch"), "FETCH_SIZE")
     wr, wn = counters(os.path.join(src, "pmc_write"), "WRITE_SIZE")
     with open(os.path.join(dst, f"{tag}_pmc_hbm_traffic.csv"), "w") as f:
-        f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), "
-                "bench.py --batch 1024 --timesteps 4\n")
+        f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), " + what + "\n")
         f.write("# FETCH_SIZE is in KB and reads exactly 1/2 of the bytes of wide coalesced reads on gfx950 "
                 "(MI355X_MICROARCH.md, HBM): corrected = 2 x raw\n")
         f.write("kernel,dispatches,fetch_raw_KB_per_dispatch,fetch_corrected_MB_per_dispatch,"
@@ -64,7 +65,7 @@ def main():
     vals = {n: counters(os.path.join(src, "pmc_sq"), n) for n in names}
     if vals["SQ_WAVE_CYCLES"][0]:
         with open(os.path.join(dst, f"{tag}_pmc_sq.csv"), "w") as f:
-            f.write("# rocprofv3 --pmc " + " ".join(names) + " (one pass, --kernel-trace only), bench.py --timesteps 4\n")
+            f.write("# rocprofv3 --pmc " + " ".join(names) + " (one pass, --kernel-trace only), " + what + "\n")
             f.write("# SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are quad-cycles summed over waves; WAIT_ANY = parked on "
                     "s_waitcnt / s_barrier, WAIT_INST_ANY = issue stall, ACTIVE_INST_ANY = issuing; MFMA busy in cycles; "
                     "GRBM_GUI_ACTIVE summed over the 8 XCDs (per-launch cycles = value / 8)\n")
