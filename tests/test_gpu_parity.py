@@ -72,8 +72,8 @@ def test_sample_matches_reference(models, name, case, want):
 
 
 def test_wide_batch_kernel_choice_matches_reference():
-    """The 256-channel transformers run pair-split at small batches and as whole-transformer launches without the split
-    (k_tf256) from ~1536 samples on (generative.py::_wide).  Both forms against the reference's golden sample, the automatic
+    """The 256-channel transformers run as head-split launches per sub-block (k_tblock32) at small batches and as whole-transformer
+    launches without the split (k_tf256) from ~1536 samples on (generative.py::_wide).  Both forms against the reference's golden sample, the automatic
     choice by batch size, and the pin that makes per-sample results independent of how a batch is sharded."""
     from moleculediffusiontransformer_amd import runtime as rt
     g = load_golden("cfg1_b2_t12_cfg7p5_sample.npz")
@@ -85,8 +85,7 @@ def test_wide_batch_kernel_choice_matches_reference():
         m.kernel_choice = choice
         outs[choice] = m.sample(seq, DEV, cond_scale=7.5, timesteps=T, noise=NoiseSource(init=init, steps=lambda i: step(i, init))).cpu()
         forms = {op.i[rt.F_NSPLIT] for op in m._engine.c.programs["eval"] if op.kind == rt.OP_TF256}
-        assert forms == ({1} if choice == "wide" else {2}) and m._engine.c.tf256 == (choice == "wide")
-        assert m._engine.handoff_status() == 0
+        assert forms == ({1} if choice == "wide" else set()) and m._engine.c.tf256 == (choice == "wide")
         assert (outs[choice] - to_t(g["out"])).abs().max() < TOL
     m.kernel_choice = "auto"
     assert m._wide(1024) is False and m._wide(2048) is True and m._wide(None) is False
@@ -269,19 +268,21 @@ def test_rccl_all_gather_runs_on_one_gpu():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = (
-        "import os, torch, torch.distributed as dist\\n"
-        "from moleculediffusiontransformer_amd.distributed import all_gather_samples, all_gather_tokens\\n"
-        "dev = torch.device('cuda', 0); torch.cuda.set_device(dev)\\n"
-        "dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)\\n"
-        "x = torch.randn(5, 16, 64, device=dev)\\n"
-        "y = all_gather_samples(x, 5, force_collective=True)\\n"
-        "assert y.data_ptr() != x.data_ptr() and torch.equal(y, x)\\n"
-        "t = torch.randint(0, 16, (5, 64), device=dev)\\n"
-        "assert torch.equal(all_gather_tokens(t, 5, 16, force_collective=True), t)\\n"
-        "z = torch.ops.mdt.all_gather_samples(x, 5)\\n"
-        "assert torch.equal(z, x)\\n"
-        "dist.barrier(); torch.cuda.synchronize(); dist.destroy_process_group(); print('RCCL_OK', dist.Backend.NCCL)\\n")
+    code = """
+import os, torch, torch.distributed as dist
+from moleculediffusiontransformer_amd.distributed import all_gather_samples, all_gather_tokens
+import moleculediffusiontransformer_amd.ops
+dev = torch.device('cuda', 0); torch.cuda.set_device(dev)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+x = torch.randn(5, 16, 64, device=dev)
+y = all_gather_samples(x, 5, force_collective=True)
+assert y.data_ptr() != x.data_ptr() and torch.equal(y, x)
+t = torch.randint(0, 16, (5, 64), device=dev)
+assert torch.equal(all_gather_tokens(t, 5, 16, force_collective=True), t)
+z = torch.ops.mdt.all_gather_samples(x, 5)
+assert torch.equal(z, x)
+dist.barrier(); torch.cuda.synchronize(); dist.destroy_process_group(); print('RCCL_OK', dist.Backend.NCCL)
+"""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=root)
     env.pop("RANK", None)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
@@ -295,3 +296,20 @@ def test_rccl_all_gather_runs_on_one_gpu():
     mg = d["multi_gpu"]
     assert d["n_gpus"] == 1 and mg["backend"].startswith("nccl") and mg["rccl_ranks_seen"] == 1 and mg["gathered_rows"] == 64
     assert mg["shard_invariance"]["bitwise_equal_to_1_rank_run"] is True
+
+
+@pytest.mark.parametrize("B", [8, 256])
+def test_repeated_sampling_is_bitwise_stable(B):
+    """The same call three times on identical noise returns identical bits, and the probe rows match the oracle -- with
+    launches of DIFFERENT data alternating (evaluations of a sampling loop), which an op-level repeat on fixed inputs cannot
+    exercise: this is the check that exposed the experimental pair-split hand-off (tools/repeat_determinism_probe.py)."""
+    m = make_model("cfg1")
+    T = 3
+    seq = synth_normal("rep/seq", (B, 12))
+    init = synth_normal("rep/init", (B, 16, 64))
+    nz = [synth_normal(f"rep/s{i}", (B, 16, 64)) for i in range(T - 1)]
+    rows = torch.tensor(sorted({0, 1, B // 2, B - 1}))
+    want = O.sample(synth_sd("cfg1"), oracle_cfg("cfg1"), seq[rows], init[rows], lambda i, x: nz[i][rows], T, 1.0, False)
+    outs = [m.sample(seq, DEV, cond_scale=1.0, timesteps=T, noise=NoiseSource(init=init, steps=lambda i: nz[i])) for _ in range(3)]
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert (outs[0].cpu()[rows] - want).abs().max() < TOL

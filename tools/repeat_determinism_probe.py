@@ -1,3 +1,6 @@
+"""Model-level repeat test (GPU box): the same sample() call N times on identical noise must return identical bits, and match the
+oracle on four probe rows -- at several batch sizes.  This is the test that exposed the pair-split hand-off (MDT_TF256_PAIR=1):
+launches with DIFFERENT data alternate here, unlike in an op-level repeat.   python tools/repeat_determinism_probe.py [repeats]"""
 import os, sys, torch
 ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT,"tests"))
