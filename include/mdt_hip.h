@@ -301,6 +301,11 @@ int mdt_program_run(const mdt_program *p, const mdt_bindings *b, int32_t B, int3
  * (transformer.py:3456-3470).  out is (B, n, D1+D2). */
 int mdt_cond_embed(const float *seq, const float *fc1_w, const float *fc1_b, const float *inv_freq,
                    float *out, int32_t B, int32_t n, int32_t D1, int32_t D2, void *stream);
+/* The pos_emb_fourier_add form of the same prelude (generative.py:844-846, graphmodel.py:338-339): the positional
+ * encoding is ADDED, e[b,i,d] = gelu(fc1_w[d] * seq[b,i] + fc1_b[d]) + PositionalEncoding1D(D)[i,d]; out is (B, n, D),
+ * inv_freq holds D/2 frequencies (text_embed_dim == embed_dim_position == D). */
+int mdt_cond_embed_add(const float *seq, const float *fc1_w, const float *fc1_b, const float *inv_freq,
+                       float *out, int32_t B, int32_t n, int32_t D, void *stream);
 
 /* ------------------------------------------------------------------ */
 /* k-diffusion preconditioning + ADPM2 sampler update                   */

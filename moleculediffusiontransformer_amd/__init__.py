@@ -11,6 +11,7 @@ from .diffusion import (ADPM2Sampler, DiffusionInpainter, DiffusionSampler, Karr
                         LogNormalDistribution, NoiseSource, Sampler)
 from .generative import (KDiffusion_mod, QMDiffusion, QMDiffusionForward, XDiffusion_x,  # noqa: F401
                          generate_and_validate, predict_properties_from_tokens, tokens_to_forward_input)
+from .graphmodel import AnalogDiffusionFull, AnalogDiffusionSparse  # noqa: F401
 from .modules import PositionalEncoding1D, UNetCFG1d  # noqa: F401
 from .netspec import UNetConfig, forward_unet_config, inverse_unet_config  # noqa: F401
 

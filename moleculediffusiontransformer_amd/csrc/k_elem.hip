@@ -304,22 +304,25 @@ __global__ __launch_bounds__(256) void k_argmax(const float* x, int32_t* tok, in
 }
 
 // e[b,i,:D1] = gelu(w*s+b), e[b,i,D1:] = [sin(i f) | cos(i f)]             (generative.py:838-850, transformer.py:3456-3470)
+// add != 0 (pos_emb_fourier_add, generative.py:844-846): e[b,i,f] = gelu(w*s+b)[f] + PositionalEncoding1D(D2)[i,f], D1 == D2
 __global__ __launch_bounds__(256) void k_cond_embed(const float* seq, const float* w, const float* bias,
-                                                     const float* inv_freq, float* out, int B, int n, int D1, int D2) {
-  const int F = D1 + D2;
+                                                     const float* inv_freq, float* out, int B, int n, int D1, int D2, int add) {
+  const int F = add ? D1 : D1 + D2;
   const int64_t total = (int64_t)B * n * F;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int f = (int)(i % F);
     const int64_t row = i / F;
     const int pos = (int)(row % n);
-    float v;
+    float v = 0.f;
     if (f < D1) {
       const float h = seq[row] * w[f] + bias[f];
       v = 0.5f * h * (1.0f + erff(h * 0.70710678118654752440f));
-    } else {
-      const int j = f - D1, half = D2 / 2;
+    }
+    if (add || f >= D1) {
+      const int j = add ? f : f - D1, half = D2 / 2;
       const float arg = (float)pos * inv_freq[j < half ? j : j - half];
-      v = j < half ? sinf(arg) : cosf(arg);
+      const float pe = j < half ? sinf(arg) : cosf(arg);
+      v = add ? v + pe : pe;
     }
     out[i] = v;
   }
@@ -437,8 +440,18 @@ int mdt_cond_embed(const float* seq, const float* fc1_w, const float* fc1_b, con
   if (B <= 0) return 0;
   if (D2 % 2) return bad("mdt_cond_embed: D2 must be even");
   hipLaunchKernelGGL(mdt::k_cond_embed, dim3(mdt::grid_for((int64_t)B * n * (D1 + D2))), dim3(256), 0,
-                     (hipStream_t)stream, seq, fc1_w, fc1_b, inv_freq, out, B, n, D1, D2);
+                     (hipStream_t)stream, seq, fc1_w, fc1_b, inv_freq, out, B, n, D1, D2, 0);
   return finish("mdt_cond_embed");
+}
+
+int mdt_cond_embed_add(const float* seq, const float* fc1_w, const float* fc1_b, const float* inv_freq, float* out,
+                       int32_t B, int32_t n, int32_t D, void* stream) {
+  if (!seq || !fc1_w || !fc1_b || !inv_freq || !out) return bad("mdt_cond_embed_add: null pointer");
+  if (B <= 0) return 0;
+  if (D <= 0 || D % 2) return bad("mdt_cond_embed_add: D must be even");
+  hipLaunchKernelGGL(mdt::k_cond_embed, dim3(mdt::grid_for((int64_t)B * n * D)), dim3(256), 0, (hipStream_t)stream, seq,
+                     fc1_w, fc1_b, inv_freq, out, B, n, D, D, 1);
+  return finish("mdt_cond_embed_add");
 }
 
 #define MDT_CHECK_TILE(name)                                                                   \

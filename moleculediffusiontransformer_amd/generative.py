@@ -148,10 +148,13 @@ class _QMBase(nn.Module):
         self.pos_emb_fourier_add = pos_emb_fourier_add
         self._text_dim = text_embed_dim
         self._pos_dim = 0
+        self._pos_add = bool(pos_emb_fourier and pos_emb_fourier_add)
         if pos_emb_fourier:
             if pos_emb_fourier_add:
-                raise NotImplementedError("pos_emb_fourier_add=True is not supported by the MI355X path")
-            text_embed_dim = text_embed_dim + embed_dim_position
+                if text_embed_dim != embed_dim_position:      # x + p_enc_1d(x) does not broadcast otherwise (generative.py:846)
+                    raise RuntimeError("pos_emb_fourier_add=True needs text_embed_dim == embed_dim_position")
+            else:
+                text_embed_dim = text_embed_dim + embed_dim_position
             self._pos_dim = embed_dim_position
             self.p_enc_1d = PositionalEncoding1D(embed_dim_position)
         self.max_length = max_length
@@ -163,8 +166,7 @@ class _QMBase(nn.Module):
                 raise TypeError("unet must be a moleculediffusiontransformer_amd UNetCFG1d")
             self.unet = unet
         else:
-            mk = inverse_unet_config if self._inverse else forward_unet_config
-            self.unet = UNetCFG1d(mk(pred_dim, channels, text_embed_dim, context_embedding_max_length))
+            self.unet = UNetCFG1d(self._unet_config(pred_dim, channels, text_embed_dim, context_embedding_max_length))
         self.diffusion = XDiffusion_x(type="k", net=self.unet,
                                       sigma_distribution=LogNormalDistribution(mean=-1.2, std=1.2),
                                       sigma_data=0.1, dynamic_threshold=0.0)
@@ -178,6 +180,10 @@ class _QMBase(nn.Module):
         self._engines = {}               # wide (bool) -> UNetEngine, for the current parameter values
         self._engine_key = None
         self.sampler_stats = {}
+
+    def _unet_config(self, pred_dim, channels, ctx_features, ctx_max_length):
+        mk = inverse_unet_config if self._inverse else forward_unet_config
+        return mk(pred_dim, channels, ctx_features, ctx_max_length)
 
     # ------------------------------------------------------------------ engine management
     def _param_key(self, device, n_ctx):
@@ -241,7 +247,7 @@ class _QMBase(nn.Module):
         seq = sequences.detach().float().to(device)
         inv = self.p_enc_1d.inv_freq.detach().float().to(device) if self._pos_dim else None
         return torch.ops.mdt.cond_embed(seq, self.fc1.weight.detach().to(device), self.fc1.bias.detach().to(device), inv,
-                                        self._pos_dim)
+                                        self._pos_dim, self._pos_add)
 
     # ------------------------------------------------------------------ seams used by the wrappers above
     def _noise_source(self, noise, B, device, sample0=0):

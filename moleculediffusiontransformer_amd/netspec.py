@@ -61,11 +61,12 @@ def forward_unet_config(pred_dim: int, channels: int, ctx_features: int,
 
 
 def sparse_unet_config(pred_dim: int, channels: int, ctx_features: int,
-                       ctx_max_length: int, patch_size: int = 8) -> UNetConfig:
+                       ctx_max_length: int, patch_size: int = 8, num_blocks: Tuple[int, ...] = (2, 2)) -> UNetConfig:
     """The U-Net of AnalogDiffusionSparse / AnalogDiffusionFull (graphmodel.py:266-283, :433-446; patch_size 8 / 4): the
-    same stack with a patching stem, two ResNet blocks and ONE transformer layer per level, no pre-transformer.  Pass it as
+    same stack with a patching stem, two (Sparse) / three (Full: num_blocks=(3, 3)) ResNet blocks and ONE transformer layer per
+    level, no pre-transformer.  Pass it as
     ``QMDiffusion(unet=UNetCFG1d(sparse_unet_config(...)))``."""
-    return UNetConfig(in_channels=pred_dim, channels=channels, patch_size=patch_size, num_blocks=(2, 2),
+    return UNetConfig(in_channels=pred_dim, channels=channels, patch_size=patch_size, num_blocks=tuple(num_blocks),
                       attentions=(1, 1), pre_transformer=0, ctx_features=ctx_features, ctx_max_length=ctx_max_length)
 
 

@@ -74,7 +74,8 @@ def _f32c(t: Tensor) -> Tensor:
 
 # ----------------------------------------------------------------------------------------------------------------------
 @custom_op("mdt::cond_embed", mutates_args=())
-def cond_embed(seq: Tensor, fc1_w: Tensor, fc1_b: Tensor, inv_freq: Optional[Tensor], pos_dim: int) -> Tensor:
+def cond_embed(seq: Tensor, fc1_w: Tensor, fc1_b: Tensor, inv_freq: Optional[Tensor], pos_dim: int, pos_add: bool = False) -> Tensor:
+    """pos_add: the positional encoding is added to the fc1 features (pos_emb_fourier_add) instead of concatenated."""
     dev = _hip(seq, fc1_w, fc1_b, inv_freq)
     lib = rt.load_library()
     seq, w, b = _f32c(seq), _f32c(fc1_w).view(-1), _f32c(fc1_b)
@@ -82,18 +83,24 @@ def cond_embed(seq: Tensor, fc1_w: Tensor, fc1_b: Tensor, inv_freq: Optional[Ten
     D1 = b.numel()
     if pos_dim and (inv_freq is None or inv_freq.numel() * 2 != pos_dim):
         raise RuntimeError("mdt::cond_embed: inv_freq must hold pos_dim / 2 frequencies")
+    if pos_add and pos_dim != D1:
+        raise RuntimeError("mdt::cond_embed: the additive form needs text_embed_dim == embed_dim_position")
     inv = _f32c(inv_freq) if pos_dim else w
-    out = torch.empty(B, n, D1 + pos_dim, device=dev)
+    out = torch.empty(B, n, D1 if pos_add else D1 + pos_dim, device=dev)
     if B:
         with torch.cuda.device(dev):
-            rt.check(lib.mdt_cond_embed(rt.ptr(seq), rt.ptr(w), rt.ptr(b), rt.ptr(inv), rt.ptr(out), B, n, D1, pos_dim,
-                                        rt.current_stream()))
+            if pos_add:
+                rt.check(lib.mdt_cond_embed_add(rt.ptr(seq), rt.ptr(w), rt.ptr(b), rt.ptr(inv), rt.ptr(out), B, n, D1,
+                                                rt.current_stream()))
+            else:
+                rt.check(lib.mdt_cond_embed(rt.ptr(seq), rt.ptr(w), rt.ptr(b), rt.ptr(inv), rt.ptr(out), B, n, D1, pos_dim,
+                                            rt.current_stream()))
     return out
 
 
 @cond_embed.register_fake
-def _(seq, fc1_w, fc1_b, inv_freq, pos_dim):
-    return seq.new_empty(seq.shape[0], seq.shape[1], fc1_b.numel() + pos_dim, dtype=torch.float32)
+def _(seq, fc1_w, fc1_b, inv_freq, pos_dim, pos_add=False):
+    return seq.new_empty(seq.shape[0], seq.shape[1], fc1_b.numel() + (0 if pos_add else pos_dim), dtype=torch.float32)
 
 
 @custom_op("mdt::precond_in", mutates_args=())

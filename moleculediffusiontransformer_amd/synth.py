@@ -91,6 +91,8 @@ MODEL_CASES = {
     "nb": ("inverse", dict(max_length=32, pred_dim=22, channels=128, context_embedding_max_length=12)),
     # an AnalogDiffusionSparse-shaped U-Net (graphmodel.py:266-283: patch_size 8, attentions [1, 1], no pre-transformer)
     "sparse": ("sparse", dict(max_length=128, pred_dim=3, channels=128, context_embedding_max_length=12)),
+    # AnalogDiffusionFull (graphmodel.py:391-446: patch_size 4, num_blocks [3, 3]) with pos_emb_fourier_add=True
+    "full": ("full", dict(max_length=64, pred_dim=8, channels=64, context_embedding_max_length=12)),
 }
 
 
@@ -99,7 +101,10 @@ def make_synth_model(case: str, device=None):
     (text_embed_dim=64 + embed_dim_position=64 = the 128 context features every notebook of the reference uses)."""
     from .generative import QMDiffusion, QMDiffusionForward
     kind, kw = MODEL_CASES[case]
-    if kind == "sparse":
+    if kind == "full":
+        from .graphmodel import AnalogDiffusionFull
+        m = AnalogDiffusionFull(text_embed_dim=64, embed_dim_position=64, pos_emb_fourier_add=True, **kw)
+    elif kind == "sparse":
         from .modules import UNetCFG1d
         from .netspec import sparse_unet_config
         unet = UNetCFG1d(sparse_unet_config(kw["pred_dim"], kw["channels"], 128, kw["context_embedding_max_length"]))

@@ -42,7 +42,8 @@ def conditioning_embedding(model, sequences: Tensor) -> Tensor:
         pos = torch.arange(x.shape[1], device=x.device, dtype=inv_freq.dtype)
         s = torch.einsum("i,j->ij", pos, inv_freq)
         emb = torch.cat((s.sin(), s.cos()), dim=-1)[:, : model.p_enc_1d.org_channels].to(x.dtype)
-        x = torch.cat((x, emb.unsqueeze(0).expand(x.shape[0], -1, -1)), dim=2)
+        emb = emb.unsqueeze(0).expand(x.shape[0], -1, -1)
+        x = x + emb if getattr(model, "pos_emb_fourier_add", False) else torch.cat((x, emb), dim=2)
     return x
 
 

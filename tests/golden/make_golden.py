@@ -58,6 +58,8 @@ class NoiseInjector:
 def embed(m, seq):
     with torch.no_grad():
         e = m.GELUact(m.fc1(seq.float().unsqueeze(2)))
+        if getattr(m, "pos_emb_fourier_add", False):          # generative.py:844-846 / graphmodel.py:338-339
+            return e + m.p_enc_1d(e)
         return torch.cat((e, m.p_enc_1d(e)), 2)
 
 

@@ -14,7 +14,7 @@ CASES = MODEL_CASES
 
 def oracle_cfg(case):
     kind, kw = CASES[case]
-    f = {"inverse": O.inverse_config, "forward": O.forward_config, "sparse": O.sparse_config}[kind]
+    f = {"inverse": O.inverse_config, "forward": O.forward_config, "sparse": O.sparse_config, "full": O.full_config}[kind]
     return f(kw["max_length"], kw["channels"], kw["pred_dim"], kw["context_embedding_max_length"])
 
 
@@ -22,8 +22,11 @@ def oracle_cfg(case):
 def synth_sd(case):
     """Reference-format state_dict (canonical 'unet.' prefix + fc1 + p_enc_1d) with synthetic weights."""
     kind, kw = CASES[case]
-    mk = {"inverse": inverse_unet_config, "forward": forward_unet_config, "sparse": sparse_unet_config}[kind]
-    ucfg = mk(kw["pred_dim"], kw["channels"], 128, kw["context_embedding_max_length"])
+    if kind == "full":
+        ucfg = sparse_unet_config(kw["pred_dim"], kw["channels"], 64, kw["context_embedding_max_length"], patch_size=4, num_blocks=(3, 3))
+    else:
+        mk = {"inverse": inverse_unet_config, "forward": forward_unet_config, "sparse": sparse_unet_config}[kind]
+        ucfg = mk(kw["pred_dim"], kw["channels"], 128, kw["context_embedding_max_length"])
     keys = [("fc1.weight", (64, 1)), ("fc1.bias", (64,)), ("p_enc_1d.inv_freq", (32,))]
     keys += unet_manifest(ucfg, "unet.")
     return synth_state_dict(keys)

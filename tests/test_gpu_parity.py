@@ -30,7 +30,7 @@ def models(request):
     return get
 
 
-@pytest.mark.parametrize("case", ["tiny", "pd22", "cfg3", "cfg1", "nb", "sparse"])
+@pytest.mark.parametrize("case", ["tiny", "pd22", "cfg3", "cfg1", "nb", "sparse", "full"])
 def test_unet_eval_and_denoise_match_reference(models, case):
     g = load_golden(f"{case}_unet.npz")
     m = models(case)
@@ -56,6 +56,8 @@ def test_unet_eval_and_denoise_match_reference(models, case):
     ("nb_b2_t6", "nb", ()),              # the notebook's trained configuration (Inverse_Diffusion.ipynb:1587-1604)
     ("nb_b2_t5_cfg2", "nb", ()),
     ("sparse_b2_t5", "sparse", ()),      # AnalogDiffusionSparse-shaped U-Net (graphmodel.py:266-283)
+    ("full_b2_t5", "full", ()),          # AnalogDiffusionFull with pos_emb_fourier_add=True (graphmodel.py:391-597)
+    ("full_b2_t4_cfg3", "full", ()),
 ])
 def test_sample_matches_reference(models, name, case, want):
     g = load_golden(f"{name}_sample.npz")

@@ -91,6 +91,34 @@ def test_sparse_unet_keeps_the_reference_checkpoint_layout():
     assert sum(p.numel() for p in m.parameters()) == int(g["nparams"])
 
 
+def test_analog_diffusion_wrappers_keep_the_reference_surface(capsys):
+    """graphmodel.py:225-597: AnalogDiffusionSparse / AnalogDiffusionFull with the reference's constructor keywords, state_dict
+    layout (Full: against the key list recorded from the reference) and pos_emb_fourier_add (text_embed_dim ==
+    embed_dim_position); sample() refuses the CPU like the other classes."""
+    from moleculediffusiontransformer_amd.graphmodel import AnalogDiffusionFull, AnalogDiffusionSparse
+    from moleculediffusiontransformer_amd.synth import make_synth_model
+    g = load_golden("full_keys.npz")
+    m = make_synth_model("full")
+    assert isinstance(m, AnalogDiffusionFull) and m.predict_neighbors is True and m.pos_emb_fourier_add is True
+    assert list(m.state_dict().keys()) == list(g["keys"])
+    assert sum(p.numel() for p in m.parameters()) == int(g["nparams"])
+    assert m.unet.config.patch_size == 4 and m.unet.config.num_blocks == (3, 3) and m.unet.config.ctx_features == 64
+    s = AnalogDiffusionSparse(max_length=128, channels=128, pred_dim=3, context_embedding_max_length=12, text_embed_dim=64,
+                              embed_dim_position=64)
+    assert "Using unet type" in capsys.readouterr().out
+    gs = load_golden("sparse_keys.npz")
+    assert list(s.state_dict().keys()) == list(gs["keys"]) and s.unet.config.patch_size == 8 and s.predict_neighbors is False
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        s.sample(torch.zeros(2, 12), "cpu", cond_scale=1.0, timesteps=4)
+    with pytest.raises(RuntimeError, match="text_embed_dim == embed_dim_position"):
+        AnalogDiffusionSparse(max_length=128, channels=128, pred_dim=3, pos_emb_fourier_add=True, text_embed_dim=32)
+    # the additive conditioning prelude of the training path equals the oracle's
+    from moleculediffusiontransformer_amd.train import conditioning_embedding
+    seq = torch.from_numpy(load_golden("full_unet.npz")["seq"])
+    emb = conditioning_embedding(m, seq)
+    assert emb.shape == (2, 12, 64) and (emb - torch.from_numpy(load_golden("full_unet.npz")["emb"])).abs().max() < 1e-6
+
+
 def test_no_cpu_fallback():
     m = QMDiffusion(max_length=32, pred_dim=16, channels=16, context_embedding_max_length=12,
                     text_embed_dim=64, embed_dim_position=64)
@@ -174,13 +202,16 @@ def test_token_chain_between_the_two_models():
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16x3", "bf16x3-wide", "bf16"])
-@pytest.mark.parametrize("case", ["tiny", "pd22", "cfg3", "cfg1", "sparse"])
+@pytest.mark.parametrize("case", ["tiny", "pd22", "cfg3", "cfg1", "sparse", "full"])
 def test_lowering_matches_reference_golden(case, mode):
     """compiler.py's op program, executed by the CPU interpreter, reproduces the reference U-Net output ('bf16': the
     reduced-precision mode, within its own budget of 2e-2 of an O(1) output per evaluation)."""
     kind, kw = CASES[case]
-    mk = {"inverse": inverse_unet_config, "forward": forward_unet_config, "sparse": sparse_unet_config}[kind]
-    ucfg = mk(kw["pred_dim"], kw["channels"], 128, kw["context_embedding_max_length"])
+    if kind == "full":
+        ucfg = sparse_unet_config(kw["pred_dim"], kw["channels"], 64, kw["context_embedding_max_length"], patch_size=4, num_blocks=(3, 3))
+    else:
+        mk = {"inverse": inverse_unet_config, "forward": forward_unet_config, "sparse": sparse_unet_config}[kind]
+        ucfg = mk(kw["pred_dim"], kw["channels"], 128, kw["context_embedding_max_length"])
     usd = {k[5:]: v for k, v in synth_sd(case).items() if k.startswith("unet.")}
     wide = mode.endswith("-wide")       # 256-channel transformers as whole-transformer launches (k_tf256)
     mode = mode.split("-")[0]

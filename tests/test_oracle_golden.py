@@ -10,7 +10,7 @@ from oracle import unet_oracle as O
 TOL = 2e-6   # oracle and reference issue the same ATen ops; observed difference is exactly 0
 
 
-@pytest.mark.parametrize("case", ["cfg1", "cfg3", "tiny", "pd22", "nb", "sparse"])
+@pytest.mark.parametrize("case", ["cfg1", "cfg3", "tiny", "pd22", "nb", "sparse", "full"])
 def test_unet_eval_matches_reference(case):
     g = load_golden(f"{case}_unet.npz")
     sd, cfg = synth_sd(case), oracle_cfg(case)
@@ -43,6 +43,8 @@ def test_unet_eval_matches_reference(case):
     ("nb_b2_t6", "nb", ()),
     ("nb_b2_t5_cfg2", "nb", ()),
     ("sparse_b2_t5", "sparse", ()),
+    ("full_b2_t5", "full", ()),          # AnalogDiffusionFull, pos_emb_fourier_add=True (graphmodel.py:391-597)
+    ("full_b2_t4_cfg3", "full", ()),
 ])
 def test_sample_matches_reference(name, case, want):
     g = load_golden(f"{name}_sample.npz")
