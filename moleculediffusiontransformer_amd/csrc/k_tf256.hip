@@ -536,31 +536,12 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), xres, vlane, sbase + (unsigned)(8 * fh + c) * 1024u, AUX_ST);
       }
       MDT_STAMP();                                       // hand-off: stores issued
-#ifdef MDT_XH_FENCE
-      __threadfence();
-#endif
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave, in front of the barrier the flag store follows
       MDT_STAMP();                                       // ... drained
       __builtin_amdgcn_s_barrier();                      // B(first hand-off tile)
       MDT_STAMP();                                       // ... every wave of the workgroup drained
       ++xround;
-#ifdef MDT_XH_RB      // experiment: read my own block back through the L2 before the flag goes out
-      {
-        f32x4 rbk[8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c)
-          rbk[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, vlane, sbase + (unsigned)(8 * fh + c) * 1024u, AUX_LD));
-        float sink = 0.f;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) sink += rbk[c][0];
-        asm volatile("" :: "v"(sink) : "memory");
-        __builtin_amdgcn_s_barrier();
-      }
-#endif
       if (wave == 0) {
-#ifdef MDT_XH_D1
-        for (int d = 0; d < 40; ++d) __builtin_amdgcn_s_sleep(127);
-#endif
         __builtin_amdgcn_raw_buffer_store_b32((int)xround, fres, 0, fown, AUX_ST);
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
 #ifdef MDT_XH_LOG
@@ -587,14 +568,8 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
         }
       }
       MDT_STAMP();                                       // ... partner's flag seen
-#ifdef MDT_XH_D2
-      if (wave == 0) for (int d = 0; d < 40; ++d) __builtin_amdgcn_s_sleep(127);
-#endif
       __builtin_amdgcn_s_barrier();                      // B(second hand-off tile): the partner's block is complete
       asm volatile("" ::: "memory");
-#ifdef MDT_XH_FENCE
-      __threadfence();
-#endif
       const unsigned sother = sbase ^ XBLOCK;            // the same block of half hh ^ 1
 #pragma unroll
       for (int half = 0; half < 2; ++half) {

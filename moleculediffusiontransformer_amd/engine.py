@@ -81,7 +81,7 @@ class UNetEngine:
             # one 128-byte flag line per (row block, half) behind 64 diagnostic words.  The flags count hand-offs monotonically
             # over the life of the buffer: zeroed here, never between launches.
             nrb = (B * c.xchg_tokens + 31) // 32
-            self.xflags = torch.zeros(64 + 64 * nrb + (8 * 4096 if os.environ.get("MDT_XH_LOG") else 0), dtype=torch.int32,
+            self.xflags = torch.zeros(64 + 64 * nrb + (8 * 4096 + 16384 if os.environ.get("MDT_XH_LOG") else 0), dtype=torch.int32,
                                       device=self.device)
             self.xbuf = torch.empty(2 * nrb * 2 * 32 * 256, device=self.device)
         self.B = B
