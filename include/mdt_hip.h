@@ -214,8 +214,8 @@ enum mdt_tblock_i {
                                        out = Wout (x + FF(x)) + bout; the W2 tiles hold Wout W2, POST = C/64 extra output
                                        tiles hold Wout (natural k order), the output bias holds Wout b2 + bout; x is left
                                        untouched                                                            */
-  MDT_B_VARIANT = 9                 /* 0: 64-row workgroups; 1: 16-row workgroups whose waves split the features
-                                       (levels with few rows); 2: 32-row workgroups, C = 256 (cross: <= 48 keys per 16 rows), weight
+  MDT_B_VARIANT = 9                 /* 0: 64-row workgroups, C = 128 (cross: <= 16 keys per 16 rows); 1: removed (round 3);
+                                       2: 32-row workgroups, C = 256 (cross: <= 48 keys per 16 rows), weight
                                        stream packed as 128-wide sub-tiles (K halves / output-row halves);
                                        3: as 2, with the heads / hidden chunks of a row block split over two
                                        workgroups: out = scratch [2][B T][C] for their partial sums;

@@ -138,7 +138,6 @@ class UNetCompiler:
                  max_time_rows: int = 1024, gemm_mode: str = "bf16x3", fuse_blocks: bool = True, tf256: bool = False):
         self.fuse_blocks = fuse_blocks
         self.fuse_c256 = os.environ.get("MDT_FUSE_C256", "1") == "1"
-        self.tb32 = os.environ.get("MDT_TB32", "1") == "1"           # C = 256 blocks on 32-row workgroups (k_tblock32)
         self.tb_split = os.environ.get("MDT_TB_SPLIT", "1") == "1"   # ... their heads split over two workgroups
         self.ff_split = os.environ.get("MDT_FF_SPLIT", "1") == "1"   # ... also the feed-forward's hidden chunks
         # ... partial sums handed to the next sub-block instead of a reduce launch.  Measured: 2511 molecules/s against
@@ -149,7 +148,7 @@ class UNetCompiler:
         self.use_resblock = os.environ.get("MDT_RESBLOCK", "1") == "1"   # Patcher / Unpatcher ResNets as ONE launch (k_resblock)
         self.convt_merge = os.environ.get("MDT_CONVT_MERGE", "1") == "1"   # ConvTranspose phases in one launch
         # Transformer1d's closing 1x1 convolution folded into its last feed-forward block (ring kernels only)
-        self.fold_out = os.environ.get("MDT_FOLD_OUT", "1") == "1" and os.environ.get("MDT_TB_LW", "1") != "0"
+        self.fold_out = os.environ.get("MDT_FOLD_OUT", "1") == "1"
         self.rconv_two = os.environ.get("MDT_RCONV2", "k1") == "1"   # concatenated inputs as ONE two-source launch ...
         self.rconv_two_k1 = os.environ.get("MDT_RCONV2", "k1") in ("1", "k1")   # ... only their 1x1 residual convolution
         # cross-attention sub-blocks: "1" fuses the shapes whose K/V rows stream through the loader-wave ring
@@ -1231,13 +1230,13 @@ class UNetCompiler:
         #                         fill only 64 CUs (self 70 us)
         #   C = 256, 32-row workgroups + loader waves (k_tblock32, self-attention / feed-forward only): the 16-row form
         #                         sits on the L2 -> LDS bandwidth roof (its weight stream is read by 256 workgroups)
-        variant = (2 if self.tb32 else 1) if c == 256 else 0
+        variant = 2 if c == 256 else 0
         split = 3 if (variant == 2 and self.tb_split) else variant     # self / cross: two workgroups per row block
         keys16 = (16 // t.rows) * self.n_ctx                        # context rows per 16 token rows
         ring_x = (c == 128 and keys16 <= 16) or (variant == 2 and keys16 <= 48)
         # C = 256: the sub-blocks of a transformer hand the residual stream on as (x, second head group's partial)
         # through ping-pong buffers, so the head split needs no reduce launch (every sub-block must be a ring kernel)
-        chain = fused and split == 3 and self.tb_chain and (not cross or (self.fuse_cross in ("1", "all") and ring_x))
+        chain = fused and split == 3 and self.tb_chain and (not cross or (self.fuse_cross == "1" and ring_x))
         pend: Optional[Ten] = None
         y_fold: Optional[Ten] = None
         for i in range(layers):
@@ -1270,8 +1269,8 @@ class UNetCompiler:
                 self.tblock(t, rt.TB_SELF, bp + "attention.", variant=split)
                 if cross:
                     self.cross_layers.append(bp + "cross_attention.")
-                    xv = split if ring_x else (1 if variant == 2 else variant)
-                    if (self.fuse_cross == "all" and keys16 <= 64) or (self.fuse_cross == "1" and ring_x):
+                    xv = split
+                    if self.fuse_cross == "1" and ring_x:
                         self.tblock(t, rt.TB_CROSS, bp + "cross_attention.", len(self.cross_layers) - 1,
                                     variant=xv)
                     elif self.fold_ok():
@@ -1550,10 +1549,9 @@ class UNetCompiler:
         # the masked pass sees the same x and time, only the context differs): the first half of the samples attends to its
         # hoisted K/V, the second half to the FixedEmbedding's.  Needs every cross-attention block on a ring kernel (the
         # only ones that take the second K/V pointer); otherwise the engine falls back to two passes.
-        tb_lw = os.environ.get("MDT_TB_LW", "1") != "0"
         cross = [op for op in eval_ops if isinstance(getattr(op, "_kv", None), tuple)]      # (folded layers: never "ring")
         ring = all(op.kind in (rt.OP_TF128, rt.OP_TF256) or
-                   (op.kind == rt.OP_TBLOCK and (op.i[rt.B_VARIANT] >= 2 or (op.i[rt.B_VARIANT] == 0 and tb_lw and op.i[rt.B_C] == 128
+                   (op.kind == rt.OP_TBLOCK and (op.i[rt.B_VARIANT] >= 2 or (op.i[rt.B_VARIANT] == 0 and op.i[rt.B_C] == 128
                                                                          and (16 // op.i[rt.B_T]) * op.i[rt.B_TK] <= 16)))
                    for op in cross)
         dual_multiple = 1

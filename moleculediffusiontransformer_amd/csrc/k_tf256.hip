@@ -134,8 +134,8 @@ constexpr int VEC_BYTES = VEC_FLOATS * 4;
 #ifndef MDT_XH_MODE
 #define MDT_XH_MODE 0
 #endif
-constexpr int AUX_ST = MDT_XH_MODE == 1 ? 17 : 16;
-constexpr int AUX_LD = MDT_XH_MODE == 0 ? 16 : 17;
+constexpr int AUX_ST = MDT_XH_MODE == 1 ? 17 : (MDT_XH_MODE == 3 ? 18 : (MDT_XH_MODE == 4 ? 19 : 16));   // 18 = sc1 nt, 19 = sc0 sc1 nt
+constexpr int AUX_LD = MDT_XH_MODE == 0 ? 16 : (MDT_XH_MODE == 3 ? 18 : (MDT_XH_MODE == 4 ? 19 : 17));
 constexpr unsigned XBLOCK = 32 * C * 4;            // bytes one workgroup hands over per round
 constexpr unsigned long long POLL_TIMEOUT = 30000000ull;   // s_memrealtime ticks (100 MHz): 0.3 s
 

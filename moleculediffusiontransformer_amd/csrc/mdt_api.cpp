@@ -152,6 +152,9 @@ static const char* validate(const mdt_op& o, int idx, char* buf, size_t nbuf) {
         return bad("cross block needs K/V and at most 64 keys per 16 rows");
       if (!o.a.space || !o.w.space || !o.bias.space) return bad("missing operand");
       if (i[MDT_B_VARIANT] < 0 || i[MDT_B_VARIANT] > 4) return bad("unknown fused-block variant");
+      if (i[MDT_B_VARIANT] == 1) return bad("variant 1 (16-row feature-split workgroups) was removed; C = 256 blocks are variants 2..4");
+      if (i[MDT_B_VARIANT] == 0 && (i[MDT_B_C] != 128 || (i[MDT_B_MODE] == MDT_TB_CROSS && (16 / i[MDT_B_T]) * i[MDT_B_TK] > 16)))
+        return bad("variant 0 serves C = 128, cross blocks with at most 16 keys per 16 rows (loader-wave kernel)");
       if (i[MDT_B_POST] && (i[MDT_B_MODE] != MDT_TB_FF || !o.out.space || i[MDT_B_VARIANT] == 1 || i[MDT_B_VARIANT] == 3 ||
                             (i[MDT_B_VARIANT] == 4 && o.p2.space)))
         return bad("a folded closing convolution needs an unsplit feed-forward block of variant 0, 2 or 4 and an output tensor");
@@ -402,9 +405,7 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
           a.nsplit = o.p2.space ? 2 : 1;
         }
         if (!missing)
-          e = o.i[MDT_B_VARIANT] >= 2   ? mdt::launch_tblock32(a, stream)
-              : o.i[MDT_B_VARIANT] == 1 ? mdt::launch_tblock16(a, stream)
-                                        : mdt::launch_tblock(a, stream);
+          e = o.i[MDT_B_VARIANT] >= 2 ? mdt::launch_tblock32(a, stream) : mdt::launch_tblock(a, stream);
         break;
       }
       case MDT_OP_TF128:

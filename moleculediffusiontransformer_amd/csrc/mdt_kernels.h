@@ -185,11 +185,10 @@ struct TBlockArgs {
   const void* pf_ptr;  // weight stream of the NEXT launch (ring kernels: pulled into the L2s by the loader waves), or nullptr
   int pf_lines;
 };
-hipError_t launch_tblock(const TBlockArgs& a, hipStream_t s);     // 64-row workgroups (k_tblock.hip)
+hipError_t launch_tblock(const TBlockArgs& a, hipStream_t s);     // variant 0: k_tblock_lw where it applies (k_tblock.hip)
 bool tblock_lw_supported(const TBlockArgs& a);                  // k_tblock_lw.hip: C = 128 self-attention / feed-forward
 hipError_t launch_tblock_lw(const TBlockArgs& a, hipStream_t s);
 hipError_t launch_tblock32(const TBlockArgs& a, hipStream_t s);   // 32-row workgroups, C = 256, sub-tile stream (k_tblock32.hip)
-hipError_t launch_tblock16(const TBlockArgs& a, hipStream_t s);   // 16-row workgroups, waves split the features (k_tblock16.hip)
 
 // MDT_OP_TF128 (k_tf128.hip): a whole Transformer1d of a C = 128 level in one launch
 struct TFArgs {
