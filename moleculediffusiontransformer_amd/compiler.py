@@ -169,13 +169,10 @@ class UNetCompiler:
         # for the five transformers against 1.25 ms as head-split launches (both bound by the per-CU weight stream); it wins
         # once the batch fills the chip without the split, so it is a per-batch choice (engine: program "eval_wide")
         self.tf256 = bool(tf256)
-        # ... and where the batch does NOT fill the chip that way, EXPERIMENTAL (MDT_TF256_PAIR=1; default 0 = one head-split
-        # launch per sub-block, k_tblock32, as in rounds 1-2): the same launch with every row block's heads split over a PAIR
-        # of workgroups that hand each other their partial sums inside the launch (k_tf256 NSPLIT = 2).  +1.7 % molecules/s
-        # same-box, every op-level test green -- and NOT shipped: in the full model, where launches with DIFFERENT data alternate,
-        # about one hand-off in 10^4 returns a 64-byte sector of an older launch's block although flags and epochs are right
-        # (profiles/r3_pair_handoff_investigation.txt)
-        self.tf256_pair = os.environ.get("MDT_TF256_PAIR", "0") == "1"
+        # ... and where the batch does NOT fill the chip that way: the same launch with every row block's heads split over a
+        # PAIR of workgroups that hand each other their partial sums inside the launch (k_tf256 NSPLIT = 2).
+        # MDT_TF256_PAIR=0: one head-split launch per sub-block (k_tblock32), the form of rounds 1-2.
+        self.tf256_pair = os.environ.get("MDT_TF256_PAIR", "1") == "1"
         self.pair_stride = int(os.environ.get("MDT_PAIR_STRIDE", "8"))
         self.xchg_tokens = 0                 # max tokens per sample over the pair-split ops (sizes the hand-off buffers)
         if gemm_mode not in ("f32", "bf16x3", "bf16"):

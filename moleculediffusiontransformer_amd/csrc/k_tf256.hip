@@ -134,6 +134,12 @@ constexpr int VEC_BYTES = VEC_FLOATS * 4;
 #ifndef MDT_XH_MODE
 #define MDT_XH_MODE 0
 #endif
+#ifndef MDT_XH_READBACK
+#define MDT_XH_READBACK 0
+#endif
+#ifndef MDT_XH_ADDR
+#define MDT_XH_ADDR 1        // 1: whole address in the VECTOR offset (scalar offset 0), as tools/ubench/pair_handoff.hip does
+#endif
 constexpr int AUX_ST = MDT_XH_MODE == 1 ? 17 : (MDT_XH_MODE == 3 ? 18 : (MDT_XH_MODE == 4 ? 19 : 16));   // 18 = sc1 nt, 19 = sc0 sc1 nt
 constexpr int AUX_LD = MDT_XH_MODE == 0 ? 16 : (MDT_XH_MODE == 3 ? 18 : (MDT_XH_MODE == 4 ? 19 : 17));
 constexpr unsigned XBLOCK = 32 * C * 4;            // bytes one workgroup hands over per round
@@ -304,7 +310,7 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
   if constexpr (NSPLIT == 2) {
     xres = __builtin_amdgcn_make_buffer_rsrc(a.xbuf, 0, 0x7fffffff, 0x00020000);
     fres = __builtin_amdgcn_make_buffer_rsrc(a.xflags, 0, 0x7fffffff, 0x00020000);
-    xround = (unsigned)__builtin_amdgcn_readfirstlane(__builtin_amdgcn_raw_buffer_load_b32(fres, 0, fown, AUX_LD));   // written by an earlier LAUNCH
+    xround = (unsigned)__builtin_amdgcn_readfirstlane(__builtin_amdgcn_raw_buffer_load_b32(fres, fown, 0, AUX_LD));   // written by an earlier LAUNCH
   }
 #ifdef MDT_XH_LOG
   xlog_epoch = xround;
@@ -533,16 +539,39 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
       for (int c = 0; c < 8; ++c) {
         const f32x4 lo_ = accT[c], hi_ = accT[8 + c];
         const f32x4 v = f32x4{fh ? hi_[0] : lo_[0], fh ? hi_[1] : lo_[1], fh ? hi_[2] : lo_[2], fh ? hi_[3] : lo_[3]};
+#if MDT_XH_ADDR
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), xres, vlane + sbase + (unsigned)(8 * fh + c) * 1024u, 0, AUX_ST);
+#else   // the form that FAILS at model level (kept for the record, -DMDT_XH_ADDR=0): wave-uniform part in the scalar offset
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), xres, vlane, sbase + (unsigned)(8 * fh + c) * 1024u, AUX_ST);
+#endif
       }
       MDT_STAMP();                                       // hand-off: stores issued
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave, in front of the barrier the flag store follows
+#if MDT_XH_READBACK
+      // ... and read the block back through the same L2 channels: a load is served behind the writes to its address, so when it
+      // returns every 64-byte sector of the stores has been performed, not only acknowledged (MDT_XH_READBACK = 1: every line;
+      // 2: one dword of the LAST sector of every 256 bytes)
+      {
+        float sink = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          if (MDT_XH_READBACK == 1) {
+            const f32x4 rbk = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, vlane, sbase + (unsigned)(8 * fh + c) * 1024u, AUX_LD));
+            sink += rbk[0] + rbk[3];
+          } else {
+            const unsigned off = (unsigned)(lane & 3) * 256u + 252u;       // lanes 0..3: last dword of each 256-byte chunk
+            sink += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xres, off, sbase + (unsigned)(8 * fh + c) * 1024u, AUX_LD));
+          }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" :: "v"(sink) : "memory");
+      }
+#endif
       MDT_STAMP();                                       // ... drained
       __builtin_amdgcn_s_barrier();                      // B(first hand-off tile)
       MDT_STAMP();                                       // ... every wave of the workgroup drained
       ++xround;
       if (wave == 0) {
-        __builtin_amdgcn_raw_buffer_store_b32((int)xround, fres, 0, fown, AUX_ST);
+        __builtin_amdgcn_raw_buffer_store_b32((int)xround, fres, fown, 0, AUX_ST);
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
 #ifdef MDT_XH_LOG
         int xtries = 0;
@@ -552,7 +581,7 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
           ++xtries;
 #endif
           asm volatile("" ::: "memory");           // a fresh load every turn (the builtin is not volatile: that bit would make it sc0 sc1)
-          const unsigned got = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(fres, 0, fown ^ 128u, AUX_LD);
+          const unsigned got = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(fres, fown ^ 128u, 0, AUX_LD);
           if ((int)(got - xround) >= 0) {
 #ifdef MDT_XH_LOG
             if (xtries == 1) ++xlog_first;
@@ -568,6 +597,9 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
         }
       }
       MDT_STAMP();                                       // ... partner's flag seen
+#ifdef MDT_XH_D2       // stress build: 135 us between the poll and the loads (made EVERY call fail with the scalar-offset form)
+      if (wave == 0) for (int d = 0; d < 40; ++d) __builtin_amdgcn_s_sleep(127);
+#endif
       __builtin_amdgcn_s_barrier();                      // B(second hand-off tile): the partner's block is complete
       asm volatile("" ::: "memory");
       const unsigned sother = sbase ^ XBLOCK;            // the same block of half hh ^ 1
@@ -576,8 +608,13 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
         f32x4 o[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c)
+#if MDT_XH_ADDR
+          o[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, vlane + sother + (unsigned)(8 * half + c) * 1024u, 0,
+                                                                                 AUX_LD));
+#else
           o[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, vlane, sother + (unsigned)(8 * half + c) * 1024u,
                                                                                  AUX_LD));
+#endif
 #pragma unroll
         for (int c = 0; c < 8; ++c) accT[8 * half + c] = hh ? (o[c] + accT[8 * half + c]) : (accT[8 * half + c] + o[c]);
       }

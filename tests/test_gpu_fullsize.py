@@ -159,9 +159,9 @@ def test_wide_path_at_batch_2048_against_the_oracle():
     rows = torch.tensor([0, 1023, 1024, 2047])
     ref = O.sample(synth_sd("cfg1"), oracle_cfg("cfg1"), seq[rows], init[rows], lambda i, x: nz[i][rows], T, 1.0, False)
     assert (out.cpu()[rows] - ref).abs().max() < TOL
-    # the head-split form on the same rows (what batches up to ~1536 run): same answer to rounding, own oracle check
+    # the pair-split form on the same rows (what batches up to ~1536 run): same answer to rounding, own oracle check
     m.kernel_choice = "narrow"
     out_n = m.sample(seq[:1024], DEV, cond_scale=1.0, timesteps=T, clamp=False,
                      noise=NoiseSource(init=init[:1024], steps=lambda i: nz[i][:1024]))
-    assert not m._engine.c.tf256
+    assert not m._engine.c.tf256 and m._engine.handoff_status() == 0
     assert (out_n.cpu()[[0, 1023]] - ref[:2]).abs().max() < TOL

@@ -794,7 +794,6 @@ def test_fused_transformer(C, T, B, layers, cross, fixed, form):
     p = "tf."
     sd = _transformer_sd(p, C, layers, cross)
     comp = UNetCompiler(cfg, 64, n_ctx, sd, tf256=(form == "whole"))
-    comp.tf256_pair = form != "whole"              # the experimental form (off by default)
     comp.pair_stride = 1 if form == "pair1" else 8
     if not (comp.tf128_ok(C, T, layers, cross) or comp.tf256_ok(C, T, layers, cross)):
         pytest.skip("shape outside the fused transformers' envelope")
@@ -864,13 +863,13 @@ def test_fused_transformer(C, T, B, layers, cross, fixed, form):
 
 @pytest.mark.parametrize("T,B,layers,cross", [(4, 1024, 2, True), (4, 37, 1, True), (16, 9, 1, False)])
 def test_pair_handoff_is_placement_independent_and_repeatable(T, B, layers, cross):
-    """The EXPERIMENTAL pair-split MDT_OP_TF256 (off by default) hands 32 x 256 partial sums between two workgroups inside the
-    launch (sc1 stores, drained, workgroup barrier, flag; poll, barrier, sc1 loads).  120 launches on ONE set of flag words (they
+    """The pair-split MDT_OP_TF256 hands 32 x 256 partial sums between two workgroups inside the launch (sc1 stores, drained,
+    workgroup barrier, flag; poll, barrier, sc1 loads).  120 launches on ONE set of flag words (they
     count monotonically across launches), partners alternately on one XCD (ids 8 apart) and on different XCDs (neighbouring ids,
     forced through mdt_set_tuning): every launch returns the same bits, which agree with the CPU interpreter and, to rounding
     (different summation order of the heads), with the whole-workgroup form.  NOTE what this test CANNOT see: every launch
-    computes the same values, so a block served from the PREVIOUS launch looks right -- that is the failure found at model
-    level, which is why the form is not on the default path."""
+    computes the same values, so a piece served from another launch's block looks right -- the failure of the first form of the
+    hand-off was found at model level (tests/test_gpu_parity.py::test_repeated_sampling_is_bitwise_stable, DESIGN.md 3.8)."""
     from moleculediffusiontransformer_amd.compiler import Ten, UNetCompiler
     from moleculediffusiontransformer_amd.netspec import inverse_unet_config
     from oracle.program_interp import Buffers, run_program
@@ -882,7 +881,6 @@ def test_pair_handoff_is_placement_independent_and_repeatable(T, B, layers, cros
 
     def build(whole):
         comp = UNetCompiler(cfg, 64, n_ctx, sd, tf256=whole)
-        comp.tf256_pair = not whole
         comp.transformer(Ten(A, 0, T, C), p, C, layers, cross, free_input=False)
         op = comp.ops[0]
         op.out = ref(A, T * C)
