@@ -134,9 +134,6 @@ constexpr int VEC_BYTES = VEC_FLOATS * 4;
 #ifndef MDT_XH_MODE
 #define MDT_XH_MODE 0
 #endif
-#ifndef MDT_XH_READBACK
-#define MDT_XH_READBACK 0
-#endif
 #ifndef MDT_XH_ADDR
 #define MDT_XH_ADDR 1        // 1: whole address in the VECTOR offset (scalar offset 0), as tools/ubench/pair_handoff.hip does
 #endif
@@ -547,25 +544,6 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
       }
       MDT_STAMP();                                       // hand-off: stores issued
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave, in front of the barrier the flag store follows
-#if MDT_XH_READBACK
-      // ... and read the block back through the same L2 channels: a load is served behind the writes to its address, so when it
-      // returns every 64-byte sector of the stores has been performed, not only acknowledged (MDT_XH_READBACK = 1: every line;
-      // 2: one dword of the LAST sector of every 256 bytes)
-      {
-        float sink = 0.f;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          if (MDT_XH_READBACK == 1) {
-            const f32x4 rbk = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, vlane, sbase + (unsigned)(8 * fh + c) * 1024u, AUX_LD));
-            sink += rbk[0] + rbk[3];
-          } else {
-            const unsigned off = (unsigned)(lane & 3) * 256u + 252u;       // lanes 0..3: last dword of each 256-byte chunk
-            sink += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xres, off, sbase + (unsigned)(8 * fh + c) * 1024u, AUX_LD));
-          }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" :: "v"(sink) : "memory");
-      }
-#endif
       MDT_STAMP();                                       // ... drained
       __builtin_amdgcn_s_barrier();                      // B(first hand-off tile)
       MDT_STAMP();                                       // ... every wave of the workgroup drained
