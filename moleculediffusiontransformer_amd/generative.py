@@ -190,10 +190,10 @@ class _QMBase(nn.Module):
         return (str(device), n_ctx, self.gemm_mode, tuple((p.data_ptr(), p._version) for p in self.unet.parameters()))
 
     def _wide(self, batch: Optional[int]) -> bool:
-        """Which form of the 256-channel transformers to run (compiler.py: MDT_TF256).  One launch per sub-block with the
-        heads split over two workgroups fills the chip at small batches; from ~1536 samples (4 tokens per sample at that
-        level: 192 workgroups of 32 rows) the whole-transformer launch without the split is faster (measured: +10 % at 2048,
-        +7 % at 4096, -11 % at 1024).  The two forms add the heads' partial sums in different orders, so they agree to
+        """Which form of the 256-channel transformers to run (compiler.py: MDT_TF256).  With the heads split over workgroup PAIRS
+        (k_tf256 NSPLIT = 2, DESIGN.md 3.8) a batch of up to 4096 rows at that level (1024 samples of 4 tokens) fills the chip;
+        above, the whole-transformer launch without the split (measured against the split forms: +10 % at 2048, +7 % at 4096
+        samples).  The two forms add the heads' partial sums in different orders, so they agree to
         rounding (1e-6 class), not bit for bit: ``kernel_choice`` = 'wide' / 'narrow' pins one of them for every batch size
         (what a sharded run does, distributed.sample_sharded / pin_kernel_choice); 'auto' decides per call."""
         if self.kernel_choice in ("wide", "narrow"):
@@ -206,7 +206,9 @@ class _QMBase(nn.Module):
                 t256 = length
             if lvl < cfg.num_layers:
                 length //= cfg.factors[lvl]
-        return bool(batch) and t256 is not None and batch * t256 >= 6144
+        # pair-split launches need both workgroups of a pair running at the same time: 2 workgroups per 32 rows, at most one per
+        # CU -- the narrow form is used while that grid fits the 256 CUs (4096 rows), the whole-transformer form above
+        return bool(batch) and t256 is not None and batch * t256 > 4096
 
     def pin_kernel_choice(self, batch: Optional[int]) -> str:
         """Resolve 'auto' for a batch of ``batch`` U-Net rows (samples, doubled under guidance) and keep that choice for every

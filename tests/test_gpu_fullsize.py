@@ -147,7 +147,7 @@ def test_configs4_at_256_steps(cfg5_256_steps, mode, budget):
 
 
 def test_wide_path_at_batch_2048_against_the_oracle():
-    """The whole-transformer form of the 256-channel level (k_tf256 without the pair split: the default from ~1536 samples)
+    """The whole-transformer form of the 256-channel level (k_tf256 without the pair split: the default above 1024 samples of 4 tokens)
     AT SIZE: B = 2048, 6 timesteps, four probe rows against the pinned oracle on identical noise (<= 1e-4)."""
     m = make_model("cfg1")
     B, T = 2048, 6
@@ -159,7 +159,7 @@ def test_wide_path_at_batch_2048_against_the_oracle():
     rows = torch.tensor([0, 1023, 1024, 2047])
     ref = O.sample(synth_sd("cfg1"), oracle_cfg("cfg1"), seq[rows], init[rows], lambda i, x: nz[i][rows], T, 1.0, False)
     assert (out.cpu()[rows] - ref).abs().max() < TOL
-    # the pair-split form on the same rows (what batches up to ~1536 run): same answer to rounding, own oracle check
+    # the pair-split form on the same rows (what batches up to 1024 run): same answer to rounding, own oracle check
     m.kernel_choice = "narrow"
     out_n = m.sample(seq[:1024], DEV, cond_scale=1.0, timesteps=T, clamp=False,
                      noise=NoiseSource(init=init[:1024], steps=lambda i: nz[i][:1024]))
