@@ -150,7 +150,11 @@ def pmc_summary():
     correction + WRITE_SIZE, separate rocprofv3 passes of THIS workload at batch 1024): (kernel name, launches in the
     profiled run, MB per launch)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.csv")))
+    import re
+    # the headline workload's summary of the newest round: profiles/r<N>_pmc_hbm_traffic.csv (NOT r<N>_<other config>_pmc_...)
+    files = [f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.csv"))
+             if re.fullmatch(r"r\d+_pmc_hbm_traffic\.csv", os.path.basename(f))]
+    files.sort(key=lambda f: int(re.match(r"r(\d+)_", os.path.basename(f)).group(1)))
     if not files:
         return None, []
     rows = []
@@ -392,11 +396,11 @@ def main():
                          "avg_launch_us": round(1e3 * ms_dom / n_dom, 2), "flops_per_launch_avg": fl_dom / n_dom})
             if dom == "k_tblock":
                 # the contract's roofline is the MFMA fraction; what binds this kernel class is not a memory level
-                roof["binding_resource"] = "per-launch latency, then instruction issue: in-kernel stamps of a 256-channel-level launch " \
-                                           "(DESIGN.md 3.5) show 26 % row round trip + LayerNorm / bf16 split before the first MFMA, 65 % " \
-                                           "streamed work at 58 % MFMA-busy (one wave per SIMD issues MFMAs, fragment ds_reads and the serial " \
-                                           "attention / softmax sections), 9 % drain; no memory level binds (LDS array ~26 % busy, weight " \
-                                           "stream at half its measured rate, same speed with 1 or 256 workgroups)"
+                roof["binding_resource"] = "LDS-DMA instruction issue of the loader waves, then the in-launch hand-off: in-kernel stamps of a " \
+                                           "pair-split 256-channel-level launch (DESIGN.md 3.8) show 74 % streamed work (one 32 KB sub-tile per " \
+                                           "~800 cycles per workgroup = 8 LDS-DMA instructions x ~100 cycles per loader wave, ~37 B/clk/CU), 15 % " \
+                                           "hand-off between the two workgroups of a row block (2.35 us per round), 5 % LayerNorm, 4 % wave-pair " \
+                                           "LDS exchange; no memory level binds (HBM ~23 % of peak over the whole evaluation, LDS array ~26 % busy)"
             if a.workload == "cfg1" and B == 1024:     # the committed PMC summary is of exactly this workload
                 roof["traffic"], roof["traffic_source"] = pmc_traffic(dom)
             extra["eval_breakdown_ms"] = {k: {"launches": n, "ms": round(t, 4),
