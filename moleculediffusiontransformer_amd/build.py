@@ -13,8 +13,11 @@ from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 INCLUDE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
-LIB = os.path.join(CSRC, "libmdt_hip.so")
-STAMP = os.path.join(CSRC, ".build_stamp")
+# MDT_LIB_TAG (tuning only): a second library next to the shipped one -- libmdt_hip_<tag>.so with its own objects and stamp --
+# so that A/B builds (MDT_BUILD_DEFS=...) are made once in the build container and travel to the GPU box side by side.
+_TAG = os.environ.get("MDT_LIB_TAG", "")
+LIB = os.path.join(CSRC, f"libmdt_hip{'_' + _TAG if _TAG else ''}.so")
+STAMP = os.path.join(CSRC, f".build_stamp{'_' + _TAG if _TAG else ''}")
 
 # (source, extra flags).  k_elem keeps the reference's separate fp32 mul/add rounding.
 SOURCES = [
@@ -89,7 +92,7 @@ def _build_locked(verbose: bool) -> str:
 
     def compile_one(item):
         src, extra = item
-        obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+        obj = os.path.join(CSRC, os.path.splitext(src)[0] + (f".{_TAG}.o" if _TAG else ".o"))
         defs = os.environ.get("MDT_BUILD_DEFS", "").split()       # tuning builds only, e.g. -DMDT_STAMPS
         cmd = [hipcc, *COMMON, *extra, *defs, "-I", INCLUDE, "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -39,6 +39,13 @@
 
 #include "mdt_kernels.h"
 
+// ring slot of tile t (run-time t): a mask, not the signed modulo (7 scalar instructions per use)
+#ifdef MDT_SLOT_MOD
+#define MDT_SLOT_IDX(t) ((t) % NS)
+#else
+#define MDT_SLOT_IDX(t) ((t) & (NS - 1))
+#endif
+
 namespace mdt {
 
 namespace {
@@ -184,7 +191,7 @@ __global__ __launch_bounds__(512) void k_tf128(TFArgs a) {
                                             // made hipcc index a merged array dynamically = scratch + vmcnt(0) per piece)
     auto pieces_of = [&](unsigned d) -> int { return (NPW > 0 && (d & 2u)) ? NPW : IPT; };
     auto issue_tile = [&](int tau, unsigned d) {
-      unsigned char* slot = smem + (tau % NS) * SLOT + iw * 1024;
+      unsigned char* slot = smem + MDT_SLOT_IDX(tau) * SLOT + iw * 1024;
       const unsigned kind = d & 3u, aux = d >> 2;
       if (NPW > 0 && kind >= 2u) {
         if constexpr (NPW > 0) {
@@ -313,7 +320,7 @@ __global__ __launch_bounds__(512) void k_tf128(TFArgs a) {
   };
 
   int tau = 0;                                       // tile being consumed
-  auto slot_of = [&](int t) -> const unsigned char* { return smem + (t % NS) * SLOT; };
+  auto slot_of = [&](int t) -> const unsigned char* { return smem + MDT_SLOT_IDX(t) * SLOT; };
 
   // One MFMA phase over the tile `tau` (k_tblock_lw.hip): 8 units; the reads of unit u+2 ride between the MFMAs of unit
   // u; for u+2 >= NU they belong to units 0/1 of the NEXT tile (kind NK), published by the barrier before unit NU-2.

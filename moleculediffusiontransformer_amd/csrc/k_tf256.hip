@@ -45,6 +45,13 @@
 
 #include "mdt_kernels.h"
 
+// ring slot of tile t (run-time t): a mask, not the signed modulo (7 scalar instructions per use)
+#ifdef MDT_SLOT_MOD
+#define MDT_SLOT_IDX(t) ((t) % NS)
+#else
+#define MDT_SLOT_IDX(t) ((t) & (NS - 1))
+#endif
+
 namespace mdt {
 
 namespace {
@@ -134,6 +141,9 @@ constexpr int VEC_BYTES = VEC_FLOATS * 4;
 #ifndef MDT_XH_MODE
 #define MDT_XH_MODE 0
 #endif
+#ifndef MDT_RING_AHEAD
+#define MDT_RING_AHEAD 2     // tiles the loader waves run ahead of the one being consumed (2 or 3; NS = 4 slots)
+#endif
 #ifndef MDT_XH_ADDR
 #define MDT_XH_ADDR 1        // 1: whole address in the VECTOR offset (scalar offset 0), as tools/ubench/pair_handoff.hip does
 #endif
@@ -214,7 +224,7 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
                                          (__attribute__((address_space(3))) void*)(vec_b + (aux & 1u) * VEC_BYTES + iw * 1024), 16, 0, 0);
     };
     auto issue_tile = [&](int tau, unsigned d) {
-      unsigned char* slot = smem + (tau % NS) * SLOT + iw * 1024;
+      unsigned char* slot = smem + MDT_SLOT_IDX(tau) * SLOT + iw * 1024;
       const unsigned kind = d & 7u, aux = d >> 3;
       if (kind == D_SCRATCH) return;
       if (kind == D_SCRATCH_VEC) { issue_vec(aux); return; }
@@ -240,29 +250,38 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
     };
     auto wait_vm = [&](int allow) {
       switch (allow) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+#define MDT_VMW(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
+        MDT_VMW(0) MDT_VMW(1) MDT_VMW(2) MDT_VMW(3) MDT_VMW(4) MDT_VMW(5) MDT_VMW(6) MDT_VMW(7) MDT_VMW(8) MDT_VMW(9) MDT_VMW(10)
+        MDT_VMW(11) MDT_VMW(12) MDT_VMW(13) MDT_VMW(14) MDT_VMW(15)
+#undef MDT_VMW
+        default: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
       }
     };
-    const unsigned d0 = tiles[0], d1 = NT > 1 ? tiles[1] : 0u;
+    // Tile k + AHEAD is issued behind B(k): the compute waves are past tile k - 1 there, and with AHEAD = 3 its slot is tile
+    // k - 1's (NS = 4).  The only accesses to that slot that may still be in flight are fragment reads issued BEFORE the barrier
+    // (phase(): units 2, 3 of a tile are read during units 0, 1), which the compute waves drain before they arrive (MDT_RING_AHEAD
+    // == 3 adds that wait to phase()).
+    constexpr int AHEAD = MDT_RING_AHEAD;
+    unsigned dq[AHEAD];                                                  // descriptors of tiles k + 1 .. k + AHEAD - 1 (+ one scratch)
     __builtin_amdgcn_s_barrier();   // P: the compute waves' row loads are queued ahead of the stream
     issue_vec(0u);                  // the first sub-block's vectors (parity 0), ahead of tile 0: covered by the first wait
-    issue_tile(0, d0);
-    if (NT > 1) issue_tile(1, d1);
-    unsigned dn = d1;                                                    // descriptor of tile k + 1
+#pragma unroll
+    for (int j = 0; j < AHEAD; ++j) {
+      const unsigned d = j < NT ? tiles[j] : 0u;
+      if (j < NT) issue_tile(j, d);
+      if (j > 0) dq[j - 1] = d;
+    }
     for (int k = 0; k < NT; ++k) {
-      const unsigned d2 = k + 2 < NT ? tiles[k + 2] : 0u;
-      wait_vm(k + 1 < NT ? pieces_of(dn) : 0);                           // tile k landed; tile k+1 may be in flight
+      const unsigned dnew = k + AHEAD < NT ? tiles[k + AHEAD] : 0u;
+      int allow = 0;
+#pragma unroll
+      for (int j = 0; j < AHEAD - 1; ++j) allow += k + 1 + j < NT ? pieces_of(dq[j]) : 0;
+      wait_vm(allow);                                                    // tile k landed; tiles k + 1 .. may be in flight
       __builtin_amdgcn_s_barrier();                                      // B(k)
-      if (k + 2 < NT) issue_tile(k + 2, d2);
-      dn = d2;
+      if (k + AHEAD < NT) issue_tile(k + AHEAD, dnew);
+#pragma unroll
+      for (int j = 0; j + 1 < AHEAD - 1; ++j) dq[j] = dq[j + 1];
+      dq[AHEAD - 2] = dnew;
     }
     prefetch_next_weights(a.pf_ptr, a.pf_lines, iw * 64 + lane);
     return;
@@ -353,7 +372,7 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
   };
 
   int tau = 0;
-  auto slot_of = [&](int t) -> unsigned char* { return smem + (t % NS) * SLOT; };
+  auto slot_of = [&](int t) -> unsigned char* { return smem + MDT_SLOT_IDX(t) * SLOT; };
 
   // One MFMA phase over a sub-tile (k_tblock32.hip): 4 units of 4 fragment reads + 6 MFMAs
   auto phase = [&](auto kind, auto offc, auto nkind, bool has_next, f32x4* acc, const bf16x8* bh, const bf16x8* bl) {
@@ -368,6 +387,7 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
       constexpr int u = decltype(uc)::value;
       if (u == NU - 2 && has_next) {
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MDT_RING_AHEAD >= 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this tile's slot is refilled behind B
         __builtin_amdgcn_s_barrier();                // B(tau + 1)
         __builtin_amdgcn_sched_barrier(0);
       }
