@@ -361,10 +361,15 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
   using J1 = std::integral_constant<int, 1>;
   using J2 = std::integral_constant<int, 2>;
   using J3 = std::integral_constant<int, 3>;
+  // LDS addresses of the fragment reads of units 2 / 3 of the NEXT phase(): computed in the shadow of the running phase's last MFMAs
+  // (or by prefetch2 where the pipeline restarts) -- address arithmetic between two phases is exposed issue time, ~5 cycles an instruction
+  unsigned pb2 = 0, pb3 = 0;
   auto prefetch2 = [&](auto kind, const unsigned char* slot, int off) {
     constexpr int KIND = decltype(kind)::value;
     const unsigned l = lds_addr(slot);
     const unsigned b0 = l + (KIND == K_O ? aO : aP(0)), b1 = l + (KIND == K_O ? aO : aP(1));
+    pb2 = l + (KIND == K_O ? aO : aP(2));
+    pb3 = l + (KIND == K_O ? aO : aP(3));
     frag_read(kind, b0, J0{}, off % 3, J0{}); frag_read(kind, b0, J0{}, off % 3, J1{});
     frag_read(kind, b0, J0{}, off % 3, J2{}); frag_read(kind, b0, J0{}, off % 3, J3{});
     frag_read(kind, b1, J1{}, (off + 1) % 3, J0{}); frag_read(kind, b1, J1{}, (off + 1) % 3, J1{});
@@ -377,12 +382,7 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
   // One MFMA phase over a sub-tile (k_tblock32.hip): 4 units of 4 fragment reads + 6 MFMAs
   auto phase = [&](auto kind, auto offc, auto nkind, bool has_next, f32x4* acc, const bf16x8* bh, const bf16x8* bl) {
     constexpr int KIND = decltype(kind)::value, OFF = decltype(offc)::value, NK = decltype(nkind)::value;
-    const unsigned lc = lds_addr(slot_of(tau)), ln = lds_addr(slot_of(tau + 1));
-    unsigned bc[4], bn[2];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) bc[k] = lc + (KIND == K_O ? aO : aP(k));
-#pragma unroll
-    for (int k = 0; k < 2; ++k) bn[k] = ln + (NK == K_O ? aO : aP(k));
+    unsigned ln = 0, bn[2] = {0u, 0u};
     auto unit = [&](auto uc) {
       constexpr int u = decltype(uc)::value;
       if (u == NU - 2 && has_next) {
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
       auto rd = [&](auto jc) {
         if (!pre) return;
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (in_phase) frag_read(kind, bc[u + 2], std::integral_constant<int, u + 2>{}, s2, jc);
+        if constexpr (in_phase) frag_read(kind, u == 0 ? pb2 : pb3, std::integral_constant<int, u + 2>{}, s2, jc);
         else frag_read(nkind, bn[u + 2 - NU], std::integral_constant<int, u + 2 - NU>{}, s2, jc);
         __builtin_amdgcn_sched_barrier(0);
       };
@@ -413,6 +413,19 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
       mm(frh[s0][0], bl[ib], 0); rd(J2{});
       mm(frh[s0][1], bl[ib], 1); rd(J3{});
       mm(frh[s0][0], bh[ib], 0);
+      if constexpr (u == 1) {                        // the next tile's slot: needed from unit 2 on
+        __builtin_amdgcn_sched_barrier(0);
+        ln = lds_addr(slot_of(tau + 1));
+        bn[0] = ln + (NK == K_O ? aO : aP(0));
+        bn[1] = ln + (NK == K_O ? aO : aP(1));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (u == NU - 1) {                   // this phase's own reads are all issued: pb2 / pb3 move on to the next tile
+        __builtin_amdgcn_sched_barrier(0);
+        pb2 = ln + (NK == K_O ? aO : aP(2));
+        pb3 = ln + (NK == K_O ? aO : aP(3));
+        __builtin_amdgcn_sched_barrier(0);
+      }
       mm(frh[s0][1], bh[ib], 1);
       __builtin_amdgcn_sched_barrier(0);
     };

@@ -100,6 +100,8 @@ def load_library(allow_build: bool = True) -> C.CDLL:
     if _lib is not None:
         return _lib
     path = _build.library_path()
+    # MDT_NO_BUILD=1 (tuning A/B only, with MDT_LIB_TAG): load the tagged library as it is, e.g. one built from an older commit
+    allow_build = allow_build and os.environ.get("MDT_NO_BUILD", "0") != "1"
     if allow_build and not _build.is_fresh():
         try:
             _build.build_library()

@@ -281,11 +281,14 @@ def test_ring_kernels_keep_their_arrays_in_registers(ring_kernel_reports):
     green), and a spill next to an in-flight inline-asm ds_read stores a register that has not landed yet.  Compile the ring
     kernels with resource remarks and bound their scratch use: 0 for k_tf128 (all 15 instantiations) and the k_rconv forms on
     the default path; k_tf256 sits at the 256-register limit of two waves per SIMD (accumulators 64 + operands 64 + three
-    fragment sets 48 + per-head tiles) and keeps a few dozen bytes of compiler-managed spills of scalars OUTSIDE the
-    fragment registers (the ISA lint below checks that none of them touches an in-flight read)."""
+    fragment sets 48 + per-head tiles) and keeps compiler-managed spills of scalars OUTSIDE the fragment registers: 36-72 bytes
+    per lane in the whole-workgroup form, 120 in the pair-split cross-attention instantiations (the hand-off's eight 16-byte
+    loads in flight next to the accumulators; 228 when round 2 ended).  Their reloads sit outside the streamed phases (4 of 664
+    MFMAs of k_tf256<6, 2> share a basic block with a scratch load), and the ISA lint below checks that none of them touches
+    an in-flight read."""
     import re
     res, _ = ring_kernel_reports
-    limits = {"k_tblock32": 24, "k_rconv": 0, "k_tf128": 0, "k_tf256": 100}     # bytes per lane
+    limits = {"k_tblock32": 24, "k_rconv": 0, "k_tf128": 0, "k_tf256": 128}     # bytes per lane
     for name, limit in limits.items():
         assert res[name], name
         for fn, v in res[name]:
