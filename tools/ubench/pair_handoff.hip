@@ -13,6 +13,8 @@
 //   MODE 4: as 1 through the compiler: __builtin_amdgcn_raw_buffer_store / load_b128 with aux = sc1 (waits and hazards tracked)
 //   MODE 5: as 4 with the wave-uniform part of every address in the instruction's SCALAR offset (an SGPR rewritten between
 //           consecutive buffer instructions) and only the lane's 16 bytes in the vector offset -- the form k_tf256.hip first used
+//   MODE 6: as 4 with PLAIN stores (aux = 0: the lines stay in the XCD's L2) and sc1 loads (L1 bypassed, L2-served): coherent only
+//           between workgroups of ONE XCD -- what a same-XCD fast path of the hand-off would cost (and what it does across XCDs)
 //   MODE 3: plain stores, vmcnt(0), barrier, lane-0 agent release (buffer_wbl2 sc1, vmcnt(0)), sc1 flag; poll, agent acquire,
 //           vmcnt(0), barrier, plain loads               -- the guide's "Valid forms", producer / consumer bullets
 // stride 1: partners on different XCDs (workgroups are dealt round robin), 8 / 128: same XCD; the XCC ids are read back
@@ -22,6 +24,7 @@
 // Build & run on the GPU box:  hipcc -O3 --offload-arch=gfx950 tools/ubench/pair_handoff.hip -o /tmp/ph && /tmp/ph
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef int i4 __attribute__((ext_vector_type(4)));
 
@@ -62,6 +65,7 @@ __global__ __launch_bounds__(512) void kpair(float* buf, unsigned* flags, unsign
       const f4 v = f4{(float)r, (float)me, (float)(threadIdx.x + 512 * k), 1.f};
       if (MODE == 0 || MODE == 3) *p = v;
       else if (MODE == 4) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4, v), rs, (unsigned)((const char*)p - (const char*)buf), 0, 16);
+      else if (MODE == 6) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4, v), rs, (unsigned)((const char*)p - (const char*)buf), 0, 0);
       else if (MODE == 5) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4, v), rs, (threadIdx.x & 63u) * 16u,
                               __builtin_amdgcn_readfirstlane((unsigned)((const char*)p - (const char*)buf) - (threadIdx.x & 63u) * 16u), 16);
       else ST_SC1();
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(512) void kpair(float* buf, unsigned* flags, unsign
     const f4* q = reinterpret_cast<const f4*>(buf) + ((size_t)(r & 1) * nwg + other) * 2048 + threadIdx.x;
     f4 v[4];
     if (MODE == 0 || MODE == 3) { for (int k = 0; k < 4; ++k) v[k] = q[512 * k]; }
-    else if (MODE == 4) { for (int k = 0; k < 4; ++k) v[k] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)((const char*)(q + 512 * k) - (const char*)buf), 0, 16)); }
+    else if (MODE == 4 || MODE == 6) { for (int k = 0; k < 4; ++k) v[k] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)((const char*)(q + 512 * k) - (const char*)buf), 0, 16)); }
     else if (MODE == 5) { for (int k = 0; k < 4; ++k) v[k] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, (threadIdx.x & 63u) * 16u,
                               __builtin_amdgcn_readfirstlane((unsigned)((const char*)(q + 512 * k) - (const char*)buf) - (threadIdx.x & 63u) * 16u), 16)); }
     else LD4_SC1();
@@ -120,20 +124,21 @@ __global__ __launch_bounds__(512) void kpair(float* buf, unsigned* flags, unsign
   if (acc == 12345.678f) sink[me] = acc;
 }
 
-int main() {
+int main(int argc, char** argv) {
   const int nwg = 256, rounds = 400;
   float *buf, *junk, *sink, *dbg; unsigned *flags, *errs, *xcc; unsigned long long* res;
   hipMalloc(&buf, (size_t)2 * nwg * 32768); hipMalloc(&flags, nwg * 128); hipMalloc(&errs, 256); hipMalloc(&res, nwg * 8);
   hipMalloc(&xcc, nwg * 4); hipMalloc(&junk, (size_t)nwg * 65536); hipMalloc(&sink, nwg * 4); hipMalloc(&dbg, 16 * 8 * 4);
   hipMemset(junk, 0, (size_t)nwg * 65536);
-  const char* names[6] = {"plain + __threadfence both sides", "sc1 stores / flag / loads, no fence", "sc1 + buffer_inv sc1 at the reader",
-                          "plain stores + agent release; agent acquire + plain loads", "sc1 through raw_buffer builtins (aux = sc1), no fence", "as 4, wave-uniform part of the address in the scalar offset"};
+  const char* names[7] = {"plain + __threadfence both sides", "sc1 stores / flag / loads, no fence", "sc1 + buffer_inv sc1 at the reader",
+                          "plain stores + agent release; agent acquire + plain loads", "sc1 through raw_buffer builtins (aux = sc1), no fence", "as 4, wave-uniform part of the address in the scalar offset",
+                          "as 4 with PLAIN stores (same-XCD form: lines kept in the shared L2), sc1 flag and loads"};
   for (int skew = 0; skew < 2; ++skew)
-    for (int mode = 0; mode < 6; ++mode)
+    for (int mode = (argc > 1 ? atoi(argv[1]) : 0); mode < (argc > 2 ? atoi(argv[2]) : 7); ++mode)
       for (int stride : {1, 8, 128}) {
         hipMemset(flags, 0, nwg * 128); hipMemset(errs, 0, 256); hipMemset(buf, 0, (size_t)2 * nwg * 32768);
 #define GO(M) hipLaunchKernelGGL(kpair<M>, dim3(nwg), dim3(512), 0, 0, buf, flags, errs, res, xcc, junk, sink, dbg, rounds, stride, skew)
-        if (mode == 0) GO(0); else if (mode == 1) GO(1); else if (mode == 2) GO(2); else if (mode == 3) GO(3); else if (mode == 4) GO(4); else GO(5);
+        if (mode == 0) GO(0); else if (mode == 1) GO(1); else if (mode == 2) GO(2); else if (mode == 3) GO(3); else if (mode == 4) GO(4); else if (mode == 5) GO(5); else GO(6);
         if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); return 1; }
         unsigned long long h[256]; unsigned e, x[256];
         hipMemcpy(h, res, nwg * 8, hipMemcpyDeviceToHost); hipMemcpy(&e, errs, 4, hipMemcpyDeviceToHost); hipMemcpy(x, xcc, nwg * 4, hipMemcpyDeviceToHost);
