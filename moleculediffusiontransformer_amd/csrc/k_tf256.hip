@@ -118,6 +118,10 @@ __device__ __forceinline__ unsigned lds_addr(const unsigned char* p) {
 
 template <int N>
 __device__ __forceinline__ void lgkm_wait() {   // at most N LDS/scalar operations still in flight
+#ifdef MDT_ABL_LGKM   // ablation (WRONG results, timing only): no wait for fragment reads -- what the waits cost
+  __builtin_amdgcn_sched_barrier(0);
+  return;
+#endif
   if constexpr (N >= 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
   else if constexpr (N >= 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
   else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
