@@ -14,6 +14,8 @@
 // global loads are issued before the current chunk's MFMAs.  The prologue (LayerNorm / GroupNorm-apply +
 // FiLM + SiLU) runs on the A tile while it is staged, the epilogue (bias, exact GELU, residual) on the
 // accumulators, so normalisation/activation tensors never round-trip through HBM.
+#include <type_traits>
+
 #include "mdt_kernels.h"
 
 namespace mdt {
@@ -30,6 +32,12 @@ __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__device__ __forceinline__ float group16_sum(float v) {     // over the 16 lanes of a lane's group
+#pragma unroll
+  for (int off = 8; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
 
@@ -77,40 +85,50 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs g) {
     rs[i] = m - b * g.r_out;
   }
 
-  // ---- LayerNorm row statistics (two-pass, one wave per row, values held in registers) ----
+  // ---- LayerNorm row statistics (two-pass, a 16-lane group per row, values held in registers) ----
+  // NQ = 64-channel pieces of a row actually present: the U-Net's LayerNorm rows are 128 / 256 channels wide, and walking all
+  // 32 pieces of the 2048-channel envelope for each of a wave's 32 rows cost more than the tile's MFMAs (pro = 1 GEMMs ran at a
+  // third of the rate of the same shapes without a prologue)
   if constexpr (PRO == 1) {
-    for (int rr = 0; rr < 32; ++rr) {
-      const int row = wave * 32 + rr;
-      const int m = m0 + row;
-      float mean = 0.f, rstd = 0.f;
-      if (m < g.M) {
-        const int b = m / g.r_out;
-        const int src = (m - b * g.r_out) * g.t_stride + g.t_off;
+    auto row_stats = [&](auto nqc) {
+      constexpr int NQ = decltype(nqc)::value;
+      // four rows per wave and turn: a 16-lane group per row, lane l of the group holds channels 64 q + 4 l .. + 3
+      const int l16 = lane & 15;
+      for (int it = 0; it < 8; ++it) {
+        const int row = wave * 32 + it * 4 + (lane >> 4);
+        const int m = m0 + row;
+        const bool valid = m < g.M;
+        const int b = valid ? m / g.r_out : 0;
+        const int src = valid ? (m - b * g.r_out) * g.t_stride + g.t_off : 0;
         const float* p = g.A + ((int64_t)b * g.r_in + src) * g.lda + g.a_col;
-        float v[32];
+        float4 v[NQ];
         float s = 0.f;
 #pragma unroll
-        for (int q = 0; q < 32; ++q) {
-          const int e = q * 64 + lane;
-          v[q] = e < g.cin ? p[e] : 0.f;
-          s += v[q];
+        for (int q = 0; q < NQ; ++q) {
+          const int e = q * 64 + l16 * 4;
+          v[q] = (valid && e < g.cin) ? *reinterpret_cast<const float4*>(p + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+          s += (v[q].x + v[q].y) + (v[q].z + v[q].w);
         }
-        mean = wave_sum(s) / (float)g.cin;
+        const float mean = group16_sum(s) / (float)g.cin;
         float ss = 0.f;
 #pragma unroll
-        for (int q = 0; q < 32; ++q) {
-          const int e = q * 64 + lane;
-          const float d = e < g.cin ? v[q] - mean : 0.f;
-          ss += d * d;
+        for (int q = 0; q < NQ; ++q) {
+          if (q * 64 + l16 * 4 < g.cin) {
+            const float dx = v[q].x - mean, dy = v[q].y - mean, dz = v[q].z - mean, dw = v[q].w - mean;
+            ss += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+          }
         }
-        const float var = wave_sum(ss) / (float)g.cin;
-        rstd = 1.0f / sqrtf(var + g.eps);
+        const float var = group16_sum(ss) / (float)g.cin;
+        if (l16 == 0) {
+          rstat[row * 2] = valid ? mean : 0.f;
+          rstat[row * 2 + 1] = valid ? 1.0f / sqrtf(var + g.eps) : 0.f;
+        }
       }
-      if (lane == 0) {
-        rstat[row * 2] = mean;
-        rstat[row * 2 + 1] = rstd;
-      }
-    }
+    };
+    if (g.cin <= 128) row_stats(std::integral_constant<int, 2>{});
+    else if (g.cin <= 256) row_stats(std::integral_constant<int, 4>{});
+    else if (g.cin <= 512) row_stats(std::integral_constant<int, 8>{});
+    else row_stats(std::integral_constant<int, 32>{});
     __syncthreads();
   }
 
