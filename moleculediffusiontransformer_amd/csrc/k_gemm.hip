@@ -277,7 +277,11 @@ template <int PRO>
 static hipError_t launch_pro(const GemmArgs& g, hipStream_t s) {
   const int mt = (g.M + BM - 1) / BM, nt = (g.N + BN - 1) / BN;
   dim3 grid((unsigned)(mt * nt), 1, (unsigned)(g.phases > 1 ? g.phases : 1)), block(NTHREADS);
-  if (g.cin % 32 == 0)
+  // 64-deep chunks where the channels allow it: one chunk is then 4096 cycles of MFMA work per wave against a fixed ~4000 cycles
+  // of staging (wait for the next chunk's loads, LDS writes, two barriers) with one workgroup per CU
+  if (g.cin % 64 == 0 && g.taps * g.cin >= 128)
+    hipLaunchKernelGGL((k_gemm<PRO, 64>), grid, block, 0, s, g);
+  else if (g.cin % 32 == 0)
     hipLaunchKernelGGL((k_gemm<PRO, 32>), grid, block, 0, s, g);
   else
     hipLaunchKernelGGL((k_gemm<PRO, 16>), grid, block, 0, s, g);
