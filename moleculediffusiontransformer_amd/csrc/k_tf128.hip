@@ -304,7 +304,11 @@ __global__ __launch_bounds__(512) void k_tf128(TFArgs a) {
     constexpr int q = j >> 1, lo = j & 1;
     constexpr int off = (KIND == K_O) ? ((2 * (u % (NCT / 2)) + q) * 16 * 128 + lo * (C * 128))
                                       : ((2 * (u & 1) + q) * 16 * 4 * C + lo * (2 * C));
+#ifdef MDT_ABL_LDSBC   // ablation (WRONG results, timing only): every lane reads the same 16 bytes -- what the fragment reads cost the LDS
+    lds_read16_off<off>(lo ? fl[set][q] : fh[set][q], base & 0x18000u);
+#else
     lds_read16_off<off>(lo ? fl[set][q] : fh[set][q], base);
+#endif
   };
   using J0 = std::integral_constant<int, 0>;
   using J1 = std::integral_constant<int, 1>;

@@ -359,7 +359,11 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
     constexpr int KIND = decltype(kind)::value, u = decltype(uc)::value, j = decltype(jc)::value;
     constexpr int q = j >> 1, lo = j & 1;
     constexpr int off = (KIND == K_O) ? ((2 * u + q) * 16 * 128 + lo * (CS * 128)) : (q * 16 * 4 * CS + lo * (2 * CS));
+#ifdef MDT_ABL_LDSBC   // ablation (WRONG results, timing only): every lane reads the same 16 bytes -- what the fragment reads cost the LDS
+    lds_read16_off<off>(lo ? frl[set][q] : frh[set][q], base & 0x18000u);
+#else
     lds_read16_off<off>(lo ? frl[set][q] : frh[set][q], base);
+#endif
   };
   using J0 = std::integral_constant<int, 0>;
   using J1 = std::integral_constant<int, 1>;
