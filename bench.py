@@ -396,13 +396,14 @@ def main():
                          "avg_launch_us": round(1e3 * ms_dom / n_dom, 2), "flops_per_launch_avg": fl_dom / n_dom})
             if dom == "k_tblock":
                 # the contract's roofline is the MFMA fraction; what binds this kernel class is not a memory level
-                roof["binding_resource"] = "the instruction stream of one wave per SIMD (MFMA + fragment ds_reads + per-tile barrier: 58 % MFMA-busy " \
-                                           "inside the streamed phases at a shader clock stretched to 1.75-1.95 GHz), then the in-launch hand-off: " \
-                                           "in-kernel stamps of a pair-split 256-channel-level launch (DESIGN.md 3.8) show 74 % streamed phases, 15 % " \
-                                           "hand-off between the two workgroups of a row block (2.35 us per round), 5 % LayerNorm, 4 % wave-pair LDS " \
-                                           "exchange; round-3 ablations: a deeper LDS-DMA ring is 4.5 % slower, no waits on fragment reads -3.6 % at most, " \
-                                           "scalar address arithmetic between phases was worth 4.9 % (DESIGN.md 3.5); no memory level binds (HBM ~23 % of " \
-                                           "peak over the whole evaluation, LDS array 14-26 % busy)"
+                roof["binding_resource"] = "the weight stream where it enters the CU, then the in-launch hand-off: LDS-DMA runs through the 64 B/clk/CU " \
+                                           "vector-memory path (a 32 KB sub-tile = 512 cycles at best, 555 measured with nothing else running) and a " \
+                                           "32-row workgroup of the 256-channel level consumes one in 650-700 cycles (384 of them MFMA); round-3 ablations " \
+                                           "of a pair-split launch (DESIGN.md 3.5): no wait for tiles to land -9 %, no workgroup barriers at all -18 %, " \
+                                           "no waits on fragment reads -3.6 %, broadcast fragment reads -4.4 % of the class, a deeper ring +4.5 % (slower); " \
+                                           "in-kernel stamps: 74 % streamed phases, 15 % hand-off between the two workgroups of a row block (2.35 us per " \
+                                           "round), 5 % LayerNorm, 4 % wave-pair LDS exchange; the shader clock is stretched to 1.75-1.95 GHz in the streamed " \
+                                           "phases; HBM ~23 % of peak over the whole evaluation"
             if a.workload == "cfg1" and B == 1024:     # the committed PMC summary is of exactly this workload
                 roof["traffic"], roof["traffic_source"] = pmc_traffic(dom)
             extra["eval_breakdown_ms"] = {k: {"launches": n, "ms": round(t, 4),

@@ -145,6 +145,11 @@ constexpr int VEC_BYTES = VEC_FLOATS * 4;
 #ifndef MDT_XH_MODE
 #define MDT_XH_MODE 0
 #endif
+#ifdef MDT_ABL_BAR            // ablation (WRONG results, timing only): no workgroup barrier anywhere -- what the per-tile synchronisation costs
+#define MDT_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#else
+#define MDT_BARRIER() __builtin_amdgcn_s_barrier()
+#endif
 #ifndef MDT_RING_AHEAD
 #define MDT_RING_AHEAD 2     // tiles the loader waves run ahead of the one being consumed (2 or 3; NS = 4 slots)
 #endif
@@ -253,6 +258,9 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
       }
     };
     auto wait_vm = [&](int allow) {
+#ifdef MDT_ABL_VMWAIT   // ablation (WRONG results, timing only): a tile is published whether or not its DMA has landed
+      return;
+#endif
       switch (allow) {
 #define MDT_VMW(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
         MDT_VMW(0) MDT_VMW(1) MDT_VMW(2) MDT_VMW(3) MDT_VMW(4) MDT_VMW(5) MDT_VMW(6) MDT_VMW(7) MDT_VMW(8) MDT_VMW(9) MDT_VMW(10)
@@ -267,7 +275,7 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
     // == 3 adds that wait to phase()).
     constexpr int AHEAD = MDT_RING_AHEAD;
     unsigned dq[AHEAD];                                                  // descriptors of tiles k + 1 .. k + AHEAD - 1 (+ one scratch)
-    __builtin_amdgcn_s_barrier();   // P: the compute waves' row loads are queued ahead of the stream
+    MDT_BARRIER();   // P: the compute waves' row loads are queued ahead of the stream
     issue_vec(0u);                  // the first sub-block's vectors (parity 0), ahead of tile 0: covered by the first wait
 #pragma unroll
     for (int j = 0; j < AHEAD; ++j) {
@@ -281,7 +289,7 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
 #pragma unroll
       for (int j = 0; j < AHEAD - 1; ++j) allow += k + 1 + j < NT ? pieces_of(dq[j]) : 0;
       wait_vm(allow);                                                    // tile k landed; tiles k + 1 .. may be in flight
-      __builtin_amdgcn_s_barrier();                                      // B(k)
+      MDT_BARRIER();                                      // B(k)
       if (k + AHEAD < NT) issue_tile(k + AHEAD, dnew);
 #pragma unroll
       for (int j = 0; j + 1 < AHEAD - 1; ++j) dq[j] = dq[j + 1];
@@ -341,7 +349,7 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) xr[ct] = *reinterpret_cast<const float4*>(xp + 16 * ct);
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();                    // P
+    MDT_BARRIER();                    // P
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) accT[ct] = f32x4{xr[ct].x, xr[ct].y, xr[ct].z, xr[ct].w};
@@ -395,8 +403,13 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
       constexpr int u = decltype(uc)::value;
       if (u == NU - 2 && has_next) {
         __builtin_amdgcn_sched_barrier(0);
+#ifndef MDT_RING_NODRAIN   // (timing experiment: without the drain the refill races this tile's last fragment reads in principle)
         if constexpr (MDT_RING_AHEAD >= 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this tile's slot is refilled behind B
-        __builtin_amdgcn_s_barrier();                // B(tau + 1)
+#endif
+        MDT_BARRIER();                // B(tau + 1)
+#ifdef MDT_STAGGER   // experiment: the feature-half-1 waves fall MDT_STAGGER x 16 cycles behind after every tile barrier
+        if (fh) { for (int d_ = 0; d_ < MDT_STAGGER; ++d_) asm volatile("s_nop 15" ::: "memory"); }
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
       constexpr int s0 = (OFF + u) % 3, s2 = (OFF + u + 2) % 3;
@@ -498,7 +511,7 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
   MDT_STAMP();                                       // entry -> row loads issued, lane constants
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   MDT_STAMP();                                       // rows arrived
-  __builtin_amdgcn_s_barrier();                      // B(0)
+  MDT_BARRIER();                      // B(0)
   prefetch2(kT, slot_of(0), 0);
   const unsigned vec_l0 = lds_addr(vec_b);
   int vpar = 0;                                      // parity of the current sub-block's vector area
@@ -554,7 +567,7 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
 #pragma unroll
     for (int c = 0; c < 8; ++c) ex[(wave * 8 + c) * 64 + lane] = accT[8 * rd_ + c];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                    // B(scratch tile): the partner's partials (and the next vectors) are in LDS
+    MDT_BARRIER();                    // B(scratch tile): the partner's partials (and the next vectors) are in LDS
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const f32x4 other = ex[((wave ^ 1) * 8 + c) * 64 + lane];
@@ -586,7 +599,7 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
       MDT_STAMP();                                       // hand-off: stores issued
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave, in front of the barrier the flag store follows
       MDT_STAMP();                                       // ... drained
-      __builtin_amdgcn_s_barrier();                      // B(first hand-off tile)
+      MDT_BARRIER();                      // B(first hand-off tile)
       MDT_STAMP();                                       // ... every wave of the workgroup drained
       ++xround;
       if (wave == 0) {
@@ -619,7 +632,7 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
 #ifdef MDT_XH_D2       // stress build: 135 us between the poll and the loads (made EVERY call fail with the scalar-offset form)
       if (wave == 0) for (int d = 0; d < 40; ++d) __builtin_amdgcn_s_sleep(127);
 #endif
-      __builtin_amdgcn_s_barrier();                      // B(second hand-off tile): the partner's block is complete
+      MDT_BARRIER();                      // B(second hand-off tile): the partner's block is complete
       asm volatile("" ::: "memory");
       const unsigned sother = sbase ^ XBLOCK;            // the same block of half hh ^ 1
 #pragma unroll
@@ -654,7 +667,7 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
     pair_handoff();
   };
   auto next_subblock = [&]() {                       // first tile of the next sub-block: always a projection sub-tile
-    __builtin_amdgcn_s_barrier();                    // B(tau)
+    MDT_BARRIER();                    // B(tau)
     prefetch2(kT, slot_of(tau), 0);
     MDT_STAMP();                                     // next sub-block's first tile there
   };
@@ -782,7 +795,7 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
         const f32x4 mine = sp0 + sp1;
         red[wave * 64 + lane] = mine;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                         // B(first output sub-tile) + partial exchange
+        MDT_BARRIER();                         // B(first output sub-tile) + partial exchange
         const f32x4 other = red[(wave ^ 1) * 64 + lane];
         prefetch2(kO, slot_of(tau), 1);
         const f32x4 s01 = fh ? (other + mine) : (mine + other);
@@ -842,7 +855,7 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
         qT[0] = zero4; qT[1] = zero4;
         phase(kT, IC0{}, kT, true, qT, xh, xl);
         phase(kT, IC1{}, kT, false, qT, xh + 4, xl + 4);
-        __builtin_amdgcn_s_barrier();                         // B(K tile)
+        MDT_BARRIER();                         // B(K tile)
         const unsigned char* sk = slot_of(tau);
         {
           f32x4 bq[2];
@@ -876,7 +889,7 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         ++tau;
-        __builtin_amdgcn_s_barrier();                         // B(V tile) + partial exchange
+        MDT_BARRIER();                         // B(V tile) + partial exchange
         const unsigned char* sv = slot_of(tau);
         float mx = -INFINITY;
 #pragma unroll
@@ -923,7 +936,7 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
           }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // V reads complete before the slot can be refilled
         ++tau;
-        __builtin_amdgcn_s_barrier();                         // B(first output sub-tile)
+        MDT_BARRIER();                         // B(first output sub-tile)
         prefetch2(kO, slot_of(tau), 1);
         bf16x8 oh[1], ol[1];
         {
@@ -951,7 +964,7 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
         oT[0] = zero4; oT[1] = zero4;
         phase(kT, IC0{}, kT, true, oT, xh, xl);               // K half 0
         phase(kT, IC1{}, kT, false, oT, xh + 4, xl + 4);      // K half 1
-        __builtin_amdgcn_s_barrier();                         // B(first W2 sub-tile)
+        MDT_BARRIER();                         // B(first W2 sub-tile)
         prefetch2(kO, slot_of(tau), 1);
         {
           f32x4 b1[2];
