@@ -340,6 +340,7 @@ def run_adpm2(engine, embedding: Tensor, pred_dim: int, num_steps: int, noise: N
 
     with torch.cuda.device(dev):
         st = rt.current_stream()
+        engine.handoff_check()                        # a time-out of the previous call's pair hand-offs is reported here
         dual = _guided_setup(engine, embedding, guided)
         c_noise = torch.tensor([v for s in steps for v in (s.w.c_noise, s.w_mid.c_noise)], dtype=torch.float32)
         engine.prepare_times(c_noise)
@@ -383,6 +384,7 @@ def run_adpm2(engine, embedding: Tensor, pred_dim: int, num_steps: int, noise: N
             rt.check(lib.mdt_clamp(rt.ptr(x), -1.0, 1.0, x.numel(), st))
             if tokens is not None:        # clamping creates ties (first maximum wins): decode the clamped sample
                 rt.check(lib.mdt_argmax_tokens(rt.ptr(x), rt.ptr(tokens), B, C, L, st))
+        engine.note_handoff()
     return x
 
 
@@ -410,6 +412,7 @@ def run_adpm2_inpaint(engine, embedding: Tensor, source: Tensor, mask: Tensor, n
 
     with torch.cuda.device(dev):
         st = rt.current_stream()
+        engine.handoff_check()
         dual = _guided_setup(engine, embedding, guided)
         c_noise = torch.tensor([v for s in steps for v in (s.w.c_noise, s.w_mid.c_noise)], dtype=torch.float32)
         engine.prepare_times(c_noise)
@@ -443,4 +446,5 @@ def run_adpm2_inpaint(engine, embedding: Tensor, source: Tensor, mask: Tensor, n
                     nz, k = next_draw()
                     rt.check(lib.mdt_add_noise(rt.ptr(x), rt.ptr(nz), s.renoise, sd, k, sample0, B, C, L, st))
         rt.check(lib.mdt_inpaint_merge(rt.ptr(x), rt.ptr(src), rt.ptr(mk), 0, 0.0, sd, 0, sample0, B, C, L, st))
+        engine.note_handoff()
     return x

@@ -93,6 +93,37 @@ class UNetEngine:
         b.ext[EXT_XFLAGS], b.ext[EXT_XBUF] = rt.ptr(getattr(self, "xflags", None)), rt.ptr(getattr(self, "xbuf", None))
         return b
 
+    # A pair hand-off that runs into its time-out (a partner workgroup was never scheduled: the pair-split launches need every
+    # workgroup of a launch resident at once) raises bit 0 of the diagnostic word on the device and the launch's rows are
+    # garbage.  Reading that word costs a synchronisation, so the sampling loops copy it to pinned host memory behind their last
+    # launch (note_handoff) and the NEXT call -- or handoff_check(wait=True) -- looks at the copy once it has arrived: a failed
+    # call is reported loudly, one call late at the latest, and no call waits for the GPU.
+    def note_handoff(self) -> None:
+        if getattr(self, "xflags", None) is None:
+            return
+        if getattr(self, "_xstat_host", None) is None:
+            self._xstat_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._xstat_event = torch.cuda.Event()
+        self._xstat_host.copy_(self.xflags[:1], non_blocking=True)
+        self._xstat_event.record()
+        self._xstat_pending = True
+
+    def handoff_check(self, wait: bool = False) -> None:
+        """Raises RuntimeError if a sampling call noted by note_handoff() had a hand-off time-out (and clears the word)."""
+        if not getattr(self, "_xstat_pending", False):
+            return
+        if wait:
+            self._xstat_event.synchronize()
+        if not self._xstat_event.query():
+            return
+        self._xstat_pending = False
+        if int(self._xstat_host[0]) != 0:
+            if getattr(self, "xflags", None) is not None:
+                self.xflags[0] = 0
+            raise RuntimeError("a pair hand-off inside a 256-channel transformer launch timed out (a partner workgroup was not "
+                               "scheduled within 0.3 s): the samples of the PREVIOUS sampling call are invalid.  The pair-split "
+                               "launches need the whole GPU; set MDT_TF256_PAIR=0 to use one launch per sub-block instead")
+
     def handoff_status(self) -> int:
         """Diagnostic word of the pair hand-offs (synchronises): 0 = fine; bit 0 = some poll ran into its time-out, i.e. the
         results of that launch are garbage (a partner workgroup never arrived).  0 when the program has no pair-split op."""

@@ -319,3 +319,25 @@ def test_repeated_sampling_is_bitwise_stable(B, cs):
     assert all(torch.equal(outs[0], o) for o in outs[1:])
     assert (outs[0].cpu()[rows] - want).abs().max() < TOL
     assert m._engine.handoff_status() == 0
+
+
+def test_handoff_timeout_is_reported_by_the_next_call():
+    """A pair hand-off that times out leaves garbage rows and raises bit 0 of the engine's diagnostic word on the device.  The
+    sampling loops copy that word to pinned host memory behind their last launch; the next call (or handoff_check(wait=True))
+    raises -- loudly, without any call having waited for the GPU.  The time-out itself is simulated by setting the word."""
+    m = make_model("cfg1")
+    seq = synth_normal("to/seq", (64, 12))
+    first = m.sample(seq, DEV, cond_scale=1.0, timesteps=2, noise=NoiseSource(seed=3))
+    eng = m._engine
+    if eng.xflags is None:
+        pytest.skip("no pair-split launch in this program")
+    eng.handoff_check(wait=True)                      # the clean call passes
+    eng.xflags[0] = 1                                 # what a timed-out poll does
+    eng.note_handoff()
+    torch.cuda.synchronize()                          # (a call that starts before the copy has arrived reports one call later)
+    with pytest.raises(RuntimeError, match="pair hand-off"):
+        m.sample(seq, DEV, cond_scale=1.0, timesteps=2, noise=NoiseSource(seed=3))
+    assert eng.handoff_status() == 0                  # reported once, cleared
+    again = m.sample(seq, DEV, cond_scale=1.0, timesteps=2, noise=NoiseSource(seed=3))
+    assert torch.equal(first, again)
+
