@@ -413,7 +413,8 @@ def main():
             alg = flops_exec * B / (avg_eval_ms * 1e-3) / 1e12
             roof.update({"kernel": "whole U-Net eval", "achieved": round(alg * mult, 2),
                          "frac": round(alg * mult / peak, 4)})
-        ue = {"ms_avg_graph_replay": round(avg_eval_ms, 4), "evals_timed": len(eval_ms),
+        ue = {"ms_avg_graph_replay": round(avg_eval_ms, 4), "ms_min_graph_replay": round(min(eval_ms), 4),
+              "ms_max_graph_replay": round(max(eval_ms), 4), "evals_timed": len(eval_ms),
               "launches": len(eng.c.programs["eval"]),
               "flops_per_sample_executed": flops_exec,
               "tflops_executed_fp32_equiv": round(flops_exec * B / (avg_eval_ms * 1e-3) / 1e12, 2)}
