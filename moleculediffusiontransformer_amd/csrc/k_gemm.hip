@@ -22,7 +22,6 @@ namespace mdt {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128;
 constexpr int BN = 64;
 constexpr int NTHREADS = 256;
 
@@ -41,7 +40,9 @@ __device__ __forceinline__ float group16_sum(float v) {     // over the 16 lanes
   return v;
 }
 
-template <int PRO, int BK>
+// BM = 128: wave w owns rows [32 w, 32 w + 32) x 64 columns (two accumulators).  BM = 64: waves as 2 x 2, rows 32 (w & 1) .., columns
+// 32 (w >> 1) .. (one accumulator) -- twice the workgroups for the layers whose 128-row tiles leave half the CUs idle (M = 4096).
+template <int PRO, int BK, int BM>
 __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs g) {
   constexpr int LDT = BK + 4;           // padded LDS row (floats)
   constexpr int C4 = BK / 4;            // float4 per tile row
@@ -94,8 +95,8 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs g) {
       constexpr int NQ = decltype(nqc)::value;
       // four rows per wave and turn: a 16-lane group per row, lane l of the group holds channels 64 q + 4 l .. + 3
       const int l16 = lane & 15;
-      for (int it = 0; it < 8; ++it) {
-        const int row = wave * 32 + it * 4 + (lane >> 4);
+      for (int it = 0; it < BM / 16; ++it) {
+        const int row = wave * (BM / 4) + it * 4 + (lane >> 4);
         const int m = m0 + row;
         const bool valid = m < g.M;
         const int b = valid ? m / g.r_out : 0;
@@ -233,28 +234,37 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs g) {
     // permutation of k, so the sum over the chunk is complete whatever the order.
 #pragma unroll
     for (int kb = 0; kb < BK / 8; ++kb) {
-      const float4 a = *reinterpret_cast<const float4*>(&As[(wave * 32 + li) * LDT + kb * 8 + 4 * lh]);
-      const float4 b0 = *reinterpret_cast<const float4*>(&Bs[li * LDT + kb * 8 + 4 * lh]);
-      const float4 b1 = *reinterpret_cast<const float4*>(&Bs[(32 + li) * LDT + kb * 8 + 4 * lh]);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
+      if constexpr (BM == 128) {
+        const float4 a = *reinterpret_cast<const float4*>(&As[(wave * 32 + li) * LDT + kb * 8 + 4 * lh]);
+        const float4 b0 = *reinterpret_cast<const float4*>(&Bs[li * LDT + kb * 8 + 4 * lh]);
+        const float4 b1 = *reinterpret_cast<const float4*>(&Bs[(32 + li) * LDT + kb * 8 + 4 * lh]);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
+      } else {
+        const float4 a = *reinterpret_cast<const float4*>(&As[((wave & 1) * 32 + li) * LDT + kb * 8 + 4 * lh]);
+        const float4 b0 = *reinterpret_cast<const float4*>(&Bs[((wave >> 1) * 32 + li) * LDT + kb * 8 + 4 * lh]);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
+      }
     }
     __syncthreads();
   }
 
   // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ----
-  const int nA = n0 + li, nB = n0 + 32 + li;
+  const int nA = n0 + (BM == 128 ? 0 : (wave >> 1) * 32) + li, nB = n0 + 32 + li;
   const float biasA = (g.bias && nA < g.N) ? g.bias[nA] : 0.f;
-  const float biasB = (g.bias && nB < g.N) ? g.bias[nB] : 0.f;
+  const float biasB = (BM == 128 && g.bias && nB < g.N) ? g.bias[nB] : 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    const int row = (BM == 128 ? wave : (wave & 1)) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
     const int m = m0 + row;
     if (m >= g.M) continue;
     const int b = m / g.r_out;
@@ -262,30 +272,37 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs g) {
     float vA = acc0[r] + biasA, vB = acc1[r] + biasB;
     if (g.act == 1) {
       vA = gelu_f(vA);
-      vB = gelu_f(vB);
+      if constexpr (BM == 128) vB = gelu_f(vB);
     }
     if (g.res) {
       if (nA < g.N) vA += g.res[orow * g.ldr + nA];
-      if (nB < g.N) vB += g.res[orow * g.ldr + nB];
+      if (BM == 128 && nB < g.N) vB += g.res[orow * g.ldr + nB];
     }
     if (nA < g.N) g.out[orow * g.ldc + g.o_col + nA] = vA;
-    if (nB < g.N) g.out[orow * g.ldc + g.o_col + nB] = vB;
+    if (BM == 128 && nB < g.N) g.out[orow * g.ldc + g.o_col + nB] = vB;
   }
 }
 
-template <int PRO>
-static hipError_t launch_pro(const GemmArgs& g, hipStream_t s) {
+template <int PRO, int BM>
+static hipError_t launch_pro_bm(const GemmArgs& g, hipStream_t s) {
   const int mt = (g.M + BM - 1) / BM, nt = (g.N + BN - 1) / BN;
   dim3 grid((unsigned)(mt * nt), 1, (unsigned)(g.phases > 1 ? g.phases : 1)), block(NTHREADS);
   // 64-deep chunks where the channels allow it: one chunk is then 4096 cycles of MFMA work per wave against a fixed ~4000 cycles
   // of staging (wait for the next chunk's loads, LDS writes, two barriers) with one workgroup per CU
   if (g.cin % 64 == 0 && g.taps * g.cin >= 128)
-    hipLaunchKernelGGL((k_gemm<PRO, 64>), grid, block, 0, s, g);
+    hipLaunchKernelGGL((k_gemm<PRO, 64, BM>), grid, block, 0, s, g);
   else if (g.cin % 32 == 0)
-    hipLaunchKernelGGL((k_gemm<PRO, 32>), grid, block, 0, s, g);
+    hipLaunchKernelGGL((k_gemm<PRO, 32, BM>), grid, block, 0, s, g);
   else
-    hipLaunchKernelGGL((k_gemm<PRO, 16>), grid, block, 0, s, g);
+    hipLaunchKernelGGL((k_gemm<PRO, 16, BM>), grid, block, 0, s, g);
   return hipGetLastError();
+}
+
+template <int PRO>
+static hipError_t launch_pro(const GemmArgs& g, hipStream_t s) {
+  // 64-row tiles while 128-row tiles would give fewer than two workgroups per CU
+  const int64_t wg128 = (int64_t)((g.M + 127) / 128) * ((g.N + BN - 1) / BN) * (g.phases > 1 ? g.phases : 1);
+  return wg128 < 512 ? launch_pro_bm<PRO, 64>(g, s) : launch_pro_bm<PRO, 128>(g, s);
 }
 
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
