@@ -150,6 +150,10 @@ constexpr int VEC_BYTES = VEC_FLOATS * 4;
 #else
 #define MDT_BARRIER() __builtin_amdgcn_s_barrier()
 #endif
+#ifndef MDT_STREAM_PF
+#define MDT_STREAM_PF 8      // tiles ahead of the one being consumed at which ONE workgroup per (XCD, half) touches the weight stream's
+#endif                       // lines (0: off).  An evaluation moves ~4 GB through the 256 MB Infinity Cache between two uses of a layer, so
+                             // every launch streams its weights from HBM: 240 against 208 us per 4-block launch (tools/pair_launch_outliers.py)
 #ifndef MDT_RING_AHEAD
 #define MDT_RING_AHEAD 2     // tiles the loader waves run ahead of the one being consumed (2 or 3; NS = 4 slots)
 #endif
@@ -283,18 +287,47 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
       if (j < NT) issue_tile(j, d);
       if (j > 0) dq[j - 1] = d;
     }
+    // L2 prefetch of the stream (MDT_STREAM_PF): workgroup ids 8 (16 with the pair split) apart share an XCD and a half under the
+    // observed round-robin placement (speed only); behind tile k + AHEAD's DMA each loader wave of the workgroup on duty
+    // touches 64 lines of weight tile k + MDT_STREAM_PF with one dword load into a register nothing else uses.  That load counts in
+    // vmcnt like the DMA pieces and returns in order, so the counted waits below allow for the ones issued in the last two turns.
+    constexpr bool PF_ON = MDT_STREAM_PF > 0 && AHEAD == 2;
+    // the duty rotates: of the workgroups of an (XCD, half) -- ids 8 NSPLIT apart -- number g takes the tiles with index % count == g,
+    // so that no workgroup's own stream pays for more than its share of the touches
+    const int pf_groups = PF_ON ? max(1, (int)gridDim.x / (8 * NSPLIT)) : 1;
+    const int pf_mine = (int)blockIdx.x / (8 * NSPLIT);
+    int pf_turn = MDT_STREAM_PF % pf_groups;                             // (k + MDT_STREAM_PF) % pf_groups, kept without a division per tile
+    unsigned pf_sink = 0;
+    int pf1 = 0, pf2 = 0;                                                // prefetch loads issued one / two turns ago
     for (int k = 0; k < NT; ++k) {
       const unsigned dnew = k + AHEAD < NT ? tiles[k + AHEAD] : 0u;
       int allow = 0;
 #pragma unroll
       for (int j = 0; j < AHEAD - 1; ++j) allow += k + 1 + j < NT ? pieces_of(dq[j]) : 0;
+      if (PF_ON && k + 1 < NT) allow += pf1 + pf2;
       wait_vm(allow);                                                    // tile k landed; tiles k + 1 .. may be in flight
       MDT_BARRIER();                                      // B(k)
       if (k + AHEAD < NT) issue_tile(k + AHEAD, dnew);
+      if constexpr (PF_ON) {
+        pf2 = pf1;
+        pf1 = 0;
+        const bool mine = pf_turn == pf_mine;
+        if (++pf_turn == pf_groups) pf_turn = 0;
+        if (mine && k + MDT_STREAM_PF < NT) {
+          const unsigned dp = tiles[k + MDT_STREAM_PF];
+          const unsigned kp = dp & 7u;
+          if (kp != D_SCRATCH && kp != D_SCRATCH_VEC && kp < D_K) {      // a weight sub-tile
+            const unsigned char* t = wsrc + (int64_t)(dp >> 3) * SLOT + (iw * 64 + lane) * 128;
+            asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(t) : "memory");
+            pf1 = 1;
+          }
+        }
+      }
 #pragma unroll
       for (int j = 0; j + 1 < AHEAD - 1; ++j) dq[j] = dq[j + 1];
       dq[AHEAD - 2] = dnew;
     }
+    asm volatile("" :: "v"(pf_sink));                                    // (the last turn waited for vmcnt(0))
     prefetch_next_weights(a.pf_ptr, a.pf_lines, iw * 64 + lane);
     return;
   }
