@@ -269,7 +269,9 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
       if ((nx.kind == MDT_OP_TBLOCK || nx.kind == MDT_OP_RCONV || nx.kind == MDT_OP_TF128 || nx.kind == MDT_OP_TF256) &&
           nx.i[MDT_W_KB] > 0 && nx.w.space == MDT_SP_WEIGHT && bd->weights) {
         pf_ptr = bd->weights + nx.w.off;
-        pf_lines = nx.i[MDT_W_KB] * 8;
+        // at most the first 2 MB: an XCD's L2 holds 4 MB, the long streams of the whole-transformer launches are pulled in from
+        // inside the launch as they go (k_tf256.hip, MDT_STREAM_PF), and every line here is fetched by all eight XCDs
+        pf_lines = (nx.i[MDT_W_KB] < 2048 ? nx.i[MDT_W_KB] : 2048) * 8;
       }
     }
     switch (o.kind) {
