@@ -39,6 +39,11 @@
 
 #include "mdt_kernels.h"
 
+// cache policy of the K / V row DMA (read once per evaluation, 1 GB in all): 2 = nt (streaming)
+#ifndef MDT_KV_CPOL
+#define MDT_KV_CPOL 2
+#endif
+
 // ring slot of tile t (run-time t): a mask, not the signed modulo (7 scalar instructions per use)
 #ifdef MDT_SLOT_MOD
 #define MDT_SLOT_IDX(t) ((t) % NS)
@@ -201,7 +206,7 @@ __global__ __launch_bounds__(512) void k_tf128(TFArgs a) {
           const unsigned char* base = reinterpret_cast<const unsigned char*>(lb + 64 * head + (kind == 3u ? 64 * a.nheads : 0));
 #pragma unroll
           for (int q = 0; q < NPW; ++q)
-            __builtin_amdgcn_global_load_lds(base + voffKV[q], (__attribute__((address_space(3))) void*)(slot + q * 4096), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(base + voffKV[q], (__attribute__((address_space(3))) void*)(slot + q * 4096), 16, 0, MDT_KV_CPOL);
         }
       } else if (RES == 2 && kind == 0u && (aux >> 20)) {
         if constexpr (RES == 2) {
