@@ -26,8 +26,10 @@
 extern "C" {
 #endif
 
-#define MDT_ABI_VERSION 3
+#define MDT_ABI_VERSION 4
 
+/* MDT_ABI_VERSION; a library built with -DMDT_TUNING (timing-only switches that may give WRONG results, csrc/mdt_kernels.h) sets
+ * bit 30 on top -- the Python binding refuses such a library for sampling. */
 int mdt_abi_version(void);
 const char *mdt_last_error(void);
 /* Process-wide tuning / test hooks (not needed for correct results): "pair_stride" = v > 0 places the two workgroups of
@@ -177,9 +179,12 @@ enum mdt_gn_f { MDT_NF_EPS = 0 };
 enum mdt_rconv_i { MDT_R_T = 0, MDT_R_C = 1, MDT_R_LDA = 2, MDT_R_LDC = 3, MDT_R_LDR = 4, MDT_R_TAPS = 5,
                    MDT_R_GSIZE = 6 /* channels per GroupNorm group, 0 = no normalisation */, MDT_R_SILU = 7,
                    MDT_R_FILM_LD = 8 /* floats between the scale and the shift row */,
-                   MDT_R_LDA2 = 9 /* floats per row of the second source (a2), if any */ };
+                   MDT_R_LDA2 = 9 /* floats per row of the second source (a2), if any */,
+                   MDT_R_WF32 = 10 /* 1: w = fp32 fragment tiles, exact fp32 MFMA products (see MDT_F_WF32) */ };
 enum mdt_rconv_f { MDT_RF_EPS = 0, MDT_RF_IN_SCALE = 1, MDT_RF_IN_SCALE2 = 2 };
-enum mdt_resblock_i { MDT_K_T = 0, MDT_K_CIN = 1, MDT_K_COUT = 2, MDT_K_FILM_LD = 3 };
+enum mdt_resblock_i { MDT_K_T = 0, MDT_K_CIN = 1, MDT_K_COUT = 2, MDT_K_FILM_LD = 3,
+                      MDT_K_WF32 = 4 /* 1: w = fp32 MFMA fragments [step][row tile][half lo][64 lanes][4] (lane (i, g) float r =
+                                        W[16 rt + i][the step's pair 8 g + 4 lo + r]), exact fp32 MFMA products */ };
 enum mdt_resblock_f { MDT_KF_EPS = 0 };
 
 enum mdt_attn_i {
@@ -254,8 +259,16 @@ enum mdt_tf128_i {
   MDT_F_NFILM = 19,      /* FiLM floats staged behind the vectors (2 C per block, padded to a multiple of 256; NVEC + NFILM <= 8192) */
   /* MDT_OP_TF256 only */
   MDT_F_NSPLIT = 20,     /* 0 / 1: one workgroup per 32-row block; 2: a pair of workgroups per block (see MDT_OP_TF256)      */
-  MDT_F_PAIR_STRIDE = 21 /* NSPLIT = 2: workgroup ids of a pair are this far apart (0 = 8: one XCD under the observed round-robin
+  MDT_F_PAIR_STRIDE = 21,/* NSPLIT = 2: workgroup ids of a pair are this far apart (0 = 8: one XCD under the observed round-robin
                             placement; 1 = neighbours on different XCDs) -- speed only                                       */
+  /* MDT_OP_TF128 and MDT_OP_TF256 */
+  MDT_F_WF32 = 22        /* product type of every projection / convolution of the launch.  0: split-bf16 -- each 32 KB weight tile is a
+                            bf16 hi plane then a lo plane, products hi*hi + hi*lo + lo*hi on bf16 MFMAs.  1: EXACT fp32 -- the same
+                            tile holds the same weights as fp32 in MFMA-fragment order: for a tile of R x K weights (64 x 128
+                            projection, 128 x 64 output) fragment (row tile rt, k-step st, half lo) is 1 KB at
+                            ((rt * (K / 32) + st) * 2 + lo) * 1024 and float r of lane i + 16 g in it is
+                            W[16 rt + i][k-slot 32 st + 8 g + 4 lo + r]; every product is a v_mfma_f32_16x16x4_f32 with fp32
+                            accumulation, i.e. the reference's fp32 arithmetic (modules.py:314-320, :350-364, :386-391, :105-112) */
 };
 enum mdt_tf128_f { MDT_FF_EPS_LN = 0, MDT_FF_SCALE = 1, MDT_FF_EPS_GN = 2, MDT_FF_EPS_RES = 3, MDT_FF_SKIP_SCALE = 4 };
 

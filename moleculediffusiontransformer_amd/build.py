@@ -30,8 +30,11 @@ SOURCES = [
     ("k_tblock_lw.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("k_tblock32.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("k_tf128.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
+    ("k_tf128_f32.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),      # the same kernels with exact fp32 MFMA products
     ("k_tf256.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
+    ("k_tf256_f32.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("k_rconv.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
+    ("k_rconv_f32.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("k_resblock.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("k_norm.hip", []),
     ("k_attn.hip", []),

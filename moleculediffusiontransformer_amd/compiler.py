@@ -179,6 +179,12 @@ class UNetCompiler:
             raise ValueError("gemm_mode must be 'f32' (exact fp32 MFMA), 'bf16x3' (split-bf16 MFMA, fp32-class) or 'bf16' "
                              "(plain bf16 products, reduced precision: layer-by-layer GEMMs only)")
         self.gemm_mode = gemm_mode
+        # Exact-fp32 mode on the SAME fused program as the default mode: the ring kernels (k_tf128, k_tf256, k_rconv,
+        # k_resblock) take fp32 fragment tiles and form every product with v_mfma_f32_16x16x4_f32; everything else (resampling
+        # convolutions, time / context programs) is the exact fp32 MFMA GEMM as before.  MDT_F32_FUSED=0: the layer-by-layer
+        # program of rounds 1-3 (k_gemm + k_attn + k_gn_act), kept as the second exact implementation the tests compare with.
+        self.wf32 = gemm_mode == "f32" and os.environ.get("MDT_F32_FUSED", "1") == "1"
+        self.ring_mode = gemm_mode == "bf16x3" or self.wf32        # may the ring kernels be used at all?
         self._packed: Dict = {}
         self._zeros_off, self._zeros_len = 0, 0
         if cfg.channels % 16:
@@ -417,7 +423,7 @@ class UNetCompiler:
     # ------------------------------------------------------------------ row-stationary convolution (MDT_OP_RCONV)
     def rconv_ok(self, rows: int, c: int, taps: int, gsize: int) -> bool:
         """Mirror of rconv_supported (csrc/k_rconv.hip) plus the policy switches."""
-        if not (self.use_rconv and self.gemm_mode == "bf16x3" and self.fuse_blocks):
+        if not (self.use_rconv and self.ring_mode and self.fuse_blocks):
             return False
         return c in (128, 256) and 0 < rows <= 16 and 16 % rows == 0 and taps in (1, 3) and gsize in (0, 4, 8, 16, 32, 64)
 
@@ -432,7 +438,7 @@ class UNetCompiler:
         nsrc = 2 if x2 is not None else 1
         assert w.shape == (c, nsrc * c, taps) and out.ld == c and out.rows == x.rows, (name, tuple(w.shape), c, taps)
         assert x2 is None or (x2.ld == c and x2.rows == x.rows and film is None)
-        tiles = [self._tile(w[64 * ch: 64 * ch + 64, s * c + 128 * kh: s * c + 128 * kh + 128, tap])
+        tiles = [self._wtile(w[64 * ch: 64 * ch + 64, s * c + 128 * kh: s * c + 128 * kh + 128, tap])
                  for s in range(nsrc) for tap in range(taps) for kh in range(c // 128) for ch in range(c // 64)]
         op = rt.MdtOp()
         op.kind = rt.OP_RCONV
@@ -450,7 +456,7 @@ class UNetCompiler:
             op.f[2] = in_scale2
         i[rt.R_T], i[rt.R_C], i[rt.R_LDA], i[rt.R_LDC], i[rt.R_TAPS] = x.rows, c, x.ld, out.ld, taps
         i[rt.R_LDR] = res.ld if res is not None else 0
-        i[rt.R_FILM_LD] = c
+        i[rt.R_FILM_LD], i[rt.R_WF32] = c, int(self.wf32)
         op.f[0], op.f[1] = 1e-5, in_scale
         if gn is not None:
             gain, nbias, gsize, eps, silu = gn
@@ -537,9 +543,10 @@ class UNetCompiler:
         return [[(0, j) if j < 16 else None for j in range(32)]]
 
     @classmethod
-    def _resblock_frags(cls, w: torch.Tensor) -> List[torch.Tensor]:
+    def _resblock_frags(cls, w: torch.Tensor, f32: bool = False) -> List[torch.Tensor]:
         """Conv1d weight [cout][c][taps] -> MFMA A-operand fragments, order (step, 16-row tile): lane i + 16 g of a
-        fragment holds W[16 rt + i][the step's pairs 8 g .. 8 g + 7]; bf16 hi plane then lo plane (1 KB each)."""
+        fragment holds W[16 rt + i][the step's pairs 8 g .. 8 g + 7]; bf16 hi plane then lo plane (1 KB each), or (f32) the
+        fp32 values as two halves of 1 KB: pairs 8 g .. 8 g + 3, then 8 g + 4 .. 8 g + 7 (_tile_f32 of the [16][32] step)."""
         cout, c, taps = w.shape
         frags = []
         for step in cls._resblock_steps(c, taps):
@@ -548,20 +555,23 @@ class UNetCompiler:
                 if tc is not None:
                     m[:, j] = w[:, tc[1], tc[0]]
             for r in range(cout // 16):
-                frags.append(cls._tile(m[16 * r: 16 * r + 16].reshape(16, 4, 8).permute(1, 0, 2).contiguous()))
+                if f32:
+                    frags.append(cls._tile_f32(m[16 * r: 16 * r + 16]))
+                else:
+                    frags.append(cls._tile(m[16 * r: 16 * r + 16].reshape(16, 4, 8).permute(1, 0, 2).contiguous()))
         return frags
 
     def resblock_ok(self, rows: int, cin: int, cout: int, groups: int, p: str) -> bool:
-        return (self.use_resblock and self.gemm_mode == "bf16x3" and self.fuse_blocks and groups == 1 and rows == 64
+        return (self.use_resblock and self.ring_mode and self.fuse_blocks and groups == 1 and rows == 64
                 and (cin, cout) in ((16, 64), (64, 16)) and (p + "to_out.weight") in self.sd)
 
     def resblock(self, x: Ten, p: str, cin: int, cout: int, free_input: bool) -> Ten:
         """ResnetBlock1d with one GroupNorm group on the 64-token level as ONE launch (MDT_OP_RESBLOCK)."""
         sd = self.sd
         y = self._new(x.rows, cout, cout)
-        frags = (self._resblock_frags(sd[p + "block1.project.weight"].float())
-                 + self._resblock_frags(sd[p + "block2.project.weight"].float())
-                 + self._resblock_frags(sd[p + "to_out.weight"].float()))
+        frags = (self._resblock_frags(sd[p + "block1.project.weight"].float(), self.wf32)
+                 + self._resblock_frags(sd[p + "block2.project.weight"].float(), self.wf32)
+                 + self._resblock_frags(sd[p + "to_out.weight"].float(), self.wf32))
         vec = torch.cat([sd[p + "block1.groupnorm.weight"], sd[p + "block1.groupnorm.bias"], sd[p + "block1.project.bias"],
                          sd[p + "block2.groupnorm.weight"], sd[p + "block2.groupnorm.bias"],
                          sd[p + "block2.project.bias"] + sd[p + "to_out.bias"]]).float()
@@ -575,7 +585,7 @@ class UNetCompiler:
         op.bias = _ref(rt.SP_WEIGHT, self.W.add(p + "resblock.vec", vec))
         op._film = ("ss", ss_off)
         i = op.i
-        i[rt.K_T], i[rt.K_CIN], i[rt.K_COUT], i[rt.K_FILM_LD] = x.rows, cin, cout, cout
+        i[rt.K_T], i[rt.K_CIN], i[rt.K_COUT], i[rt.K_FILM_LD], i[rt.K_WF32] = x.rows, cin, cout, cout, int(self.wf32)
         op.f[0] = 1e-5
         self._emit(op)
         self.flops += 2 * x.rows * (3 * cin * cout + 3 * cout * cout + cin * cout)
@@ -646,7 +656,7 @@ class UNetCompiler:
     _SLOT_PERM = [32 * (s >> 5) + 16 * ((s & 7) >> 2) + 4 * ((s >> 3) & 3) + (s & 3) for s in range(64)]
 
     def can_fuse_transformer(self, c: int, rows: int, cross: bool) -> bool:
-        if self.gemm_mode != "bf16x3" or not self.fuse_blocks:
+        if self.gemm_mode != "bf16x3" or not self.fuse_blocks:      # (the per-sub-block kernels exist with split-bf16 products only)
             return False
         if c not in (128, 256) or rows > 16 or 16 % rows or self.cfg.head_features != 64:
             return False
@@ -664,6 +674,20 @@ class UNetCompiler:
         hi = w.to(torch.bfloat16)
         lo = (w - hi.float()).to(torch.bfloat16)
         return torch.cat([hi.contiguous().view(-1), lo.contiguous().view(-1)]).view(torch.float32)
+
+    @staticmethod
+    def _tile_f32(w: torch.Tensor) -> torch.Tensor:
+        """[rows][cols] fp32 (rows % 16 == 0, cols % 32 == 0, columns in k-slot order) -> the fp32 FRAGMENT tile of the exact-fp32
+        ring kernels (MDT_F_WF32, include/mdt_hip.h): fragment (row tile rt, k-step st, half lo) is 1 KB at
+        ((rt * (cols / 32) + st) * 2 + lo) * 1024, float r of lane i + 16 g in it = w[16 rt + i][32 st + 8 g + 4 lo + r].  Same
+        size as the two bf16 planes of _tile, same weights, every value kept exactly."""
+        rows, cols = w.shape
+        assert rows % 16 == 0 and cols % 32 == 0, (rows, cols)
+        return (w.float().reshape(rows // 16, 16, cols // 32, 4, 2, 4).permute(0, 2, 4, 3, 1, 5).contiguous().view(-1))
+
+    def _wtile(self, w: torch.Tensor) -> torch.Tensor:
+        """A ring-kernel weight tile in the format of this compilation's product type."""
+        return self._tile_f32(w) if self.wf32 else self._tile(w)
 
     def tblock(self, t: Ten, mode: int, p: str, cross_index: Optional[int] = None, variant: int = 0,
                x_out: Optional[Ten] = None, p_in: Optional[Ten] = None, p_out: Optional[Ten] = None,
@@ -776,7 +800,7 @@ class UNetCompiler:
     _ACC_PERM = [16 * (2 * (k >> 5) + ((k & 7) >> 2)) + 4 * ((k >> 3) & 3) + (k & 3) for k in range(128)]
 
     def tf128_ok(self, c: int, rows: int, layers: int, cross: bool, res_kind: int = 0, n_res: int = 0) -> bool:
-        if not (self.tf128 and self.gemm_mode == "bf16x3" and self.fuse_blocks and self.fold_out):
+        if not (self.tf128 and self.ring_mode and self.fuse_blocks and self.fold_out):
             return False
         if c != 128 or rows > 16 or 16 % rows or self.cfg.head_features != 64 or (c * self.cfg.ff_mult) % 64:
             return False
@@ -797,7 +821,7 @@ class UNetCompiler:
     def res128_ok(self, p: str, c: int, rows: int, groups: int, two_source: bool) -> bool:
         """Can the ResnetBlock1d at prefix p run inside a k_tf128 launch (csrc/k_tf128.hip, RES = 1 / 2)?  GroupNorm groups of 16
         or 32 channels (statistics on whole 16-channel accumulator tiles), C -> C (single source) or 2C -> C with to_out."""
-        if not (self.res128 and self.tf128 and self.gemm_mode == "bf16x3" and self.fuse_blocks and self.fold_out):
+        if not (self.res128 and self.tf128 and self.ring_mode and self.fuse_blocks and self.fold_out):
             return False
         if c != 128 or rows > 16 or 16 % rows or groups <= 0:
             return False
@@ -828,7 +852,7 @@ class UNetCompiler:
 
         def wtile(t: torch.Tensor, kind: int) -> None:            # kind 0: projection tile [64][128], 1: output tile [128][64]
             desc.append(kind | (len(tiles) << 2))
-            tiles.append(self._tile(t))
+            tiles.append(self._wtile(t))
 
         def conv3_tiles(w: torch.Tensor) -> None:                 # [c][c][3] -> (tap, output half) projection tiles
             for tap in range(3):
@@ -956,7 +980,7 @@ class UNetCompiler:
         i[rt.F_C], i[rt.F_T], i[rt.F_NT], i[rt.F_NVEC] = c, rows, len(desc), nvec
         i[rt.F_TK], i[rt.F_KV_BSTRIDE], i[rt.F_LDKV], i[rt.F_HEADS] = self.n_ctx, self.n_ctx, 2 * mid, heads
         i[rt.F_HAS_IN], i[rt.F_NBLOCKS], i[rt.F_NFF], i[rt.F_NPOST] = int(layers > 0), layers, nff, (c // 64 if layers > 0 else 0)
-        i[rt.F_CROSS], i[rt.F_KV_LSTRIDE] = int(cross), self.n_ctx * 2 * mid
+        i[rt.F_CROSS], i[rt.F_KV_LSTRIDE], i[rt.F_WF32] = int(cross), self.n_ctx * 2 * mid, int(self.wf32)
         op.f[0], op.f[1], op.f[2] = 1e-5, float(cfg.head_features) ** -0.5, 1e-6
         if cross:
             op._kv = ("kv", cross0)
@@ -967,7 +991,7 @@ class UNetCompiler:
         return y
 
     def tf256_ok(self, c: int, rows: int, layers: int, cross: bool) -> bool:
-        if not ((self.tf256 or self.tf256_pair) and self.gemm_mode == "bf16x3" and self.fuse_blocks and self.fold_out):
+        if not ((self.tf256 or self.tf256_pair) and self.ring_mode and self.fuse_blocks and self.fold_out):
             return False
         if c != 256 or rows > 16 or 16 % rows or self.cfg.head_features != 64 or layers < 1:
             return False
@@ -998,7 +1022,7 @@ class UNetCompiler:
 
         def sub(t: torch.Tensor, kind: int, hh: int) -> None:
             descs[hh].append(kind | (len(tiles) << 3))
-            tiles.append(self._tile(t))
+            tiles.append(self._wtile(t))
 
         def ptile(w: torch.Tensor, hh: int) -> None:         # [64][256] projection tile -> its two K halves
             wp = w[:, acc]
@@ -1098,7 +1122,7 @@ class UNetCompiler:
             self.xchg_tokens = max(self.xchg_tokens, rows)
         i[rt.F_TK], i[rt.F_KV_BSTRIDE], i[rt.F_LDKV], i[rt.F_HEADS] = self.n_ctx, self.n_ctx, 2 * mid, heads
         i[rt.F_HAS_IN], i[rt.F_NBLOCKS], i[rt.F_NFF], i[rt.F_NPOST] = 1, layers, nff, 2 * (c // 64)
-        i[rt.F_CROSS], i[rt.F_KV_LSTRIDE] = int(cross), self.n_ctx * 2 * mid
+        i[rt.F_CROSS], i[rt.F_KV_LSTRIDE], i[rt.F_WF32] = int(cross), self.n_ctx * 2 * mid, int(self.wf32)
         op.f[0], op.f[1], op.f[2] = 1e-5, float(cfg.head_features) ** -0.5, 1e-6
         if cross:
             op._kv = ("kv", cross0)

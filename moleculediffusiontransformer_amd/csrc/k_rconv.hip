@@ -26,6 +26,12 @@
 
 #include "mdt_kernels.h"
 
+// Compiled twice: as is (split-bf16 products, launch_rconv) and through k_rconv_f32.hip with MDT_TF_F32 = 1 (exact fp32 MFMA
+// products on fp32 fragment tiles, launch_rconv_f32; tile format and MFMA order as k_tf128.hip).
+#ifndef MDT_TF_F32
+#define MDT_TF_F32 0
+#endif
+
 namespace mdt {
 
 namespace {
@@ -58,18 +64,27 @@ MDT_XG(xg32_max, "v_permlane32_swap_b32", fmaxf(a, b))
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 #define MDT_MFMA_BF16 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define MDT_MFMA_F32 __builtin_amdgcn_mfma_f32_16x16x4f32
+constexpr bool F32 = MDT_TF_F32 != 0;   // product type of this translation unit
 
 constexpr int CS = 128;         // k-width of a weight tile
 constexpr int SLOT = 256 * CS;  // bytes per tile (bf16 hi plane + lo plane)
 constexpr int NS = 4;           // ring slots
 constexpr int IPT = CS / 16;    // DMA pieces per tile per loader wave
 
+// 8 values of one k-step -> its two 128-bit operand registers: bf16 hi / lo planes, or (F32) the values themselves, slots
+// 0..3 in `hi`, 4..7 in `lo` (k_tf128.hip)
 __device__ __forceinline__ void split8_rc(const float v[8], bf16x8& hi, bf16x8& lo) {
+  if constexpr (F32) {
+    hi = __builtin_bit_cast(bf16x8, f32x4{v[0], v[1], v[2], v[3]});
+    lo = __builtin_bit_cast(bf16x8, f32x4{v[4], v[5], v[6], v[7]});
+  } else {
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const __bf16 h = (__bf16)v[e];
-    hi[e] = h;
-    lo[e] = (__bf16)(v[e] - (float)h);
+    for (int e = 0; e < 8; ++e) {
+      const __bf16 h = (__bf16)v[e];
+      hi[e] = h;
+      lo[e] = (__bf16)(v[e] - (float)h);
+    }
   }
 }
 
@@ -114,8 +129,9 @@ __device__ __forceinline__ bf16x8 row_shift(const bf16x8& v, bool keep) {
 // half the weight stream per workgroup, twice the workgroups (the 4096-row level has only 128 row blocks).
 // PRO: 2 = GroupNorm + FiLM + SiLU prologue (all run-time optional), 1 = without FiLM, 0 = no prologue at all -- the
 // leaner instantiations exist for the two-source form, which the parameter registers push over the register budget
-template <int RTW, int C, int TAPS, int NSPLIT, int NSRC, int PRO>
+template <int RTW, int C, int TAPS, int NSPLIT, int NSRC, int PRO, bool F32_>
 __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
+  static_assert(F32_ == F32, "one product type per translation unit");
   constexpr int NST = C / 32;               // k-steps of the input channels
   constexpr int NKH = C / CS;               // K halves (tiles per tap per chunk)
   constexpr int NCHT = C / 64;              // 64-feature output chunks in total
@@ -144,7 +160,7 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
 #pragma unroll
     for (int q = 0; q < IPT; ++q) {
       const int U = 2 * (iw + 4 * q);
-      voffP[q] = (unsigned)(U * (2 * CS) + ((xP ^ (U & 15)) << 4) + baseP);
+      voffP[q] = F32 ? (unsigned)((iw + 4 * q) * 1024 + lane * 16) : (unsigned)(U * (2 * CS) + ((xP ^ (U & 15)) << 4) + baseP);
     }
     auto issue_tile = [&](int tau) {
       // stream order (tap, K half, chunk): this workgroup's chunks are NCH consecutive ones of every (tap, K half)
@@ -204,7 +220,8 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
 #pragma unroll
   for (int st = 0; st < 4; ++st) {
     const int lc = 4 * st + g;
-    aP[st] = fh * (2 * 16 * 4 * CS) + i * (4 * CS) + ((lc & ~15) | ((lc & 15) ^ i)) * 16;
+    // F32: fragment (feature tile ft, k-step st, half lo) at ft * 8192 + st * 2048 + lo * 1024, the lane's 16 bytes inside
+    aP[st] = F32 ? lane * 16 + fh * 16384 + st * 2048 : fh * (2 * 16 * 4 * CS) + i * (4 * CS) + ((lc & ~15) | ((lc & 15) ^ i)) * 16;
   }
   bf16x8 frh[3][2], frl[3][2];
   // read j (= 2 q + plane) of unit u; `base` = LDS address of the slot + the lane's swizzled part for the unit's
@@ -212,7 +229,8 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
   auto frag_read = [&](unsigned base, auto uc, int set, auto jc) {
     constexpr int u = decltype(uc)::value, j = decltype(jc)::value;
     constexpr int q = j >> 1, lo = j & 1;
-    constexpr int off = (RTW == 4) ? ((2 * (u & 1) + q) * 16 * 4 * CS + lo * (2 * CS)) : (q * 16 * 4 * CS + lo * (2 * CS));
+    constexpr int off = F32 ? ((RTW == 4) ? ((2 * (u & 1) + q) * 8192 + lo * 1024) : (q * 8192 + lo * 1024))
+                            : ((RTW == 4) ? ((2 * (u & 1) + q) * 16 * 4 * CS + lo * (2 * CS)) : (q * 16 * 4 * CS + lo * (2 * CS)));
     lds_read16_off_rc<off>(lo ? frl[set][q] : frh[set][q], base);
   };
   using J0 = std::integral_constant<int, 0>;
@@ -548,12 +566,29 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
           auto mm = [&](const bf16x8& w, const bf16x8& x, int q) {
             acc[c][ia + q] = MDT_MFMA_BF16(w, x, acc[c][ia + q], 0, 0, 0);
           };
-          mm(frl[s0][0], oph[ib], 0); rd(J0{});
-          mm(frl[s0][1], oph[ib], 1); rd(J1{});
-          mm(frh[s0][0], opl[ib], 0); rd(J2{});
-          mm(frh[s0][1], opl[ib], 1); rd(J3{});
-          mm(frh[s0][0], oph[ib], 0);
-          mm(frh[s0][1], oph[ib], 1);
+          if constexpr (F32) {
+            // exact fp32: fragment (q, half) x operand half, four 16x16x4 MFMAs each, the two accumulators alternating
+            auto mm4 = [&](const bf16x8& w0, const bf16x8& w1, const bf16x8& x, auto r0c) {
+              constexpr int r0 = decltype(r0c)::value;
+              const f32x4 a0 = __builtin_bit_cast(f32x4, w0), a1 = __builtin_bit_cast(f32x4, w1), xb = __builtin_bit_cast(f32x4, x);
+#pragma unroll
+              for (int r = r0; r < r0 + 2; ++r) {
+                acc[c][ia] = MDT_MFMA_F32(a0[r], xb[r], acc[c][ia], 0, 0, 0);
+                acc[c][ia + 1] = MDT_MFMA_F32(a1[r], xb[r], acc[c][ia + 1], 0, 0, 0);
+              }
+            };
+            mm4(frh[s0][0], frh[s0][1], oph[ib], J0{}); rd(J0{});
+            mm4(frh[s0][0], frh[s0][1], oph[ib], J2{}); rd(J1{});
+            mm4(frl[s0][0], frl[s0][1], opl[ib], J0{}); rd(J2{});
+            mm4(frl[s0][0], frl[s0][1], opl[ib], J2{}); rd(J3{});
+          } else {
+            mm(frl[s0][0], oph[ib], 0); rd(J0{});
+            mm(frl[s0][1], oph[ib], 1); rd(J1{});
+            mm(frh[s0][0], opl[ib], 0); rd(J2{});
+            mm(frh[s0][1], opl[ib], 1); rd(J3{});
+            mm(frh[s0][0], oph[ib], 0);
+            mm(frh[s0][1], oph[ib], 1);
+          }
           __builtin_amdgcn_sched_barrier(0);
         };
         unit(std::integral_constant<int, 0>{}); unit(std::integral_constant<int, 1>{});
@@ -600,12 +635,12 @@ static hipError_t launch_rc2(const RConvArgs& a, hipStream_t s) {
   const size_t smem = (size_t)NS * SLOT + (RTW == 2 ? SLOT : 0);      // ring (+ operand exchange area)
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rconv<RTW, C, TAPS, NSPLIT, NSRC, PRO>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rconv<RTW, C, TAPS, NSPLIT, NSRC, PRO, F32>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
     attr_set = true;
   }
   const int rows = 16 * RTW;
-  hipLaunchKernelGGL((k_rconv<RTW, C, TAPS, NSPLIT, NSRC, PRO>), dim3((unsigned)((a.M + rows - 1) / rows), NSPLIT), dim3(512), smem, s, a);
+  hipLaunchKernelGGL((k_rconv<RTW, C, TAPS, NSPLIT, NSRC, PRO, F32>), dim3((unsigned)((a.M + rows - 1) / rows), NSPLIT), dim3(512), smem, s, a);
   return hipGetLastError();
 }
 
@@ -616,6 +651,9 @@ static hipError_t launch_rc(const RConvArgs& a, hipStream_t s) {
   return a.gsize > 0 ? launch_rc2<RTW, C, TAPS, NSPLIT, 2, 1>(a, s) : launch_rc2<RTW, C, TAPS, NSPLIT, 2, 0>(a, s);
 }
 
+#if MDT_TF_F32
+hipError_t launch_rconv_f32(const RConvArgs& a, hipStream_t s) {
+#else
 bool rconv_supported(int C, int T, int taps, int gsize) {
   if (C != 128 && C != 256) return false;
   if (T <= 0 || 16 % T || (taps != 1 && taps != 3)) return false;
@@ -623,6 +661,8 @@ bool rconv_supported(int C, int T, int taps, int gsize) {
 }
 
 hipError_t launch_rconv(const RConvArgs& a, hipStream_t s) {
+  if (a.wf32) return launch_rconv_f32(a, s);           // exact-fp32 products: the instantiations of k_rconv_f32.hip
+#endif
   if (a.M <= 0) return hipSuccess;
   if (!rconv_supported(a.C, a.T, a.taps, a.gsize) || (a.gsize > 0 && (!a.gamma || !a.beta))) return hipErrorInvalidValue;
   if (a.x2 && a.film) return hipErrorInvalidValue;   // FiLM only ever precedes a single-source convolution

@@ -29,11 +29,13 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 #define MDT_MFMA_BF16 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define MDT_MFMA_F32 __builtin_amdgcn_mfma_f32_16x16x4f32
 
 constexpr int T = 64;                    // tokens per sample
 constexpr int ROWS = T + 2;              // + one zero row on either end
 
-__host__ __device__ constexpr int pitch_of(int c) { return 2 * c + 16; }
+__host__ __device__ constexpr int pitch_of(int c) { return 2 * c + 16; }      // bf16 planes
+__host__ __device__ constexpr int pitch32_of(int c) { return 4 * c + 16; }    // fp32 planes (F32): conflict-free float4 reads of 16 rows
 __host__ __device__ constexpr int ksteps_of(int c) { return c == 64 ? 6 : 2; }   // k = 3 convolution over c channels
 __host__ __device__ constexpr int rsteps_of(int c) { return c == 64 ? 2 : 1; }   // 1 x 1 convolution over c channels
 
@@ -77,35 +79,42 @@ __device__ __forceinline__ float silu(float t) { return t * __builtin_amdgcn_rcp
 
 // byte offset (inside a plane) of the 16-byte B fragment of lane (i, g) for k-step s of a k = 3 convolution over C
 // channels per tap; tokens 16 w + i.  Row r of a plane is token r - 1; row 0 is zero.
-template <int C>
+// F32: one fp32 plane instead of the hi / lo pair; the lane's 8 k-slots are 32 bytes = two float4 (slots 0..3 | 4..7)
+template <int C, bool F32>
 __device__ __forceinline__ int conv_frag_off(int s, int w, int i, int g) {
+  constexpr int P = F32 ? pitch32_of(C) : pitch_of(C), E = F32 ? 4 : 2;
   if constexpr (C == 64) {
     const int tap = s >> 1;
-    return (16 * w + i + tap) * pitch_of(C) + (32 * (s & 1) + 8 * g) * 2;
+    return (16 * w + i + tap) * P + (32 * (s & 1) + 8 * g) * E;
   } else {
     const int tap = 2 * s + (g >> 1);                // step 0: taps 0 | 1, step 1: tap 2 | nothing
-    return (tap < 3 ? (16 * w + i + tap) * pitch_of(C) : 0) + 8 * (g & 1) * 2;
+    return (tap < 3 ? (16 * w + i + tap) * P : 0) + 8 * (g & 1) * E;
   }
 }
 // ... of the 1 x 1 convolution (centre tap) over C channels
-template <int C>
+template <int C, bool F32>
 __device__ __forceinline__ int res_frag_off(int s, int w, int i, int g) {
-  if constexpr (C == 64) return (16 * w + i + 1) * pitch_of(C) + (32 * s + 8 * g) * 2;
-  else return (g < 2 ? (16 * w + i + 1) * pitch_of(C) : 0) + 8 * (g & 1) * 2;
+  constexpr int P = F32 ? pitch32_of(C) : pitch_of(C), E = F32 ? 4 : 2;
+  if constexpr (C == 64) return (16 * w + i + 1) * P + (32 * s + 8 * g) * E;
+  else return (g < 2 ? (16 * w + i + 1) * P : 0) + 8 * (g & 1) * E;
 }
 
 }  // namespace
 
-template <int CIN, int COUT>
+// F32: the weights are fp32 MFMA fragments [step][row tile][half][64 lanes][4] (lane (i, g) float r of half lo = W[16 rt + i][the
+// step's pair 8 g + 4 lo + r]), the activation planes fp32, every product an exact fp32 MFMA (v_mfma_f32_16x16x4_f32: slot
+// (g, 4 lo + r) of a 32-wide bf16 step is contraction index g of MFMA (lo, r)) -- the reference's arithmetic (modules.py:105-112)
+template <int CIN, int COUT, bool F32>
 __global__ __launch_bounds__(512) void k_resblock(ResBlockArgs a) {
   constexpr int RT = COUT / 16;                          // 16-channel row tiles of both convolutions' outputs
   constexpr int K1 = ksteps_of(CIN);                     // conv1 k-steps
   constexpr int K2 = ksteps_of(COUT);                    // conv2 k-steps ...
   constexpr int KR = rsteps_of(CIN);                     // ... followed by the 1 x 1 to_out steps on the raw input
   constexpr int WBYTES = (K1 + K2 + KR) * RT * 2 * 1024; // fragment tiles: [step][row tile][hi | lo][64 lanes][16 B]
-  constexpr int PIN = pitch_of(CIN), POUT = pitch_of(COUT);
+  constexpr int PIN = F32 ? pitch32_of(CIN) : pitch_of(CIN), POUT = F32 ? pitch32_of(COUT) : pitch_of(COUT);
   constexpr int PL_IN = ROWS * PIN, PL_OUT = ROWS * POUT;   // bytes per plane
-  constexpr int SAMPLE = 4 * PL_IN + 2 * PL_OUT;            // x hi | x lo | a1 hi | a1 lo | a2 hi | a2 lo
+  constexpr int NPL = F32 ? 1 : 2;                          // planes per tensor
+  constexpr int SAMPLE = 2 * NPL * PL_IN + NPL * PL_OUT;    // x hi | x lo | a1 hi | a1 lo | a2 hi | a2 lo   (F32: x | a1 | a2)
   constexpr int NV = T * CIN / 4 / 256;                     // float4 per thread of one sample's input
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   unsigned char* wl = smem;
@@ -115,8 +124,8 @@ __global__ __launch_bounds__(512) void k_resblock(ResBlockArgs a) {
   const int half = tid >> 8, w = (tid >> 6) & 3;
   const int i = lane & 15, g = lane >> 4;
   unsigned char* sm = smem + WBYTES + half * SAMPLE;
-  unsigned char* xh = sm, *xl = sm + PL_IN, *a1h = sm + 2 * PL_IN, *a1l = sm + 3 * PL_IN;
-  unsigned char* a2h = sm + 4 * PL_IN, *a2l = sm + 4 * PL_IN + PL_OUT;
+  unsigned char* xh = sm, *xl = sm + (NPL - 1) * PL_IN, *a1h = sm + NPL * PL_IN, *a1l = sm + (2 * NPL - 1) * PL_IN;
+  unsigned char* a2h = sm + 2 * NPL * PL_IN, *a2l = sm + 2 * NPL * PL_IN + (NPL - 1) * PL_OUT;     // (F32: the "l" pointers are unused)
 
   // ---- once per workgroup: weights -> LDS, zero rows, per-channel vectors -> registers ----
   {
@@ -131,15 +140,15 @@ __global__ __launch_bounds__(512) void k_resblock(ResBlockArgs a) {
     for (int k = 0; k < NW; ++k)
       if (tid + 512 * k < WBYTES / 16) dst[tid + 512 * k] = wv[k];
     // rows 0 and ROWS - 1 of the six planes of this half
-    for (int k = t; k < 4 * (PIN / 4) ; k += 256) {
+    for (int k = t; k < 2 * NPL * (PIN / 4) ; k += 256) {
       const int pl = k / (PIN / 4), o = k % (PIN / 4);
       reinterpret_cast<float*>(sm + pl * PL_IN)[o] = 0.f;
       reinterpret_cast<float*>(sm + pl * PL_IN + (ROWS - 1) * PIN)[o] = 0.f;
     }
-    for (int k = t; k < 2 * (POUT / 4); k += 256) {
+    for (int k = t; k < NPL * (POUT / 4); k += 256) {
       const int pl = k / (POUT / 4), o = k % (POUT / 4);
-      reinterpret_cast<float*>(sm + 4 * PL_IN + pl * PL_OUT)[o] = 0.f;
-      reinterpret_cast<float*>(sm + 4 * PL_IN + pl * PL_OUT + (ROWS - 1) * POUT)[o] = 0.f;
+      reinterpret_cast<float*>(sm + 2 * NPL * PL_IN + pl * PL_OUT)[o] = 0.f;
+      reinterpret_cast<float*>(sm + 2 * NPL * PL_IN + pl * PL_OUT + (ROWS - 1) * POUT)[o] = 0.f;
     }
   }
   // vec = gamma1[CIN] | beta1[CIN] | b1[COUT] | gamma2[COUT] | beta2[COUT] | bout[COUT]  (bout = b2 + to_out bias)
@@ -178,11 +187,11 @@ __global__ __launch_bounds__(512) void k_resblock(ResBlockArgs a) {
   // fragment addresses
   int o1[K1], o2[K2], orr[KR];
 #pragma unroll
-  for (int s = 0; s < K1; ++s) o1[s] = conv_frag_off<CIN>(s, w, i, g);
+  for (int s = 0; s < K1; ++s) o1[s] = conv_frag_off<CIN, F32>(s, w, i, g);
 #pragma unroll
-  for (int s = 0; s < K2; ++s) o2[s] = conv_frag_off<COUT>(s, w, i, g);
+  for (int s = 0; s < K2; ++s) o2[s] = conv_frag_off<COUT, F32>(s, w, i, g);
 #pragma unroll
-  for (int s = 0; s < KR; ++s) orr[s] = res_frag_off<CIN>(s, w, i, g);
+  for (int s = 0; s < KR; ++s) orr[s] = res_frag_off<CIN, F32>(s, w, i, g);
   const unsigned char* wlane = wl + lane * 16;
 
   // mean and 1 / sqrt(var + eps) over the sample (4 waves x 64 lanes x N values): two-pass inside the wave, then the
@@ -235,34 +244,75 @@ __global__ __launch_bounds__(512) void k_resblock(ResBlockArgs a) {
         float av[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) av[e] = silu((xv[j][e] - mean1) * rstd1 * ga[e] + be[e]);
-        bf16x4 h, l;
-        split4(xv[j], h, l);
-        *reinterpret_cast<bf16x4*>(xh + (tok + 1) * PIN + 8 * c4) = h;
-        *reinterpret_cast<bf16x4*>(xl + (tok + 1) * PIN + 8 * c4) = l;
-        split4(av, h, l);
-        *reinterpret_cast<bf16x4*>(a1h + (tok + 1) * PIN + 8 * c4) = h;
-        *reinterpret_cast<bf16x4*>(a1l + (tok + 1) * PIN + 8 * c4) = l;
+        if constexpr (F32) {
+          *reinterpret_cast<f32x4*>(xh + (tok + 1) * PIN + 16 * c4) = f32x4{xv[j][0], xv[j][1], xv[j][2], xv[j][3]};
+          *reinterpret_cast<f32x4*>(a1h + (tok + 1) * PIN + 16 * c4) = f32x4{av[0], av[1], av[2], av[3]};
+        } else {
+          bf16x4 h, l;
+          split4(xv[j], h, l);
+          *reinterpret_cast<bf16x4*>(xh + (tok + 1) * PIN + 8 * c4) = h;
+          *reinterpret_cast<bf16x4*>(xl + (tok + 1) * PIN + 8 * c4) = l;
+          split4(av, h, l);
+          *reinterpret_cast<bf16x4*>(a1h + (tok + 1) * PIN + 8 * c4) = h;
+          *reinterpret_cast<bf16x4*>(a1l + (tok + 1) * PIN + 8 * c4) = l;
+        }
       }
     }
     if (it + 1 < niter) request_rows(it + 1);        // lands under the two convolutions
     __syncthreads();
     // ---- conv1 (transposed): h^T[16 rt + 4 g + r][16 w + i] ----
-    f32x4 acc[RT];
+    f32x4 acc[RT], acc2[RT];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4{b1[rt].x, b1[rt].y, b1[rt].z, b1[rt].w};
+    for (int rt = 0; rt < RT; ++rt) { acc[rt] = f32x4{b1[rt].x, b1[rt].y, b1[rt].z, b1[rt].w}; acc2[rt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    // one 32-wide k-step: B operand at byte offset `off` of the plane pair (ph, pl), weight fragments of step `ws`
+    auto kstep = [&](const unsigned char* ph, const unsigned char* pl, int off, int ws) __attribute__((always_inline)) {
+      if constexpr (F32) {
+        // exact fp32: the lane's 8 k-slots are two float4 of ONE plane; (half, r) = one 16x16x4 MFMA per row tile.  Two partial
+        // accumulators per row tile (even / odd r) so that no MFMA waits for the one issued just before it (RT = 1: the whole
+        // convolution would otherwise be one dependent chain)
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(ph + off), b1 = *reinterpret_cast<const f32x4*>(ph + off + 16);
+        f32x4 w0[RT], w1[RT];
 #pragma unroll
-    for (int s1 = 0; s1 < K1; ++s1) {
-      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(a1h + o1[s1]);
-      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(a1l + o1[s1]);
+        for (int rt = 0; rt < RT; ++rt) {
+          w0[rt] = *reinterpret_cast<const f32x4*>(wlane + ((ws * RT + rt) * 2 + 0) * 1024);
+          w1[rt] = *reinterpret_cast<const f32x4*>(wlane + ((ws * RT + rt) * 2 + 1) * 1024);
+        }
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        const bf16x8 wh = *reinterpret_cast<const bf16x8*>(wlane + ((s1 * RT + rt) * 2 + 0) * 1024);
-        const bf16x8 wlo = *reinterpret_cast<const bf16x8*>(wlane + ((s1 * RT + rt) * 2 + 1) * 1024);
-        acc[rt] = MDT_MFMA_BF16(wlo, bh, acc[rt], 0, 0, 0);
-        acc[rt] = MDT_MFMA_BF16(wh, bl, acc[rt], 0, 0, 0);
-        acc[rt] = MDT_MFMA_BF16(wh, bh, acc[rt], 0, 0, 0);
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) {
+            if (r & 1) acc2[rt] = MDT_MFMA_F32(w0[rt][r], b0[r], acc2[rt], 0, 0, 0);
+            else acc[rt] = MDT_MFMA_F32(w0[rt][r], b0[r], acc[rt], 0, 0, 0);
+          }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) {
+            if (r & 1) acc2[rt] = MDT_MFMA_F32(w1[rt][r], b1[r], acc2[rt], 0, 0, 0);
+            else acc[rt] = MDT_MFMA_F32(w1[rt][r], b1[r], acc[rt], 0, 0, 0);
+          }
+      } else {
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(ph + off);
+        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(pl + off);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const bf16x8 wh = *reinterpret_cast<const bf16x8*>(wlane + ((ws * RT + rt) * 2 + 0) * 1024);
+          const bf16x8 wlo = *reinterpret_cast<const bf16x8*>(wlane + ((ws * RT + rt) * 2 + 1) * 1024);
+          acc[rt] = MDT_MFMA_BF16(wlo, bh, acc[rt], 0, 0, 0);
+          acc[rt] = MDT_MFMA_BF16(wh, bl, acc[rt], 0, 0, 0);
+          acc[rt] = MDT_MFMA_BF16(wh, bh, acc[rt], 0, 0, 0);
+        }
       }
-    }
+    };
+    auto fold_acc2 = [&]() __attribute__((always_inline)) {
+      if constexpr (F32) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) { acc[rt] += acc2[rt]; acc2[rt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      }
+    };
+#pragma unroll
+    for (int s1 = 0; s1 < K1; ++s1) kstep(a1h, a1l, o1[s1], s1);
+    fold_acc2();
     // ---- GroupNorm 2 + FiLM + SiLU on the accumulators, split -> a2 planes ----
     float mean2, rstd2;
     sample_stats([&](int k) { return acc[k >> 2][k & 3]; }, std::integral_constant<int, 4 * RT>{}, 1, mean2, rstd2);
@@ -272,10 +322,14 @@ __global__ __launch_bounds__(512) void k_resblock(ResBlockArgs a) {
       float av[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) av[r] = silu((acc[rt][r] - mean2) * rstd2 * fav[r] + fbv[r]);
-      bf16x4 h, l;
-      split4(av, h, l);
-      *reinterpret_cast<bf16x4*>(a2h + (16 * w + i + 1) * POUT + (16 * rt + 4 * g) * 2) = h;
-      *reinterpret_cast<bf16x4*>(a2l + (16 * w + i + 1) * POUT + (16 * rt + 4 * g) * 2) = l;
+      if constexpr (F32) {
+        *reinterpret_cast<f32x4*>(a2h + (16 * w + i + 1) * POUT + (16 * rt + 4 * g) * 4) = f32x4{av[0], av[1], av[2], av[3]};
+      } else {
+        bf16x4 h, l;
+        split4(av, h, l);
+        *reinterpret_cast<bf16x4*>(a2h + (16 * w + i + 1) * POUT + (16 * rt + 4 * g) * 2) = h;
+        *reinterpret_cast<bf16x4*>(a2l + (16 * w + i + 1) * POUT + (16 * rt + 4 * g) * 2) = l;
+      }
     }
     __syncthreads();
     // ---- conv2 + to_out (1 x 1 on the raw input) ----
@@ -283,19 +337,10 @@ __global__ __launch_bounds__(512) void k_resblock(ResBlockArgs a) {
     for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4{bo[rt].x, bo[rt].y, bo[rt].z, bo[rt].w};
 #pragma unroll
     for (int s2 = 0; s2 < K2 + KR; ++s2) {
-      const unsigned char* ph = s2 < K2 ? a2h + o2[s2 < K2 ? s2 : 0] : xh + orr[s2 < K2 ? 0 : s2 - K2];
-      const unsigned char* pl = s2 < K2 ? a2l + o2[s2 < K2 ? s2 : 0] : xl + orr[s2 < K2 ? 0 : s2 - K2];
-      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(ph);
-      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(pl);
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        const bf16x8 wh = *reinterpret_cast<const bf16x8*>(wlane + (((K1 + s2) * RT + rt) * 2 + 0) * 1024);
-        const bf16x8 wlo = *reinterpret_cast<const bf16x8*>(wlane + (((K1 + s2) * RT + rt) * 2 + 1) * 1024);
-        acc[rt] = MDT_MFMA_BF16(wlo, bh, acc[rt], 0, 0, 0);
-        acc[rt] = MDT_MFMA_BF16(wh, bl, acc[rt], 0, 0, 0);
-        acc[rt] = MDT_MFMA_BF16(wh, bh, acc[rt], 0, 0, 0);
-      }
+      if (s2 < K2) kstep(a2h, a2l, o2[s2 < K2 ? s2 : 0], K1 + s2);
+      else kstep(xh, xl, orr[s2 < K2 ? 0 : s2 - K2], K1 + s2);
     }
+    fold_acc2();
     if (live) {
       float* yo = a.out + ((int64_t)b * T + 16 * w + i) * COUT + 4 * g;
 #pragma unroll
@@ -310,27 +355,28 @@ bool resblock_supported(int T_, int cin, int cout) {
   return T_ == T && ((cin == 16 && cout == 64) || (cin == 64 && cout == 16));
 }
 
-template <int CIN, int COUT>
+template <int CIN, int COUT, bool F32>
 static hipError_t launch_rb(const ResBlockArgs& a, hipStream_t s) {
   constexpr int RT = COUT / 16;
   constexpr int WBYTES = (ksteps_of(CIN) + ksteps_of(COUT) + rsteps_of(CIN)) * RT * 2 * 1024;
-  constexpr int SAMPLE = 4 * ROWS * pitch_of(CIN) + 2 * ROWS * pitch_of(COUT);
+  constexpr int SAMPLE = F32 ? 2 * ROWS * pitch32_of(CIN) + ROWS * pitch32_of(COUT) : 4 * ROWS * pitch_of(CIN) + 2 * ROWS * pitch_of(COUT);
   const size_t smem = (size_t)WBYTES + 2 * SAMPLE + 2 * 4 * 4 * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resblock<CIN, COUT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resblock<CIN, COUT, F32>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(160 * 1024));
     attr_set = true;
   }
   const int pairs = (a.B + 1) / 2;
-  hipLaunchKernelGGL((k_resblock<CIN, COUT>), dim3((unsigned)(pairs < 256 ? pairs : 256)), dim3(512), smem, s, a);
+  hipLaunchKernelGGL((k_resblock<CIN, COUT, F32>), dim3((unsigned)(pairs < 256 ? pairs : 256)), dim3(512), smem, s, a);
   return hipGetLastError();
 }
 
 hipError_t launch_resblock(const ResBlockArgs& a, hipStream_t s) {
   if (a.B <= 0) return hipSuccess;
   if (!resblock_supported(a.T, a.cin, a.cout)) return hipErrorInvalidValue;
-  return a.cin == 16 ? launch_rb<16, 64>(a, s) : launch_rb<64, 16>(a, s);
+  if (a.wf32) return a.cin == 16 ? launch_rb<16, 64, true>(a, s) : launch_rb<64, 16, true>(a, s);
+  return a.cin == 16 ? launch_rb<16, 64, false>(a, s) : launch_rb<64, 16, false>(a, s);
 }
 
 }  // namespace mdt

@@ -39,6 +39,12 @@
 
 #include "mdt_kernels.h"
 
+// This file is compiled twice: as is (split-bf16 products, launch_tf128) and through k_tf128_f32.hip with MDT_TF_F32 = 1 (the
+// exact-fp32 instantiations, launch_tf128_f32) -- two translation units that build in parallel.
+#ifndef MDT_TF_F32
+#define MDT_TF_F32 0
+#endif
+
 // cache policy of the K / V row DMA (read once per evaluation, 1 GB in all): 2 = nt (streaming)
 #ifndef MDT_KV_CPOL
 #define MDT_KV_CPOL 2
@@ -89,12 +95,22 @@ __device__ __forceinline__ float gelu_tf(float x) {   // exact-erf GELU, branch-
   return 0.5f * x * (1.0f + copysignf(erfa, x));
 }
 
+// 8 values of one k-step -> the two 128-bit operand registers of the step.  Split-bf16 products (F32 = false): bf16 hi plane /
+// lo plane (v = hi + lo to 2^-17).  Exact fp32 products (F32 = true): the values themselves, slots e = 0..3 in `hi`, 4..7 in
+// `lo` (bit casts: the operand arrays keep one type for both instantiations; an fp32 k-step is eight 16x16x4 MFMAs, slot
+// (g, e = 4 lo + r) of the bf16 step being contraction index g of MFMA (lo, r))
+template <bool F32>
 __device__ __forceinline__ void split8_tf(const float v[8], bf16x8& hi, bf16x8& lo) {
+  if constexpr (F32) {
+    hi = __builtin_bit_cast(bf16x8, f32x4{v[0], v[1], v[2], v[3]});
+    lo = __builtin_bit_cast(bf16x8, f32x4{v[4], v[5], v[6], v[7]});
+  } else {
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const __bf16 h = (__bf16)v[e];
-    hi[e] = h;
-    lo[e] = (__bf16)(v[e] - (float)h);
+    for (int e = 0; e < 8; ++e) {
+      const __bf16 h = (__bf16)v[e];
+      hi[e] = h;
+      lo[e] = (__bf16)(v[e] - (float)h);
+    }
   }
 }
 
@@ -146,7 +162,13 @@ __device__ __forceinline__ bf16x8 row_shift_tf(const bf16x8& v, bool keep) {
 
 // NPW: LDS-DMA pieces per loader wave per K / V tile = ceil(context rows of the workgroup / 16); 0 = no cross segment
 // RES: ResNet blocks in front of the transformer (0 none, 1 single source + skip stores, 2 two sources)
-template <int NPW, int RES>
+// F32: weight tiles are fp32 FRAGMENT tiles and every projection / convolution product is an exact fp32 MFMA
+//      (v_mfma_f32_16x16x4_f32) -- the reference's arithmetic (modules.py:314-320, :350-364, :386-391, :105-112).  A tile holds the
+//      same 64 x 128 (or 128 x 64) weights in the same 32 KB: fragment (row tile rt, k-step st, half lo) = 1 KB at
+//      ((rt * steps + st) * 2 + lo) * 1024, lane (i, g) float r = W[16 rt + i][k-slot 32 st + 8 g + 4 lo + r] (packed by
+//      compiler.py::_tile_f32), so a conflict-free ds_read_b128 at lane * 16 feeds four MFMAs and the loader waves copy the
+//      tile linearly.  Same ring, same barriers, same operand registers; 16 / 3 x the MFMA cycles per tile (MFMA-bound).
+template <int NPW, int RES, bool F32>
 __global__ __launch_bounds__(512) void k_tf128(TFArgs a) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
 
@@ -170,8 +192,9 @@ __global__ __launch_bounds__(512) void k_tf128(TFArgs a) {
     for (int q = 0; q < IPT; ++q) {
       const int inst = iw + 4 * q;
       const int U = 2 * inst;
-      voffP[q] = (unsigned)(U * (2 * C) + ((xP ^ (U & 15)) << 4) + baseP);
-      voffO[q] = (unsigned)(((inst * 8) / C) * (128 * C) + ((inst * 8) % C) * 128 + ((xO ^ (4 * (inst & 1))) << 4) + baseO);
+      voffP[q] = F32 ? (unsigned)(inst * 1024 + lane * 16) : (unsigned)(U * (2 * C) + ((xP ^ (U & 15)) << 4) + baseP);
+      voffO[q] = F32 ? (unsigned)(inst * 1024 + lane * 16)
+                     : (unsigned)(((inst * 8) / C) * (128 * C) + ((inst * 8) % C) * 128 + ((xO ^ (4 * (inst & 1))) << 4) + baseO);
     }
     // K / V tiles: row R = (sample, key) of the workgroup's samples, 256 B per row and head, chunks swizzled with R & 15
     const int sample0 = blockIdx.x * (64 / a.T);
@@ -298,17 +321,19 @@ __global__ __launch_bounds__(512) void k_tf128(TFArgs a) {
 #pragma unroll
   for (int st = 0; st < NST; ++st) {
     const int lc = 4 * st + g;
-    aP[st] = i * (4 * C) + ((lc & ~15) | ((lc & 15) ^ i)) * 16;
+    aP[st] = F32 ? lane * 16 : i * (4 * C) + ((lc & ~15) | ((lc & 15) ^ i)) * 16;      // F32: the k-step is in the immediate
   }
 #pragma unroll
-  for (int sp = 0; sp < 2; ++sp) aO[sp] = i * 128 + ((4 * sp + g) ^ ((i >> 1) & 7)) * 16;
+  for (int sp = 0; sp < 2; ++sp) aO[sp] = F32 ? lane * 16 : i * 128 + ((4 * sp + g) ^ ((i >> 1) & 7)) * 16;
 
   bf16x8 fh[3][2], fl[3][2];
   auto frag_read = [&](auto kind, unsigned base, auto uc, int set, auto jc) __attribute__((always_inline)) {
     constexpr int KIND = decltype(kind)::value, u = decltype(uc)::value, j = decltype(jc)::value;
     constexpr int q = j >> 1, lo = j & 1;
-    constexpr int off = (KIND == K_O) ? ((2 * (u % (NCT / 2)) + q) * 16 * 128 + lo * (C * 128))
-                                      : ((2 * (u & 1) + q) * 16 * 4 * C + lo * (2 * C));
+    constexpr int off = F32 ? ((KIND == K_O) ? ((2 * (u % (NCT / 2)) + q) * 4096 + (u / (NCT / 2)) * 2048 + lo * 1024)
+                                             : ((2 * (u & 1) + q) * 8192 + (u >> 1) * 2048 + lo * 1024))
+                            : ((KIND == K_O) ? ((2 * (u % (NCT / 2)) + q) * 16 * 128 + lo * (C * 128))
+                                             : ((2 * (u & 1) + q) * 16 * 4 * C + lo * (2 * C)));
 #ifdef MDT_ABL_LDSBC   // ablation (WRONG results, timing only): every lane reads the same 16 bytes -- what the fragment reads cost the LDS
     lds_read16_off<off>(lo ? fl[set][q] : fh[set][q], base & 0x18000u);
 #else
@@ -369,12 +394,35 @@ __global__ __launch_bounds__(512) void k_tf128(TFArgs a) {
         if constexpr (KIND == K_N) acc[ia + q] = MDT_MFMA_BF16(x, w, acc[ia + q], 0, 0, 0);
         else acc[ia + q] = MDT_MFMA_BF16(w, x, acc[ia + q], 0, 0, 0);
       };
-      mm(fl[s0][0], bh[ib], 0); rd(J0{});
-      mm(fl[s0][1], bh[ib], 1); rd(J1{});
-      mm(fh[s0][0], bl[ib], 0); rd(J2{});
-      mm(fh[s0][1], bl[ib], 1); rd(J3{});
-      mm(fh[s0][0], bh[ib], 0);
-      mm(fh[s0][1], bh[ib], 1);
+      if constexpr (F32) {
+        // exact fp32: fragment (q, half) x operand half, four 16x16x4 MFMAs each (r = contraction sub-step); the two
+        // accumulators alternate so that no MFMA waits for the one issued just before it
+        auto mm4 = [&](const bf16x8& w0, const bf16x8& w1, const bf16x8& x, auto r0c) __attribute__((always_inline)) {
+          constexpr int r0 = decltype(r0c)::value;
+          const f32x4 a0 = __builtin_bit_cast(f32x4, w0), a1 = __builtin_bit_cast(f32x4, w1), xb = __builtin_bit_cast(f32x4, x);
+#pragma unroll
+          for (int r = r0; r < r0 + 2; ++r) {
+            if constexpr (KIND == K_N) {
+              acc[ia] = MDT_MFMA_F32(xb[r], a0[r], acc[ia], 0, 0, 0);
+              acc[ia + 1] = MDT_MFMA_F32(xb[r], a1[r], acc[ia + 1], 0, 0, 0);
+            } else {
+              acc[ia] = MDT_MFMA_F32(a0[r], xb[r], acc[ia], 0, 0, 0);
+              acc[ia + 1] = MDT_MFMA_F32(a1[r], xb[r], acc[ia + 1], 0, 0, 0);
+            }
+          }
+        };
+        mm4(fh[s0][0], fh[s0][1], bh[ib], J0{}); rd(J0{});
+        mm4(fh[s0][0], fh[s0][1], bh[ib], J2{}); rd(J1{});
+        mm4(fl[s0][0], fl[s0][1], bl[ib], J0{}); rd(J2{});
+        mm4(fl[s0][0], fl[s0][1], bl[ib], J2{}); rd(J3{});
+      } else {
+        mm(fl[s0][0], bh[ib], 0); rd(J0{});
+        mm(fl[s0][1], bh[ib], 1); rd(J1{});
+        mm(fh[s0][0], bl[ib], 0); rd(J2{});
+        mm(fh[s0][1], bl[ib], 1); rd(J3{});
+        mm(fh[s0][0], bh[ib], 0);
+        mm(fh[s0][1], bh[ib], 1);
+      }
       __builtin_amdgcn_sched_barrier(0);
     };
     unit(std::integral_constant<int, 0>{}); unit(std::integral_constant<int, 1>{});
@@ -441,7 +489,7 @@ __global__ __launch_bounds__(512) void k_tf128(TFArgs a) {
       float v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = mvalid ? (accT[2 * st + (e >> 2)][e & 3] - mean) * rstd : 0.f;
-      split8_tf(v, xh[st], xl[st]);
+      split8_tf<F32>(v, xh[st], xl[st]);
     }
   };
   // accT += vec[off + 16 ct + 4 g + r] (the sub-block's output bias: accumulators start from residual + bias)
@@ -529,7 +577,7 @@ __global__ __launch_bounds__(512) void k_tf128(TFArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[4 * hf + r] = mvalid ? u[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-u[r])) : 0.f;
         }
-        split8_tf(v, xh[st], xl[st]);
+        split8_tf<F32>(v, xh[st], xl[st]);
       }
     };
     auto raw_operands = [&](const f32x4* src) __attribute__((always_inline)) {
@@ -538,7 +586,7 @@ __global__ __launch_bounds__(512) void k_tf128(TFArgs a) {
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = mvalid ? src[2 * st + (e >> 2)][e & 3] : 0.f;
-        split8_tf(v, xh[st], xl[st]);
+        split8_tf<F32>(v, xh[st], xl[st]);
       }
     };
     auto set_vec = [&](f32x4* acc, const float* p, bool add) __attribute__((always_inline)) {
@@ -775,7 +823,7 @@ __global__ __launch_bounds__(512) void k_tf128(TFArgs a) {
           float v[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = oT[2 * sp + (e >> 2)][e & 3];
-          split8_tf(v, oh[sp], ol[sp]);
+          split8_tf<F32>(v, oh[sp], ol[sp]);
         }
         phase(kO, IC1{}, kT, true, accT, oh, ol);      // a tile always follows (cross / feed-forward of this block)
       }
@@ -861,7 +909,7 @@ __global__ __launch_bounds__(512) void k_tf128(TFArgs a) {
           float v[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = oT[2 * sp + (e >> 2)][e & 3];
-          split8_tf(v, oh[sp], ol[sp]);
+          split8_tf<F32>(v, oh[sp], ol[sp]);
         }
         phase(kO, IC1{}, kT, true, accT, oh, ol);      // the feed-forward block's tiles follow
       }
@@ -901,7 +949,7 @@ __global__ __launch_bounds__(512) void k_tf128(TFArgs a) {
           float v[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = oT[2 * sp + (e >> 2)][e & 3];
-          split8_tf(v, oh[sp], ol[sp]);
+          split8_tf<F32>(v, oh[sp], ol[sp]);
         }
         if (npost > 0 && !more) phase(kO, IC1{}, kO, true, accT, oh, ol);   // the folded convolution's tiles follow
         else phase(kO, IC1{}, kT, more || !last_blk, accT, oh, ol);
@@ -923,38 +971,43 @@ __global__ __launch_bounds__(512) void k_tf128(TFArgs a) {
   }
 }
 
-template <int NPW, int RES>
+template <int NPW, int RES, bool F32>
 static hipError_t launch_tf(const TFArgs& a, hipStream_t s) {
   const size_t smem = (size_t)NS * SLOT + (size_t)(a.nvec + (RES > 0 ? a.nfilm : 0)) * sizeof(float);   // ring + vectors [+ FiLM rows]
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tf128<NPW, RES>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tf128<NPW, RES, F32>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_tf128<NPW, RES>), dim3((unsigned)((a.M + 63) / 64)), dim3(512), smem, s, a);
+  hipLaunchKernelGGL((k_tf128<NPW, RES, F32>), dim3((unsigned)((a.M + 63) / 64)), dim3(512), smem, s, a);
   return hipGetLastError();
 }
 
+template <int RES, bool F32>
+static hipError_t launch_tf_res(const TFArgs& a, hipStream_t s, bool cross) {
+  if (!cross) return launch_tf<0, RES, F32>(a, s);
+  switch (((64 / a.T) * a.Tk + 15) / 16) {
+    case 1: return launch_tf<1, RES, F32>(a, s);
+    case 2: return launch_tf<2, RES, F32>(a, s);
+    case 3: return launch_tf<3, RES, F32>(a, s);
+    case 4: return launch_tf<4, RES, F32>(a, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+#if MDT_TF_F32
+hipError_t launch_tf128_f32(const TFArgs& a, hipStream_t s) {
+#else
 bool tf128_supported(int T, int Tk, int nvec, bool cross) {
   if (T <= 0 || 16 % T || nvec <= 0 || nvec % 256 || nvec > 8192) return false;     // 32 KB of vectors behind the 128 KB ring
   if (cross && (Tk <= 0 || (16 / T) * Tk > 16)) return false;                         // one key tile per wave (k_tblock_lw.hip)
   return true;
 }
 
-template <int RES>
-static hipError_t launch_tf_res(const TFArgs& a, hipStream_t s, bool cross) {
-  if (!cross) return launch_tf<0, RES>(a, s);
-  switch (((64 / a.T) * a.Tk + 15) / 16) {
-    case 1: return launch_tf<1, RES>(a, s);
-    case 2: return launch_tf<2, RES>(a, s);
-    case 3: return launch_tf<3, RES>(a, s);
-    case 4: return launch_tf<4, RES>(a, s);
-    default: return hipErrorInvalidValue;
-  }
-}
-
 hipError_t launch_tf128(const TFArgs& a, hipStream_t s) {
+  if (a.wf32) return launch_tf128_f32(a, s);           // exact-fp32 products: the instantiations of k_tf128_f32.hip
+#endif
   if (a.M <= 0) return hipSuccess;
   const bool cross = a.kv != nullptr;
   if (!tf128_supported(a.T, a.Tk, a.nvec, cross) || a.nblocks < 0 || a.NT <= 0 || a.nheads <= 0 || a.nff <= 0)
@@ -965,10 +1018,11 @@ hipError_t launch_tf128(const TFArgs& a, hipStream_t s) {
   if (a.n_res > 0 && (!a.skip || !a.film || a.nfilm % 256 || a.nfilm < 2 * C * a.n_res || a.nvec + a.nfilm > 8192))
     return hipErrorInvalidValue;
   if (a.nblocks == 0 && a.has_in) return hipErrorInvalidValue;
+  constexpr bool kF32 = MDT_TF_F32 != 0;
   switch (a.res_kind) {
-    case 0: return launch_tf_res<0>(a, s, cross);
-    case 1: return launch_tf_res<1>(a, s, cross);
-    default: return launch_tf_res<2>(a, s, cross);
+    case 0: return launch_tf_res<0, kF32>(a, s, cross);
+    case 1: return launch_tf_res<1, kF32>(a, s, cross);
+    default: return launch_tf_res<2, kF32>(a, s, cross);
   }
 }
 

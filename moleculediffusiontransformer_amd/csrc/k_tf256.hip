@@ -45,6 +45,12 @@
 
 #include "mdt_kernels.h"
 
+// Compiled twice: as is (split-bf16 products, launch_tf256) and through k_tf256_f32.hip with MDT_TF_F32 = 1 (exact fp32 MFMA
+// products, launch_tf256_f32) -- two translation units that build in parallel.
+#ifndef MDT_TF_F32
+#define MDT_TF_F32 0
+#endif
+
 // cache policy of the K / V row DMA (read once per evaluation, 1 GB in all): 2 = nt (streaming)
 #ifndef MDT_KV_CPOL
 #define MDT_KV_CPOL 2
@@ -97,12 +103,20 @@ __device__ __forceinline__ float gelu_tf(float x) {   // exact-erf GELU, branch-
   return 0.5f * x * (1.0f + copysignf(erfa, x));
 }
 
+// 8 values of one k-step -> its two 128-bit operand registers: bf16 hi / lo planes, or (F32) the values themselves, slots
+// 0..3 in `hi`, 4..7 in `lo` (k_tf128.hip)
+template <bool F32>
 __device__ __forceinline__ void split8_tf(const float v[8], bf16x8& hi, bf16x8& lo) {
+  if constexpr (F32) {
+    hi = __builtin_bit_cast(bf16x8, f32x4{v[0], v[1], v[2], v[3]});
+    lo = __builtin_bit_cast(bf16x8, f32x4{v[4], v[5], v[6], v[7]});
+  } else {
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const __bf16 h = (__bf16)v[e];
-    hi[e] = h;
-    lo[e] = (__bf16)(v[e] - (float)h);
+    for (int e = 0; e < 8; ++e) {
+      const __bf16 h = (__bf16)v[e];
+      hi[e] = h;
+      lo[e] = (__bf16)(v[e] - (float)h);
+    }
   }
 }
 
@@ -174,7 +188,11 @@ constexpr unsigned long long POLL_TIMEOUT = 30000000ull;   // s_memrealtime tick
 
 // NPW: LDS-DMA pieces per loader wave per K / V tile = ceil(context rows of the workgroup / 16); 0 = no cross-attention
 // NSPLIT: 1 = one workgroup per 32-row block; 2 = a pair of workgroups per block (see the head of the file)
-template <int NPW, int NSPLIT>
+// F32: fp32 fragment sub-tiles and exact fp32 MFMA products (v_mfma_f32_16x16x4_f32), as k_tf128.hip: a [64][128] projection
+//      sub-tile is fragments (feature tile ft, k-step st, half lo) at ft * 8192 + st * 2048 + lo * 1024, a [128][64] output
+//      sub-tile (row tile ct, k-step sp, half lo) at ct * 4096 + sp * 2048 + lo * 1024; lane (i, g) float r of a fragment =
+//      W[16 rt + i][k-slot 32 st + 8 g + 4 lo + r].  The loader waves copy such a sub-tile linearly.
+template <int NPW, int NSPLIT, bool F32>
 __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   unsigned char* red_b = smem + NS * SLOT;
@@ -211,8 +229,9 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
     for (int q = 0; q < IPT; ++q) {
       const int inst = iw + 4 * q;
       const int U = 2 * inst;
-      voffP[q] = (unsigned)(U * (2 * CS) + ((xP ^ (U & 15)) << 4) + baseP);
-      voffO[q] = (unsigned)(((inst * 8) / CS) * (128 * CS) + ((inst * 8) % CS) * 128 + ((xO ^ (4 * (inst & 1))) << 4) + baseO);
+      voffP[q] = F32 ? (unsigned)(inst * 1024 + lane * 16) : (unsigned)(U * (2 * CS) + ((xP ^ (U & 15)) << 4) + baseP);
+      voffO[q] = F32 ? (unsigned)(inst * 1024 + lane * 16)
+                     : (unsigned)(((inst * 8) / CS) * (128 * CS) + ((inst * 8) % CS) * 128 + ((xO ^ (4 * (inst & 1))) << 4) + baseO);
     }
     const int sample0 = rb * (32 / a.T);
     const bool second = a.kv2 && sample0 >= a.nsamples / 2;      // dual batch: shared K / V rows for the second half
@@ -302,7 +321,7 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
     const int pf_groups = PF_ON ? max(1, (int)gridDim.x / (8 * NSPLIT)) : 1;
     const int pf_mine = (int)blockIdx.x / (8 * NSPLIT);
     int pf_turn = MDT_STREAM_PF % pf_groups;                             // (k + MDT_STREAM_PF) % pf_groups, kept without a division per tile
-    unsigned pf_sink = 0;
+    unsigned char* pf_sink_b = vec_b + 2 * VEC_BYTES;                     // 1 KB behind the vector areas (launch_tf2 sizes it)
     int pf1 = 0, pf2 = 0;                                                // prefetch loads issued one / two turns ago
     for (int k = 0; k < NT; ++k) {
       const unsigned dnew = k + AHEAD < NT ? tiles[k + AHEAD] : 0u;
@@ -323,7 +342,11 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
           const unsigned kp = dp & 7u;
           if (kp != D_SCRATCH && kp != D_SCRATCH_VEC && kp < D_K) {      // a weight sub-tile
             const unsigned char* t = wsrc + (int64_t)(dp >> 3) * SLOT + (iw * 64 + lane) * 128;
-            asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(t) : "memory");
+            // one dword per lane by LDS-DMA into a sink nothing reads: no landing REGISTER at all (an inline-asm global_load with
+            // a live "+v" register is the hazard class of mdt_kernels.h: prefetch_next_weights, and a load whose value the
+            // compiler can see is waited for with vmcnt(0) on the spot -- HBM latency in the loader's per-tile turn).  Counts in
+            // vmcnt like the DMA pieces and completes in order with them.
+            __builtin_amdgcn_global_load_lds(t, (__attribute__((address_space(3))) void*)(pf_sink_b + iw * 256), 4, 0, 0);
             pf1 = 1;
           }
         }
@@ -332,7 +355,6 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
       for (int j = 0; j + 1 < AHEAD - 1; ++j) dq[j] = dq[j + 1];
       dq[AHEAD - 2] = dnew;
     }
-    asm volatile("" :: "v"(pf_sink));                                    // (the last turn waited for vmcnt(0))
     prefetch_next_weights(a.pf_ptr, a.pf_lines, iw * 64 + lane);
     return;
   }
@@ -396,15 +418,18 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
   // fragment addressing inside a sub-tile (k_tblock32.hip), this wave's feature half folded in
   // aP(st) = fh * 16384 + i * 512 + ((4 st + g) ^ i) * 16 = aP0 ^ (64 st): ONE register instead of four (4 st only touches bits 6-7 of
   // the address, which nothing else carries into)
-  const int aP0 = fh * (2 * 16 * 4 * CS) + i * (4 * CS) + ((g ^ i) & 15) * 16;
-  auto aP = [&](int st) -> int { return aP0 ^ (64 * st); };
-  const int aO = i * 128 + ((4 * fh + g) ^ ((i >> 1) & 7)) * 16;
+  // F32: fragment tiles -- the lane's 16 bytes, this wave's feature tiles (projection: ft = 2 fh + q) or k-step (output: sp = fh)
+  // and the k-step of a projection unit in the base, the rest in the immediate
+  const int aP0 = F32 ? lane * 16 + fh * 16384 : fh * (2 * 16 * 4 * CS) + i * (4 * CS) + ((g ^ i) & 15) * 16;
+  auto aP = [&](int st) -> int { return F32 ? aP0 : aP0 ^ (64 * st); };          // (F32: the k-step is in the immediate too)
+  const int aO = F32 ? lane * 16 + fh * 2048 : i * 128 + ((4 * fh + g) ^ ((i >> 1) & 7)) * 16;
 
   bf16x8 frh[3][2], frl[3][2];
   auto frag_read = [&](auto kind, unsigned base, auto uc, int set, auto jc) {
     constexpr int KIND = decltype(kind)::value, u = decltype(uc)::value, j = decltype(jc)::value;
     constexpr int q = j >> 1, lo = j & 1;
-    constexpr int off = (KIND == K_O) ? ((2 * u + q) * 16 * 128 + lo * (CS * 128)) : (q * 16 * 4 * CS + lo * (2 * CS));
+    constexpr int off = F32 ? ((KIND == K_O) ? ((2 * u + q) * 4096 + lo * 1024) : (q * 8192 + u * 2048 + lo * 1024))
+                            : ((KIND == K_O) ? ((2 * u + q) * 16 * 128 + lo * (CS * 128)) : (q * 16 * 4 * CS + lo * (2 * CS)));
 #ifdef MDT_ABL_LDSBC   // ablation (WRONG results, timing only): every lane reads the same 16 bytes -- what the fragment reads cost the LDS
     lds_read16_off<off>(lo ? frl[set][q] : frh[set][q], base & 0x18000u);
 #else
@@ -421,6 +446,12 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
   auto prefetch2 = [&](auto kind, const unsigned char* slot, int off) {
     constexpr int KIND = decltype(kind)::value;
     const unsigned l = lds_addr(slot);
+    if constexpr (F32) {                             // two fragment sets, one unit ahead (phase()): unit 0 -> set 0
+      const unsigned b = l + (KIND == K_O ? aO : aP0);
+      frag_read(kind, b, J0{}, 0, J0{}); frag_read(kind, b, J0{}, 0, J1{});
+      frag_read(kind, b, J0{}, 0, J2{}); frag_read(kind, b, J0{}, 0, J3{});
+      return;
+    }
     const unsigned b0 = l + (KIND == K_O ? aO : aP(0)), b1 = l + (KIND == K_O ? aO : aP(1));
     pb2 = l + (KIND == K_O ? aO : aP(2));
     pb3 = l + (KIND == K_O ? aO : aP(3));
@@ -436,6 +467,59 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
   // One MFMA phase over a sub-tile (k_tblock32.hip): 4 units of 4 fragment reads + 6 MFMAs
   auto phase = [&](auto kind, auto offc, auto nkind, bool has_next, f32x4* acc, const bf16x8* bh, const bf16x8* bl) {
     constexpr int KIND = decltype(kind)::value, OFF = decltype(offc)::value, NK = decltype(nkind)::value;
+    if constexpr (F32) {
+      // Exact fp32 products: a unit is 4 fragment reads + 16 MFMAs of 8 passes (512 MFMA-pipe cycles against 96 of the split
+      // form), so ONE unit of read-ahead covers the LDS latency many times over: two fragment sets (16 registers fewer than the
+      // three of the split form -- this kernel sits at the 256-register limit), unit u + 1 read during unit u into set (u + 1) & 1,
+      // the barrier that publishes the next sub-tile in front of the last unit.  NU is even: every phase starts on set 0 and OFF
+      // is not used.  All fragment addresses are slot base + one lane constant + immediate.
+      const unsigned lc = lds_addr(slot_of(tau)) + (KIND == K_O ? aO : aP0);
+      const unsigned lnx = lds_addr(slot_of(tau + 1)) + (NK == K_O ? aO : aP0);
+      auto unit32 = [&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        if (u == NU - 1 && has_next) {
+          __builtin_amdgcn_sched_barrier(0);
+          MDT_BARRIER();                // B(tau + 1)
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        lgkm_wait<0>();                 // set u & 1 (read during the previous unit) has landed
+        constexpr int s0 = u & 1, s1 = (u + 1) & 1;
+        constexpr bool in_phase = u + 1 < NU;
+        const bool pre = in_phase || has_next;
+        constexpr int ia = (KIND == K_O) ? 2 * u : 0, ib = (KIND == K_O) ? 0 : u;
+        auto rd = [&](auto jc) {
+          if (!pre) return;
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (in_phase) frag_read(kind, lc, std::integral_constant<int, u + 1>{}, s1, jc);
+          else frag_read(nkind, lnx, std::integral_constant<int, 0>{}, s1, jc);
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        // fragment (q, half) x operand half: four 16x16x4 MFMAs each (r = contraction sub-step), the two accumulators alternating
+        auto mm4 = [&](const bf16x8& w0, const bf16x8& w1, const bf16x8& x, auto r0c) {
+          constexpr int r0 = decltype(r0c)::value;
+          const f32x4 a0 = __builtin_bit_cast(f32x4, w0), a1 = __builtin_bit_cast(f32x4, w1), xb = __builtin_bit_cast(f32x4, x);
+#pragma unroll
+          for (int r = r0; r < r0 + 2; ++r) {
+            if constexpr (KIND == K_N) {
+              acc[ia] = MDT_MFMA_F32(xb[r], a0[r], acc[ia], 0, 0, 0);
+              acc[ia + 1] = MDT_MFMA_F32(xb[r], a1[r], acc[ia + 1], 0, 0, 0);
+            } else {
+              acc[ia] = MDT_MFMA_F32(a0[r], xb[r], acc[ia], 0, 0, 0);
+              acc[ia + 1] = MDT_MFMA_F32(a1[r], xb[r], acc[ia + 1], 0, 0, 0);
+            }
+          }
+        };
+        mm4(frh[s0][0], frh[s0][1], bh[ib], J0{}); rd(J0{});
+        mm4(frh[s0][0], frh[s0][1], bh[ib], J2{}); rd(J1{});
+        mm4(frl[s0][0], frl[s0][1], bl[ib], J0{}); rd(J2{});
+        mm4(frl[s0][0], frl[s0][1], bl[ib], J2{}); rd(J3{});
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      unit32(std::integral_constant<int, 0>{}); unit32(std::integral_constant<int, 1>{});
+      unit32(std::integral_constant<int, 2>{}); unit32(std::integral_constant<int, 3>{});
+      ++tau;
+      return;
+    }
     unsigned ln = 0, bn[2] = {0u, 0u};
     auto unit = [&](auto uc) {
       constexpr int u = decltype(uc)::value;
@@ -581,7 +665,7 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
       float v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = mvalid ? (accT[2 * st + (e >> 2)][e & 3] - mean) * rstd : 0.f;
-      split8_tf(v, xh[st], xl[st]);
+      split8_tf<F32>(v, xh[st], xl[st]);
     }
   };
   // start of a sub-block: wave fh = 0 carries residual + output bias (or the bias alone), wave fh = 1 starts from zero
@@ -869,7 +953,7 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
           float v[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = oT[e >> 2][e & 3];
-          split8_tf(v, oh[0], ol[0]);
+          split8_tf<F32>(v, oh[0], ol[0]);
         }
         MDT_HSTAMP();                                           // attention core done
         phase(kO, IC1{}, kO, true, accT, oh, ol);               // output rows 0..127
@@ -981,7 +1065,7 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
           float v[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = oT[e >> 2][e & 3];
-          split8_tf(v, oh[0], ol[0]);
+          split8_tf<F32>(v, oh[0], ol[0]);
         }
         phase(kO, IC1{}, kO, true, accT, oh, ol);
         phase(kO, IC2{}, kT, more, accT + 8, oh, ol);
@@ -1018,7 +1102,7 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
           float v[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = oT[e >> 2][e & 3];
-          split8_tf(v, oh[0], ol[0]);
+          split8_tf<F32>(v, oh[0], ol[0]);
         }
         phase(kO, IC1{}, kO, true, accT, oh, ol);
         if (npost > 0 && !more) phase(kO, IC2{}, kO, true, accT + 8, oh, ol);   // the folded convolution's sub-tiles follow
@@ -1107,44 +1191,50 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
   }
 }
 
-template <int NPW, int NSPLIT>
+template <int NPW, int NSPLIT, bool F32>
 static hipError_t launch_tf2(const TFArgs& a, hipStream_t s) {
-  const size_t smem = (size_t)NS * SLOT + RED_BYTES + 2 * VEC_BYTES;
+  const size_t smem = (size_t)NS * SLOT + RED_BYTES + 2 * VEC_BYTES + 1024;   // ring, S^T exchange, vectors, prefetch sink
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tf256<NPW, NSPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tf256<NPW, NSPLIT, F32>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(160 * 1024));
     attr_set = true;
   }
   const int nrb = (a.M + 31) / 32;
   unsigned grid = (unsigned)nrb;
   if (NSPLIT == 2) grid = 2u * (unsigned)a.pair_stride * (unsigned)((nrb + a.pair_stride - 1) / a.pair_stride);
-  hipLaunchKernelGGL((k_tf256<NPW, NSPLIT>), dim3(grid), dim3(512), smem, s, a);
+  hipLaunchKernelGGL((k_tf256<NPW, NSPLIT, F32>), dim3(grid), dim3(512), smem, s, a);
   return hipGetLastError();
 }
 
+template <int NSPLIT>
+static hipError_t launch_tf256_n(const TFArgs& a, hipStream_t s) {
+  constexpr bool kF32 = MDT_TF_F32 != 0;
+  const bool cross = a.kv != nullptr;
+  if (!cross) return launch_tf2<0, NSPLIT, kF32>(a, s);
+  switch (((32 / a.T) * a.Tk + 15) / 16) {
+    case 1: return launch_tf2<1, NSPLIT, kF32>(a, s);
+    case 2: return launch_tf2<2, NSPLIT, kF32>(a, s);
+    case 3: return launch_tf2<3, NSPLIT, kF32>(a, s);
+    case 4: return launch_tf2<4, NSPLIT, kF32>(a, s);
+    case 5: return launch_tf2<5, NSPLIT, kF32>(a, s);
+    case 6: return launch_tf2<6, NSPLIT, kF32>(a, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+#if MDT_TF_F32
+hipError_t launch_tf256_f32(const TFArgs& a, hipStream_t s) {
+#else
 bool tf256_supported(int T, int Tk, int nheads, int nff, bool cross) {
   if (T <= 0 || 16 % T || nheads != 8 || nff != 8) return false;        // vectors: [bq 512 | bo 256] / [b1 512 | b2 256]
   if (cross && (Tk <= 0 || (16 / T) * Tk > 48)) return false;           // three key tiles per wave (k_tblock32.hip)
   return true;
 }
 
-template <int NSPLIT>
-static hipError_t launch_tf256_n(const TFArgs& a, hipStream_t s) {
-  const bool cross = a.kv != nullptr;
-  if (!cross) return launch_tf2<0, NSPLIT>(a, s);
-  switch (((32 / a.T) * a.Tk + 15) / 16) {
-    case 1: return launch_tf2<1, NSPLIT>(a, s);
-    case 2: return launch_tf2<2, NSPLIT>(a, s);
-    case 3: return launch_tf2<3, NSPLIT>(a, s);
-    case 4: return launch_tf2<4, NSPLIT>(a, s);
-    case 5: return launch_tf2<5, NSPLIT>(a, s);
-    case 6: return launch_tf2<6, NSPLIT>(a, s);
-    default: return hipErrorInvalidValue;
-  }
-}
-
 hipError_t launch_tf256(const TFArgs& a, hipStream_t s) {
+  if (a.wf32) return launch_tf256_f32(a, s);           // exact-fp32 products: the instantiations of k_tf256_f32.hip
+#endif
   if (a.M <= 0) return hipSuccess;
   const bool cross = a.kv != nullptr;
   if (!tf256_supported(a.T, a.Tk, a.nheads, a.nff, cross) || a.nblocks <= 0 || a.NT <= 0) return hipErrorInvalidValue;

@@ -47,7 +47,11 @@ int mdt_set_tuning(const char* key, int32_t value) {
   return 1;
 }
 const char* mdt_last_error(void) { return g_err.c_str(); }
+#ifdef MDT_TUNING
+int mdt_abi_version(void) { return MDT_ABI_VERSION | MDT_ABI_TUNING_BIT; }   // a timing-only build (mdt_kernels.h)
+#else
 int mdt_abi_version(void) { return MDT_ABI_VERSION; }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 static const char* validate(const mdt_op& o, int idx, char* buf, size_t nbuf) {
@@ -117,11 +121,13 @@ static const char* validate(const mdt_op& o, int idx, char* buf, size_t nbuf) {
         return bad("shape not supported by the row-stationary convolution");
       if (!o.a.space || !o.w.space || !o.out.space) return bad("missing operand");
       if (o.i[MDT_R_GSIZE] > 0 && (!o.p0.space || !o.p1.space)) return bad("GroupNorm prologue needs gain and bias");
+      if (o.i[MDT_R_WF32] != 0 && o.i[MDT_R_WF32] != 1) return bad("WF32 must be 0 (split-bf16 tiles) or 1 (fp32 fragment tiles)");
       break;
     case MDT_OP_RESBLOCK:
       if (!mdt::resblock_supported(o.i[MDT_K_T], o.i[MDT_K_CIN], o.i[MDT_K_COUT]))
         return bad("shape not supported by the fused ResNet block");
       if (!o.a.space || !o.w.space || !o.bias.space || !o.out.space) return bad("missing operand");
+      if (o.i[MDT_K_WF32] != 0 && o.i[MDT_K_WF32] != 1) return bad("WF32 must be 0 (split-bf16 fragments) or 1 (fp32 fragments)");
       break;
     case MDT_OP_ATTN:
       if (o.i[MDT_A_T] <= 0 || o.i[MDT_A_T] > 64 || o.i[MDT_A_TK] <= 0 || o.i[MDT_A_TK] > 64)
@@ -173,6 +179,7 @@ static const char* validate(const mdt_op& o, int idx, char* buf, size_t nbuf) {
       if (i[MDT_F_NBLOCKS] < 0 || i[MDT_F_NT] <= 0 || i[MDT_F_HEADS] <= 0 || i[MDT_F_HEADS] > 16 || i[MDT_F_NFF] <= 0)
         return bad("bad block / tile / head counts");
       if (i[MDT_F_NPOST] != 0 && i[MDT_F_NPOST] != 2) return bad("npost must be 0 or 2");
+      if (i[MDT_F_WF32] != 0 && i[MDT_F_WF32] != 1) return bad("WF32 must be 0 (split-bf16 tiles) or 1 (fp32 fragment tiles)");
       if (!o.a.space || !o.out.space || !o.w.space || !o.bias.space || !o.p0.space) return bad("missing operand");
       if (i[MDT_F_CROSS] && !o.a2.space) return bad("cross-attention blocks need the hoisted K/V rows");
       if (i[MDT_F_RES_KIND] < 0 || i[MDT_F_RES_KIND] > 2 || (i[MDT_F_RES_KIND] == 0) != (i[MDT_F_N_RES] == 0) || i[MDT_F_N_RES] < 0 ||
@@ -192,6 +199,7 @@ static const char* validate(const mdt_op& o, int idx, char* buf, size_t nbuf) {
         return bad("shape not supported by the fused transformer (tokens per sample must divide 16, 8 heads, hidden 512, <= 48 context rows per 16 tokens)");
       if (i[MDT_F_NBLOCKS] <= 0 || i[MDT_F_NT] <= 0 || i[MDT_F_NVEC] <= 0 || i[MDT_F_NVEC] % 768) return bad("bad block / tile / vector counts");
       if (i[MDT_F_NPOST] != 0 && i[MDT_F_NPOST] != 8) return bad("npost must be 0 or 8");
+      if (i[MDT_F_WF32] != 0 && i[MDT_F_WF32] != 1) return bad("WF32 must be 0 (split-bf16 tiles) or 1 (fp32 fragment tiles)");
       if (!o.a.space || !o.out.space || !o.w.space || !o.bias.space || !o.p0.space) return bad("missing operand");
       if (i[MDT_F_CROSS] && !o.a2.space) return bad("cross-attention blocks need the hoisted K/V rows");
       if (i[MDT_F_NSPLIT] != 0 && i[MDT_F_NSPLIT] != 1 && i[MDT_F_NSPLIT] != 2) return bad("NSPLIT must be 1 or 2");
@@ -338,7 +346,7 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
         a.ldr = o.i[MDT_R_LDR]; a.taps = o.i[MDT_R_TAPS]; a.gsize = o.i[MDT_R_GSIZE]; a.silu = o.i[MDT_R_SILU];
         a.film_ld = o.i[MDT_R_FILM_LD]; a.eps = o.f[MDT_RF_EPS]; a.in_scale = o.f[MDT_RF_IN_SCALE];
         a.lda2 = o.i[MDT_R_LDA2]; a.in_scale2 = o.f[MDT_RF_IN_SCALE2];
-        a.pf_ptr = pf_ptr; a.pf_lines = pf_lines;
+        a.pf_ptr = pf_ptr; a.pf_lines = pf_lines; a.wf32 = o.i[MDT_R_WF32];
         if (!missing) e = mdt::launch_rconv(a, stream);
         break;
       }
@@ -346,7 +354,7 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
         mdt::ResBlockArgs a;
         a.x = ptr(o.a); a.out = ptr(o.out); a.w = ptr(o.w); a.vec = ptr(o.bias); a.film = ptr(o.p3);
         a.B = B; a.T = o.i[MDT_K_T]; a.cin = o.i[MDT_K_CIN]; a.cout = o.i[MDT_K_COUT]; a.film_ld = o.i[MDT_K_FILM_LD];
-        a.eps = o.f[MDT_KF_EPS];
+        a.eps = o.f[MDT_KF_EPS]; a.wf32 = o.i[MDT_K_WF32];
         if (!missing) e = mdt::launch_resblock(a, stream);
         break;
       }
@@ -438,6 +446,7 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
         a.pair_stride = g_pair_stride > 0 ? g_pair_stride : (i[MDT_F_PAIR_STRIDE] > 0 ? i[MDT_F_PAIR_STRIDE] : 8);
         a.xflags = a.nsplit == 2 ? reinterpret_cast<unsigned*>(const_cast<float*>(ptr(o.p2))) : nullptr;
         a.xbuf = a.nsplit == 2 ? const_cast<float*>(ptr(o.p3)) : nullptr;
+        a.wf32 = i[MDT_F_WF32];
         if (i[MDT_F_KV2]) {
           const int per_wg = (wide ? 32 : 64) / a.T;
           if (!o.p1.space || B % 2 || (B / 2) % (per_wg > 0 ? per_wg : 1))

@@ -4,6 +4,18 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Tuning builds.  The switches below exist to TIME a section of a ring kernel with it compiled out or altered; every one of them
+// produces WRONG (or unsynchronised) results.  They compile only together with -DMDT_TUNING, and a library built that way
+// identifies itself: mdt_abi_version() carries MDT_ABI_TUNING_BIT, which runtime.load_library() refuses unless the caller
+// (a tool under tools/) sets MDT_ALLOW_TUNING=1 -- a timing-only library cannot be loaded for real sampling by accident.
+#if (defined(MDT_ABL_BAR) || defined(MDT_ABL_VMWAIT) || defined(MDT_ABL_LGKM) || defined(MDT_ABL_LDSBC) || defined(MDT_ABL_GELU) ||     \
+     defined(MDT_ABL_ATTN) || defined(MDT_RING_NODRAIN) || defined(MDT_STAGGER) || defined(MDT_XH_D2) ||                               \
+     (defined(MDT_XH_ADDR) && MDT_XH_ADDR == 0) || (defined(MDT_XH_MODE) && MDT_XH_MODE != 0)) &&                                       \
+    !defined(MDT_TUNING)
+#error "MDT_ABL_* / MDT_RING_NODRAIN / MDT_STAGGER / MDT_XH_D2 / MDT_XH_ADDR=0 / MDT_XH_MODE!=0 give wrong results: timing builds only, add -DMDT_TUNING"
+#endif
+#define MDT_ABI_TUNING_BIT 0x40000000
+
 // priority of the loader waves of the ring kernels (s_setprio): 3 = their few instructions issue ahead of the MFMA waves
 #ifndef MDT_LOADER_PRIO
 #define MDT_LOADER_PRIO 3
@@ -133,9 +145,11 @@ struct RConvArgs {
   float eps, in_scale, in_scale2;
   const void* pf_ptr;  // weight stream of the NEXT launch (pulled into the L2s by the idle loader waves), or nullptr
   int pf_lines;        // ... its size in 128-byte lines
+  int wf32;            // 1: fp32 fragment tiles, exact fp32 MFMA products (MDT_R_WF32)
 };
 bool rconv_supported(int C, int T, int taps, int gsize);
 hipError_t launch_rconv(const RConvArgs& a, hipStream_t s);
+hipError_t launch_rconv_f32(const RConvArgs& a, hipStream_t s);   // (k_rconv_f32.hip); reached through launch_rconv
 
 // MDT_OP_RESBLOCK (k_resblock.hip): a whole ResnetBlock1d of the 64-token level (one GroupNorm group) in one launch
 struct ResBlockArgs {
@@ -146,6 +160,7 @@ struct ResBlockArgs {
   const float* film;   // [scale | shift] rows film_ld apart, or nullptr
   int B, T, cin, cout, film_ld;
   float eps;
+  int wf32;            // 1: w = fp32 MFMA fragments [step][row tile][half][64 lanes][4], exact fp32 products (MDT_K_WF32)
 };
 bool resblock_supported(int T, int cin, int cout);
 hipError_t launch_resblock(const ResBlockArgs& a, hipStream_t s);
@@ -225,15 +240,18 @@ struct TFArgs {
   int pair_stride;       // workgroup ids of a pair are this far apart (8: same XCD as observed; 1: neighbours)
   float* xbuf;           // hand-off blocks [2 parities][row blocks][2 halves][32 x 256] fp32
   unsigned* xflags;      // [0..63] diagnostics (bit 0 of word 0: a poll timed out); from word 64: one 128-byte line per (row block, half)
+  int wf32;              // 1: `w` holds fp32 FRAGMENT tiles, every projection / convolution product is an exact fp32 MFMA (MDT_F_WF32)
 };
 bool tf128_supported(int T, int Tk, int nvec, bool cross);
 hipError_t launch_tf128(const TFArgs& a, hipStream_t s);
+hipError_t launch_tf128_f32(const TFArgs& a, hipStream_t s);    // the exact-fp32 instantiations (k_tf128_f32.hip); reached through launch_tf128
 // MDT_OP_TF256 (k_tf256.hip): the same for a C = 256 level, 32-row workgroups.  Differences in the streams: tile
 // descriptors are kind (3 bits: 0 projection sub-tile, 1 output sub-tile, 2 K rows, 3 V rows, 4 scratch, 5 scratch + the next
 // sub-block's vectors) | aux << 3; every sub-block is followed by two scratch tiles; vectors are 768 floats per sub-block
 // ([bq 512 | bo 256], [b1 512 | b2 256], to_in: [bias 256]); npost = 8 sub-tiles.
 bool tf256_supported(int T, int Tk, int nheads, int nff, bool cross);
 hipError_t launch_tf256(const TFArgs& a, hipStream_t s);
+hipError_t launch_tf256_f32(const TFArgs& a, hipStream_t s);    // (k_tf256_f32.hip); reached through launch_tf256
 
 hipError_t launch_concat(const float* a, const float* b, float* out, int64_t rows, int ca, int cb, float scale_b,
                          hipStream_t s);

@@ -12,7 +12,8 @@ from typing import Optional
 from . import build as _build
 
 N_EXT = 8
-ABI_VERSION = 3        # MDT_ABI_VERSION of include/mdt_hip.h this binding was written against
+ABI_VERSION = 4        # MDT_ABI_VERSION of include/mdt_hip.h this binding was written against
+ABI_TUNING_BIT = 0x40000000   # set in mdt_abi_version() by a -DMDT_TUNING build (csrc/mdt_kernels.h)
 SP_NONE, SP_WEIGHT, SP_ACT, SP_SHR, SP_EXT0 = 0, 1, 2, 3, 4
 OP_GEMM, OP_GN_STATS, OP_ATTN, OP_CONCAT, OP_PATCH, OP_TIME_EMBED, OP_TBLOCK, OP_GN_ACT, OP_RCONV = 1, 2, 3, 4, 5, 6, 7, 8, 9
 OP_RESBLOCK = 10
@@ -35,13 +36,13 @@ A_T, A_TK, A_HEADS, A_LDQ, A_LDKV, A_LDO, A_KV_BSTRIDE, A_OUT16, A_QCOL, A_KCOL 
 C_ROWS, C_CA, C_CB = range(3)
 P_ROWS_IN, P_C_IN, P_LD_IN, P_LD_OUT, P_PATCH, P_INVERSE = range(6)
 T_HALF, T_LD = range(2)
-R_T, R_C, R_LDA, R_LDC, R_LDR, R_TAPS, R_GSIZE, R_SILU, R_FILM_LD, R_LDA2 = range(10)
-K_T, K_CIN, K_COUT, K_FILM_LD = range(4)
+R_T, R_C, R_LDA, R_LDC, R_LDR, R_TAPS, R_GSIZE, R_SILU, R_FILM_LD, R_LDA2, R_WF32 = range(11)
+K_T, K_CIN, K_COUT, K_FILM_LD, K_WF32 = range(5)
 B_MODE, B_C, B_T, B_NCHUNK, B_NBIAS, B_TK, B_KV_BSTRIDE, B_LDKV, B_HEADS, B_VARIANT, B_POST = range(11)
 B_KV2 = 11
 # MDT_OP_TF128 (enum mdt_tf128_i)
 (F_C, F_T, F_NT, F_NVEC, F_TK, F_KV_BSTRIDE, F_LDKV, F_HEADS, F_HAS_IN, F_NBLOCKS, F_NFF, F_NPOST, F_KV2, F_CROSS,
- F_KV_LSTRIDE, F_RES_KIND, F_N_RES, F_RES_PAIR1, F_RES_PAIR2, F_NFILM, F_NSPLIT, F_PAIR_STRIDE) = range(22)
+ F_KV_LSTRIDE, F_RES_KIND, F_N_RES, F_RES_PAIR1, F_RES_PAIR2, F_NFILM, F_NSPLIT, F_PAIR_STRIDE, F_WF32) = range(23)
 FF_EPS_LN, FF_SCALE, FF_EPS_GN, FF_EPS_RES, FF_SKIP_SCALE = range(5)
 
 
@@ -120,7 +121,14 @@ def load_library(allow_build: bool = True) -> C.CDLL:
         fn = getattr(lib, name)   # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.mdt_abi_version() != ABI_VERSION:
+    abi = lib.mdt_abi_version()
+    if abi & ABI_TUNING_BIT:
+        # built with -DMDT_TUNING: may contain ablation switches that give WRONG results (csrc/mdt_kernels.h)
+        if os.environ.get("MDT_ALLOW_TUNING", "0") != "1":
+            raise RuntimeError(f"{path} is a TUNING build (-DMDT_TUNING: timing-only switches that give wrong results may be "
+                               "compiled in); it is refused for sampling.  Tools that time such builds set MDT_ALLOW_TUNING=1")
+        abi &= ~ABI_TUNING_BIT
+    if abi != ABI_VERSION:
         raise RuntimeError(f"libmdt_hip.so ABI version {lib.mdt_abi_version()} != {ABI_VERSION} expected by this package: rebuild it")
     _lib = lib
     return lib

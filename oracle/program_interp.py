@@ -214,9 +214,15 @@ def run_program(ops, bufs: Buffers, B: int, n_shared_rows: int = 0) -> None:
 _SLOT_PERM = [32 * (s >> 5) + 16 * ((s & 7) >> 2) + 4 * ((s >> 3) & 3) + (s & 3) for s in range(64)]
 
 
-def _untile(stream: torch.Tensor, k: int, rows: int, cols: int) -> torch.Tensor:
-    """Tile k of the weight stream (bf16 hi plane then lo plane, 256*C bytes) -> fp32 [rows][cols]."""
+def _untile(stream: torch.Tensor, k: int, rows: int, cols: int, f32: bool = False) -> torch.Tensor:
+    """Tile k of the weight stream -> fp32 [rows][cols].  Split-bf16 format: bf16 hi plane then lo plane (256*C bytes).
+    f32 (MDT_F_WF32 / MDT_R_WF32 / MDT_K_WF32, include/mdt_hip.h): the same bytes hold fp32 MFMA fragments -- fragment
+    (row tile rt, k-step st, half lo) at ((rt * (cols / 32) + st) * 2 + lo) * 256 floats, float r of lane i + 16 g =
+    W[16 rt + i][32 st + 8 g + 4 lo + r]."""
     n = rows * cols                       # bf16 elements per plane; tile = 2 n bf16 = n floats
+    if f32:
+        raw = stream[k * n: (k + 1) * n].contiguous().view(rows // 16, cols // 32, 2, 4, 16, 4)   # [rt][st][lo][g][i][r]
+        return raw.permute(0, 4, 1, 3, 2, 5).reshape(rows, cols).clone()
     raw = stream[k * n: (k + 1) * n].contiguous().view(torch.bfloat16)
     return (raw[:n].float() + raw[n:].float()).view(rows, cols)
 
@@ -255,7 +261,7 @@ def _rconv(op, bufs: Buffers, B: int) -> None:
         for tap in range(taps):
             for kh in range(nkh):
                 for ch in range(nch):
-                    w[64 * ch: 64 * ch + 64, s_ * C + 128 * kh: s_ * C + 128 * kh + 128, tap] = _untile(stream, k, 64, 128)
+                    w[64 * ch: 64 * ch + 64, s_ * C + 128 * kh: s_ * C + 128 * kh + 128, tap] = _untile(stream, k, 64, 128, bool(i[rt.R_WF32]))
                     k += 1
     bias = bufs.view(op.bias, B, C) if op.bias.space != rt.SP_NONE else None
     o = F.conv1d(y.transpose(1, 2), w, bias, padding=taps // 2).transpose(1, 2)
@@ -288,7 +294,10 @@ def _resblock(op, bufs: Buffers, B: int) -> None:
         w = torch.zeros(n, c, taps)
         for step in _resblock_steps(c, taps):
             for r in range(n // 16):
-                m = _untile(stream, k, 64, 8).view(4, 16, 8).permute(1, 0, 2).reshape(16, 32)   # lane 16 g + i -> [i][8 g + e]
+                if i[rt.K_WF32]:
+                    m = _untile(stream, k, 16, 32, True)
+                else:
+                    m = _untile(stream, k, 64, 8).view(4, 16, 8).permute(1, 0, 2).reshape(16, 32)   # lane 16 g + i -> [i][8 g + e]
                 k += 1
                 for j, tc in enumerate(step):
                     if tc is not None:
@@ -396,6 +405,7 @@ def _tf128(op, bufs: Buffers, B: int) -> None:
     C, T, NT, nvec = i[rt.F_C], i[rt.F_T], i[rt.F_NT], i[rt.F_NVEC]
     Tk, bs, ldkv, H = i[rt.F_TK], i[rt.F_KV_BSTRIDE], i[rt.F_LDKV], i[rt.F_HEADS]
     nblocks, nff, npost, cross = i[rt.F_NBLOCKS], i[rt.F_NFF], i[rt.F_NPOST], bool(i[rt.F_CROSS])
+    wf32 = bool(i[rt.F_WF32])          # fp32 fragment tiles (exact-fp32 products) instead of bf16 hi / lo planes
     desc = bufs.view(op.p0, B, NT).contiguous().view(torch.int32).tolist()
     nw = sum(1 for d in desc if (d & 3) < 2 and not (d >> 22))          # (aux bit 20: the skip rows of a ResNet block)
     stream = bufs.view(op.w, B, nw * 64 * C)
@@ -410,13 +420,13 @@ def _tf128(op, bufs: Buffers, B: int) -> None:
         d = desc[cur["t"]]
         cur["t"] += 1
         assert d & 3 == 0, "expected a projection tile"
-        return _untile(stream, d >> 2, 64, C)[:, inv_acc]
+        return _untile(stream, d >> 2, 64, C, wf32)[:, inv_acc]
 
     def O(natural_from: Optional[int] = None):     # next output tile -> [C, 64]
         d = desc[cur["t"]]
         cur["t"] += 1
         assert d & 3 == 1, "expected an output tile"
-        t = _untile(stream, d >> 2, C, 64)
+        t = _untile(stream, d >> 2, C, 64, wf32)
         if natural_from is None:
             return t[:, inv_slot]
         cols = torch.tensor(_ACC_PERM[natural_from: natural_from + 64]) - natural_from     # accumulator order inside the chunk
@@ -547,6 +557,7 @@ def _tf256(op, bufs: Buffers, B: int) -> None:
     Tk, bs, ldkv, H = i[rt.F_TK], i[rt.F_KV_BSTRIDE], i[rt.F_LDKV], i[rt.F_HEADS]
     nblocks, nff, npost, cross = i[rt.F_NBLOCKS], i[rt.F_NFF], i[rt.F_NPOST], bool(i[rt.F_CROSS])
     nsplit = 2 if i[rt.F_NSPLIT] == 2 else 1
+    wf32 = bool(i[rt.F_WF32])
     desc_all = bufs.view(op.p0, B, nsplit * NT).contiguous().view(torch.int32).tolist()
     tabs = [desc_all[h * NT: (h + 1) * NT] for h in range(nsplit)]
     nw = 1 + max(d >> 3 for d in desc_all if (d & 7) < 2)
@@ -570,11 +581,11 @@ def _tf256(op, bufs: Buffers, B: int) -> None:
 
     def P(hh=0):                   # projection tile = two K-half sub-tiles -> [64, C], natural K order
         a_, b_ = take(0, hh), take(0, hh)
-        return torch.cat([_untile(stream, a_, 64, 128), _untile(stream, b_, 64, 128)], dim=1)[:, inv_acc]
+        return torch.cat([_untile(stream, a_, 64, 128, wf32), _untile(stream, b_, 64, 128, wf32)], dim=1)[:, inv_acc]
 
     def O(hh=0, natural_from: Optional[int] = None):     # output tile = two row-half sub-tiles -> [C, 64]
         a_, b_ = take(1, hh), take(1, hh)
-        t = torch.cat([_untile(stream, a_, 128, 64), _untile(stream, b_, 128, 64)], dim=0)
+        t = torch.cat([_untile(stream, a_, 128, 64, wf32), _untile(stream, b_, 128, 64, wf32)], dim=0)
         if natural_from is None:
             return t[:, inv_slot]
         cols = accp[natural_from: natural_from + 64] - natural_from

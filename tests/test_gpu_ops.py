@@ -12,6 +12,20 @@ pytestmark = pytest.mark.gpu
 W, A, S, E0 = rt.SP_WEIGHT, rt.SP_ACT, rt.SP_SHR, rt.SP_EXT0
 
 
+@pytest.fixture(params=["bf16x3", "f32"])
+def prod(request, monkeypatch):
+    """Product type of the ring kernels under test: split-bf16 tiles (hi*hi + hi*lo + lo*hi on bf16 MFMAs) or fp32 fragment tiles
+    with exact fp32 MFMA products (MDT_F_WF32 / MDT_R_WF32 / MDT_K_WF32).  Same ops, same interpreter, same closed forms: every
+    UNetCompiler a test builds with the default mode is built in this one."""
+    from moleculediffusiontransformer_amd import compiler
+    orig = compiler.UNetCompiler.__init__
+
+    def init(self, cfg, length, cond_len, sd, max_time_rows=1024, gemm_mode="bf16x3", fuse_blocks=True, tf256=False):
+        orig(self, cfg, length, cond_len, sd, max_time_rows, request.param if gemm_mode == "bf16x3" else gemm_mode, fuse_blocks, tf256)
+    monkeypatch.setattr(compiler.UNetCompiler, "__init__", init)
+    return request.param
+
+
 def gemm_op(**kw):
     op = rt.MdtOp()
     op.kind = rt.OP_GEMM
@@ -573,7 +587,7 @@ def test_gn_act(B, R, C, G, film, silu, eps):
     (256, 4, 9, 1, 0, False, 0.7071),      # its 1x1 residual convolution on the raw concatenation
     (128, 16, 5, 1, 0, False, 0.5),
 ])
-def test_row_stationary_conv_two_sources(C, T, B, taps, gsize, silu, in_scale2):
+def test_row_stationary_conv_two_sources(C, T, B, taps, gsize, silu, in_scale2, prod):
     """k_rconv on a concatenated input that is never materialised: prologue + taps for source a, then for source b,
     into the same accumulators (second exchange barrier, fragment-set rotation between the sources)."""
     from moleculediffusiontransformer_amd.compiler import Ten, UNetCompiler
@@ -610,7 +624,7 @@ def test_row_stationary_conv_two_sources(C, T, B, taps, gsize, silu, in_scale2):
     (128, 8, 6, 1, 0, False, False, "accumulate", 1.0),      # plain 1x1 conv (to_out), 8 tokens per sample
     (256, 1, 33, 3, 32, False, True, None, 1.0),       # one token per sample: both neighbours are padding
 ])
-def test_row_stationary_conv(C, T, B, taps, gsize, film, silu, res, in_scale):
+def test_row_stationary_conv(C, T, B, taps, gsize, film, silu, res, in_scale, prod):
     """k_rconv (GroupNorm + FiLM + SiLU prologue, DPP-shifted taps, loader-wave weight ring) against the interpreter
     and against torch's group_norm / conv1d."""
     from moleculediffusiontransformer_amd.compiler import Ten, UNetCompiler
@@ -687,7 +701,7 @@ def _resblock_case(cin, cout, film):
 
 @pytest.mark.parametrize("cin,cout", [(16, 64), (64, 16)])
 @pytest.mark.parametrize("B,film", [(1, True), (2, False), (7, True), (1030, True)])
-def test_fused_resnet_block(cin, cout, B, film):
+def test_fused_resnet_block(cin, cout, B, film, prod):
     """k_resblock (the Patcher / Unpatcher ResnetBlock1d in one launch; odd batches leave half a workgroup idle, 1030
     samples wrap the persistent loop) against the interpreter and against torch's group_norm / conv1d."""
     comp, op, shr, closed_form = _resblock_case(cin, cout, film)
@@ -777,7 +791,7 @@ def _handoff_ext(B, T):
     (128, 8, 9, 1, False, False), (128, 2, 33, 1, False, False), (128, 16, 1030, 1, True, False),
     (256, 4, 37, 2, True, False), (256, 4, 5, 2, False, False), (256, 4, 9, 4, True, True), (256, 16, 3, 1, False, False),
     (256, 8, 11, 1, True, False), (256, 1, 70, 1, True, False), (256, 4, 1030, 1, True, False)])
-def test_fused_transformer(C, T, B, layers, cross, fixed, form):
+def test_fused_transformer(C, T, B, layers, cross, fixed, form, prod):
     """MDT_OP_TF128 / MDT_OP_TF256 (k_tf128.hip, k_tf256.hip): a whole Transformer1d in one launch, against (i) the CPU
     interpreter of the op (tile order, K-column permutation to the accumulator layout, vector layout) and (ii) the
     reference's module arithmetic written out with torch ops (modules.py:469-524, :401-410, :350-364, :314-320).
@@ -801,6 +815,7 @@ def test_fused_transformer(C, T, B, layers, cross, fixed, form):
     y = comp.transformer(x, p, C, layers, cross, free_input=False)
     assert [o.kind for o in comp.ops] == [rt.OP_TF128 if C == 128 else rt.OP_TF256]
     op = comp.ops[0]
+    assert op.i[rt.F_WF32] == int(prod == "f32")
     assert op.i[rt.F_NSPLIT] == (2 if (C == 256 and form != "whole") else (1 if C == 256 else 0))
     ext = _handoff_ext(B, T) if form != "whole" else {}
     kv_floats = n_ctx * 2 * mid
@@ -862,7 +877,7 @@ def test_fused_transformer(C, T, B, layers, cross, fixed, form):
 
 
 @pytest.mark.parametrize("T,B,layers,cross", [(4, 1024, 2, True), (4, 37, 1, True), (16, 9, 1, False)])
-def test_pair_handoff_is_placement_independent_and_repeatable(T, B, layers, cross):
+def test_pair_handoff_is_placement_independent_and_repeatable(T, B, layers, cross, prod):
     """The pair-split MDT_OP_TF256 hands 32 x 256 partial sums between two workgroups inside the launch (sc1 stores, drained,
     workgroup barrier, flag; poll, barrier, sc1 loads).  120 launches on ONE set of flag words (they
     count monotonically across launches), partners alternately on one XCD (ids 8 apart) and on different XCDs (neighbouring ids,
@@ -947,7 +962,7 @@ def _resnet_sd(p, c, cin, seed0):
     (2, 8, 9, 2, 1, False),
     (2, 16, 33, 1, 1, True),
 ])
-def test_resnet_blocks_inside_the_transformer_launch(kind, T, B, n_res, layers, cross):
+def test_resnet_blocks_inside_the_transformer_launch(kind, T, B, n_res, layers, cross, prod):
     """MDT_OP_TF128 with MDT_F_RES_KIND 1 / 2 (k_tf128.hip RES = 1 / 2): ResnetBlock1d blocks of the 128-channel level in front
     of the transformer in one launch, against (i) the CPU interpreter of the op and (ii) the reference's module arithmetic
     (modules.py:145-205: GroupNorm -> [FiLM] -> SiLU -> Conv1d(k = 3), twice, + to_out(x) | x; :828-829: cat with the scaled

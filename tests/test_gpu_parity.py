@@ -17,17 +17,27 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-@pytest.fixture(scope="module", params=["bf16x3", "f32"])
+@pytest.fixture(scope="module", params=["bf16x3", "f32", "f32-layers"])
 def models(request):
-    """Every parity test runs with both GEMM kernels: split-bf16 MFMA (default) and exact fp32 MFMA."""
+    """Every parity test runs with both product types on the SAME fused program -- split-bf16 MFMA (default) and exact fp32
+    MFMA ('f32': fp32 fragment tiles in the ring kernels) -- and with the exact mode's layer-by-layer form (MDT_F32_FUSED=0:
+    k_gemm + k_attn + k_gn_act, the second exact implementation)."""
+    import os
     cache = {}
+    mode, _, form = request.param.partition("-")
+    old = os.environ.get("MDT_F32_FUSED")
+    os.environ["MDT_F32_FUSED"] = "0" if form == "layers" else "1"      # read when an engine is compiled
 
     def get(case):
         if case not in cache:
             cache[case] = make_model(case)
-            cache[case].gemm_mode = request.param
+            cache[case].gemm_mode = mode
         return cache[case]
-    return get
+    yield get
+    if old is None:
+        del os.environ["MDT_F32_FUSED"]
+    else:
+        os.environ["MDT_F32_FUSED"] = old
 
 
 @pytest.mark.parametrize("case", ["tiny", "pd22", "cfg3", "cfg1", "nb", "sparse", "full"])
@@ -301,14 +311,16 @@ dist.barrier(); torch.cuda.synchronize(); dist.destroy_process_group(); print('R
     assert mg["shard_invariance"]["bitwise_equal_to_1_rank_run"] is True
 
 
+@pytest.mark.parametrize("mode", ["bf16x3", "f32"])
 @pytest.mark.parametrize("B,cs", [(8, 1.0), (256, 1.0), (1024, 1.0), (256, 3.0)])
-def test_repeated_sampling_is_bitwise_stable(B, cs):
+def test_repeated_sampling_is_bitwise_stable(B, cs, mode):
     """The same call six times on identical noise returns identical bits, and the probe rows match the oracle -- with launches of
     DIFFERENT data alternating (evaluations of a sampling loop), which an op-level repeat on fixed inputs cannot exercise.  This is
     the check that exposed the first form of the pair hand-off (wave-uniform part of the addresses in the buffer instructions'
     SCALAR offset: a piece in 10^5-10^7 arrived from another block; B = 1024 differed in every call; DESIGN.md 3.8,
     tools/repeat_determinism_probe.py)."""
     m = make_model("cfg1")
+    m.gemm_mode = mode                 # 'f32': the same fused program (pair hand-offs included) with exact fp32 products
     T = 3 if B < 1024 else 2
     seq = synth_normal("rep/seq", (B, 12))
     init = synth_normal("rep/init", (B, 16, 64))
@@ -319,6 +331,9 @@ def test_repeated_sampling_is_bitwise_stable(B, cs):
     assert all(torch.equal(outs[0], o) for o in outs[1:])
     assert (outs[0].cpu()[rows] - want).abs().max() < TOL
     assert m._engine.handoff_status() == 0
+    from moleculediffusiontransformer_amd import runtime as rt
+    ev = m._engine.c.programs["eval"]
+    assert len(ev) == 42 and all(op.i[rt.F_WF32] == int(mode == "f32") for op in ev if op.kind in (rt.OP_TF128, rt.OP_TF256))
 
 
 def test_handoff_timeout_is_reported_by_the_next_call():

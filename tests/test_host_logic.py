@@ -26,7 +26,7 @@ def test_c_abi_exports_every_declared_symbol():
     assert declared == set(rt.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.mdt_abi_version() == rt.ABI_VERSION == 3
+    assert lib.mdt_abi_version() == rt.ABI_VERSION == 4      # (no MDT_ABI_TUNING_BIT: not a timing-only build)
     assert ctypes.sizeof(rt.MdtOp) == 8 + 10 * 16 + 24 * 4 + 8 * 4
     bad = rt.MdtOp()
     bad.kind = 1   # GEMM with cin == 0
@@ -201,11 +201,15 @@ def test_token_chain_between_the_two_models():
     assert tokens_to_forward_input(t, 3).tolist() == [[3.0, 5.0, 1.0], [2.0, 2.0, 0.0], [0.0, 0.0, 0.0]]
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16x3", "bf16x3-wide", "bf16"])
+@pytest.mark.parametrize("mode", ["f32", "f32-wide", "f32-layers", "bf16x3", "bf16x3-wide", "bf16"])
 @pytest.mark.parametrize("case", ["tiny", "pd22", "cfg3", "cfg1", "sparse", "full"])
-def test_lowering_matches_reference_golden(case, mode):
+def test_lowering_matches_reference_golden(case, mode, monkeypatch):
     """compiler.py's op program, executed by the CPU interpreter, reproduces the reference U-Net output ('bf16': the
-    reduced-precision mode, within its own budget of 2e-2 of an O(1) output per evaluation)."""
+    reduced-precision mode, within its own budget of 2e-2 of an O(1) output per evaluation).  'f32' is the exact-fp32 mode on
+    the SAME fused program as the default mode (fp32 fragment tiles in the ring kernels' ops), 'f32-layers' its layer-by-layer
+    form (MDT_F32_FUSED=0)."""
+    if mode == "f32-layers":
+        monkeypatch.setenv("MDT_F32_FUSED", "0")
     kind, kw = CASES[case]
     if kind == "full":
         ucfg = sparse_unet_config(kw["pred_dim"], kw["channels"], 64, kw["context_embedding_max_length"], patch_size=4, num_blocks=(3, 3))
@@ -214,6 +218,7 @@ def test_lowering_matches_reference_golden(case, mode):
         ucfg = mk(kw["pred_dim"], kw["channels"], 128, kw["context_embedding_max_length"])
     usd = {k[5:]: v for k, v in synth_sd(case).items() if k.startswith("unet.")}
     wide = mode.endswith("-wide")       # 256-channel transformers as whole-transformer launches (k_tf256)
+    layers = mode.endswith("-layers")
     mode = mode.split("-")[0]
     if wide and case not in ("cfg1", "sparse"):
         pytest.skip("no 256-channel fused transformer in this configuration")
@@ -221,6 +226,17 @@ def test_lowering_matches_reference_golden(case, mode):
                       gemm_mode=mode, tf256=wide)
     if wide:
         assert any(op.kind == rt.OP_TF256 for op in cu.programs["eval"])
+    ring = (rt.OP_TF128, rt.OP_TF256, rt.OP_RCONV, rt.OP_RESBLOCK, rt.OP_TBLOCK)
+    if mode == "f32" and layers:
+        assert not any(op.kind in ring for op in cu.programs["eval"])
+    elif mode == "f32" and case == "cfg1":
+        # the fused program of the default mode, op for op, with fp32 fragment tiles
+        ref = compile_unet(ucfg, kw["max_length"], kw["context_embedding_max_length"], usd, max_time_rows=4, gemm_mode="bf16x3", tf256=wide)
+        assert [op.kind for op in cu.programs["eval"]] == [op.kind for op in ref.programs["eval"]] and len(cu.programs["eval"]) == 42
+        wf = {rt.OP_TF128: rt.F_WF32, rt.OP_TF256: rt.F_WF32, rt.OP_RCONV: rt.R_WF32, rt.OP_RESBLOCK: rt.K_WF32}
+        assert all(op.i[wf[op.kind]] == 1 for op in cu.programs["eval"] if op.kind in wf)
+        assert all(op.i[wf[op.kind]] == 0 for op in ref.programs["eval"] if op.kind in wf)
+        assert all(op.a2.space == rt.SP_NONE for op in cu.programs["eval"] if op.kind == rt.OP_GEMM)     # exact fp32 GEMMs: no lo plane
     if mode == "bf16" and case in ("cfg1", "cfg3", "sparse"):
         assert any(op.kind == rt.OP_PREP16 for op in cu.programs["eval"])       # regular layers: bf16 x bf16 GEMM
         assert any(op.kind == rt.OP_GEMM and op.i[rt.G_WFMT] == 6 for op in cu.programs["eval"])   # bf16 hidden layer
@@ -256,7 +272,7 @@ def test_lowering_matches_reference_golden(case, mode):
     assert abs(cu.flops_per_sample_eval - {"cfg1": 388.7e6}.get(case, cu.flops_per_sample_eval)) < 1e6
 
 
-_RING_UNITS = ("k_tblock32", "k_rconv", "k_tf128", "k_tf256")
+_RING_UNITS = ("k_tblock32", "k_rconv", "k_tf128", "k_tf256", "k_rconv_f32", "k_tf128_f32", "k_tf256_f32")
 
 
 @pytest.fixture(scope="module")
@@ -288,16 +304,18 @@ def test_ring_kernels_keep_their_arrays_in_registers(ring_kernel_reports):
     an in-flight read."""
     import re
     res, _ = ring_kernel_reports
-    limits = {"k_tblock32": 24, "k_rconv": 0, "k_tf128": 0, "k_tf256": 128}     # bytes per lane
+    # The exact-fp32 instantiations (round 4: *_f32 units) are all at ZERO: k_tf256's fp32 phase needs two fragment sets instead
+    # of three (a unit is 512 MFMA-pipe cycles, one unit of read-ahead covers the LDS latency), which is what the split form lacks.
+    limits = {"k_tblock32": 24, "k_rconv": 0, "k_tf128": 0, "k_tf256": 128,     # bytes per lane
+              "k_rconv_f32": 0, "k_tf128_f32": 0, "k_tf256_f32": 0}
     for name, limit in limits.items():
         assert res[name], name
         for fn, v in res[name]:
-            if name == "k_rconv" and re.search(r"ELi2ELi[01]EEEvNS_9RConvArgsE$", fn):
-                # two-source instantiations <..., NSRC = 2, PRO>: only the 1x1 form without a prologue (PRO = 0) is on the
+            if name.startswith("k_rconv") and re.search(r"ELi2ELi[01]ELb[01]EEEvNS_9RConvArgsE$", fn):
+                # two-source instantiations <..., NSRC = 2, PRO, F32>: only the 1x1 form without a prologue (PRO = 0) is on the
                 # default path (the concatenated inputs' residual convolution; C = 128, or C = 256 with the output channels
                 # split over two workgroups)
-                if not (fn.endswith("ELi4ELi128ELi1ELi1ELi2ELi0EEEvNS_9RConvArgsE") or
-                        fn.endswith("ELi2ELi256ELi1ELi2ELi2ELi0EEEvNS_9RConvArgsE")):
+                if not re.search(r"(ELi4ELi128ELi1ELi1ELi2ELi0|ELi2ELi256ELi1ELi2ELi2ELi0)ELb[01]EEEvNS_9RConvArgsE$", fn):
                     continue
             assert 0 <= v["scratch"] <= limit, (fn, v)
 
@@ -324,8 +342,9 @@ def test_no_instruction_touches_an_in_flight_fragment_read(ring_kernel_reports):
             assert not violations, (name, kernel, violations[:3])
 
 
+@pytest.mark.parametrize("mode", ["bf16x3", "f32"])
 @pytest.mark.parametrize("cin,cout", [(16, 64), (64, 16)])
-def test_fused_resnet_block_lowering(cin, cout):
+def test_fused_resnet_block_lowering(cin, cout, mode):
     """MDT_OP_RESBLOCK on the CPU side: the compiler's MFMA-fragment packing (k-steps enumerate (tap, channel) pairs,
     lane i + 16 g holds pairs 8 g .. 8 g + 7 of weight row i) and the interpreter's unpacking are inverse to each other,
     and the interpreted op is the reference ResnetBlock1d (modules.py:145-205) with one GroupNorm group."""
@@ -339,10 +358,11 @@ def test_fused_resnet_block_lowering(cin, cout):
           p + "block2.groupnorm.weight": 1 + 0.1 * r(cout), p + "block2.groupnorm.bias": 0.1 * r(cout),
           p + "block2.project.weight": r(cout, cout, 3, scale=(3 * cout) ** -0.5), p + "block2.project.bias": 0.1 * r(cout),
           p + "to_out.weight": r(cout, cin, 1, scale=cin ** -0.5), p + "to_out.bias": 0.1 * r(cout)}
-    comp = UNetCompiler(inverse_unet_config(16, 64, 128, 12), 64, 12, sd)
+    comp = UNetCompiler(inverse_unet_config(16, 64, 128, 12), 64, 12, sd, gemm_mode=mode)
     comp.resnet(Ten(rt.SP_ACT, 0, 64, cin), p, cin, cout, 1, free_input=False)
     assert [op.kind for op in comp.ops] == [rt.OP_RESBLOCK]
     op = comp.ops[0]
+    assert op.i[rt.K_WF32] == int(mode == "f32")
     op.out = rt.MdtRef(rt.SP_ACT, 0, 64 * cin)
     op.p3 = rt.MdtRef(rt.SP_SHR, 0, 0)
     B = 3
