@@ -34,9 +34,20 @@ int mdt_abi_version(void);
 const char *mdt_last_error(void);
 /* Process-wide tuning / test hooks (not needed for correct results): "pair_stride" = v > 0 places the two workgroups of
  * every pair-split MDT_OP_TF256 v workgroup ids apart whatever the op says (1: neighbours, i.e. different XCDs; 0: back to
- * the ops' own value); "tile16" = 0 | 1 | 2 forces a tile of the bf16 x bf16 GEMM (-1: automatic).  Returns 0, or 1 for an
- * unknown key. */
+ * the ops' own value); "tile16" = 0 | 1 | 2 forces a tile of the bf16 x bf16 GEMM (-1: automatic); "pair_capacity": see
+ * mdt_pair_capacity.  Returns 0, or 1 for an unknown key. */
 int mdt_set_tuning(const char *key, int32_t value);
+/* Workgroups of a pair-split MDT_OP_TF256 launch that the current device keeps resident at the same time: compute units x
+ * workgroups per compute unit (hipDeviceGetAttribute / hipOccupancyMaxActiveBlocksPerMultiprocessor; 256 on an MI355X), 0 if
+ * unknown.  The two workgroups of a pair wait for each other inside the launch, so mdt_program_run never puts more than this
+ * many into one launch: a larger batch runs as several launches over consecutive row-block ranges (same results).  The host
+ * reads it to choose between the pair-split and the whole-workgroup form by batch size (generative.py::_wide).
+ * mdt_set_tuning("pair_capacity", v > 0) replaces it (tests: force chunking on a small batch; 0 = back to the device's). */
+int32_t mdt_pair_capacity(void);
+/* Test hook: enqueue a kernel of n_workgroups workgroups that only HOLD compute units -- each allocates lds_bytes of LDS (<= 160
+ * KiB: nothing else fits next to it) and spins for `ticks` of the 100 MHz real-time counter.  Used to break the co-residency
+ * of pair-split launches on purpose (another stream holding most of the device) and check that the failure is reported. */
+int mdt_test_occupy(int32_t n_workgroups, int32_t lds_bytes, uint64_t ticks, void *stream);
 
 /* ------------------------------------------------------------------ */
 /* U-Net evaluation as an op program                                   */

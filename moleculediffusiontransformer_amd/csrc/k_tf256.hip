@@ -210,7 +210,7 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
     const int S = a.pair_stride, id = blockIdx.x;
     const int grp = id / (2 * S), w = id - grp * 2 * S;
     hh = w / S;
-    rb = grp * S + (w - hh * S);
+    rb = a.rb_base + grp * S + (w - hh * S);        // (rb_base: first row block of this launch, see launch_tf2)
     if (rb >= nrb) return;                          // padding of the last group: both partners leave
   }
 
@@ -1191,6 +1191,12 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
   }
 }
 
+#if MDT_TF_F32
+extern int g_pair_capacity_override;
+#else
+int g_pair_capacity_override = 0;     // tests (mdt_set_tuning("pair_capacity", v)): pretend the device runs only v workgroups at once
+#endif
+
 template <int NPW, int NSPLIT, bool F32>
 static hipError_t launch_tf2(const TFArgs& a, hipStream_t s) {
   const size_t smem = (size_t)NS * SLOT + RED_BYTES + 2 * VEC_BYTES + 1024;   // ring, S^T exchange, vectors, prefetch sink
@@ -1201,10 +1207,42 @@ static hipError_t launch_tf2(const TFArgs& a, hipStream_t s) {
     attr_set = true;
   }
   const int nrb = (a.M + 31) / 32;
-  unsigned grid = (unsigned)nrb;
-  if (NSPLIT == 2) grid = 2u * (unsigned)a.pair_stride * (unsigned)((nrb + a.pair_stride - 1) / a.pair_stride);
-  hipLaunchKernelGGL((k_tf256<NPW, NSPLIT, F32>), dim3(grid), dim3(512), smem, s, a);
-  return hipGetLastError();
+  if constexpr (NSPLIT == 1) {
+    hipLaunchKernelGGL((k_tf256<NPW, NSPLIT, F32>), dim3((unsigned)nrb), dim3(512), smem, s, a);
+    return hipGetLastError();
+  } else {
+    // The two workgroups of a pair spin on each other's flag, so BOTH must be resident at the same time: a launch may not hold
+    // more workgroups than the device runs at once.  capacity = compute units x workgroups of THIS kernel per compute unit
+    // (hipOccupancyMaxActiveBlocksPerMultiprocessor: 1, the LDS ring fills the CU), asked once per device.  A batch with more
+    // row blocks runs as several launches over consecutive row-block ranges (stream order = one after the other; every pair
+    // lives inside one launch, flags and hand-off blocks are indexed by the global row block) -- the results are those of a
+    // single launch, so a pinned 'narrow' kernel choice stays valid, and bitwise shard-invariant, at any batch size.
+    // (What this cannot see -- compute units held by another stream or process, CU masks -- ends in the polls' time-out and the
+    //  status word that sample() checks before it returns, engine.py.)
+    static int cap_of[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (cap_of[dev] == 0) {
+      int cus = 0, per_cu = 0;
+      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return hipErrorInvalidDevice;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&k_tf256<NPW, NSPLIT, F32>), 512, smem) != hipSuccess)
+        return hipErrorInvalidValue;
+      cap_of[dev] = cus * per_cu > 0 ? cus * per_cu : -1;
+    }
+    const int S = a.pair_stride;
+    const int groups_fit = g_pair_capacity_override > 0 ? g_pair_capacity_override / (2 * S) : cap_of[dev] / (2 * S);
+    if (groups_fit < 1) return hipErrorLaunchOutOfResources;          // not even one group of 2 S workgroups is co-resident
+    const int ngroups = (nrb + S - 1) / S;
+    for (int g0 = 0; g0 < ngroups; g0 += groups_fit) {
+      TFArgs b = a;
+      b.rb_base = g0 * S;
+      const int ng = ngroups - g0 < groups_fit ? ngroups - g0 : groups_fit;
+      hipLaunchKernelGGL((k_tf256<NPW, NSPLIT, F32>), dim3(2u * (unsigned)S * (unsigned)ng), dim3(512), smem, s, b);
+      const hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+  }
 }
 
 template <int NSPLIT>
@@ -1226,6 +1264,18 @@ static hipError_t launch_tf256_n(const TFArgs& a, hipStream_t s) {
 #if MDT_TF_F32
 hipError_t launch_tf256_f32(const TFArgs& a, hipStream_t s) {
 #else
+// workgroups of a pair-split launch that are resident at the same time on the current device (0 if it cannot be determined)
+int tf256_pair_capacity() {
+  if (g_pair_capacity_override > 0) return g_pair_capacity_override;
+  int dev = 0, cus = 0, per_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  const size_t smem = (size_t)NS * SLOT + RED_BYTES + 2 * VEC_BYTES + 1024;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tf256<6, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&k_tf256<6, 2, false>), 512, smem) != hipSuccess) return 0;
+  return cus * per_cu;
+}
+
 bool tf256_supported(int T, int Tk, int nheads, int nff, bool cross) {
   if (T <= 0 || 16 % T || nheads != 8 || nff != 8) return false;        // vectors: [bq 512 | bo 256] / [b1 512 | b2 256]
   if (cross && (Tk <= 0 || (16 / T) * Tk > 48)) return false;           // three key tiles per wave (k_tblock32.hip)

@@ -24,6 +24,17 @@ int hip_fail(const char* what, hipError_t e) {
 }
 }  // namespace
 
+// mdt_test_occupy: a kernel that does nothing but HOLD compute units -- every workgroup allocates `lds` bytes of LDS (so that
+// nothing else fits next to it) and spins on the 100 MHz real-time counter for `ticks`.  Test infrastructure for the pair
+// hand-off's failure path (tests/test_gpu_parity.py): with most of the device held by another stream, the partners of a
+// pair-split launch are not resident together, their polls time out, and sample() must raise instead of returning garbage.
+__global__ void k_test_occupy(unsigned long long ticks) {
+  extern __shared__ unsigned char hog_lds[];
+  if (threadIdx.x == 0) hog_lds[0] = 1;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+
 struct mdt_program {
   std::vector<mdt_op> ops;
 };
@@ -43,10 +54,19 @@ int mdt_set_tuning(const char* key, int32_t value) {
   const std::string k = key ? key : "";
   if (k == "pair_stride") { g_pair_stride = value; return 0; }
   if (k == "tile16") { mdt::set_tile16(value); return 0; }
+  if (k == "pair_capacity") { mdt::g_pair_capacity_override = value > 0 ? value : 0; return 0; }
   g_err = "mdt_set_tuning: unknown key '" + k + "'";
   return 1;
 }
 const char* mdt_last_error(void) { return g_err.c_str(); }
+int32_t mdt_pair_capacity(void) { return mdt::tf256_pair_capacity(); }
+int mdt_test_occupy(int32_t n_workgroups, int32_t lds_bytes, uint64_t ticks, void* stream) {
+  if (n_workgroups <= 0 || lds_bytes < 0 || lds_bytes > 160 * 1024) return fail("mdt_test_occupy: bad arguments");
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_test_occupy), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL(k_test_occupy, dim3((unsigned)n_workgroups), dim3(64), (size_t)lds_bytes, (hipStream_t)stream, (unsigned long long)ticks);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : hip_fail("mdt_test_occupy", e);
+}
 #ifdef MDT_TUNING
 int mdt_abi_version(void) { return MDT_ABI_VERSION | MDT_ABI_TUNING_BIT; }   // a timing-only build (mdt_kernels.h)
 #else
@@ -446,7 +466,7 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
         a.pair_stride = g_pair_stride > 0 ? g_pair_stride : (i[MDT_F_PAIR_STRIDE] > 0 ? i[MDT_F_PAIR_STRIDE] : 8);
         a.xflags = a.nsplit == 2 ? reinterpret_cast<unsigned*>(const_cast<float*>(ptr(o.p2))) : nullptr;
         a.xbuf = a.nsplit == 2 ? const_cast<float*>(ptr(o.p3)) : nullptr;
-        a.wf32 = i[MDT_F_WF32];
+        a.wf32 = i[MDT_F_WF32]; a.rb_base = 0;
         if (i[MDT_F_KV2]) {
           const int per_wg = (wide ? 32 : 64) / a.T;
           if (!o.p1.space || B % 2 || (B / 2) % (per_wg > 0 ? per_wg : 1))

@@ -241,6 +241,7 @@ struct TFArgs {
   float* xbuf;           // hand-off blocks [2 parities][row blocks][2 halves][32 x 256] fp32
   unsigned* xflags;      // [0..63] diagnostics (bit 0 of word 0: a poll timed out); from word 64: one 128-byte line per (row block, half)
   int wf32;              // 1: `w` holds fp32 FRAGMENT tiles, every projection / convolution product is an exact fp32 MFMA (MDT_F_WF32)
+  int rb_base;           // pair-split launches: first row block of THIS launch (launch_tf256 chunks a batch that does not fit the device)
 };
 bool tf128_supported(int T, int Tk, int nvec, bool cross);
 hipError_t launch_tf128(const TFArgs& a, hipStream_t s);
@@ -251,7 +252,9 @@ hipError_t launch_tf128_f32(const TFArgs& a, hipStream_t s);    // the exact-fp3
 // ([bq 512 | bo 256], [b1 512 | b2 256], to_in: [bias 256]); npost = 8 sub-tiles.
 bool tf256_supported(int T, int Tk, int nheads, int nff, bool cross);
 hipError_t launch_tf256(const TFArgs& a, hipStream_t s);
-hipError_t launch_tf256_f32(const TFArgs& a, hipStream_t s);    // (k_tf256_f32.hip); reached through launch_tf256
+hipError_t launch_tf256_f32(const TFArgs& a, hipStream_t s);
+int tf256_pair_capacity();              // workgroups of a pair-split launch resident at once on the current device
+extern int g_pair_capacity_override;    // tests: > 0 replaces the device's capacity    // (k_tf256_f32.hip); reached through launch_tf256
 
 hipError_t launch_concat(const float* a, const float* b, float* out, int64_t rows, int ca, int cb, float scale_b,
                          hipStream_t s);

@@ -93,11 +93,15 @@ class UNetEngine:
         b.ext[EXT_XFLAGS], b.ext[EXT_XBUF] = rt.ptr(getattr(self, "xflags", None)), rt.ptr(getattr(self, "xbuf", None))
         return b
 
-    # A pair hand-off that runs into its time-out (a partner workgroup was never scheduled: the pair-split launches need every
-    # workgroup of a launch resident at once) raises bit 0 of the diagnostic word on the device and the launch's rows are
-    # garbage.  Reading that word costs a synchronisation, so the sampling loops copy it to pinned host memory behind their last
-    # launch (note_handoff) and the NEXT call -- or handoff_check(wait=True) -- looks at the copy once it has arrived: a failed
-    # call is reported loudly, one call late at the latest, and no call waits for the GPU.
+    # A pair hand-off that runs into its time-out (a partner workgroup was never scheduled: the two workgroups of a pair must be
+    # resident at the same time; launch_tf256 never puts more workgroups into a launch than the device runs at once, but compute
+    # units held by another stream or process, or a CU mask, are invisible to it) raises bit 0 of the diagnostic word on the
+    # device and the launch's rows are garbage.  Every sampling loop and every net() evaluation copies that word to pinned host
+    # memory behind its last launch (note_handoff) and -- by default -- WAITS for the copy and raises before any result is
+    # returned (sync_handoff_check: one event wait per call; VERDICT r3 #9 / ADVICE r3).  Pipelined callers may defer the look
+    # to the next call or to an explicit handoff_check(wait=True) (model.defer_handoff_check).
+    sync_handoff_check = True
+
     def note_handoff(self) -> None:
         if getattr(self, "xflags", None) is None:
             return
@@ -107,9 +111,11 @@ class UNetEngine:
         self._xstat_host.copy_(self.xflags[:1], non_blocking=True)
         self._xstat_event.record()
         self._xstat_pending = True
+        if self.sync_handoff_check:
+            self.handoff_check(wait=True)
 
     def handoff_check(self, wait: bool = False) -> None:
-        """Raises RuntimeError if a sampling call noted by note_handoff() had a hand-off time-out (and clears the word)."""
+        """Raises RuntimeError if a call noted by note_handoff() had a hand-off time-out (and clears the word)."""
         if not getattr(self, "_xstat_pending", False):
             return
         if wait:
@@ -120,9 +126,11 @@ class UNetEngine:
         if int(self._xstat_host[0]) != 0:
             if getattr(self, "xflags", None) is not None:
                 self.xflags[0] = 0
-            raise RuntimeError("a pair hand-off inside a 256-channel transformer launch timed out (a partner workgroup was not "
-                               "scheduled within 0.3 s): the samples of the PREVIOUS sampling call are invalid.  The pair-split "
-                               "launches need the whole GPU; set MDT_TF256_PAIR=0 to use one launch per sub-block instead")
+            when = "this" if wait else "the PREVIOUS"
+            raise RuntimeError(f"a pair hand-off inside a 256-channel transformer launch timed out (a partner workgroup was not "
+                               f"scheduled within 0.3 s): the results of {when} call are invalid.  The pair-split launches need "
+                               "their workgroups resident at the same time (compute units taken by another stream or process?); "
+                               "set model.kernel_choice = 'wide' or MDT_TF256_PAIR=0 for forms without in-launch hand-offs")
 
     def handoff_status(self) -> int:
         """Diagnostic word of the pair hand-offs (synchronises): 0 = fine; bit 0 = some poll ran into its time-out, i.e. the

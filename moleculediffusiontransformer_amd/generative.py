@@ -176,6 +176,12 @@ class _QMBase(nn.Module):
         self.gemm_mode = os.environ.get("MDT_GEMM", "bf16x3")
         # form of the 256-channel transformers: 'auto' (by the batch of each call), 'wide', 'narrow' (see _wide)
         self.kernel_choice = {"1": "wide", "0": "narrow"}.get(os.environ.get("MDT_TF256", "auto"), "auto")
+        # A pair hand-off that times out (a partner workgroup was not resident: compute units held by another stream / process)
+        # leaves garbage rows and a status word on the device.  By default every sampling call and every net() / denoise_fn()
+        # evaluation waits for that word before it returns (one event wait per call) and raises RuntimeError.  A pipelined caller
+        # that issues calls back to back may set this True (or MDT_DEFER_HANDOFF=1): the word is then looked at by the NEXT call,
+        # or by engine.handoff_check(wait=True) when the caller synchronises anyway.
+        self.defer_handoff_check = os.environ.get("MDT_DEFER_HANDOFF", "0") == "1"
         self._engine: Optional[UNetEngine] = None
         self._engines = {}               # wide (bool) -> UNetEngine, for the current parameter values
         self._engine_key = None
@@ -206,9 +212,13 @@ class _QMBase(nn.Module):
                 t256 = length
             if lvl < cfg.num_layers:
                 length //= cfg.factors[lvl]
-        # pair-split launches need both workgroups of a pair running at the same time: 2 workgroups per 32 rows, at most one per
-        # CU -- the narrow form is used while that grid fits the 256 CUs (4096 rows), the whole-transformer form above
-        return bool(batch) and t256 is not None and batch * t256 > 4096
+        # pair-split launches need both workgroups of a pair running at the same time: 2 workgroups per 32 rows, and the device
+        # keeps rt.pair_capacity() of them resident at once (compute units x occupancy, asked from the device: 256 on an MI355X,
+        # i.e. 4096 rows).  The narrow form is used while ONE launch holds the level; above, the whole-transformer form is faster
+        # (a pinned 'narrow' stays correct at any batch: launch_tf256 splits it into launches that fit, csrc/k_tf256.hip)
+        if not batch or t256 is None:
+            return False
+        return 2 * ((batch * t256 + 31) // 32) > rt.pair_capacity()
 
     def pin_kernel_choice(self, batch: Optional[int]) -> str:
         """Resolve 'auto' for a batch of ``batch`` U-Net rows (samples, doubled under guidance) and keep that choice for every
@@ -239,6 +249,7 @@ class _QMBase(nn.Module):
             compiled = compile_unet(self.unet.config, self.max_length, n_ctx, sd, gemm_mode=self.gemm_mode, tf256=wide)
             self._engines[wide] = UNetEngine(compiled, device)
         self._engine = self._engines[wide]
+        self._engine.sync_handoff_check = not self.defer_handoff_check
         return self._engine
 
     # ------------------------------------------------------------------ conditioning prelude

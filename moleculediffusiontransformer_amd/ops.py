@@ -272,12 +272,15 @@ def unet_eval(xin: Tensor, embedding: Tensor, c_noise: float, embedding_scale: f
         eng.prepare_times(torch.tensor([float(c_noise)]))
         eng.select_time(0)
         eng.xin.copy_(xin)
+        eng.handoff_check()
         pred = eng.eval(False)
         if embedding_scale != 1.0:
             um = eng.eval(True)
             rt.check(lib.mdt_cfg_mix(rt.ptr(pred), rt.ptr(um), rt.ptr(pred), float(embedding_scale), pred.numel(),
                                      rt.current_stream()))
-        return pred.clone()
+        out = pred.clone()
+        eng.note_handoff()          # pair hand-off status: checked before the prediction is returned (engine.py)
+        return out
 
 
 @unet_eval.register_fake

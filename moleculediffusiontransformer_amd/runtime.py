@@ -68,6 +68,8 @@ SYMBOLS = {
     "mdt_abi_version": (_I, []),
     "mdt_last_error": (C.c_char_p, []),
     "mdt_set_tuning": (_I, [C.c_char_p, _I]),
+    "mdt_pair_capacity": (_I, []),
+    "mdt_test_occupy": (_I, [_I, _I, _U64, _P]),
     "mdt_program_create": (_P, [C.POINTER(MdtOp), _I]),
     "mdt_program_destroy": (None, [_P]),
     "mdt_program_num_ops": (_I, [_P]),
@@ -132,6 +134,15 @@ def load_library(allow_build: bool = True) -> C.CDLL:
         raise RuntimeError(f"libmdt_hip.so ABI version {lib.mdt_abi_version()} != {ABI_VERSION} expected by this package: rebuild it")
     _lib = lib
     return lib
+
+
+def pair_capacity() -> int:
+    """Workgroups of a pair-split 256-channel transformer launch that the current device keeps resident at once
+    (mdt_pair_capacity: compute units x occupancy; 256 on an MI355X)."""
+    n = int(load_library().mdt_pair_capacity())
+    if n <= 0:
+        raise RuntimeError("libmdt_hip: the device's co-residency capacity for pair-split launches could not be determined")
+    return n
 
 
 def check(rc: int) -> None:

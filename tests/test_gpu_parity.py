@@ -313,12 +313,13 @@ dist.barrier(); torch.cuda.synchronize(); dist.destroy_process_group(); print('R
 
 @pytest.mark.parametrize("mode", ["bf16x3", "f32"])
 @pytest.mark.parametrize("B,cs", [(8, 1.0), (256, 1.0), (1024, 1.0), (256, 3.0)])
-def test_repeated_sampling_is_bitwise_stable(B, cs, mode):
+def test_repeated_sampling_is_bitwise_stable(B, cs, mode, monkeypatch):
     """The same call six times on identical noise returns identical bits, and the probe rows match the oracle -- with launches of
     DIFFERENT data alternating (evaluations of a sampling loop), which an op-level repeat on fixed inputs cannot exercise.  This is
     the check that exposed the first form of the pair hand-off (wave-uniform part of the addresses in the buffer instructions'
     SCALAR offset: a piece in 10^5-10^7 arrived from another block; B = 1024 differed in every call; DESIGN.md 3.8,
     tools/repeat_determinism_probe.py)."""
+    monkeypatch.setenv("MDT_F32_FUSED", "1")     # (the module-scoped `models` fixture of the layer-by-layer form may still be alive)
     m = make_model("cfg1")
     m.gemm_mode = mode                 # 'f32': the same fused program (pair hand-offs included) with exact fp32 products
     T = 3 if B < 1024 else 2
@@ -336,23 +337,103 @@ def test_repeated_sampling_is_bitwise_stable(B, cs, mode):
     assert len(ev) == 42 and all(op.i[rt.F_WF32] == int(mode == "f32") for op in ev if op.kind in (rt.OP_TF128, rt.OP_TF256))
 
 
-def test_handoff_timeout_is_reported_by_the_next_call():
-    """A pair hand-off that times out leaves garbage rows and raises bit 0 of the engine's diagnostic word on the device.  The
-    sampling loops copy that word to pinned host memory behind their last launch; the next call (or handoff_check(wait=True))
-    raises -- loudly, without any call having waited for the GPU.  The time-out itself is simulated by setting the word."""
+def test_handoff_timeout_is_reported_before_the_call_returns():
+    """A pair hand-off that times out leaves garbage rows and raises bit 0 of the engine's diagnostic word on the device.  Every
+    sampling call copies that word to pinned host memory behind its last launch and WAITS for it before returning (VERDICT r3:
+    a caller who samples once and uses the tensor must learn); with model.defer_handoff_check the look moves to the next call.
+    The time-out itself is simulated here by setting the word (the real thing: the next test)."""
     m = make_model("cfg1")
     seq = synth_normal("to/seq", (64, 12))
     first = m.sample(seq, DEV, cond_scale=1.0, timesteps=2, noise=NoiseSource(seed=3))
     eng = m._engine
     if eng.xflags is None:
         pytest.skip("no pair-split launch in this program")
-    eng.handoff_check(wait=True)                      # the clean call passes
-    eng.xflags[0] = 1                                 # what a timed-out poll does
-    eng.note_handoff()
-    torch.cuda.synchronize()                          # (a call that starts before the copy has arrived reports one call later)
-    with pytest.raises(RuntimeError, match="pair hand-off"):
+    assert eng.sync_handoff_check and not getattr(eng, "_xstat_pending", False)      # the clean call was checked before it returned
+    eng.xflags[0] = 1                                 # what a timed-out poll does (sticky until reported)
+    with pytest.raises(RuntimeError, match="results of this call are invalid"):
         m.sample(seq, DEV, cond_scale=1.0, timesteps=2, noise=NoiseSource(seed=3))
     assert eng.handoff_status() == 0                  # reported once, cleared
     again = m.sample(seq, DEV, cond_scale=1.0, timesteps=2, noise=NoiseSource(seed=3))
     assert torch.equal(first, again)
+    # net(x, t) / denoise_fn evaluations are checked the same way (ADVICE r3: they never looked at the word)
+    eng.xflags[0] = 1
+    emb = m._embed(seq, DEV)
+    with pytest.raises(RuntimeError, match="pair hand-off"):
+        m.unet(torch.zeros(64, 16, 64, device=DEV), torch.tensor(0.5), embedding=emb, embedding_scale=1.0)
+    # the opt-out for pipelined callers: the failed call returns, the NEXT one raises
+    m.defer_handoff_check = True
+    m.sample(seq, DEV, cond_scale=1.0, timesteps=2, noise=NoiseSource(seed=3))
+    assert not m._engine.sync_handoff_check
+    m._engine.xflags[0] = 1
+    m.sample(seq, DEV, cond_scale=1.0, timesteps=2, noise=NoiseSource(seed=3))       # returns: deferred
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="PREVIOUS call"):
+        m.sample(seq, DEV, cond_scale=1.0, timesteps=2, noise=NoiseSource(seed=3))
+    m.defer_handoff_check = False
 
+
+def test_pair_split_launch_without_co_residency_fails_loudly_or_is_correct():
+    """The real thing: a kernel on a SECOND stream holds all but two compute units for 1.2 s (mdt_test_occupy:
+    160 KiB of LDS per workgroup, nothing fits next to it) while a 1024-sample call with pair-split launches (256 workgroups, the
+    partners 8 ids apart) is enqueued.  The first workgroups to run do not find their partners resident, their polls give up after
+    0.3 s and leave garbage.  Whatever the interleaving: sample() either raises RuntimeError before returning or returns the
+    bits of an undisturbed call -- never silent garbage."""
+    from moleculediffusiontransformer_amd import runtime as rt
+    lib = rt.load_library()
+    m = make_model("cfg1")
+    m.kernel_choice = "narrow"
+    B = 1024
+    seq = synth_normal("hog/seq", (B, 12))
+    run = lambda: m.sample(seq, DEV, cond_scale=1.0, timesteps=2, noise=NoiseSource(seed=5))   # noqa: E731
+    clean = run()
+    assert any(op.kind == rt.OP_TF256 and op.i[rt.F_NSPLIT] == 2 for op in m._engine.c.programs["eval"])
+    cap = rt.pair_capacity()
+    assert cap >= 64
+    side = torch.cuda.Stream(device=DEV)
+    outcomes = []
+    for hold in (cap - 2, cap - 16):
+        with torch.cuda.device(DEV):
+            rt.check(lib.mdt_test_occupy(hold, 160 * 1024, 120_000_000, side.cuda_stream))      # 1.2 s
+        try:
+            out = run()
+            outcomes.append("ok")
+            assert torch.equal(out, clean), "a disturbed call returned without an error AND with different bits"
+        except RuntimeError as e:
+            assert "pair hand-off" in str(e)
+            outcomes.append("raised")
+        torch.cuda.synchronize()
+    assert m._engine.handoff_status() == 0                 # nothing left unreported
+    assert torch.equal(run(), clean)                       # and the engine is usable afterwards
+    print("outcomes with the device held:", outcomes)
+
+
+def test_pair_split_batch_larger_than_the_device_runs_in_chunks():
+    """a pinned 'narrow' kernel choice used to put 2 x ceil(rows / 32) workgroups into ONE launch whatever the batch --
+    beyond the device's co-residency capacity forward progress hung on dispatch order.  launch_tf256 now asks the device
+    (mdt_pair_capacity = compute units x occupancy) and splits such a batch into launches that fit; here the capacity is forced
+    down to 32 workgroups (mdt_set_tuning) so that B = 64 (8 row blocks, 16 workgroups per launch at stride 8 -> 2 per launch...)
+    runs in several launches: same bits as the single launch, flags count as before."""
+    from moleculediffusiontransformer_amd import runtime as rt
+    lib = rt.load_library()
+    m = make_model("cfg1")
+    m.kernel_choice = "narrow"
+    B = 200                                                # 800 rows = 25 row blocks at the 256-channel level
+    seq = synth_normal("chunk/seq", (B, 12))
+    run = lambda: m.sample(seq, DEV, cond_scale=1.0, timesteps=3, noise=NoiseSource(seed=11))   # noqa: E731
+    assert rt.pair_capacity() >= 64
+    one = run()
+    try:
+        assert lib.mdt_set_tuning(b"pair_capacity", 16) == 0          # one group of 2 x 8 workgroups per launch: 4 launches
+        assert rt.pair_capacity() == 16
+        m._engine._graphs.clear()                                      # re-capture with the chunked launches
+        many = run()
+        assert lib.mdt_set_tuning(b"pair_capacity", 8) == 0           # not even one group fits: refused, loudly
+        m._engine._graphs.clear()
+        with pytest.raises(RuntimeError, match="launch failed"):
+            run()
+    finally:
+        lib.mdt_set_tuning(b"pair_capacity", 0)
+        m._engine._graphs.clear()
+    assert torch.equal(one, many)
+    m.kernel_choice = "auto"
+    assert m._wide(1024) is False and m._wide(1025) is True           # 'auto' follows the device's capacity (256 on an MI355X)

@@ -335,6 +335,15 @@ def test_no_instruction_touches_an_in_flight_fragment_read(ring_kernel_reports):
     assert isa_lint.lint_kernel(two + ["v_mfma_f32_16x16x32_bf16 v[20:23], v[4:7], v[12:15], v[20:23]"]) == []
     assert len(isa_lint.lint_kernel(two + ["v_mfma_f32_16x16x32_bf16 v[20:23], v[8:11], v[12:15], v[20:23]"])) == 1
     assert len(isa_lint.lint_kernel([rd, "scratch_store_dword off, v6, off offset:4", "s_waitcnt lgkmcnt(0)"])) == 1
+    # round 4: the same for vector-memory loads (vmcnt counts loads, stores and LDS-DMA of the wave, in issue order)
+    gl = "global_load_dword v9, v[2:3], off"
+    assert len(isa_lint.lint_kernel([gl, "v_or_b32_e32 v10, v10, v9", "s_waitcnt vmcnt(0)"])) == 1
+    assert isa_lint.lint_kernel([gl, "s_waitcnt vmcnt(0)", "v_or_b32_e32 v10, v10, v9"]) == []
+    dma = "global_load_lds_dwordx4 v[4:5], off"                 # LDS-DMA: counts in vmcnt, no landing register
+    assert isa_lint.lint_kernel([gl, dma, "s_waitcnt vmcnt(1)", "v_mov_b32_e32 v11, v9"]) == []
+    assert len(isa_lint.lint_kernel([gl, dma, "s_waitcnt vmcnt(2)", "v_mov_b32_e32 v11, v9"])) == 1
+    assert len(isa_lint.lint_kernel(["buffer_load_dwordx4 v[20:23], v1, s[4:7], 0 offen sc1", "v_add_f32_e32 v30, v21, v30"])) == 1
+    assert isa_lint.lint_kernel([gl, "global_load_dword v9, v[2:3], off offset:128", "s_waitcnt vmcnt(0)", "v_mov_b32_e32 v1, v9"]) == []
     _, lint = ring_kernel_reports
     for name, (report, n_reads) in lint.items():
         assert n_reads > 100, (name, n_reads)

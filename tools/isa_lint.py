@@ -20,6 +20,14 @@ that issued it).  Reads that stay in flight ACROSS a branch are not followed: th
 their waits with correlated run-time flags (has_next / more), which a path-insensitive analysis turns into hundreds of
 infeasible hazards; those hand-offs stay covered by the repeated-launch bit-equality tests (tests/test_gpu_ops.py).
 
+Round 4: the same property for VECTOR-MEMORY loads (`global_load_* / buffer_load_* / scratch_load_* / flat_load_*` with a
+VGPR destination; LDS-DMA forms have none).  vmcnt counts every vector-memory operation of the wave (loads, stores, LDS-DMA,
+atomics) and they retire in issue order, which is also what the kernels' hand-counted `s_waitcnt vmcnt(N)` rely on: a load is
+retired by `vmcnt(n)` once at least n vector-memory operations were issued behind it (6-bit counter: 64 younger operations
+retire it by themselves).  Compiler-placed loads satisfy this by construction; the check is there for inline-asm loads whose
+landing register the compiler believes valid at once (`k_tf256`'s in-launch L2 prefetch was one; it is an LDS-DMA
+into a sink now and has no landing register at all).
+
     python tools/isa_lint.py k_tf256 [k_tf128 ...]       # exit status 1 on any violation
 """
 import os
@@ -34,6 +42,9 @@ import kernel_resources as kr  # noqa: E402
 VREG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
 LABEL = re.compile(r"^([.\w$]+):")
 LGKM = re.compile(r"lgkmcnt\((\d+)\)")
+VMCNT = re.compile(r"vmcnt\((\d+)\)")
+VMEM_PREFIX = ("global_", "buffer_", "scratch_", "flat_", "tbuffer_")
+VCAP = 64
 SMEM_PREFIX = ("s_load_", "s_buffer_load_", "s_memtime", "s_memrealtime", "s_scratch_load", "s_atc_probe", "s_dcache")
 CAP = 16
 
@@ -105,12 +116,36 @@ def lint_kernel(lines):
     out = []
     for label, ins in blocks_of(lines):
         pend = {}            # position of the ds_read -> [dest vgprs, text, younger LGKM ops, younger LDS ops]
+        pendv = {}           # position of a vector-memory load -> [dest vgprs, text, younger vector-memory ops]
         smem = False
         for pos, s in enumerate(ins):
             parts = s.split(None, 1)
             op, rest = parts[0], (parts[1] if len(parts) > 1 else "")
             is_read = op.startswith(("ds_read", "ds_load"))
             touched = vregs(rest)
+            is_vmem = op.startswith(VMEM_PREFIX)
+            is_vload = is_vmem and "_load_" in op and "_lds_" not in op and not re.search(r"\blds\b", rest)
+            if pendv and touched:
+                for rid in list(pendv):
+                    hit = pendv[rid][0] & touched
+                    if not hit:
+                        continue
+                    if is_vload and hit <= vregs(rest.split(",")[0]) and not (pendv[rid][0] & vregs(",".join(rest.split(",")[1:]))):
+                        del pendv[rid]         # a later load into the same registers: vector-memory loads return in order
+                        continue
+                    out.append(f"[{label}] '{s}' touches v{sorted(hit)} of in-flight '{pendv[rid][1]}' "
+                               f"({pendv[rid][2]} vector-memory op(s) issued since)")
+            if op == "s_waitcnt":
+                m = VMCNT.search(rest)
+                if m:
+                    n = int(m.group(1))
+                    pendv = {} if n == 0 else {r: v for r, v in pendv.items() if v[2] < n}
+            if is_vmem:
+                for v in pendv.values():
+                    v[2] += 1
+                pendv = {r: v for r, v in pendv.items() if v[2] < VCAP}
+                if is_vload:
+                    pendv[pos] = [frozenset(vregs(rest.split(",")[0])), s, 0]
             if pend and touched:
                 for rid in list(pend):
                     hit = pend[rid][0] & touched
@@ -154,7 +189,7 @@ def lint_unit(name: str, defs=()):
         raise RuntimeError(f"no kernels found in the assembly of {name}")
     report, n_reads = {}, 0
     for kn, lines in kernels.items():
-        n_reads += sum(1 for s in lines if s.startswith(("ds_read", "ds_load")))
+        n_reads += sum(1 for s in lines if s.startswith(("ds_read", "ds_load")))      # (vector-memory loads are checked too)
         report[kn] = lint_kernel(lines)
     return report, n_reads
 
