@@ -326,10 +326,11 @@ int mdt_program_run(const mdt_program *p, const mdt_bindings *b, int32_t B, int3
 int mdt_cond_embed(const float *seq, const float *fc1_w, const float *fc1_b, const float *inv_freq,
                    float *out, int32_t B, int32_t n, int32_t D1, int32_t D2, void *stream);
 /* The pos_emb_fourier_add form of the same prelude (generative.py:844-846, graphmodel.py:338-339): the positional
- * encoding is ADDED, e[b,i,d] = gelu(fc1_w[d] * seq[b,i] + fc1_b[d]) + PositionalEncoding1D(D)[i,d]; out is (B, n, D),
- * inv_freq holds D/2 frequencies (text_embed_dim == embed_dim_position == D). */
+ * encoding is ADDED, e[b,i,d] = gelu(fc1_w[d] * seq[b,i] + fc1_b[d]) + PositionalEncoding1D(D2)[i,d] for d < D1 <= D2: the
+ * reference's encoding returns its first `orig_ch` = D1 columns of [sin (D2/2 frequencies) | cos (D2/2)] (transformer.py:3456-3470),
+ * so text_embed_dim may be smaller than embed_dim_position; out is (B, n, D1), inv_freq holds D2/2 frequencies. */
 int mdt_cond_embed_add(const float *seq, const float *fc1_w, const float *fc1_b, const float *inv_freq,
-                       float *out, int32_t B, int32_t n, int32_t D, void *stream);
+                       float *out, int32_t B, int32_t n, int32_t D1, int32_t D2, void *stream);
 
 /* ------------------------------------------------------------------ */
 /* k-diffusion preconditioning + ADPM2 sampler update                   */

@@ -304,7 +304,8 @@ __global__ __launch_bounds__(256) void k_argmax(const float* x, int32_t* tok, in
 }
 
 // e[b,i,:D1] = gelu(w*s+b), e[b,i,D1:] = [sin(i f) | cos(i f)]             (generative.py:838-850, transformer.py:3456-3470)
-// add != 0 (pos_emb_fourier_add, generative.py:844-846): e[b,i,f] = gelu(w*s+b)[f] + PositionalEncoding1D(D2)[i,f], D1 == D2
+// add != 0 (pos_emb_fourier_add, generative.py:844-846): e[b,i,f] = gelu(w*s+b)[f] + PositionalEncoding1D(D2)[i,f], f < D1 <= D2
+// (the reference's encoding returns emb[:, :, :orig_ch], the FIRST D1 columns of [sin (D2/2) | cos (D2/2)], transformer.py:3470)
 __global__ __launch_bounds__(256) void k_cond_embed(const float* seq, const float* w, const float* bias,
                                                      const float* inv_freq, float* out, int B, int n, int D1, int D2, int add) {
   const int F = add ? D1 : D1 + D2;
@@ -445,12 +446,12 @@ int mdt_cond_embed(const float* seq, const float* fc1_w, const float* fc1_b, con
 }
 
 int mdt_cond_embed_add(const float* seq, const float* fc1_w, const float* fc1_b, const float* inv_freq, float* out,
-                       int32_t B, int32_t n, int32_t D, void* stream) {
+                       int32_t B, int32_t n, int32_t D1, int32_t D2, void* stream) {
   if (!seq || !fc1_w || !fc1_b || !inv_freq || !out) return bad("mdt_cond_embed_add: null pointer");
   if (B <= 0) return 0;
-  if (D <= 0 || D % 2) return bad("mdt_cond_embed_add: D must be even");
-  hipLaunchKernelGGL(mdt::k_cond_embed, dim3(mdt::grid_for((int64_t)B * n * D)), dim3(256), 0, (hipStream_t)stream, seq,
-                     fc1_w, fc1_b, inv_freq, out, B, n, D, D, 1);
+  if (D1 <= 0 || D2 <= 0 || D2 % 2 || D1 > D2) return bad("mdt_cond_embed_add: need 0 < D1 <= D2, D2 even");
+  hipLaunchKernelGGL(mdt::k_cond_embed, dim3(mdt::grid_for((int64_t)B * n * D1)), dim3(256), 0, (hipStream_t)stream, seq,
+                     fc1_w, fc1_b, inv_freq, out, B, n, D1, D2, 1);
   return finish("mdt_cond_embed_add");
 }
 

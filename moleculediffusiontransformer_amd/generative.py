@@ -151,8 +151,11 @@ class _QMBase(nn.Module):
         self._pos_add = bool(pos_emb_fourier and pos_emb_fourier_add)
         if pos_emb_fourier:
             if pos_emb_fourier_add:
-                if text_embed_dim != embed_dim_position:      # x + p_enc_1d(x) does not broadcast otherwise (generative.py:846)
-                    raise RuntimeError("pos_emb_fourier_add=True needs text_embed_dim == embed_dim_position")
+                # x + p_enc_1d(x): the encoding returns its first text_embed_dim columns (transformer.py:3470), so any
+                # text_embed_dim <= embed_dim_position works as in the reference; a larger one does not broadcast there either
+                if text_embed_dim > embed_dim_position:
+                    raise RuntimeError("pos_emb_fourier_add=True needs text_embed_dim <= embed_dim_position "
+                                       "(x + p_enc_1d(x) does not broadcast otherwise, generative.py:846)")
             else:
                 text_embed_dim = text_embed_dim + embed_dim_position
             self._pos_dim = embed_dim_position

@@ -15,10 +15,15 @@ max_neighbors = 5        # graphmodel.py's module-level constant used by forward
 
 
 def pad_sequence(output_xyz: torch.Tensor, max_length: int) -> torch.Tensor:
-    """graphmodel.py's helper: zero-pad (B, C, n) on the right to (B, C, max_length)."""
+    """graphmodel.py:220-223: zero-pad (B, C, n) on the right to (B, C, max_length).  As there, n > max_length is an error
+    (the slice assignment does not fit); unlike there the result stays on the input's device and dtype (the reference
+    allocates torch.zeros on the CPU whatever the input)."""
     B, C, n = output_xyz.shape
+    if n > max_length:
+        raise RuntimeError(f"The expanded size of the tensor ({max_length}) must match the existing size ({n}) at non-singleton "
+                           "dimension 2: sequences longer than max_length cannot be padded (graphmodel.py:222)")
     out = torch.zeros(B, C, max_length, dtype=output_xyz.dtype, device=output_xyz.device)
-    out[:, :, : min(n, max_length)] = output_xyz[:, :, :max_length]
+    out[:, :, :n] = output_xyz
     return out
 
 
@@ -40,8 +45,8 @@ class _AnalogBase(_QMBase):
                                   num_blocks=self._blocks)
 
     def forward(self, sequences, output):
-        """graphmodel.py:316-353 / :497-545: xyz rows (and the neighbour rows with predict_neighbors) padded to max_length,
-        then the diffusion loss on the conditioning embedding."""
+        """AnalogDiffusionSparse.forward (graphmodel.py:316-353): xyz rows (and the max_neighbors neighbour rows with
+        predict_neighbors) padded to max_length, then the diffusion loss on the conditioning embedding."""
         from .train import conditioning_embedding
         xyz = pad_sequence(output[:, 1:4, :], self.max_length)
         if self.predict_neighbors:
@@ -66,3 +71,13 @@ class AnalogDiffusionFull(_AnalogBase):
                  predict_neighbors=True):
         super().__init__(max_length, channels, pred_dim, context_embedding_max_length, unet_type, pos_emb_fourier,
                          pos_emb_fourier_add, text_embed_dim, embed_dim_position, predict_neighbors)
+
+    def forward(self, sequences, output):
+        """AnalogDiffusionFull.forward (graphmodel.py:497-545) -- NOT the Sparse recipe: no padding; the neighbour rows are
+        output[:, 4:4 + max_length, :] (max_length rows, not max_neighbors); with predict_neighbors the target is
+        cat(xyz rows, neighbour rows), without it the packed `output` goes to the diffusion as it is (node-number row
+        included), exactly as the reference does."""
+        from .train import conditioning_embedding
+        if self.predict_neighbors:
+            output = torch.cat((output[:, 1:4, :], output[:, 4:4 + self.max_length, :]), 1)
+        return self.diffusion(output, embedding=conditioning_embedding(self, sequences))

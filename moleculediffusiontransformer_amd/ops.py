@@ -83,14 +83,15 @@ def cond_embed(seq: Tensor, fc1_w: Tensor, fc1_b: Tensor, inv_freq: Optional[Ten
     D1 = b.numel()
     if pos_dim and (inv_freq is None or inv_freq.numel() * 2 != pos_dim):
         raise RuntimeError("mdt::cond_embed: inv_freq must hold pos_dim / 2 frequencies")
-    if pos_add and pos_dim != D1:
-        raise RuntimeError("mdt::cond_embed: the additive form needs text_embed_dim == embed_dim_position")
+    if pos_add and D1 > pos_dim:
+        raise RuntimeError("mdt::cond_embed: the additive form needs text_embed_dim <= embed_dim_position (the encoding has "
+                           "embed_dim_position columns, of which the first text_embed_dim are added)")
     inv = _f32c(inv_freq) if pos_dim else w
     out = torch.empty(B, n, D1 if pos_add else D1 + pos_dim, device=dev)
     if B:
         with torch.cuda.device(dev):
             if pos_add:
-                rt.check(lib.mdt_cond_embed_add(rt.ptr(seq), rt.ptr(w), rt.ptr(b), rt.ptr(inv), rt.ptr(out), B, n, D1,
+                rt.check(lib.mdt_cond_embed_add(rt.ptr(seq), rt.ptr(w), rt.ptr(b), rt.ptr(inv), rt.ptr(out), B, n, D1, pos_dim,
                                                 rt.current_stream()))
             else:
                 rt.check(lib.mdt_cond_embed(rt.ptr(seq), rt.ptr(w), rt.ptr(b), rt.ptr(inv), rt.ptr(out), B, n, D1, pos_dim,

@@ -75,7 +75,7 @@ SYMBOLS = {
     "mdt_program_num_ops": (_I, [_P]),
     "mdt_program_run": (_I, [_P, C.POINTER(MdtBindings), _I, _I, _I, _I, _P]),
     "mdt_cond_embed": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "mdt_cond_embed_add": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "mdt_cond_embed_add": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "mdt_precond_in": (_I, [_P, _P, _F, _I, _I, _I, _I, _P]),
     "mdt_precond_out": (_I, [_P, _P, _P, _F, _F, _I, _I, _I, _I, _P]),
     "mdt_cfg_mix": (_I, [_P, _P, _P, _F, _L, _P]),

@@ -41,7 +41,8 @@ def conditioning_embedding(model, sequences: Tensor) -> Tensor:
         inv_freq = model.p_enc_1d.inv_freq
         pos = torch.arange(x.shape[1], device=x.device, dtype=inv_freq.dtype)
         s = torch.einsum("i,j->ij", pos, inv_freq)
-        emb = torch.cat((s.sin(), s.cos()), dim=-1)[:, : model.p_enc_1d.org_channels].to(x.dtype)
+        # PositionalEncoding1D.forward returns emb[:, :, :orig_ch] with orig_ch = the INPUT's channel count (transformer.py:3460-3470)
+        emb = torch.cat((s.sin(), s.cos()), dim=-1)[:, : x.shape[-1]].to(x.dtype)
         emb = emb.unsqueeze(0).expand(x.shape[0], -1, -1)
         x = x + emb if getattr(model, "pos_emb_fourier_add", False) else torch.cat((x, emb), dim=2)
     return x

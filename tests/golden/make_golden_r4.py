@@ -1,0 +1,66 @@
+"""Round-4 fixtures from the REAL reference (build container only):
+
+    python tests/golden/make_golden_r4.py
+
+  analog_forward.npz   what AnalogDiffusionSparse.forward / AnalogDiffusionFull.forward (graphmodel.py:316-353 / :497-545) hand to
+                       self.diffusion -- the training target sliced / padded from the packed `output` rows and the conditioning
+                       embedding -- with predict_neighbors on and off (Full is NOT the Sparse recipe)
+  add_embed_d32.npz    the additive conditioning prelude with text_embed_dim (32) < embed_dim_position (64): the encoding's first
+                       32 columns are added (transformer.py:3456-3470)
+
+Only inputs and outputs are stored.
+"""
+import os
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_golden as G  # noqa: E402  (imports the reference)
+from moleculediffusiontransformer_amd.synth import synth_normal  # noqa: E402
+
+
+class _Rec(torch.nn.Module):
+    def forward(self, output, embedding=None):
+        self.output, self.embedding = output.detach().clone(), embedding.detach().clone()
+        return torch.zeros(())
+
+
+def main():
+    import MoleculeDiffusion.graphmodel as gm  # type: ignore
+    from MoleculeDiffusion.graphmodel import AnalogDiffusionFull, AnalogDiffusionSparse  # type: ignore
+    # graphmodel.py:320 reads a module global `max_neighbors` that the file itself never defines (the reference's notebooks set
+    # it); 5 = the neighbour rows of the packed graphs there, and what moleculediffusiontransformer_amd.graphmodel uses
+    gm.max_neighbors = 5
+    out = {}
+    seq = synth_normal("r4/analog/seq", (2, 12))
+    packed = synth_normal("r4/analog/packed", (2, 9, 10))          # node numbers | xyz | 5 neighbour rows, 10 positions
+    out["seq"], out["packed"] = seq.numpy(), packed.numpy()
+    for pn in (False, True):
+        sp = AnalogDiffusionSparse(max_length=16, channels=32, pred_dim=8 if pn else 3, context_embedding_max_length=12,
+                                   unet_type="cfg", text_embed_dim=64, embed_dim_position=64, predict_neighbors=pn)
+        sp.diffusion = _Rec()
+        sp.forward(seq, packed)
+        out[f"sparse_pn{int(pn)}_target"] = sp.diffusion.output.numpy()
+        out[f"sparse_pn{int(pn)}_emb"] = sp.diffusion.embedding.numpy()
+        fu = AnalogDiffusionFull(max_length=16, channels=32, pred_dim=8, context_embedding_max_length=12, unet_type="cfg",
+                                 text_embed_dim=64, embed_dim_position=64, predict_neighbors=pn)
+        fu.diffusion = _Rec()
+        fu.forward(seq, packed)
+        out[f"full_pn{int(pn)}_target"] = fu.diffusion.output.numpy()
+    G.save("analog_forward.npz", **out)
+
+    m = AnalogDiffusionSparse(max_length=16, channels=32, pred_dim=3, context_embedding_max_length=12, unet_type="cfg",
+                              pos_emb_fourier=True, pos_emb_fourier_add=True, text_embed_dim=32, embed_dim_position=64)
+    w, b = synth_normal("r4/add/fc1_w", (32, 1)), synth_normal("r4/add/fc1_b", (32,))
+    with torch.no_grad():
+        m.fc1.weight.copy_(w)
+        m.fc1.bias.copy_(b)
+    m.diffusion = _Rec()
+    m.forward(seq, packed)
+    G.save("add_embed_d32.npz", seq=seq.numpy(), fc1_w=w.numpy(), fc1_b=b.numpy(), emb=m.diffusion.embedding.numpy())
+
+
+if __name__ == "__main__":
+    main()

@@ -169,3 +169,20 @@ def test_torch_ops_namespace_matches_the_class_surface():
         torch.ops.mdt.unet_eval(xin[:, :8], emb, 0.0, 1.0, h)           # wrong shape
     with pytest.raises(RuntimeError):
         torch.ops.mdt.precond_in(x.cpu(), 1.0, 16)                       # not a HIP tensor
+
+
+def test_additive_prelude_with_a_narrower_text_embedding():
+    """pos_emb_fourier_add with text_embed_dim (32) < embed_dim_position (64): mdt_cond_embed_add adds the first 32 columns of
+    the 64-column encoding, as the reference's x + p_enc_1d(x) does (transformer.py:3456-3470) -- against the
+    embedding recorded from the real reference."""
+    from conftest import load_golden
+    from moleculediffusiontransformer_amd.graphmodel import AnalogDiffusionSparse
+    a = load_golden("add_embed_d32.npz")
+    m = AnalogDiffusionSparse(max_length=16, channels=32, pred_dim=3, context_embedding_max_length=12, pos_emb_fourier=True,
+                              pos_emb_fourier_add=True, text_embed_dim=32, embed_dim_position=64)
+    with torch.no_grad():
+        m.fc1.weight.copy_(torch.from_numpy(a["fc1_w"]))
+        m.fc1.bias.copy_(torch.from_numpy(a["fc1_b"]))
+    m = m.to(DEV)
+    emb = m._embed(torch.from_numpy(a["seq"]), DEV)
+    assert emb.shape == (2, 12, 32) and (emb.cpu() - torch.from_numpy(a["emb"])).abs().max() < 1e-6

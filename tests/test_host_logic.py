@@ -110,13 +110,53 @@ def test_analog_diffusion_wrappers_keep_the_reference_surface(capsys):
     assert list(s.state_dict().keys()) == list(gs["keys"]) and s.unet.config.patch_size == 8 and s.predict_neighbors is False
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         s.sample(torch.zeros(2, 12), "cpu", cond_scale=1.0, timesteps=4)
-    with pytest.raises(RuntimeError, match="text_embed_dim == embed_dim_position"):
-        AnalogDiffusionSparse(max_length=128, channels=128, pred_dim=3, pos_emb_fourier_add=True, text_embed_dim=32)
+    with pytest.raises(RuntimeError, match="text_embed_dim <= embed_dim_position"):     # x + p_enc_1d(x) does not broadcast there either
+        AnalogDiffusionSparse(max_length=128, channels=128, pred_dim=3, pos_emb_fourier_add=True, text_embed_dim=128)
     # the additive conditioning prelude of the training path equals the oracle's
     from moleculediffusiontransformer_amd.train import conditioning_embedding
     seq = torch.from_numpy(load_golden("full_unet.npz")["seq"])
     emb = conditioning_embedding(m, seq)
     assert emb.shape == (2, 12, 64) and (emb - torch.from_numpy(load_golden("full_unet.npz")["emb"])).abs().max() < 1e-6
+
+
+class _Rec(torch.nn.Module):
+    def forward(self, output, embedding=None):
+        self.output, self.embedding = output, embedding
+        return torch.zeros(())
+
+
+def test_analog_forward_slices_and_additive_prelude_match_the_reference():
+    """ADVICE r3.  (i) AnalogDiffusionFull.forward is NOT the Sparse recipe (graphmodel.py:497-545: no padding, neighbour rows
+    4 : 4 + max_length, the raw packed rows without predict_neighbors); Sparse pads xyz (+ max_neighbors rows) to max_length
+    (:316-353) and, like the reference's pad_sequence, refuses sequences longer than max_length.  (ii) pos_emb_fourier_add with
+    text_embed_dim < embed_dim_position adds the encoding's first text_embed_dim columns (transformer.py:3470).  Both against
+    tensors recorded from the real reference (tests/golden/make_golden_r4.py)."""
+    from moleculediffusiontransformer_amd.graphmodel import AnalogDiffusionFull, AnalogDiffusionSparse, pad_sequence
+    g = load_golden("analog_forward.npz")
+    seq, packed = torch.from_numpy(g["seq"]), torch.from_numpy(g["packed"])
+    for pn in (False, True):
+        sp = AnalogDiffusionSparse(max_length=16, channels=32, pred_dim=8 if pn else 3, context_embedding_max_length=12,
+                                   text_embed_dim=64, embed_dim_position=64, predict_neighbors=pn)
+        sp.diffusion = _Rec()
+        sp.forward(seq, packed)
+        assert torch.equal(sp.diffusion.output, torch.from_numpy(g[f"sparse_pn{int(pn)}_target"]))
+        fu = AnalogDiffusionFull(max_length=16, channels=32, pred_dim=8, context_embedding_max_length=12, text_embed_dim=64,
+                                 embed_dim_position=64, predict_neighbors=pn)
+        fu.diffusion = _Rec()
+        fu.forward(seq, packed)
+        assert torch.equal(fu.diffusion.output, torch.from_numpy(g[f"full_pn{int(pn)}_target"]))
+    with pytest.raises(RuntimeError, match="must match the existing size"):
+        pad_sequence(torch.zeros(1, 3, 20), 16)
+    a = load_golden("add_embed_d32.npz")
+    m = AnalogDiffusionSparse(max_length=16, channels=32, pred_dim=3, context_embedding_max_length=12, pos_emb_fourier=True,
+                              pos_emb_fourier_add=True, text_embed_dim=32, embed_dim_position=64)
+    with torch.no_grad():
+        m.fc1.weight.copy_(torch.from_numpy(a["fc1_w"]))
+        m.fc1.bias.copy_(torch.from_numpy(a["fc1_b"]))
+    m.diffusion = _Rec()
+    m.forward(torch.from_numpy(a["seq"]), packed)
+    assert m.diffusion.embedding.shape == (2, 12, 32) and m.unet.config.ctx_features == 32
+    assert (m.diffusion.embedding - torch.from_numpy(a["emb"])).abs().max() < 1e-6
 
 
 def test_no_cpu_fallback():
