@@ -556,9 +556,9 @@ def main():
                 res = {}
                 for name, nbuf, call in (
                         ("k_adpm2_mid", 4, lambda: lib.mdt_adpm2_mid(rt.ptr(x), rt.ptr(pred), rt.ptr(xm), rt.ptr(xin), 0.5, 0.5, 1.0, -0.1,
-                                                                     0.7, batch, C_, L_, Cp_, st)),
+                                                                     0.7, batch, C_, L_, Cp_, 0, st)),
                         ("k_adpm2_next", 5, lambda: lib.mdt_adpm2_next(rt.ptr(x), rt.ptr(xm), rt.ptr(pred), 0, rt.ptr(xin), 0.5, 0.5, 1.0,
-                                                                       -0.1, 0.01, 0.7, 9, 1, 0, batch, C_, L_, Cp_, 0, st))):
+                                                                       -0.1, 0.01, 0.7, 9, 1, 0, batch, C_, L_, Cp_, 0, 0, st))):
                     for _ in range(5):
                         rt.check(call())
                     tm = rt.EventTimer(1)

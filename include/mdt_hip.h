@@ -339,10 +339,18 @@ int mdt_cond_embed_add(const float *seq, const float *fc1_w, const float *fc1_b,
  * written token-major with channels padded to Cp (pad = 0). */
 int mdt_precond_in(const float *x, float *xin, float c_in, int32_t B, int32_t C, int32_t L, int32_t Cp,
                    void *stream);
-/* KDiffusion_mod.denoise_fn output (diffusion.py:811-814, clip :75-77):
- *   D = clamp(c_skip * x + c_out * pred, -1, 1);   pred is token-major (B, L, Cp). */
+/* KDiffusion_mod.denoise_fn output (diffusion.py:811-814, clip :75-88):
+ *   D = clip(c_skip * x + c_out * pred);   pred is token-major (B, L, Cp).
+ * clip = clamp to [-1, 1] (dyn_scale == NULL: dynamic_threshold = 0.0, what every class of the reference passes), or dynamic
+ * thresholding: dyn_scale[b] = max(quantile(|c_skip x + c_out pred|, q), 1) per sample (mdt_dyn_scale), D = clamp(., -s, s) / s.
+ * The same optional argument on mdt_adpm2_mid / mdt_adpm2_next, whose denoise stage is this one.
+ * The (L x Cp) tile of a sample is staged in LDS: L * (Cp + 1) * 4 <= 160 KiB (max_length = 1024 at Cp = 16: 68 KiB). */
 int mdt_precond_out(const float *x, const float *pred, float *D, float c_skip, float c_out, int32_t B,
-                    int32_t C, int32_t L, int32_t Cp, void *stream);
+                    int32_t C, int32_t L, int32_t Cp, const float *dyn_scale, void *stream);
+/* clip()'s dynamic threshold (diffusion.py:78-85): scale[b] = max(torch.quantile(|c_skip x[b] + c_out pred[b]|.flatten(), q), 1),
+ * 0 < q <= 1, linear interpolation between the neighbouring order statistics as torch.quantile; C * L <= 32768. */
+int mdt_dyn_scale(const float *x, const float *pred, float *scale, float c_skip, float c_out, float q, int32_t B,
+                  int32_t C, int32_t L, int32_t Cp, void *stream);
 /* UNetCFG1d.forward guidance mix (modules.py:1253): out = um + (cond - um) * scale, token-major. */
 int mdt_cfg_mix(const float *cond, const float *uncond, float *out, float scale, int64_t n, void *stream);
 /* First half of ADPM2Sampler.step (diffusion.py:506-508) fused with the denoise output:
@@ -350,7 +358,7 @@ int mdt_cfg_mix(const float *cond, const float *uncond, float *out, float scale,
  * and, for the next U-Net call, xin_mid = c_in_mid * x_mid (token-major, padded). */
 int mdt_adpm2_mid(const float *x, const float *pred, float *x_mid, float *xin_mid, float c_skip,
                   float c_out, float sigma, float dt_mid, float c_in_mid, int32_t B, int32_t C, int32_t L,
-                  int32_t Cp, void *stream);
+                  int32_t Cp, const float *dyn_scale, void *stream);
 /* Second half (diffusion.py:510-515):
  *   D = clamp(c_skip*x_mid + c_out*pred, -1, 1); d_mid = (x_mid - D) / sigma_mid;
  *   x = x + d_mid * dt_down;  x = x + noise * sigma_up   (in place on x)
@@ -363,7 +371,7 @@ int mdt_adpm2_mid(const float *x, const float *pred, float *x_mid, float *xin_mi
 int mdt_adpm2_next(float *x, const float *x_mid, const float *pred, const float *noise, float *xin_next,
                    float c_skip, float c_out, float sigma_mid, float dt_down, float sigma_up,
                    float c_in_next, uint64_t seed, uint32_t step, int64_t sample0, int32_t B, int32_t C,
-                   int32_t L, int32_t Cp, int32_t *tokens, void *stream);
+                   int32_t L, int32_t Cp, int32_t *tokens, const float *dyn_scale, void *stream);
 /* One Euler move of ADPM2Sampler.step when the denoised tensor comes from a caller-supplied fn
  * (Sampler.forward(noise, fn, sigmas, num_steps) seam, diffusion.py:352, :502-515); all tensors (B, C, L):
  *   out = x_base + ((x_from - denoised) / sigma) * dt   [+ noise * sigma_up]

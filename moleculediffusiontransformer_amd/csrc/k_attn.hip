@@ -136,9 +136,133 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
   }
 }
 
+// The same operator for LONG sequences (more than 64 queries or keys per sample: the reference's default max_length = 1024 puts
+// 256 tokens on the first attention level, generative.py:720-776): one wave per (sample, head, 16-query tile), the keys in
+// chunks of 64 with a running maximum / sum (online softmax) -- the probabilities of a chunk are formed against the running
+// maximum, the accumulated O^T and sum are rescaled when it moves; the result is divided by the sum once at the end.  Layouts,
+// MFMA operand maps and exactness (fp32 MFMA, expf) as k_attn above; mathematically the same softmax, rounding differs from
+// the two-pass form by a few ulp.
+__global__ __launch_bounds__(256) void k_attn_long(AttnArgs a) {
+  constexpr int D = 64, KTM = 4;
+  const int QT = (a.T + 15) >> 4;
+  const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wid >= (int64_t)a.batch * a.heads * QT) return;
+  const int qt = (int)(wid % QT);
+  const int bh = (int)(wid / QT);
+  const int b = bh / a.heads, h = bh % a.heads;
+  const int lane = threadIdx.x & 63;
+  const int lo = lane & 15, g = lane >> 4;
+  const float* q = a.q + (int64_t)b * a.T * a.ldq + h * D;
+  const float* k = a.k + (int64_t)b * a.kv_bstride * a.ldkv + h * D;
+  const float* v = k + a.heads * D;
+  const int i = qt * 16 + lo;
+  float qr[16];
+  {
+    const float4* p = reinterpret_cast<const float4*>(q + (int64_t)(i < a.T ? i : 0) * a.ldq + 16 * g);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float4 t = p[c];
+      qr[4 * c] = t.x; qr[4 * c + 1] = t.y; qr[4 * c + 2] = t.z; qr[4 * c + 3] = t.w;
+    }
+  }
+  f32x4 acc[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+  for (int k0 = 0; k0 < a.Tk; k0 += 16 * KTM) {
+    float kr[KTM][16], vr[KTM][16];
+#pragma unroll
+    for (int kt = 0; kt < KTM; ++kt) {
+      const int j = k0 + kt * 16 + lo;
+      const float4* p = reinterpret_cast<const float4*>(k + (int64_t)(j < a.Tk ? j : 0) * a.ldkv + 16 * g);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float4 t = p[c];
+        kr[kt][4 * c] = t.x; kr[kt][4 * c + 1] = t.y; kr[kt][4 * c + 2] = t.z; kr[kt][4 * c + 3] = t.w;
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int jj = k0 + kt * 16 + 4 * g + s;
+        const float* vrow = v + (int64_t)(jj < a.Tk ? jj : 0) * a.ldkv + lo;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) vr[kt][4 * s + dt] = jj < a.Tk ? vrow[16 * dt] : 0.f;
+      }
+    }
+    f32x4 st[KTM];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < KTM; ++kt) {
+      f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0;
+#pragma unroll
+      for (int s = 0; s < 16; s += 2) {
+        s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[kt][s], qr[s], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[kt][s + 1], qr[s + 1], s1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int jj = k0 + kt * 16 + 4 * g + r;
+        const float sv = jj < a.Tk ? (s0[r] + s1[r]) * a.scale : -INFINITY;
+        st[kt][r] = sv;
+        mx = fmaxf(mx, sv);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);                 // finite: every chunk holds at least one real key
+    const float alpha = expf(m_run - m_new);              // exp(-inf) = 0 on the first chunk
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < KTM; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = expf(st[kt][r] - m_new);
+        st[kt][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    l_run = l_run * alpha + sum;
+    m_run = m_new;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) acc[dt] *= alpha;
+#pragma unroll
+    for (int kt = 0; kt < KTM; ++kt)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+          acc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[kt][4 * s + dt], st[kt][s], acc[dt], 0, 0, 0);
+  }
+  if (i >= a.T) return;
+  const float inv = 1.0f / l_run;
+  if (a.out16) {
+    unsigned short* o16 = reinterpret_cast<unsigned short*>(a.out) + (int64_t)b * a.T * a.ldo + h * D;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      unsigned short hh[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) hh[r] = __builtin_bit_cast(unsigned short, (__bf16)(acc[dt][r] * inv));
+      *reinterpret_cast<uint2*>(o16 + (int64_t)i * a.ldo + 16 * dt + 4 * g) =
+          make_uint2(hh[0] | ((unsigned)hh[1] << 16), hh[2] | ((unsigned)hh[3] << 16));
+    }
+  } else {
+    float* o = a.out + (int64_t)b * a.T * a.ldo + h * D;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+      *reinterpret_cast<float4*>(o + (int64_t)i * a.ldo + 16 * dt + 4 * g) =
+          make_float4(acc[dt][0] * inv, acc[dt][1] * inv, acc[dt][2] * inv, acc[dt][3] * inv);
+  }
+}
+
 hipError_t launch_attn(const AttnArgs& a, hipStream_t s) {
   if (a.batch <= 0) return hipSuccess;
-  if (a.T > 64 || a.Tk > 64 || a.ldq % 4 || a.ldkv % 4 || a.ldo % 4) return hipErrorInvalidValue;
+  if (a.T <= 0 || a.Tk <= 0 || a.T > 8192 || a.Tk > 8192 || a.ldq % 4 || a.ldkv % 4 || a.ldo % 4) return hipErrorInvalidValue;
+  if (a.T > 64 || a.Tk > 64) {
+    const int64_t w = (int64_t)a.batch * a.heads * ((a.T + 15) / 16);
+    if ((w + 3) / 4 > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_attn_long, dim3((unsigned)((w + 3) / 4)), dim3(256), 0, s, a);
+    return hipGetLastError();
+  }
   const int waves = a.batch * a.heads;
   if (a.Tk <= 16)
     hipLaunchKernelGGL(k_attn<1>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a);

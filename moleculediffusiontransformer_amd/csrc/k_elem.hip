@@ -50,6 +50,9 @@ __device__ __forceinline__ float4 normal4(uint64_t seed, uint32_t step, uint64_t
 }
 
 __device__ __forceinline__ float clamp1(float v) { return fminf(fmaxf(v, -1.0f), 1.0f); }
+// clip() of the denoised value (diffusion.py:75-88): static clamp to [-1, 1], or -- dynamic thresholding, s = the sample's
+// max(quantile(|x_denoised|, q), 1) from k_dyn_scale -- clamp to [-s, s] and divide by s
+__device__ __forceinline__ float clip_dyn(float v, float s) { return s > 0.f ? fminf(fmaxf(v, -s), s) / s : clamp1(v); }
 
 // Token-major tile <-> LDS helpers (tile pitch Cp + 1 floats).
 __device__ __forceinline__ void tile_load(float* tile, const float* src, int L, int Cp) {
@@ -98,9 +101,10 @@ __global__ __launch_bounds__(256) void k_precond_in(const float* x, float* xin, 
 
 // D = clamp(c_skip*x + c_out*pred, -1, 1)                                  (diffusion.py:811-814)
 __global__ __launch_bounds__(256) void k_precond_out(const float* x, const float* pred, float* D, float c_skip,
-                                                      float c_out, int C, int L, int Cp) {
+                                                      float c_out, int C, int L, int Cp, const float* dscale) {
   extern __shared__ float tile[];
   const int b = blockIdx.x;
+  const float ds = dscale ? dscale[b] : 0.f;
   tile_load(tile, pred + (int64_t)b * L * Cp, L, Cp);
   __syncthreads();
   const int l4n = L / 4;
@@ -109,20 +113,65 @@ __global__ __launch_bounds__(256) void k_precond_out(const float* x, const float
     const int64_t o = (int64_t)b * C * L + c * L + l;
     const float4 v = *reinterpret_cast<const float4*>(x + o);
     float4 d;
-    d.x = clamp1(c_skip * v.x + c_out * tile[(l + 0) * (Cp + 1) + c]);
-    d.y = clamp1(c_skip * v.y + c_out * tile[(l + 1) * (Cp + 1) + c]);
-    d.z = clamp1(c_skip * v.z + c_out * tile[(l + 2) * (Cp + 1) + c]);
-    d.w = clamp1(c_skip * v.w + c_out * tile[(l + 3) * (Cp + 1) + c]);
+    d.x = clip_dyn(c_skip * v.x + c_out * tile[(l + 0) * (Cp + 1) + c], ds);
+    d.y = clip_dyn(c_skip * v.y + c_out * tile[(l + 1) * (Cp + 1) + c], ds);
+    d.z = clip_dyn(c_skip * v.z + c_out * tile[(l + 2) * (Cp + 1) + c], ds);
+    d.w = clip_dyn(c_skip * v.w + c_out * tile[(l + 3) * (Cp + 1) + c], ds);
     *reinterpret_cast<float4*>(D + o) = d;
+  }
+}
+
+// Dynamic thresholding (clip() with dynamic_threshold = q > 0, diffusion.py:78-88): per sample
+//   scale[b] = max(torch.quantile(|c_skip x + c_out pred|.flatten(), q), 1)
+// One workgroup per sample: the N = C L magnitudes are sorted in LDS (bitonic, padded with +inf to a power of two) and the
+// quantile is torch's linear interpolation between the two neighbouring order statistics: rank = q (N - 1) in fp32,
+// lerp(v[floor], v[ceil], rank - floor) with ATen's two-sided formula.  The consumers (k_precond_out / k_adpm2_mid / k_adpm2_next)
+// then clamp to [-scale, scale] and divide.  Rarely used (every class of the reference passes 0.0): simple, not tuned.
+__global__ __launch_bounds__(256) void k_dyn_scale(const float* x, const float* pred, float* scale, float c_skip, float c_out,
+                                                    float q, int C, int L, int Cp, int npad) {
+  extern __shared__ float tile[];
+  const int b = blockIdx.x, N = C * L;
+  const float* xb = x + (int64_t)b * N;
+  const float* pb = pred + (int64_t)b * L * Cp;
+  for (int e = threadIdx.x; e < npad; e += blockDim.x) {
+    float v = INFINITY;
+    if (e < N) {
+      const int c = e / L, l = e - c * L;
+      v = fabsf(c_skip * xb[e] + c_out * pb[l * Cp + c]);
+    }
+    tile[e] = v;
+  }
+  __syncthreads();
+  for (int k = 2; k <= npad; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int e = threadIdx.x; e < npad; e += blockDim.x) {
+        const int p = e ^ j;
+        if (p > e) {
+          const float a0 = tile[e], a1 = tile[p];
+          const bool up = (e & k) == 0;
+          if ((a0 > a1) == up) { tile[e] = a1; tile[p] = a0; }
+        }
+      }
+      __syncthreads();
+    }
+  if (threadIdx.x == 0) {
+    const float rank = q * (float)(N - 1);
+    const float below = floorf(rank), above = ceilf(rank);
+    const float w = rank - below;
+    const float v0 = tile[(int)below], v1 = tile[(int)above];
+    const float diff = v1 - v0;
+    const float qv = fabsf(w) < 0.5f ? v0 + w * diff : v1 - diff * (1.0f - w);
+    scale[b] = fmaxf(qv, 1.0f);
   }
 }
 
 // First half of ADPM2Sampler.step fused with denoise_fn's output stage   (diffusion.py:506-508, :811-814)
 __global__ __launch_bounds__(256) void k_adpm2_mid(const float* x, const float* pred, float* x_mid, float* xin_mid,
                                                     float c_skip, float c_out, float sigma, float dt_mid,
-                                                    float c_in_mid, int C, int L, int Cp) {
+                                                    float c_in_mid, int C, int L, int Cp, const float* dscale) {
   extern __shared__ float tile[];
   const int b = blockIdx.x;
+  const float ds = dscale ? dscale[b] : 0.f;
   tile_load(tile, pred + (int64_t)b * L * Cp, L, Cp);
   __syncthreads();
   const int l4n = L / 4;
@@ -135,7 +184,7 @@ __global__ __launch_bounds__(256) void k_adpm2_mid(const float* x, const float* 
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       float* t = tile + (l + q) * (Cp + 1) + c;
-      const float den = clamp1(c_skip * xv[q] + c_out * (*t));
+      const float den = clip_dyn(c_skip * xv[q] + c_out * (*t), ds);
       const float d = (xv[q] - den) / sigma;
       xm[q] = xv[q] + d * dt_mid;
       *t = c_in_mid * xm[q];   // same thread owns (l, c): in-place reuse of the tile for xin_mid
@@ -155,9 +204,10 @@ __global__ __launch_bounds__(256) void k_adpm2_next(float* x, const float* x_mid
                                                      const float* noise, float* xin_next, float c_skip, float c_out,
                                                      float sigma_mid, float dt_down, float sigma_up, float c_in_next,
                                                      uint64_t seed, uint32_t step, int64_t sample0, int C, int L,
-                                                     int Cp, int32_t* tokens) {
+                                                     int Cp, int32_t* tokens, const float* dscale) {
   extern __shared__ float tile[];
   const int b = blockIdx.x;
+  const float ds = dscale ? dscale[b] : 0.f;
   tile_load(tile, pred + (int64_t)b * L * Cp, L, Cp);
   __syncthreads();
   const int l4n = L / 4;
@@ -175,7 +225,7 @@ __global__ __launch_bounds__(256) void k_adpm2_next(float* x, const float* x_mid
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       float* t = tile + (l + q) * (Cp + 1) + c;
-      const float den = clamp1(c_skip * mv[q] + c_out * (*t));
+      const float den = clip_dyn(c_skip * mv[q] + c_out * (*t), ds);
       const float d = (mv[q] - den) / sigma_mid;
       float xx = xv[q] + d * dt_down;
       xx = xx + nv[q] * sigma_up;
@@ -455,45 +505,74 @@ int mdt_cond_embed_add(const float* seq, const float* fc1_w, const float* fc1_b,
   return finish("mdt_cond_embed_add");
 }
 
+// the sampler kernels stage one sample's (L x Cp) tile in LDS: up to the CU's 160 KiB (the default limit of a launch is 64 KiB:
+// raised once per kernel).  max_length = 1024 (the reference constructors' default) at 16 padded channels is 68 KiB.
 #define MDT_CHECK_TILE(name)                                                                   \
   if (B <= 0) return 0;                                                                        \
   if (L % 4 || Cp % 16 || Cp < C) return bad(name ": need L % 4 == 0, Cp % 16 == 0, Cp >= C"); \
-  if (tile_bytes(L, Cp) > 64 * 1024) return bad(name ": (L, Cp) tile exceeds 64 KiB of LDS");
+  if (tile_bytes(L, Cp) > 160 * 1024) return bad(name ": (L, Cp) tile exceeds the 160 KiB of LDS of a compute unit");
+#define MDT_BIG_LDS(kernel)                                                                                          \
+  do {                                                                                                                \
+    static bool set_ = false;                                                                                         \
+    if (!set_) {                                                                                                      \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      set_ = true;                                                                                                    \
+    }                                                                                                                 \
+  } while (0)
 
 int mdt_precond_in(const float* x, float* xin, float c_in, int32_t B, int32_t C, int32_t L, int32_t Cp,
                    void* stream) {
   MDT_CHECK_TILE("mdt_precond_in")
+  MDT_BIG_LDS(mdt::k_precond_in);
   hipLaunchKernelGGL(mdt::k_precond_in, dim3(B), dim3(256), tile_bytes(L, Cp), (hipStream_t)stream, x, xin, c_in, C, L,
                      Cp);
   return finish("mdt_precond_in");
 }
 
 int mdt_precond_out(const float* x, const float* pred, float* D, float c_skip, float c_out, int32_t B, int32_t C,
-                    int32_t L, int32_t Cp, void* stream) {
+                    int32_t L, int32_t Cp, const float* dyn_scale, void* stream) {
   MDT_CHECK_TILE("mdt_precond_out")
+  MDT_BIG_LDS(mdt::k_precond_out);
   hipLaunchKernelGGL(mdt::k_precond_out, dim3(B), dim3(256), tile_bytes(L, Cp), (hipStream_t)stream, x, pred, D,
-                     c_skip, c_out, C, L, Cp);
+                     c_skip, c_out, C, L, Cp, dyn_scale);
   return finish("mdt_precond_out");
+}
+
+int mdt_dyn_scale(const float* x, const float* pred, float* scale, float c_skip, float c_out, float q, int32_t B, int32_t C,
+                  int32_t L, int32_t Cp, void* stream) {
+  if (B <= 0) return 0;
+  if (!x || !pred || !scale) return bad("mdt_dyn_scale: null pointer");
+  if (!(q > 0.0f && q <= 1.0f)) return bad("mdt_dyn_scale: the quantile must lie in (0, 1]");
+  if (C <= 0 || L <= 0 || Cp < C) return bad("mdt_dyn_scale: bad dims");
+  int npad = 1;
+  while (npad < C * L) npad <<= 1;
+  if ((size_t)npad * sizeof(float) > 160 * 1024) return bad("mdt_dyn_scale: C * L exceeds 32768 values (the sort runs in one compute unit's LDS)");
+  MDT_BIG_LDS(mdt::k_dyn_scale);
+  hipLaunchKernelGGL(mdt::k_dyn_scale, dim3(B), dim3(256), (size_t)npad * sizeof(float), (hipStream_t)stream, x, pred, scale,
+                     c_skip, c_out, q, C, L, Cp, npad);
+  return finish("mdt_dyn_scale");
 }
 
 int mdt_adpm2_mid(const float* x, const float* pred, float* x_mid, float* xin_mid, float c_skip, float c_out,
                   float sigma, float dt_mid, float c_in_mid, int32_t B, int32_t C, int32_t L, int32_t Cp,
-                  void* stream) {
+                  const float* dyn_scale, void* stream) {
   MDT_CHECK_TILE("mdt_adpm2_mid")
+  MDT_BIG_LDS(mdt::k_adpm2_mid);
   hipLaunchKernelGGL(mdt::k_adpm2_mid, dim3(B), dim3(256), tile_bytes(L, Cp), (hipStream_t)stream, x, pred, x_mid,
-                     xin_mid, c_skip, c_out, sigma, dt_mid, c_in_mid, C, L, Cp);
+                     xin_mid, c_skip, c_out, sigma, dt_mid, c_in_mid, C, L, Cp, dyn_scale);
   return finish("mdt_adpm2_mid");
 }
 
 int mdt_adpm2_next(float* x, const float* x_mid, const float* pred, const float* noise, float* xin_next, float c_skip,
                    float c_out, float sigma_mid, float dt_down, float sigma_up, float c_in_next, uint64_t seed,
                    uint32_t step, int64_t sample0, int32_t B, int32_t C, int32_t L, int32_t Cp, int32_t* tokens,
-                   void* stream) {
+                   const float* dyn_scale, void* stream) {
   MDT_CHECK_TILE("mdt_adpm2_next")
   if (tokens && xin_next) return bad("mdt_adpm2_next: tokens are decoded on the LAST update of a call (xin_next == NULL)");
+  MDT_BIG_LDS(mdt::k_adpm2_next);
   hipLaunchKernelGGL(mdt::k_adpm2_next, dim3(B), dim3(256), tile_bytes(L, Cp), (hipStream_t)stream, x, x_mid, pred,
                      noise, xin_next, c_skip, c_out, sigma_mid, dt_down, sigma_up, c_in_next, seed, step, sample0, C, L,
-                     Cp, tokens);
+                     Cp, tokens, dyn_scale);
   return finish("mdt_adpm2_next");
 }
 

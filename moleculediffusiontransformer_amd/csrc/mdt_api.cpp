@@ -150,8 +150,8 @@ static const char* validate(const mdt_op& o, int idx, char* buf, size_t nbuf) {
       if (o.i[MDT_K_WF32] != 0 && o.i[MDT_K_WF32] != 1) return bad("WF32 must be 0 (split-bf16 fragments) or 1 (fp32 fragments)");
       break;
     case MDT_OP_ATTN:
-      if (o.i[MDT_A_T] <= 0 || o.i[MDT_A_T] > 64 || o.i[MDT_A_TK] <= 0 || o.i[MDT_A_TK] > 64)
-        return bad("attention supports 1..64 queries and keys per sample");
+      if (o.i[MDT_A_T] <= 0 || o.i[MDT_A_T] > 8192 || o.i[MDT_A_TK] <= 0 || o.i[MDT_A_TK] > 8192)
+        return bad("attention supports 1..8192 queries and keys per sample (more than 64 of either: the online-softmax kernel)");
       if (o.i[MDT_A_QCOL] < 0 || o.i[MDT_A_KCOL] < 0 || o.i[MDT_A_QCOL] % 4 || o.i[MDT_A_KCOL] % 4) return bad("bad q / k column offset");
       if (!o.a.space || !o.a2.space || !o.out.space) return bad("missing operand");
       break;

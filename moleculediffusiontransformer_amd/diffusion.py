@@ -339,7 +339,8 @@ def _guided_eval(engine, lib, B: int, guided: bool, dual: bool, embedding_scale:
 
 def run_adpm2(engine, embedding: Tensor, pred_dim: int, num_steps: int, noise: NoiseSource,
               schedule, sampler: ADPM2Sampler, sigma_data: float, embedding_scale: float = 1.0,
-              clamp: bool = False, trace: Optional[dict] = None, timer=None, tokens: Optional[Tensor] = None) -> Tensor:
+              clamp: bool = False, trace: Optional[dict] = None, timer=None, tokens: Optional[Tensor] = None,
+              dynamic_threshold: float = 0.0) -> Tensor:
     """DiffusionSampler.forward (diffusion.py:577-591) + ADPM2Sampler.forward (:517-524) +
     KDiffusion_mod.denoise_fn (:798-814) + UNetCFG1d.forward (modules.py:1228-1255) on the GPU.
     ``tokens`` (B, L) int32: also the decode step after the path, argmax over channels of the final sample
@@ -361,6 +362,13 @@ def run_adpm2(engine, embedding: Tensor, pred_dim: int, num_steps: int, noise: N
         x = torch.empty(B, C, L, device=dev)
         x_mid = torch.empty_like(x)
         seed = noise.seed or 0
+        dscale = torch.empty(B, device=dev) if dynamic_threshold else None      # clip()'s per-sample dynamic threshold
+
+        def dyn(xs, pred, w):
+            if dscale is not None:
+                rt.check(lib.mdt_dyn_scale(rt.ptr(xs), rt.ptr(pred), rt.ptr(dscale), w.c_skip, w.c_out, float(dynamic_threshold),
+                                           B, C, L, Cp, st))
+            return rt.ptr(dscale)
         init = None if noise.init is None else _f32(noise.init, dev)
         rt.check(lib.mdt_init_noise(rt.ptr(x), rt.ptr(init), float(sigmas[0]), seed, 0, noise.sample0, B, C, L, st))
         if not steps:
@@ -382,7 +390,7 @@ def run_adpm2(engine, embedding: Tensor, pred_dim: int, num_steps: int, noise: N
         for i, s in enumerate(steps):
             pred = unet(2 * i)
             rt.check(lib.mdt_adpm2_mid(rt.ptr(x), rt.ptr(pred), rt.ptr(x_mid), rt.ptr(engine.xin), s.w.c_skip,
-                                       s.w.c_out, s.sigma, s.dt_mid, s.w_mid.c_in, B, C, L, Cp, st))
+                                       s.w.c_out, s.sigma, s.dt_mid, s.w_mid.c_in, B, C, L, Cp, dyn(x, pred, s.w), st))
             pred = unet(2 * i + 1)
             nz = None if noise.steps is None else _f32(noise.steps(i), dev)
             last = i + 1 == len(steps)
@@ -390,7 +398,7 @@ def run_adpm2(engine, embedding: Tensor, pred_dim: int, num_steps: int, noise: N
             rt.check(lib.mdt_adpm2_next(rt.ptr(x), rt.ptr(x_mid), rt.ptr(pred), rt.ptr(nz),
                                         0 if last else rt.ptr(engine.xin), s.w_mid.c_skip, s.w_mid.c_out,
                                         s.sigma_mid, s.dt_down, s.sigma_up, c_in_next, seed, i + 1, noise.sample0,
-                                        B, C, L, Cp, rt.ptr(tokens) if (last and not clamp) else 0, st))
+                                        B, C, L, Cp, rt.ptr(tokens) if (last and not clamp) else 0, dyn(x_mid, pred, s.w_mid), st))
             if trace is not None and (i + 1) in trace.get("want", ()):
                 trace[i + 1] = x.clone()
         if clamp:
@@ -404,7 +412,7 @@ def run_adpm2(engine, embedding: Tensor, pred_dim: int, num_steps: int, noise: N
 def run_adpm2_inpaint(engine, embedding: Tensor, source: Tensor, mask: Tensor, num_steps: int, num_resamples: int,
                       draw: Optional[Callable[[], Tensor]], seed: Optional[int], schedule,
                       sampler: ADPM2Sampler, sigma_data: float, embedding_scale: float = 1.0,
-                      sample0: int = 0) -> Tensor:
+                      sample0: int = 0, dynamic_threshold: float = 0.0) -> Tensor:
     """ADPM2Sampler.inpaint (diffusion.py:526-549) behind DiffusionInpainter.forward (:612-625).
     ``draw()`` returns the next torch.randn_like tensor in the reference's call order (parity mode);
     otherwise draws come from the counter-based generator keyed by (seed, draw index)."""
@@ -433,6 +441,13 @@ def run_adpm2_inpaint(engine, embedding: Tensor, source: Tensor, mask: Tensor, n
         mk = mask.to(device=dev).to(torch.uint8).contiguous()
         x = torch.empty(B, C, L, device=dev)
         x_mid = torch.empty_like(x)
+        dscale = torch.empty(B, device=dev) if dynamic_threshold else None
+
+        def dyn(xs, pred, w):
+            if dscale is not None:
+                rt.check(lib.mdt_dyn_scale(rt.ptr(xs), rt.ptr(pred), rt.ptr(dscale), w.c_skip, w.c_out, float(dynamic_threshold),
+                                           B, C, L, Cp, st))
+            return rt.ptr(dscale)
         sd = seed or 0
         nz, k = next_draw()
         rt.check(lib.mdt_init_noise(rt.ptr(x), rt.ptr(nz), float(sigmas[0]), sd, k, sample0, B, C, L, st))
@@ -449,12 +464,12 @@ def run_adpm2_inpaint(engine, embedding: Tensor, source: Tensor, mask: Tensor, n
                 rt.check(lib.mdt_precond_in(rt.ptr(x), rt.ptr(engine.xin), s.w.c_in, B, C, L, Cp, st))
                 pred = unet(2 * i)
                 rt.check(lib.mdt_adpm2_mid(rt.ptr(x), rt.ptr(pred), rt.ptr(x_mid), rt.ptr(engine.xin), s.w.c_skip,
-                                           s.w.c_out, s.sigma, s.dt_mid, s.w_mid.c_in, B, C, L, Cp, st))
+                                           s.w.c_out, s.sigma, s.dt_mid, s.w_mid.c_in, B, C, L, Cp, dyn(x, pred, s.w), st))
                 pred = unet(2 * i + 1)
                 nz, k = next_draw()
                 rt.check(lib.mdt_adpm2_next(rt.ptr(x), rt.ptr(x_mid), rt.ptr(pred), rt.ptr(nz), 0, s.w_mid.c_skip,
                                             s.w_mid.c_out, s.sigma_mid, s.dt_down, s.sigma_up, 0.0, sd, k, sample0,
-                                            B, C, L, Cp, 0, st))
+                                            B, C, L, Cp, 0, dyn(x_mid, pred, s.w_mid), st))
                 if r < num_resamples - 1:
                     nz, k = next_draw()
                     rt.check(lib.mdt_add_noise(rt.ptr(x), rt.ptr(nz), s.renoise, sd, k, sample0, B, C, L, st))

@@ -31,8 +31,8 @@ class KDiffusion_mod(nn.Module):
 
     def __init__(self, net: nn.Module, *, sigma_distribution, sigma_data: float, dynamic_threshold: float = 0.0):
         super().__init__()
-        if dynamic_threshold != 0.0:
-            raise NotImplementedError("dynamic thresholding is not on the sampling path of QMDiffusion*")
+        if not 0.0 <= dynamic_threshold <= 1.0:
+            raise ValueError("dynamic_threshold is a quantile: 0 (static clamp to [-1, 1]) ... 1")
         self.net = net
         self.sigma_data = sigma_data
         self.sigma_distribution = sigma_distribution
@@ -118,12 +118,13 @@ class _FusedLoop:
             init = None if ns.init is None else ns.init.to(device=emb.device, dtype=torch.float32)
             out, t = torch.ops.mdt.sample(emb, init, None, torch.as_tensor(sigmas, dtype=torch.float32).cpu(),
                                           ops.register_engine(eng), o.pred_dim, float(sampler.rho), float(sigma_data), float(scale),
-                                          bool(x.get("clamp", False)), int(ns.seed or 0), int(ns.sample0), tok is not None)
+                                          bool(x.get("clamp", False)), int(ns.seed or 0), int(ns.sample0), tok is not None,
+                                          float(o.diffusion.diffusion.dynamic_threshold))
             if tok is not None:
                 tok.copy_(t)
             return out
         return run_adpm2(eng, emb, o.pred_dim, num_steps, ns, sigmas, sampler, sigma_data, scale, bool(x.get("clamp", False)),
-                         x.get("trace"), x.get("timer"), x.get("tokens"))
+                         x.get("trace"), x.get("timer"), x.get("tokens"), float(o.diffusion.diffusion.dynamic_threshold))
 
     def inpaint(self, source, mask, sampler, sigmas, num_steps, num_resamples):
         o, emb = self.owner, self.kw["embedding"]
@@ -133,7 +134,8 @@ class _FusedLoop:
         if draw is None and seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         return run_adpm2_inpaint(eng, emb, source, mask, num_steps, num_resamples, draw, seed, sigmas, sampler,
-                                 o.diffusion.diffusion.sigma_data, self.kw.get("embedding_scale", 1.0))
+                                 o.diffusion.diffusion.sigma_data, self.kw.get("embedding_scale", 1.0),
+                                 dynamic_threshold=float(o.diffusion.diffusion.dynamic_threshold))
 
 
 class _QMBase(nn.Module):
@@ -312,7 +314,7 @@ class _QMBase(nn.Module):
         with torch.no_grad():
             xin = torch.ops.mdt.precond_in(x_noisy, w.c_in, eng.c.in_pad)
             pred = torch.ops.mdt.unet_eval(xin, embedding, w.c_noise, float(embedding_scale), ops.register_engine(eng))
-            return torch.ops.mdt.precond_out(x_noisy, pred, w.c_skip, w.c_out)
+            return torch.ops.mdt.precond_out(x_noisy, pred, w.c_skip, w.c_out, float(self.diffusion.diffusion.dynamic_threshold))
 
     # ------------------------------------------------------------------ public API (reference signatures)
     def forward(self, sequences, output):

@@ -124,8 +124,20 @@ def _(x, c_in, Cp):
     return x.new_empty(x.shape[0], x.shape[2], Cp, dtype=torch.float32)
 
 
+def _dyn_scale(lib, x: Tensor, pred: Tensor, c_skip: float, c_out: float, q: float) -> Optional[Tensor]:
+    """clip()'s per-sample dynamic threshold (diffusion.py:78-85) for the denoise stage of the next kernel, or None for q == 0."""
+    if not q:
+        return None
+    B, C, L = x.shape
+    scale = torch.empty(B, device=x.device)
+    rt.check(lib.mdt_dyn_scale(rt.ptr(x), rt.ptr(pred), rt.ptr(scale), float(c_skip), float(c_out), float(q), B, C, L,
+                               pred.shape[2], rt.current_stream()))
+    return scale
+
+
 @custom_op("mdt::precond_out", mutates_args=())
-def precond_out(x: Tensor, pred: Tensor, c_skip: float, c_out: float) -> Tensor:
+def precond_out(x: Tensor, pred: Tensor, c_skip: float, c_out: float, dynamic_threshold: float = 0.0) -> Tensor:
+    """D = clip(c_skip x + c_out pred, dynamic_threshold) (diffusion.py:811-814, :75-88)."""
     dev = _hip(x, pred)
     lib = rt.load_library()
     x, pred = _f32c(x), _f32c(pred)
@@ -135,13 +147,14 @@ def precond_out(x: Tensor, pred: Tensor, c_skip: float, c_out: float) -> Tensor:
     out = torch.empty_like(x)
     if B:
         with torch.cuda.device(dev):
+            ds = _dyn_scale(lib, x, pred, c_skip, c_out, dynamic_threshold)
             rt.check(lib.mdt_precond_out(rt.ptr(x), rt.ptr(pred), rt.ptr(out), float(c_skip), float(c_out), B, C, L,
-                                         pred.shape[2], rt.current_stream()))
+                                         pred.shape[2], rt.ptr(ds), rt.current_stream()))
     return out
 
 
 @precond_out.register_fake
-def _(x, pred, c_skip, c_out):
+def _(x, pred, c_skip, c_out, dynamic_threshold=0.0):
     return x.new_empty(x.shape, dtype=torch.float32)
 
 
@@ -166,7 +179,7 @@ def _(cond, uncond, scale):
 
 @custom_op("mdt::adpm2_mid", mutates_args=())
 def adpm2_mid(x: Tensor, pred: Tensor, c_skip: float, c_out: float, sigma: float, dt_mid: float,
-              c_in_mid: float) -> Tuple[Tensor, Tensor]:
+              c_in_mid: float, dynamic_threshold: float = 0.0) -> Tuple[Tensor, Tensor]:
     dev = _hip(x, pred)
     lib = rt.load_library()
     x, pred = _f32c(x), _f32c(pred)
@@ -176,20 +189,21 @@ def adpm2_mid(x: Tensor, pred: Tensor, c_skip: float, c_out: float, sigma: float
     xin = torch.zeros(B, L, Cp, device=dev)
     if B:
         with torch.cuda.device(dev):
+            ds = _dyn_scale(lib, x, pred, c_skip, c_out, dynamic_threshold)
             rt.check(lib.mdt_adpm2_mid(rt.ptr(x), rt.ptr(pred), rt.ptr(x_mid), rt.ptr(xin), float(c_skip), float(c_out),
-                                       float(sigma), float(dt_mid), float(c_in_mid), B, C, L, Cp, rt.current_stream()))
+                                       float(sigma), float(dt_mid), float(c_in_mid), B, C, L, Cp, rt.ptr(ds), rt.current_stream()))
     return x_mid, xin
 
 
 @adpm2_mid.register_fake
-def _(x, pred, c_skip, c_out, sigma, dt_mid, c_in_mid):
+def _(x, pred, c_skip, c_out, sigma, dt_mid, c_in_mid, dynamic_threshold=0.0):
     return x.new_empty(x.shape, dtype=torch.float32), pred.new_empty(pred.shape, dtype=torch.float32)
 
 
 @custom_op("mdt::adpm2_next", mutates_args=())
 def adpm2_next(x: Tensor, x_mid: Tensor, pred: Tensor, noise: Optional[Tensor], c_skip: float, c_out: float,
                sigma_mid: float, dt_down: float, sigma_up: float, c_in_next: float, seed: int, step: int,
-               sample0: int) -> Tuple[Tensor, Tensor]:
+               sample0: int, dynamic_threshold: float = 0.0) -> Tuple[Tensor, Tensor]:
     """Returns (x_next, xin_next); noise None = counter-based generator keyed by (seed, step, sample0 + b)."""
     dev = _hip(x, x_mid, pred, noise)
     lib = rt.load_library()
@@ -200,14 +214,15 @@ def adpm2_next(x: Tensor, x_mid: Tensor, pred: Tensor, noise: Optional[Tensor], 
     xin = torch.zeros(B, L, Cp, device=dev)
     if B:
         with torch.cuda.device(dev):
+            ds = _dyn_scale(lib, x_mid, pred, c_skip, c_out, dynamic_threshold)
             rt.check(lib.mdt_adpm2_next(rt.ptr(xn), rt.ptr(x_mid), rt.ptr(pred), rt.ptr(nz), rt.ptr(xin), float(c_skip),
                                         float(c_out), float(sigma_mid), float(dt_down), float(sigma_up), float(c_in_next),
-                                        int(seed), int(step), int(sample0), B, C, L, Cp, 0, rt.current_stream()))
+                                        int(seed), int(step), int(sample0), B, C, L, Cp, 0, rt.ptr(ds), rt.current_stream()))
     return xn, xin
 
 
 @adpm2_next.register_fake
-def _(x, x_mid, pred, noise, c_skip, c_out, sigma_mid, dt_down, sigma_up, c_in_next, seed, step, sample0):
+def _(x, x_mid, pred, noise, c_skip, c_out, sigma_mid, dt_down, sigma_up, c_in_next, seed, step, sample0, dynamic_threshold=0.0):
     return x.new_empty(x.shape, dtype=torch.float32), pred.new_empty(pred.shape, dtype=torch.float32)
 
 
@@ -292,7 +307,7 @@ def _(xin, embedding, c_noise, embedding_scale, handle):
 @custom_op("mdt::sample", mutates_args=())
 def sample(embedding: Tensor, init_noise: Optional[Tensor], step_noise: Optional[Tensor], sigmas: Tensor, handle: int,
            pred_dim: int, rho: float, sigma_data: float, embedding_scale: float, clamp: bool, seed: int, sample0: int,
-           want_tokens: bool) -> Tuple[Tensor, Tensor]:
+           want_tokens: bool, dynamic_threshold: float = 0.0) -> Tuple[Tensor, Tensor]:
     """The whole ADPM2 loop for an evaluated sigma schedule (num_steps + 1 values).  init_noise (B, C, L) / step_noise
     (num_steps - 1, B, C, L): explicit draws in the reference's call order; each one that is None comes from the counter-based
     generator keyed by (seed, draw index, sample0 + b) instead.  Returns (x (B, C, L), tokens (B, L) int32 or an empty tensor)."""
@@ -312,13 +327,13 @@ def sample(embedding: Tensor, init_noise: Optional[Tensor], step_noise: Optional
         ns.steps = lambda i: step_noise[i]
     tok = torch.zeros(B, eng.c.length, dtype=torch.int32, device=dev) if want_tokens else None
     x = run_adpm2(eng, embedding, pred_dim, num_steps, ns, sigmas, ADPM2Sampler(rho=rho), float(sigma_data),
-                  float(embedding_scale), bool(clamp), None, None, tok if B else None)
+                  float(embedding_scale), bool(clamp), None, None, tok if B else None, float(dynamic_threshold))
     return x, (tok if want_tokens else torch.empty(0, dtype=torch.int32, device=dev))
 
 
 @sample.register_fake
 def _(embedding, init_noise, step_noise, sigmas, handle, pred_dim, rho, sigma_data, embedding_scale, clamp, seed, sample0,
-      want_tokens):
+      want_tokens, dynamic_threshold=0.0):
     eng = _engine(handle)
     B = embedding.shape[0]
     return (embedding.new_empty(B, pred_dim, eng.c.length, dtype=torch.float32),

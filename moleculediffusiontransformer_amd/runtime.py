@@ -77,10 +77,11 @@ SYMBOLS = {
     "mdt_cond_embed": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "mdt_cond_embed_add": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "mdt_precond_in": (_I, [_P, _P, _F, _I, _I, _I, _I, _P]),
-    "mdt_precond_out": (_I, [_P, _P, _P, _F, _F, _I, _I, _I, _I, _P]),
+    "mdt_precond_out": (_I, [_P, _P, _P, _F, _F, _I, _I, _I, _I, _P, _P]),
+    "mdt_dyn_scale": (_I, [_P, _P, _P, _F, _F, _F, _I, _I, _I, _I, _P]),
     "mdt_cfg_mix": (_I, [_P, _P, _P, _F, _L, _P]),
-    "mdt_adpm2_mid": (_I, [_P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _I, _I, _I, _P]),
-    "mdt_adpm2_next": (_I, [_P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _U64, _U32, _L, _I, _I, _I, _I, _P, _P]),
+    "mdt_adpm2_mid": (_I, [_P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _I, _I, _I, _P, _P]),
+    "mdt_adpm2_next": (_I, [_P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _U64, _U32, _L, _I, _I, _I, _I, _P, _P, _P]),
     "mdt_adpm2_euler": (_I, [_P, _P, _P, _P, _P, _F, _F, _F, _I, _U64, _U32, _L, _I, _I, _I, _P]),
     "mdt_init_noise": (_I, [_P, _P, _F, _U64, _U32, _L, _I, _I, _I, _P]),
     "mdt_clamp": (_I, [_P, _F, _F, _L, _P]),

@@ -246,13 +246,13 @@ def test_sampler_kernels_match_reference_arithmetic():
         want[:, :, :C] = (c_in * x).transpose(1, 2)
         assert torch.equal(xin.cpu(), want)
         D = torch.empty_like(gx)
-        rt.check(lib.mdt_precond_out(rt.ptr(gx), rt.ptr(gp), rt.ptr(D), c_skip, c_out, B, C, L, Cp, st))
+        rt.check(lib.mdt_precond_out(rt.ptr(gx), rt.ptr(gp), rt.ptr(D), c_skip, c_out, B, C, L, Cp, 0, st))
         p = pred[:, :, :C].transpose(1, 2)
         den = (c_skip * x + c_out * p).clamp(-1.0, 1.0)
         assert torch.equal(D.cpu(), den)
         out_mid, xin_mid = torch.empty_like(gx), torch.empty_like(xin)
         rt.check(lib.mdt_adpm2_mid(rt.ptr(gx), rt.ptr(gp), rt.ptr(out_mid), rt.ptr(xin_mid), c_skip, c_out, sigma,
-                                   dt_mid, c_in, B, C, L, Cp, st))
+                                   dt_mid, c_in, B, C, L, Cp, 0, st))
         sg = torch.tensor(sigma)
         x_mid = x + ((x - den) / sg) * torch.tensor(dt_mid)
         assert torch.equal(out_mid.cpu(), x_mid)
@@ -260,7 +260,7 @@ def test_sampler_kernels_match_reference_arithmetic():
         assert float(xin_mid[:, :, C:].abs().max()) == 0.0
         x2 = gx.clone()
         rt.check(lib.mdt_adpm2_next(rt.ptr(x2), rt.ptr(gxm), rt.ptr(gp), rt.ptr(gnz), rt.ptr(xin_mid), c_skip, c_out,
-                                    sigma_mid, dt_down, up, c_in, 0, 0, 0, B, C, L, Cp, 0, st))
+                                    sigma_mid, dt_down, up, c_in, 0, 0, 0, B, C, L, Cp, 0, 0, st))
         den2 = (c_skip * xm + c_out * p).clamp(-1.0, 1.0)
         want = x + ((xm - den2) / torch.tensor(sigma_mid)) * torch.tensor(dt_down)
         want = want + nz * torch.tensor(up)
