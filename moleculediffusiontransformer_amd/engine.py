@@ -42,14 +42,14 @@ class UNetEngine:
                     raise
                 raise RuntimeError(
                     f"U-Net configuration outside the envelope of the MI355X kernels (max_length={compiled.length}, "
-                    f"channels={compiled.cfg.channels}, patch_size={compiled.cfg.patch_size}): {e}.  Supported: self-attention "
-                    "levels with at most 64 tokens per sample unless they run on the fused blocks (C in {128, 256}, tokens "
-                    "dividing 16), head_features 64, channels a multiple of 16 -- see DESIGN.md section 8") from e
+                    f"channels={compiled.cfg.channels}, patch_size={compiled.cfg.patch_size}): {e}.  Supported: at most 8192 "
+                    "tokens per sample on an attention level, head_features 64, channels a multiple of 16 -- see DESIGN.md "
+                    "section 8") from e
             tile = compiled.length * (compiled.in_pad + 1) * 4
-            if tile > 64 * 1024:
+            if tile > 160 * 1024:
                 raise RuntimeError(f"max_length={compiled.length} with {compiled.in_pad} (padded) channels needs a {tile}-byte "
-                                   "sampler tile; the preconditioning / update kernels stage one sample in 64 KiB of LDS "
-                                   "(max_length * (pred_dim_padded + 1) * 4 <= 65536) -- see DESIGN.md section 8")
+                                   "sampler tile; the preconditioning / update kernels stage one sample in the 160 KiB of LDS of a "
+                                   "compute unit (max_length * (pred_dim_padded + 1) * 4 <= 163840) -- see DESIGN.md section 8")
         if use_graph is None:
             use_graph = os.environ.get("MDT_GRAPH", "1") != "0"
         self.use_graph = use_graph

@@ -8,6 +8,10 @@
   add_embed_d32.npz    the additive conditioning prelude with text_embed_dim (32) < embed_dim_position (64): the encoding's first
                        32 columns are added (transformer.py:3456-3470)
 
+  dynthr.npz           clip() with dynamic_threshold > 0 (diffusion.py:75-88) on heavy-tailed inputs, and a 6-step sample of the
+                       tiny inverse model with KDiffusion_mod.dynamic_threshold = 0.9 (every class hard-codes 0.0; the attribute is
+                       read at denoise time, diffusion.py:814)
+
 Only inputs and outputs are stored.
 """
 import os
@@ -62,5 +66,26 @@ def main():
     G.save("add_embed_d32.npz", seq=seq.numpy(), fc1_w=w.numpy(), fc1_b=b.numpy(), emb=m.diffusion.embedding.numpy())
 
 
+def dynthr():
+    import MoleculeDiffusion.diffusion as MD  # type: ignore
+    out = {}
+    x = synth_normal("r4/dyn/x", (3, 16, 64)) * torch.tensor([0.5, 2.0, 6.0]).view(3, 1, 1)
+    out["x"] = x.numpy()
+    for q in (0.5, 0.9, 0.995, 1.0):
+        out[f"clip_q{q}"] = MD.clip(x.clone(), dynamic_threshold=q).numpy()
+    m = G.build("inverse", max_length=32, pred_dim=16, channels=16, context_embedding_max_length=12, text_embed_dim=64,
+                embed_dim_position=64)
+    m.diffusion.diffusion.dynamic_threshold = 0.9
+    seq = synth_normal("tiny/seq", (3, 12))
+    inj = G.NoiseInjector("tiny_dyn_t6")
+    with inj:
+        y = m.sample(seq, "cpu", cond_scale=1.0, timesteps=6, clamp=False)
+    out["seq"], out["sample_q0.9_t6"] = seq.numpy(), y.detach().numpy()
+    G.save("dynthr.npz", **out)
+
+
 if __name__ == "__main__":
+    if "dynthr" in sys.argv:
+        dynthr()
+        sys.exit(0)
     main()

@@ -165,3 +165,29 @@ def test_wide_path_at_batch_2048_against_the_oracle():
                      noise=NoiseSource(init=init[:1024], steps=lambda i: nz[i][:1024]))
     assert not m._engine.c.tf256 and m._engine.handoff_status() == 0
     assert (out_n.cpu()[[0, 1023]] - ref[:2]).abs().max() < TOL
+
+
+def test_reference_default_constructor_samples():
+    """QMDiffusion() with NO arguments -- the reference's defaults (generative.py:720-736: max_length 1024, channels 128, pred_dim 1,
+    32 conditioning tokens, text_embed_dim 1024 + embed_dim_position 64 = 1088 context features) -- builds, samples on the GPU and
+    agrees with the oracle on identical noise (B = 1, 2 timesteps = 2 U-Net evaluations).  Rounds 1-3 refused this configuration
+    at engine construction (sampler tile above 64 KiB of LDS, 256-token attention level)."""
+    import torch
+    from moleculediffusiontransformer_amd import NoiseSource, QMDiffusion
+    from moleculediffusiontransformer_amd.netspec import inverse_unet_config, unet_manifest
+    from moleculediffusiontransformer_amd.synth import synth_normal, synth_state_dict
+    from oracle import unet_oracle as O
+    m = QMDiffusion()
+    assert m.max_length == 1024 and m.unet.config.ctx_features == 1088 and m.unet.config.ctx_max_length == 32
+    m.load_state_dict(synth_state_dict([(k, tuple(v.shape)) for k, v in m.state_dict().items()]))
+    m = m.to(DEV)
+    keys = [("fc1.weight", (1024, 1)), ("fc1.bias", (1024,)), ("p_enc_1d.inv_freq", (32,))]
+    keys += unet_manifest(inverse_unet_config(1, 128, 1088, 32), "unet.")
+    sd = synth_state_dict(keys)
+    cfg = O.inverse_config(1024, 128, 1, 32, text_embed_dim=1024, embed_dim_position=64)
+    seq = synth_normal("default/seq", (1, 32))
+    init = synth_normal("default/init", (1, 1, 1024))
+    nz = [synth_normal("default/s0", (1, 1, 1024))]
+    want = O.sample(sd, cfg, seq, init, lambda i, x: nz[i], 2, 1.0, False)
+    out = m.sample(seq, DEV, cond_scale=1.0, timesteps=2, noise=NoiseSource(init=init, steps=lambda i: nz[i]))
+    assert out.shape == (1, 1, 1024) and (out.cpu() - want).abs().max() < 1e-4

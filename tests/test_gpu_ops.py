@@ -153,7 +153,10 @@ def test_gn_stats_and_groupnorm_prologue(B, R, C, G, N, film, silu, eps):
 
 
 @pytest.mark.parametrize("B,T,Tk,shared", [(3, 16, 16, False), (2, 16, 12, False), (5, 4, 4, False), (2, 4, 12, True),
-                                           (2, 1, 64, False), (1, 32, 32, False), (3, 16, 12, True)])
+                                           (2, 1, 64, False), (1, 32, 32, False), (3, 16, 12, True),
+                                           # more than 64 queries / keys per sample: k_attn_long (online softmax over key chunks)
+                                           (2, 256, 256, False), (1, 100, 70, False), (2, 256, 32, True), (1, 20, 300, False),
+                                           (1, 1024, 1024, False)])
 def test_attention(B, T, Tk, shared):
     H, D = 8, 64
     act = torch.cat([rnd(B * T * H * D, seed=1), rnd(B * Tk * 2 * H * D, seed=2), torch.zeros(B * T * H * D)])

@@ -186,3 +186,65 @@ def test_additive_prelude_with_a_narrower_text_embedding():
     m = m.to(DEV)
     emb = m._embed(torch.from_numpy(a["seq"]), DEV)
     assert emb.shape == (2, 12, 32) and (emb.cpu() - torch.from_numpy(a["emb"])).abs().max() < 1e-6
+
+
+def test_dynamic_thresholding_on_the_gpu_path():
+    """clip() with dynamic_threshold > 0 (diffusion.py:75-88; VERDICT r3 'envelope holes'): mdt_dyn_scale (per-sample quantile of
+    |x_denoised| by an in-LDS sort, torch.quantile's interpolation) feeding the denoise stage of mdt_precond_out / mdt_adpm2_mid /
+    mdt_adpm2_next -- against clip() vectors and a 6-step sample recorded from the real reference with
+    KDiffusion_mod.dynamic_threshold = 0.9."""
+    g = load_golden("dynthr.npz")
+    x = to_t(g["x"]).to(DEV)
+    B, C, L = x.shape
+    pred = torch.zeros(B, L, 16, device=DEV)
+    for q in (0.5, 0.9, 0.995, 1.0):        # c_skip = 1, c_out = 0: x_denoised = x
+        got = torch.ops.mdt.precond_out(x, pred, 1.0, 0.0, q)
+        assert (got.cpu() - to_t(g[f"clip_q{q}"])).abs().max() < 1e-6, q
+    m = make_model("tiny")
+    assert m.diffusion.diffusion.dynamic_threshold == 0.0
+    m.diffusion.diffusion.dynamic_threshold = 0.9
+    ref = to_t(g["sample_q0.9_t6"])
+    init, step = noise_fns("tiny_dyn_t6", tuple(ref.shape))
+    out = m.sample(to_t(g["seq"]), DEV, cond_scale=1.0, timesteps=6, clamp=False,
+                   noise=NoiseSource(init=init, steps=lambda i: step(i, init)))
+    assert (out.cpu() - ref).abs().max() < 1e-4
+    # the per-step path (net -> denoise_fn) applies the same clip
+    emb = m._embed(to_t(g["seq"]), DEV)
+    d = m.diffusion.diffusion.denoise_fn(init.to(DEV) * 2.5, sigma=torch.tensor(2.5), embedding=emb, embedding_scale=1.0)
+    from helpers import oracle_cfg, synth_sd
+    from oracle import unet_oracle as O
+    want = O.denoise(synth_sd("tiny"), oracle_cfg("tiny"), init * 2.5, torch.tensor(2.5), emb.cpu(), 1.0, dynamic_threshold=0.9)
+    assert (d.cpu() - want).abs().max() < 5e-5
+    with pytest.raises(ValueError, match="quantile"):
+        from moleculediffusiontransformer_amd.generative import KDiffusion_mod
+        KDiffusion_mod(net=m.unet, sigma_distribution=None, sigma_data=0.1, dynamic_threshold=1.5)
+
+
+def test_default_max_length_1024_runs_and_matches_the_oracle():
+    """The reference constructors' default max_length = 1024 (generative.py:720-736; VERDICT r3 'envelope holes'): the sampler
+    kernels stage a 1024 x 17 float tile (68 KiB, above the 64 KiB default LDS limit of a launch) and the first attention level
+    has 256 tokens per sample (k_attn_long: online softmax over key chunks).  A narrow model (channels 32) so that the CPU
+    oracle finishes in seconds; 3 timesteps, B = 2, against the oracle on identical noise, plus the cross-attention level with
+    a 32-token context (the default context_embedding_max_length)."""
+    from helpers import oracle_cfg  # noqa: F401
+    from moleculediffusiontransformer_amd.netspec import inverse_unet_config, unet_manifest
+    from oracle import unet_oracle as O
+    kw = dict(max_length=1024, pred_dim=1, channels=32, context_embedding_max_length=32)
+    m = QMDiffusion(text_embed_dim=64, embed_dim_position=64, **kw)
+    m.load_state_dict(synth_state_dict([(k, tuple(v.shape)) for k, v in m.state_dict().items()]))
+    m = m.to(DEV)
+    keys = [("fc1.weight", (64, 1)), ("fc1.bias", (64,)), ("p_enc_1d.inv_freq", (32,))]
+    keys += unet_manifest(inverse_unet_config(1, 32, 128, 32), "unet.")
+    sd = synth_state_dict(keys)
+    cfg = O.inverse_config(1024, 32, 1, 32)
+    B, T = 2, 3
+    seq = synth_normal("l1024/seq", (B, 32))
+    init = synth_normal("l1024/init", (B, 1, 1024))
+    nz = [synth_normal(f"l1024/s{i}", (B, 1, 1024)) for i in range(T - 1)]
+    want = O.sample(sd, cfg, seq, init, lambda i, x: nz[i], T, 1.0, False)
+    out = m.sample(seq, DEV, cond_scale=1.0, timesteps=T, noise=NoiseSource(init=init, steps=lambda i: nz[i]))
+    assert out.shape == (B, 1, 1024)
+    assert (out.cpu() - want).abs().max() < 1e-4
+    from moleculediffusiontransformer_amd import runtime as rt
+    ev = m._engine.c.programs["eval"]
+    assert any(op.kind == rt.OP_ATTN and op.i[rt.A_T] == 256 for op in ev)          # the long-sequence kernel was on the path

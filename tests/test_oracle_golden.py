@@ -101,3 +101,18 @@ def test_schedule_and_scalars_kats():
     w = O.scale_weights(torch.full((4,), 9.0))
     assert float(w[0].flatten()[0]) == 0.000123441539471969
     assert float(w[3][0]) == 0.5493061542510986
+
+
+def test_dynamic_thresholding_matches_reference():
+    """clip() with dynamic_threshold > 0 (diffusion.py:75-88) and a sample with KDiffusion_mod.dynamic_threshold = 0.9: the
+    oracle against vectors from the real reference (tests/golden/make_golden_r4.py dynthr)."""
+    g = load_golden("dynthr.npz")
+    x = to_t(g["x"])
+    for q in (0.5, 0.9, 0.995, 1.0):
+        assert torch.equal(O.clip(x, q), to_t(g[f"clip_q{q}"]))
+    assert torch.equal(O.clip(x, 0.0), x.clamp(-1.0, 1.0))
+    sd, cfg = synth_sd("tiny"), oracle_cfg("tiny")
+    ref = to_t(g["sample_q0.9_t6"])
+    init, step = noise_fns("tiny_dyn_t6", tuple(ref.shape))
+    out = O.sample(sd, cfg, to_t(g["seq"]), init, step, 6, 1.0, False, None, 0.9)
+    assert (out - ref).abs().max() <= TOL
