@@ -433,7 +433,8 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
 #ifdef MDT_ABL_LDSBC   // ablation (WRONG results, timing only): every lane reads the same 16 bytes -- what the fragment reads cost the LDS
     lds_read16_off<off>(lo ? frl[set][q] : frh[set][q], base & 0x18000u);
 #else
-    lds_read16_off<off>(lo ? frl[set][q] : frh[set][q], base);
+    if constexpr (F32) lds_read16_off<off>(frh[set][q], base);            // (exact fp32: one pair per set, see phase())
+    else lds_read16_off<off>(lo ? frl[set][q] : frh[set][q], base);
 #endif
   };
   using J0 = std::integral_constant<int, 0>;
@@ -446,10 +447,9 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
   auto prefetch2 = [&](auto kind, const unsigned char* slot, int off) {
     constexpr int KIND = decltype(kind)::value;
     const unsigned l = lds_addr(slot);
-    if constexpr (F32) {                             // two fragment sets, one unit ahead (phase()): unit 0 -> set 0
+    if constexpr (F32) {                             // two sets of ONE fragment pair, half a unit ahead (phase()): half-unit 0 -> set 0
       const unsigned b = l + (KIND == K_O ? aO : aP0);
-      frag_read(kind, b, J0{}, 0, J0{}); frag_read(kind, b, J0{}, 0, J1{});
-      frag_read(kind, b, J0{}, 0, J2{}); frag_read(kind, b, J0{}, 0, J3{});
+      frag_read(kind, b, J0{}, 0, J0{}); frag_read(kind, b, J0{}, 0, J2{});
       return;
     }
     const unsigned b0 = l + (KIND == K_O ? aO : aP(0)), b1 = l + (KIND == K_O ? aO : aP(1));
@@ -463,41 +463,60 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
 
   int tau = 0;
   auto slot_of = [&](int t) -> unsigned char* { return smem + MDT_SLOT_IDX(t) * SLOT; };
+  // An opaque copy of the lane id.  Addresses that are needed once per sub-block or head (vector rows, the exchange areas, the
+  // hand-off blocks, the final store) are formed from it WHERE THEY ARE USED: computed once at the top of the kernel from the
+  // real lane id they are live for the whole launch and -- this kernel sits at the 256-register limit -- are what hipcc spills
+  // after to_in and reloads in front of every use (up to 120 bytes of scratch per lane).
+  // (The exact-fp32 instantiations have 16 registers to spare -- two fragment sets -- and compile to zero scratch with these
+  //  values hoisted; made opaque there, the same code spills 76-136 bytes around the S^T MFMAs.  So: opaque for split-bf16 only.)
+  auto lane_now = [&]() -> int {
+    if constexpr (F32) return lane;
+    // read from the hardware (v_mbcnt: the number of lanes below this one), not from `lane`: threadIdx.x then has no late use
+    // either, and it was the last register spilled across the block loop
+    int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(l));
+    return l;
+  };
 
   // One MFMA phase over a sub-tile (k_tblock32.hip): 4 units of 4 fragment reads + 6 MFMAs
   auto phase = [&](auto kind, auto offc, auto nkind, bool has_next, f32x4* acc, const bf16x8* bh, const bf16x8* bl) {
     constexpr int KIND = decltype(kind)::value, OFF = decltype(offc)::value, NK = decltype(nkind)::value;
     if constexpr (F32) {
-      // Exact fp32 products: a unit is 4 fragment reads + 16 MFMAs of 8 passes (512 MFMA-pipe cycles against 96 of the split
-      // form), so ONE unit of read-ahead covers the LDS latency many times over: two fragment sets (16 registers fewer than the
-      // three of the split form -- this kernel sits at the 256-register limit), unit u + 1 read during unit u into set (u + 1) & 1,
-      // the barrier that publishes the next sub-tile in front of the last unit.  NU is even: every phase starts on set 0 and OFF
-      // is not used.  All fragment addresses are slot base + one lane constant + immediate.
+      // Exact fp32 products: a fragment pair (the two feature tiles q of one operand half) feeds 8 MFMAs of 8 passes = 256
+      // MFMA-pipe cycles, so HALF a unit of read-ahead covers the LDS latency: the pipeline keeps two sets of ONE pair in
+      // flight (frh[set][q]: 16 registers against the 48 of the split form's three full sets -- this kernel sits at the
+      // 256-register limit, and with the slack every fp32 instantiation compiles to zero scratch).  Half-unit v = 2 u + half
+      // reads pair v + 1 into set (v + 1) & 1 between its MFMAs; the barrier that publishes the next sub-tile sits in front of
+      // the last half-unit.  2 NU is even: every phase starts on set 0 and OFF is not used.  All fragment addresses are slot
+      // base + one lane constant + immediate.
       const unsigned lc = lds_addr(slot_of(tau)) + (KIND == K_O ? aO : aP0);
       const unsigned lnx = lds_addr(slot_of(tau + 1)) + (NK == K_O ? aO : aP0);
-      auto unit32 = [&](auto uc) {
-        constexpr int u = decltype(uc)::value;
-        if (u == NU - 1 && has_next) {
+      auto half32 = [&](auto vc) {
+        constexpr int v = decltype(vc)::value, u = v >> 1, hl = v & 1;
+        if (v == 2 * NU - 1 && has_next) {
           __builtin_amdgcn_sched_barrier(0);
           MDT_BARRIER();                // B(tau + 1)
           __builtin_amdgcn_sched_barrier(0);
         }
-        lgkm_wait<0>();                 // set u & 1 (read during the previous unit) has landed
-        constexpr int s0 = u & 1, s1 = (u + 1) & 1;
-        constexpr bool in_phase = u + 1 < NU;
+        lgkm_wait<0>();                 // pair v (read during the previous half-unit) has landed
+        constexpr int s0 = v & 1, s1 = (v + 1) & 1;
+        constexpr bool in_phase = v + 1 < 2 * NU;
         const bool pre = in_phase || has_next;
         constexpr int ia = (KIND == K_O) ? 2 * u : 0, ib = (KIND == K_O) ? 0 : u;
-        auto rd = [&](auto jc) {
+        auto rd = [&](auto qc) {        // fragment (q, half) of half-unit v + 1: read j = 2 q + half
           if (!pre) return;
+          constexpr int q = decltype(qc)::value;
           __builtin_amdgcn_sched_barrier(0);
-          if constexpr (in_phase) frag_read(kind, lc, std::integral_constant<int, u + 1>{}, s1, jc);
-          else frag_read(nkind, lnx, std::integral_constant<int, 0>{}, s1, jc);
+          constexpr int un = (v + 1) / 2, jn = 2 * q + ((v + 1) & 1);
+          if constexpr (in_phase) frag_read(kind, lc, std::integral_constant<int, un>{}, s1, std::integral_constant<int, jn>{});
+          else frag_read(nkind, lnx, std::integral_constant<int, 0>{}, s1, std::integral_constant<int, 2 * q>{});
           __builtin_amdgcn_sched_barrier(0);
         };
-        // fragment (q, half) x operand half: four 16x16x4 MFMAs each (r = contraction sub-step), the two accumulators alternating
-        auto mm4 = [&](const bf16x8& w0, const bf16x8& w1, const bf16x8& x, auto r0c) {
+        // pair x operand half: four 16x16x4 MFMAs per feature tile (r = contraction sub-step), the two accumulators alternating
+        const f32x4 a0 = __builtin_bit_cast(f32x4, frh[s0][0]), a1 = __builtin_bit_cast(f32x4, frh[s0][1]);
+        const f32x4 xb = __builtin_bit_cast(f32x4, hl ? bl[ib] : bh[ib]);
+        auto mm2 = [&](auto r0c) {
           constexpr int r0 = decltype(r0c)::value;
-          const f32x4 a0 = __builtin_bit_cast(f32x4, w0), a1 = __builtin_bit_cast(f32x4, w1), xb = __builtin_bit_cast(f32x4, x);
 #pragma unroll
           for (int r = r0; r < r0 + 2; ++r) {
             if constexpr (KIND == K_N) {
@@ -509,14 +528,14 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
             }
           }
         };
-        mm4(frh[s0][0], frh[s0][1], bh[ib], J0{}); rd(J0{});
-        mm4(frh[s0][0], frh[s0][1], bh[ib], J2{}); rd(J1{});
-        mm4(frl[s0][0], frl[s0][1], bl[ib], J0{}); rd(J2{});
-        mm4(frl[s0][0], frl[s0][1], bl[ib], J2{}); rd(J3{});
+        mm2(J0{}); rd(J0{});
+        mm2(J2{}); rd(J1{});
         __builtin_amdgcn_sched_barrier(0);
       };
-      unit32(std::integral_constant<int, 0>{}); unit32(std::integral_constant<int, 1>{});
-      unit32(std::integral_constant<int, 2>{}); unit32(std::integral_constant<int, 3>{});
+      half32(std::integral_constant<int, 0>{}); half32(std::integral_constant<int, 1>{});
+      half32(std::integral_constant<int, 2>{}); half32(std::integral_constant<int, 3>{});
+      half32(std::integral_constant<int, 4>{}); half32(std::integral_constant<int, 5>{});
+      half32(std::integral_constant<int, 6>{}); half32(std::integral_constant<int, 7>{});
       ++tau;
       return;
     }
@@ -583,35 +602,52 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
   const IC1 kN{};
   const IC2 kO{};
 
-  const int samp_q = i / a.T;
-  unsigned kbits = 0;                                // bit r: key 4 g + r belongs to this lane's sample (self-attention mask)
-#pragma unroll
-  for (int r = 0; r < 4; ++r) kbits |= ((4 * g + r) / a.T == samp_q) ? (1u << r) : 0u;
+  // (the self-attention mask -- bit r: key 4 g + r belongs to this lane's sample -- is formed per head, see lane_now())
   const float scale2 = a.scale * 1.44269504088896340736f;
-  int nkeys = 0, Rw = 0;
-  unsigned okbits = 0;
   // K / V rows of this wave inside a K / V tile: row R = Rw + 16 kt + (i | 4 g + r), 256 bytes, 16-byte chunks XOR-swizzled with
   // R & 15 (independent of kt): ONE base per operand, the key tile kt is an immediate offset of 4096 bytes and the second
   // 16-feature half is the base ^ 64.  Rows past the wave's keys (up to row 95 of the 128-row slot) hold other samples' rows or
   // older tiles -- finite fp32 bit patterns in either case (every slot is filled by weight sub-tiles before the first K / V
   // tile: bf16 pairs whose upper half is a finite bf16) -- and meet a probability of exactly 0.
-  unsigned kb0 = 0, vb0[4] = {0, 0, 0, 0};
-  if constexpr (NPW > 0) {
-    nkeys = (16 / a.T) * a.Tk;
-    Rw = rt * nkeys;
-    kb0 = (unsigned)((Rw + i) * 256 + (((8 * fh + g) ^ ((Rw + i) & 15)) << 4));
+  // These six lane constants (kb0, vb0[4], okbits) are RECOMPUTED at every cross-attention head from an opaque copy of the lane
+  // id (cross_consts below, ~30 VALU instructions): kept live across the whole launch they were the registers hipcc spilled
+  // after to_in and reloaded at every head (44 of the 120 bytes of scratch of the pair-split instantiations).
+  const int nkeys = NPW > 0 ? (16 / a.T) * a.Tk : 0;
+  const int tsh = __builtin_ctz((unsigned)a.T);      // T is a power of two dividing 16 (launch_tf256 checks)
+  // bit r: key 4 g + r belongs to this lane's sample (self-attention mask)
+  auto self_mask = [&](int l) -> unsigned {
+    const int sq = (l & 15) >> tsh, g4 = 4 * (l >> 4);
+    unsigned kb = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) kb |= (((g4 + r) >> tsh) == sq) ? (1u << r) : 0u;
+    return kb;
+  };
+  auto cross_consts = [&](int l, unsigned& kb0, unsigned (&vb0)[4], unsigned& okbits) {
+    const int i_ = l & 15, g_ = l >> 4;
+    const int Rw = rt * nkeys;
+    kb0 = (unsigned)((Rw + i_) * 256 + (((8 * fh + g_) ^ ((Rw + i_) & 15)) << 4));
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int R = Rw + 4 * g + r;
-      vb0[r] = (unsigned)(R * 256 + (i & 3) * 4 + (((8 * fh + (i >> 2)) ^ (R & 15)) << 4));
+      const int R = Rw + 4 * g_ + r;
+      vb0[r] = (unsigned)(R * 256 + (i_ & 3) * 4 + (((8 * fh + (i_ >> 2)) ^ (R & 15)) << 4));
     }
+    const int k_lo = (i_ >> tsh) * a.Tk, k_hi = k_lo + a.Tk;       // this lane's sample owns keys [k_lo, k_hi) of the wave's
+    okbits = 0;
 #pragma unroll
     for (int kt = 0; kt < KTM; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int jj = 16 * kt + 4 * g + r;
-        if (jj < nkeys && (jj / a.Tk) == samp_q) okbits |= 1u << (4 * kt + r);
+        const int jj = 16 * kt + 4 * g_ + r;
+        if (jj >= k_lo && jj < k_hi) okbits |= 1u << (4 * kt + r);
       }
+  };
+  // The variables themselves live here; the split-bf16 instantiations ASSIGN them at every head (from the opaque lane id, so
+  // that they are dead in between), the exact-fp32 ones once, now.  (No copies into per-head arrays: a register array that is
+  // copied element-wise through a reference ends up in scratch memory -- 148 bytes per lane when this was tried.)
+  unsigned kbits = 0, kb0 = 0, vb0[4] = {0, 0, 0, 0}, okbits = 0;
+  if constexpr (F32) {
+    kbits = self_mask(lane);
+    if constexpr (NPW > 0) cross_consts(lane, kb0, vb0, okbits);
   }
   const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
   const float t1 = a.T > 1 ? 1.f : 0.f, t2 = a.T > 2 ? 1.f : 0.f, t4 = a.T > 4 ? 1.f : 0.f, t8 = a.T > 8 ? 1.f : 0.f;
@@ -670,7 +706,7 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
   };
   // start of a sub-block: wave fh = 0 carries residual + output bias (or the bias alone), wave fh = 1 starts from zero
   auto start_acc = [&](int off, bool keep_residual) {
-    const float* p = reinterpret_cast<const float*>(vec_b + vpar * VEC_BYTES) + off + 4 * g;
+    const float* p = reinterpret_cast<const float*>(vec_b + vpar * VEC_BYTES) + off + 4 * (lane_now() >> 4);
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
       const float4 b = *reinterpret_cast<const float4*>(p + 16 * ct);
@@ -685,14 +721,14 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
   // still executed (the loaders count them) but nothing follows.
   auto exchange_half = [&](auto rdc) {               // accumulator tiles 8 rd .. 8 rd + 7 (compile-time register indices)
     constexpr int rd_ = decltype(rdc)::value;
-    f32x4* ex = reinterpret_cast<f32x4*>(slot_of(tau));
+    f32x4* ex = reinterpret_cast<f32x4*>(slot_of(tau)) + lane_now();
 #pragma unroll
-    for (int c = 0; c < 8; ++c) ex[(wave * 8 + c) * 64 + lane] = accT[8 * rd_ + c];
+    for (int c = 0; c < 8; ++c) ex[(wave * 8 + c) * 64] = accT[8 * rd_ + c];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     MDT_BARRIER();                    // B(scratch tile): the partner's partials (and the next vectors) are in LDS
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      const f32x4 other = ex[((wave ^ 1) * 8 + c) * 64 + lane];
+      const f32x4 other = ex[((wave ^ 1) * 8 + c) * 64];
       accT[8 * rd_ + c] = fh ? (other + accT[8 * rd_ + c]) : (accT[8 * rd_ + c] + other);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // read before the slot can be refilled (two barriers later)
@@ -707,7 +743,7 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
       // wave-uniform part of the addresses in the scalar offset (an SGPR), the lane's 16 bytes in the vector offset
       const unsigned sbase = __builtin_amdgcn_readfirstlane(
           (((unsigned)(xn & 1) * (unsigned)nrb + (unsigned)rb) * 2u + (unsigned)hh) * XBLOCK + (unsigned)rt * (16u * 1024u));
-      const unsigned vlane = (unsigned)lane * 16u;
+      const unsigned vlane = (unsigned)lane_now() * 16u;
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         const f32x4 lo_ = accT[c], hi_ = accT[8 + c];
@@ -745,7 +781,7 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
           }
           __builtin_amdgcn_s_sleep(2);
           if (__builtin_amdgcn_s_memrealtime() - t0 > POLL_TIMEOUT) {   // never hang the GPU: flag the launch and go on
-            if (lane == 0) atomicOr(a.xflags, 1u);
+            if (lane_now() == 0) atomicOr(a.xflags, 1u);
             break;
           }
         }
@@ -822,7 +858,7 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
     make_operands(false);
     // this wave produces output channels 64 c + 32 fh + 16 q + (4 g + r), i.e. accumulator tiles 4 c + 2 fh + q, complete
     // sums (both K halves); the other tiles stay zero and arrive through the exchanges; bias on wave 0 (of half 0) only
-    const float* bp = reinterpret_cast<const float*>(vec_b + vpar * VEC_BYTES) + 4 * g;
+    const float* bp = reinterpret_cast<const float*>(vec_b + vpar * VEC_BYTES) + 4 * (lane_now() >> 4);
     if constexpr (NSPLIT == 1) {
       auto in_chunk = [&](auto cc, auto o0, auto o1, bool more) {
         constexpr int c = decltype(cc)::value;
@@ -871,7 +907,7 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
   const int h0 = hh * nheads, f0 = hh * nff;
   for (int blk = 0; blk < a.nblocks; ++blk) {
     const bool last_blk = blk + 1 == a.nblocks;
-    const unsigned bias_l = 128u * (unsigned)fh + 16u * (unsigned)g;     // + parity base + 256 (global head / chunk)
+    const unsigned bias_l = 128u * (unsigned)fh + 16u * (unsigned)(lane_now() >> 4);     // + parity base + 256 (global head / chunk)
     // ================= x += Attention(x) =================
     {
       make_operands(true);
@@ -915,14 +951,16 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
           sp1 = MDT_MFMA_F32(kTt[1][r], qT[1][r], sp1, 0, 0, 0);
         }
         const f32x4 mine = sp0 + sp1;
-        red[wave * 64 + lane] = mine;
+        f32x4* redl = red + lane_now();
+        redl[wave * 64] = mine;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         MDT_BARRIER();                         // B(first output sub-tile) + partial exchange
-        const f32x4 other = red[(wave ^ 1) * 64 + lane];
+        const f32x4 other = redl[(wave ^ 1) * 64];
         prefetch2(kO, slot_of(tau), 1);
         const f32x4 s01 = fh ? (other + mine) : (mine + other);
         f32x4 st;
         float mx = -INFINITY;
+        if constexpr (!F32) kbits = self_mask(lane_now());
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float sv = ((kbits >> r) & 1u) ? s01[r] * scale2 : -INFINITY;
@@ -979,6 +1017,7 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
         phase(kT, IC1{}, kT, false, qT, xh + 4, xl + 4);
         MDT_BARRIER();                         // B(K tile)
         const unsigned char* sk = slot_of(tau);
+        if constexpr (!F32) cross_consts(lane_now(), kb0, vb0, okbits);      // per head, from the opaque lane id (see lane_now())
         {
           f32x4 bq[2];
           lds_read_f4_off<0>(bq[0], bl + 256 * h); lds_read_f4_off<64>(bq[1], bl + 256 * h);
@@ -1004,10 +1043,11 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
         for (int kt = 0; kt < KTM; ++kt) { sp0[kt] = MDT_MFMA_F32(k0[kt].z, qT[0][2], sp0[kt], 0, 0, 0); sp1[kt] = MDT_MFMA_F32(k1[kt].z, qT[1][2], sp1[kt], 0, 0, 0); }
 #pragma unroll
         for (int kt = 0; kt < KTM; ++kt) { sp0[kt] = MDT_MFMA_F32(k0[kt].w, qT[0][3], sp0[kt], 0, 0, 0); sp1[kt] = MDT_MFMA_F32(k1[kt].w, qT[1][3], sp1[kt], 0, 0, 0); }
+        f32x4* redl = red + lane_now();
 #pragma unroll
         for (int kt = 0; kt < KTM; ++kt) {
           st[kt] = sp0[kt] + sp1[kt];
-          red[(kt * 4 + wave) * 64 + lane] = st[kt];
+          redl[(kt * 4 + wave) * 64] = st[kt];
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         ++tau;
@@ -1016,7 +1056,7 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
         float mx = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < KTM; ++kt) {
-          const f32x4 other = red[(kt * 4 + (wave ^ 1)) * 64 + lane];
+          const f32x4 other = redl[(kt * 4 + (wave ^ 1)) * 64];
           const f32x4 s01 = fh ? (other + st[kt]) : (st[kt] + other);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -1167,9 +1207,11 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
     }
   }
 #endif
-  if (mvalid) {
+  const int ln_end = lane_now();                     // (row index and lane group re-derived here: see lane_now())
+  const int m_end = rb * 32 + rt * 16 + (ln_end & 15);
+  if (m_end < a.M) {
     if constexpr (NSPLIT == 1) {
-      float* xo = a.out + (int64_t)m * C + 4 * g + 128 * fh;
+      float* xo = a.out + (int64_t)m_end * C + 4 * (ln_end >> 4) + 128 * fh;
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         // (component-wise value selects: a select between the two array ELEMENTS becomes a select of their addresses and
@@ -1178,7 +1220,7 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
         store_nt(xo + 16 * c, make_float4(fh ? hi_[0] : lo_[0], fh ? hi_[1] : lo_[1], fh ? hi_[2] : lo_[2], fh ? hi_[3] : lo_[3]));
       }
     } else {
-      float* xo = a.out + (int64_t)m * C + 4 * g + 128 * fh + 64 * hh;
+      float* xo = a.out + (int64_t)m_end * C + 4 * (ln_end >> 4) + 128 * fh + 64 * hh;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const f32x4 q0 = accT[c], q1 = accT[4 + c], q2 = accT[8 + c], q3 = accT[12 + c];
