@@ -27,7 +27,15 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};   // source of padded rows
 
-__device__ __forceinline__ float gelu16(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// exact-erf GELU with the branch-free erf of the ring kernels (Abramowitz-Stegun 7.1.26, |error| < 1.5e-7: far inside this mode's
+// bf16 budget): the erff of round 3 made the feed-forward up-projection's epilogue VALU-bound
+__device__ __forceinline__ float gelu16(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float erfa = 1.0f - poly * __expf(-z * z);
+  return 0.5f * x * (1.0f + copysignf(erfa, x));
+}
 
 template <int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(64 * WM * WN) void k_gemm_b16(Gemm16Args g) {
@@ -134,46 +142,68 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_b16(Gemm16Args g) {
     compute(kc & 1);
   }
 
-  // ---- epilogue.  32x32 C/D layout: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) ----
+  // ---- epilogue.  32x32 C/D layout: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5): for a fixed register a
+  // half-wave holds 32 consecutive columns of ONE row.  Written straight from the accumulators that is 128-byte segments, one
+  // row per instruction, and -- what hurt -- the residual comes back the same way: 4-byte loads, one round trip per register pair
+  // (round 3: the GEMMs with a residual ran at 160-220 TFLOP/s against 480-600 for the same shapes without, 14 % of a configs[4]
+  // evaluation).  Now every wave parks one 32 x (32 TN) block of its accumulators in its own corner of the (idle) staging LDS as
+  // fp32 rows of pitch 72 floats (both the accumulator-order writes and the row-order reads are conflict-free) and walks it row
+  // by row: 16 lanes per row, float4 each -- bias, GELU, residual (float4 loads, all requested before the first store of the
+  // pass) and the fp32 store and / or the bf16 store as 16- / 8-byte accesses of 256- / 128-byte row segments.
+  __syncthreads();                                  // every wave is done reading the last stage
+  constexpr int EP = 72;                            // floats per parked row
+  float* ws = reinterpret_cast<float*>(smem) + wave * (32 * EP);
+  static_assert(NW * 32 * EP * 4 <= 2 * STAGE, "parking area inside the staging buffers");
+  unsigned short* o16 = g.out16 ? reinterpret_cast<unsigned short*>(g.out) : g.copy16;
+  const int ld16 = g.out16 ? g.ldc : g.N, oc16 = g.out16 ? g.o_col : 0;
+  const int er = lane >> 4, ec = (lane & 15) * 4;   // this lane's row inside a group of 4 rows, its first column
 #pragma unroll
-  for (int b = 0; b < TN; ++b) {
-    const int col = n0 + wc * 32 * TN + b * 32 + li;
-    const bool cok = col < g.N;
-    const float bias = (g.bias && cok) ? g.bias[col] : 0.f;
-    // Register pairs (r, r + 1) are two consecutive rows of one column.  fp32 output: plain stores.  bf16 output (out16: the
-    // only reader is another bf16 x bf16 GEMM; ldc in bf16 elements) or bf16 COPY of the fp32 output (copy16: the residual
-    // stream as the next GEMM's A operand): neighbouring lanes swap one value of each pair, so that a lane stores two
-    // consecutive columns of ONE row as 4 bytes.
-    unsigned short* o16 = g.out16 ? reinterpret_cast<unsigned short*>(g.out) : g.copy16;
-    const int ld16 = g.out16 ? g.ldc : g.N, oc16 = g.out16 ? g.o_col : 0;
-    const bool odd = li & 1;
+  for (int a = 0; a < TM; ++a) {
 #pragma unroll
-    for (int a = 0; a < TM; ++a)
+    for (int b = 0; b < TN; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        const int mb = m0 + wr * 32 * TM + a * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
-        const bool ok0 = cok && mb < g.M, ok1 = cok && mb + 1 < g.M;
-        float v0 = acc[a][b][r] + bias, v1 = acc[a][b][r + 1] + bias;
-        if (g.act == 1) { v0 = gelu16(v0); v1 = gelu16(v1); }
-        if (g.res) {
-          if (ok0) v0 += g.res[(int64_t)mb * g.ldr + col];
-          if (ok1) v1 += g.res[(int64_t)(mb + 1) * g.ldr + col];
+      for (int r = 0; r < 16; ++r) ws[((r & 3) + 8 * (r >> 2) + 4 * lh) * EP + b * 32 + li] = acc[a][b][r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // same wave writes and reads: no barrier needed
+    constexpr int CW = 32 * TN;                                   // columns of the block (64)
+    constexpr int RPP = 64 / (CW / 4);                            // rows per pass of the wave (4)
+    const int mrow0 = m0 + wr * 32 * TM + a * 32, ncol = n0 + wc * CW + ec;
+    const bool cok = ec < CW && ncol < g.N;                       // (N is a multiple of 16: a float4 never straddles it)
+    float4 bia = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g.bias && cok) bia = *reinterpret_cast<const float4*>(g.bias + ncol);
+#pragma unroll
+    for (int p0 = 0; p0 < 32; p0 += 4 * RPP) {                    // 4 row groups per batch: their residual loads fly together
+      float4 v[4], rs[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int row = p0 + u * RPP + er, m = mrow0 + row;
+        ok[u] = cok && m < g.M;
+        v[u] = *reinterpret_cast<const float4*>(ws + row * EP + ec);
+        rs[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g.res && ok[u]) rs[u] = *reinterpret_cast<const float4*>(g.res + (int64_t)m * g.ldr + ncol);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int m = mrow0 + p0 + u * RPP + er;
+        float x[4] = {v[u].x + bia.x, v[u].y + bia.y, v[u].z + bia.z, v[u].w + bia.w};
+        if (g.act == 1) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) x[k] = gelu16(x[k]);
         }
-        if (!g.out16) {
-          if (ok0) g.out[(int64_t)mb * g.ldc + g.o_col + col] = v0;
-          if (ok1) g.out[(int64_t)(mb + 1) * g.ldc + g.o_col + col] = v1;
-        }
-        if (o16) {
-          const float recv = __shfl_xor(odd ? v0 : v1, 1, 64);
-          const float lo = odd ? recv : v0, hi = odd ? v1 : recv;
-          const int m = mb + (odd ? 1 : 0);
-          if (cok && m < g.M) {
-            const unsigned pk = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)lo) |
-                                ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)hi) << 16);
-            *reinterpret_cast<unsigned*>(o16 + (int64_t)m * ld16 + oc16 + (col & ~1)) = pk;
+        x[0] += rs[u].x; x[1] += rs[u].y; x[2] += rs[u].z; x[3] += rs[u].w;
+        if (ok[u]) {
+          if (!g.out16) *reinterpret_cast<float4*>(g.out + (int64_t)m * g.ldc + g.o_col + ncol) = make_float4(x[0], x[1], x[2], x[3]);
+          if (o16) {
+            unsigned short h[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) h[k] = __builtin_bit_cast(unsigned short, (__bf16)x[k]);
+            *reinterpret_cast<uint2*>(o16 + (int64_t)m * ld16 + oc16 + ncol) =
+                make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
           }
         }
       }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the block has been read before the next one is parked
   }
 }
 
@@ -233,6 +263,59 @@ __global__ __launch_bounds__(256) void k_prep16(Prep16Args g) {
   unsigned short* dst = g.out + (int64_t)row * g.cin;
   float mean = 0.f, rstd = 1.f;
   if constexpr (PRO == 1) {
+    if (g.cin <= 1024) {
+      // LayerNorm of a row of up to 1024 channels with the row held in registers: ONE pass over memory instead of three
+      // (round 3: 2.9-3.1 TB/s for this kernel; the statistics re-read the row from the L2 twice).  Lane `sub` of the row's 16
+      // lanes owns the 8-channel groups sub, sub + 16, ...: the same 32-byte pieces it converts and writes below.
+      float4 xa[8], xb[8];
+      const int ng = g.cin / 8;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int e = sub + 16 * k;
+        const bool in = e < ng;
+        xa[k] = in ? *reinterpret_cast<const float4*>(src + 8 * e) : make_float4(0.f, 0.f, 0.f, 0.f);
+        xb[k] = in ? *reinterpret_cast<const float4*>(src + 8 * e + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += ((xa[k].x + xa[k].y) + (xa[k].z + xa[k].w)) + ((xb[k].x + xb[k].y) + (xb[k].z + xb[k].w));
+#pragma unroll
+      for (int off = 8; off >= 1; off >>= 1) s += __shfl_xor(s, off, 16);
+      mean = s / (float)g.cin;
+      float ss = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (sub + 16 * k < ng) {
+          const float d[8] = {xa[k].x - mean, xa[k].y - mean, xa[k].z - mean, xa[k].w - mean,
+                              xb[k].x - mean, xb[k].y - mean, xb[k].z - mean, xb[k].w - mean};
+          ss += ((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) + ((d[4] * d[4] + d[5] * d[5]) + (d[6] * d[6] + d[7] * d[7]));
+        }
+      }
+#pragma unroll
+      for (int off = 8; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 16);
+      rstd = 1.0f / sqrtf(ss / (float)g.cin + g.eps);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int e = sub + 16 * k;
+        if (e < ng) {
+          const int c0 = 8 * e;
+          const float4 g0 = *reinterpret_cast<const float4*>(g.p0 + c0), g1 = *reinterpret_cast<const float4*>(g.p0 + c0 + 4);
+          const float4 b0 = *reinterpret_cast<const float4*>(g.p1 + c0), b1 = *reinterpret_cast<const float4*>(g.p1 + c0 + 4);
+          const float x[8] = {(xa[k].x - mean) * rstd * g0.x + b0.x, (xa[k].y - mean) * rstd * g0.y + b0.y,
+                              (xa[k].z - mean) * rstd * g0.z + b0.z, (xa[k].w - mean) * rstd * g0.w + b0.w,
+                              (xb[k].x - mean) * rstd * g1.x + b1.x, (xb[k].y - mean) * rstd * g1.y + b1.y,
+                              (xb[k].z - mean) * rstd * g1.z + b1.z, (xb[k].w - mean) * rstd * g1.w + b1.w};
+          unsigned short h[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) h[q] = __builtin_bit_cast(unsigned short, (__bf16)x[q]);
+          uint4 o;
+          o.x = h[0] | ((unsigned)h[1] << 16); o.y = h[2] | ((unsigned)h[3] << 16);
+          o.z = h[4] | ((unsigned)h[5] << 16); o.w = h[6] | ((unsigned)h[7] << 16);
+          *reinterpret_cast<uint4*>(dst + c0) = o;
+        }
+      }
+      return;
+    }
     float s = 0.f;
     for (int e = sub; e < g.cin / 4; e += 16) {
       const float4 v = reinterpret_cast<const float4*>(src)[e];
