@@ -436,6 +436,10 @@ class UNetCompiler:
         gain / bias offsets then hold 2C entries."""
         c = x.ld
         nsrc = 2 if x2 is not None else 1
+        if taps == 3 and x.rows == 1:
+            # ONE token per sample (configs[2]'s 256-channel level): both neighbours of a k = 3 convolution are zero padding
+            # (modules.py:105-112: padding = 1), their products are exactly 0 -- only the centre tap is streamed and multiplied
+            w, taps = w[:, :, 1:2], 1
         assert w.shape == (c, nsrc * c, taps) and out.ld == c and out.rows == x.rows, (name, tuple(w.shape), c, taps)
         assert x2 is None or (x2.ld == c and x2.rows == x.rows and film is None)
         tiles = [self._wtile(w[64 * ch: 64 * ch + 64, s * c + 128 * kh: s * c + 128 * kh + 128, tap])
@@ -466,7 +470,7 @@ class UNetCompiler:
         if isinstance(film, tuple):
             op._film = film
         self._emit(op)
-        self.flops += 2 * x.rows * c * c * taps * nsrc
+        self.flops += 2 * x.rows * c * c * taps * nsrc            # executed (the skipped padding products are not counted)
 
     def _resnet_rconv(self, xa: Ten, xb: Optional[Ten], scale_b: float, p: str, c: int, groups: int,
                       free_input: bool) -> Ten:
