@@ -11,6 +11,8 @@
 //   * O^T = V^T P^T  (A = V^T, B = P^T).  With the k-mapping j = 4*kq + s the B operand of step s for lane
 //     quarter kq is exactly that lane's own accumulator register r = s: the probabilities never move.
 //   * O^T lands as [d = 16dt + 4g + r][i]: each lane stores 4 consecutive features (16 B) of its query row.
+#include <algorithm>
+
 #include "mdt_kernels.h"
 
 namespace mdt {
@@ -288,139 +290,260 @@ hipError_t launch_attn(const AttnArgs& a, hipStream_t s) {
 //                  row 16 kt + 4 g + s at floats [64 half + 4 lo, +4), a full 256 B row segment per lane quarter, and
 //                  lane (query, g) ends with out[query][64 half + 16 g + 4 r .. +4) per r = one dwordx4 store.
 // ------------------------------------------------------------------------------------------------------------------
-// RT row tiles of ONE sample per wave: the context rows (both operand layouts) are loaded once per wave, so with RT = 2 a
-// sample with 17..32 (token, head) rows reads its 2 x 32 KB of context once instead of twice -- the launch is bound by that
-// L2 -> CU traffic (4096 samples x 2 tiles x 72 KB = 590 MB per launch), not by its MFMAs.
-template <int KT, int RT>
-__global__ __launch_bounds__(256) void k_attn_ctx(AttnArgs a) {
-  constexpr int D = 128;
-  const int R = a.T * a.heads;                         // rows per sample
-  const int QG = ((R + 15) / 16 + RT - 1) / RT;        // waves per sample
-  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (wid >= a.batch * QG) return;
-  const int b = wid / QG, qg = wid % QG;
-  const int lane = threadIdx.x & 63;
-  const int lo = lane & 15, g = lane >> 4;
-  const float* q = a.q + (int64_t)b * R * D;           // rows (token, head) are contiguous 128-float vectors
-  const float* c = a.k + (int64_t)b * a.kv_bstride * a.ldkv;
-  float* o = a.out + (int64_t)b * R * D;
+// lane-group exchanges over +-16 / +-32 lanes with the gfx950 permlane swaps (k_rconv.hip: VALU, no LDS round trip)
+#define MDT_XG(NAME, INSN, COMBINE)                                                      \
+  __device__ __forceinline__ float NAME(float v) {                                       \
+    float a = v, b = v;                                                                  \
+    asm("s_nop 1\n\t" INSN " %0, %1" : "+v"(a), "+v"(b));                                \
+    return COMBINE;                                                                      \
+  }
+MDT_XG(xg16_add, "v_permlane16_swap_b32", a + b)
+MDT_XG(xg32_add, "v_permlane32_swap_b32", a + b)
+MDT_XG(xg16_max, "v_permlane16_swap_b32", fmaxf(a, b))
+MDT_XG(xg32_max, "v_permlane32_swap_b32", fmaxf(a, b))
+#undef MDT_XG
 
-  int i[RT];
-  float qr[RT][32];
-#pragma unroll
-  for (int t = 0; t < RT; ++t) {
-    i[t] = (qg * RT + t) * 16 + lo;
-    const float4* p = reinterpret_cast<const float4*>(q + (int64_t)(i[t] < R ? i[t] : 0) * D + 4 * g);
-#pragma unroll
-    for (int cc = 0; cc < 8; ++cc) {
-      const float4 v = p[4 * cc];
-      qr[t][4 * cc] = v.x; qr[t][4 * cc + 1] = v.y; qr[t][4 * cc + 2] = v.z; qr[t][4 * cc + 3] = v.w;
-    }
-  }
-  f32x4 st[RT][KT];
-  float mx[RT];
-#pragma unroll
-  for (int t = 0; t < RT; ++t) mx[t] = -INFINITY;
-#pragma unroll
-  for (int kt = 0; kt < KT; ++kt) {
-    const int j = kt * 16 + lo;                        // A operand of S^T: key row j
-    const float4* p = reinterpret_cast<const float4*>(c + (int64_t)(j < a.Tk ? j : 0) * a.ldkv + 4 * g);
-    float kr[32];
-#pragma unroll
-    for (int cc = 0; cc < 8; ++cc) {
-      const float4 v = p[4 * cc];
-      kr[4 * cc] = v.x; kr[4 * cc + 1] = v.y; kr[4 * cc + 2] = v.z; kr[4 * cc + 3] = v.w;
-    }
-#pragma unroll
-    for (int t = 0; t < RT; ++t) {
-      f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0;
-#pragma unroll
-      for (int s_ = 0; s_ < 32; s_ += 2) {
-        s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[s_], qr[t][s_], s0, 0, 0, 0);
-        s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[s_ + 1], qr[t][s_ + 1], s1, 0, 0, 0);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int jj = kt * 16 + 4 * g + r;
-        const float sv = jj < a.Tk ? (s0[r] + s1[r]) * a.scale : -INFINITY;
-        st[t][kt][r] = sv;
-        mx[t] = fmaxf(mx[t], sv);
-      }
-    }
-  }
-#pragma unroll
-  for (int t = 0; t < RT; ++t) {
-    mx[t] = fmaxf(mx[t], __shfl_xor(mx[t], 16, 64));
-    mx[t] = fmaxf(mx[t], __shfl_xor(mx[t], 32, 64));
-    float sum = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float e = expf(st[t][kt][r] - mx[t]);
-        st[t][kt][r] = e;
-        sum += e;
-      }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.0f / sum;
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt) st[t][kt] *= inv;  // masked keys: exactly 0, times a finite (clamped) row below
-  }
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    f32x4 acc[RT][4];
-#pragma unroll
-    for (int t = 0; t < RT; ++t)
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) acc[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-      float4 vr[4];
-#pragma unroll
-      for (int s_ = 0; s_ < 4; ++s_) {
-        const int jj = kt * 16 + 4 * g + s_;           // key row this lane quarter feeds at step s
-        vr[s_] = *reinterpret_cast<const float4*>(c + (int64_t)(jj < a.Tk ? jj : 0) * a.ldkv + 64 * half + 4 * lo);
-      }
-#pragma unroll
-      for (int t = 0; t < RT; ++t)
-#pragma unroll
-        for (int s_ = 0; s_ < 4; ++s_) {
-          const float pr = st[t][kt][s_];
-          acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[s_].x, pr, acc[t][0], 0, 0, 0);
-          acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[s_].y, pr, acc[t][1], 0, 0, 0);
-          acc[t][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[s_].z, pr, acc[t][2], 0, 0, 0);
-          acc[t][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[s_].w, pr, acc[t][3], 0, 0, 0);
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < RT; ++t)
-      if (i[t] < R) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          *reinterpret_cast<float4*>(o + (int64_t)i[t] * D + 64 * half + 16 * g + 4 * r) =
-              make_float4(acc[t][0][r], acc[t][1][r], acc[t][2][r], acc[t][3][r]);
-      }
-  }
+__device__ __forceinline__ void lds_read_f4(f32x4& dst, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const unsigned char* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)p;
 }
 
+// Round 4: the context streams through LDS.  The first form loaded its operands straight from global memory into registers
+// (one dependent round trip per 16-key tile, then a second pass over the same rows for the value side): 3.1-3.8 TB/s with the
+// waves stalled on issue.  Now every wave owns a two-slot ring of 8 KB in LDS and walks a flat stream of
+// (work unit, 16-key chunk) pairs: the chunk two ahead is in flight by LDS-DMA (1 KB per instruction, fully coalesced) while
+// the current one is used for BOTH contractions out of LDS -- an online softmax (running maximum and sum per query row,
+// accumulators rescaled per chunk) needs each context row once.  The ring is private to the wave: no barrier anywhere, a
+// counted s_waitcnt vmcnt is the only synchronisation (loads return in order; the output stores of the previous unit are issued
+// a whole chunk before the next wait so that they are never what it waits for).
+//   LDS image of a chunk: 16 rows x 512 B, the 16-byte slots of a row XOR-swizzled with the row number THROUGH THE SOURCE ADDRESS
+//   of the DMA (its LDS side is lane-linear): the S-side reads (16 lanes = 16 rows, one slot) and the O-side reads (16 lanes =
+//   16 slots of one row) are both conflict-free.
 template <int RT>
-static void launch_attn_ctx_rt(const AttnArgs& a, hipStream_t s) {
-  const int qg = ((a.T * a.heads + 15) / 16 + RT - 1) / RT;
-  const dim3 grid((unsigned)((a.batch * qg + 3) / 4)), block(256);
-  switch ((a.Tk + 15) / 16) {
-    case 1: hipLaunchKernelGGL((k_attn_ctx<1, RT>), grid, block, 0, s, a); break;
-    case 2: hipLaunchKernelGGL((k_attn_ctx<2, RT>), grid, block, 0, s, a); break;
-    case 3: hipLaunchKernelGGL((k_attn_ctx<3, RT>), grid, block, 0, s, a); break;
-    default: hipLaunchKernelGGL((k_attn_ctx<4, RT>), grid, block, 0, s, a); break;
+__global__ __launch_bounds__(256, 2) void k_attn_ctx(AttnArgs a) {
+  constexpr int D = 128, CH = 8192;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds_all[4 * 2 * CH];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lo = lane & 15, g = lane >> 4;
+  unsigned char* ring = lds_all + wv * (2 * CH);
+  const int R = a.T * a.heads;                         // rows per sample
+  const int QG = (R + 16 * RT - 1) / (16 * RT);        // work units per sample
+  const int NCH = (a.Tk + 15) >> 4;                    // 16-key chunks per unit
+  const int W = gridDim.x * 4, total = a.batch * QG;
+  int u = blockIdx.x * 4 + wv;                         // this wave's units: u, u + W, ...
+  if (u >= total) return;
+  const int u0 = u;
+
+  // ---- the DMA side.  Stream elements of a unit: its RT query tiles (16 rows of q' each), then its NCH context chunks; every
+  // element is 16 rows x 512 B = one slot = eight 1 KB instructions, element sj goes to slot sj & 1.  The query rows travel the
+  // same way (and are copied LDS -> registers when their element is consumed) so that the launch has NO compiler-visible vector
+  // load: with one pending, hipcc guards its use -- and every LDS read behind an LDS-DMA -- with s_waitcnt vmcnt(0), which is
+  // the whole look-ahead.  Past the wave's last element the same eight instructions re-read an element of its first unit into
+  // the (free) slot: the counted wait below is vmcnt(8) on every path.
+  int su = u, se = 0, sj = 0;                          // next stream element to issue: unit, element of the unit, stream index
+  const int l5 = lane >> 5, p15 = lane & 15, p16 = lane & 16;
+  auto issue_next = [&]() {
+#if defined(MDT_TUNING) && defined(MDT_ABL_CTX_NODMA)   // timing only: the ring is filled twice and never again
+    if (sj >= 2) { ++sj; if (++se == RT + NCH) { se = 0; su += W; } return; }
+#endif
+    const int uu = su < total ? su : u0;
+    const int b = uu / QG, qg = uu - b * QG;
+    const bool isq = se < RT;
+    const unsigned char* base = isq ? reinterpret_cast<const unsigned char*>(a.q + (int64_t)b * R * D)
+                                    : reinterpret_cast<const unsigned char*>(a.k + (int64_t)b * a.kv_bstride * a.ldkv);
+    const int row0 = isq ? (qg * RT + se) * 16 : (se - RT) * 16, nrows = isq ? R : a.Tk, ld4 = (isq ? D : a.ldkv) * 4;
+    unsigned char* dst = ring + (sj & 1) * CH;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = 2 * i + l5;                        // row of the element this lane's 16 bytes belong to
+      int row = row0 + r;
+      row = row < nrows ? row : 0;                     // rows past the end: any valid row (masked scores / unstored outputs)
+      const int logical = p16 | (p15 ^ r);
+      __builtin_amdgcn_global_load_lds(base + (int64_t)row * ld4 + logical * 16, (lds_ptr)(dst + i * 1024), 16, 0, 0);
+    }
+    ++sj;
+    if (++se == RT + NCH) { se = 0; su += W; }
+  };
+
+  // S side: lane (key lo, quarter g) reads slot 4 cc + g of row lo (cc & 4 is the upper half of the row: +256 bytes);
+  // O side: lane (feature group lo, quarter g) reads slot 16 half + lo of row 4 g + s
+  unsigned aS[4], aV[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    aS[c] = lo * 512 + (((4 * c + g) ^ lo) << 4);
+    const int jr = 4 * g + c;
+    aV[c] = jr * 512 + ((lo ^ jr) << 4);
   }
+  f32x4 qr[RT][8];                                     // qr[t][cc][e] = q'[row lo of tile t][16 cc + 4 g + e]
+  int qi[RT];
+
+  f32x4 acc[RT][2][4];
+  float mx[RT], ls[RT];
+  int prev_unit = -1, prev_qi[RT];
+  auto store_prev = [&]() {                            // normalise and write the finished unit out of the accumulators
+    const int b = prev_unit / QG;
+    float* o = a.out + (int64_t)b * R * D;
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      const float inv = 1.0f / xg32_add(xg16_add(ls[t]));
+      if (prev_qi[t] < R) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            *reinterpret_cast<float4*>(o + (int64_t)prev_qi[t] * D + 64 * half + 16 * g + 4 * r) =
+                make_float4(acc[t][half][0][r] * inv, acc[t][half][1][r] * inv, acc[t][half][2][r] * inv, acc[t][half][3][r] * inv);
+      }
+    }
+  };
+
+  issue_next();
+  issue_next();
+  int j = 0;                                           // stream index of the element being consumed
+  for (; u < total; u += W) {
+    {
+      const int b = u / QG, qg = u - b * QG;
+#pragma unroll
+      for (int t = 0; t < RT; ++t, ++j) {              // the unit's query tiles: LDS -> registers (the S-side read pattern)
+        qi[t] = (qg * RT + t) * 16 + lo;
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        const unsigned cur = lds_addr(ring + (j & 1) * CH);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) lds_read_f4(qr[t][cc], cur + aS[cc & 3] + (cc & 4) * 64);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        issue_next();
+      }
+    }
+    for (int k = 0; k < NCH; ++k, ++j) {
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // element j has landed (eight younger loads may be in flight)
+      // fragment reads as inline asm with hand-counted lgkmcnt waits (the ring kernels' way, tools/isa_lint.py checks the
+      // landing registers): a compiler-visible LDS read behind an LDS-DMA costs an s_waitcnt vmcnt(0) -- the whole look-ahead
+      const unsigned cur = lds_addr(ring + (j & 1) * CH);
+      f32x4 st[RT];
+      f32x4 kr4[8], vr[2][4];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc) lds_read_f4(kr4[cc], cur + aS[cc & 3] + (cc & 4) * 64);
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) lds_read_f4(vr[0][s_], cur + aV[s_]);
+      asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
+        f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0;
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) {
+#if defined(MDT_TUNING) && defined(MDT_ABL_CTX_NOS)      // timing only: one of the 32 score MFMAs
+          if (cc) { s0[0] += kr4[cc][0] * qr[t][cc][1]; continue; }
+#endif
+          s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kr4[cc][0], qr[t][cc][0], s0, 0, 0, 0);
+          s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kr4[cc][1], qr[t][cc][1], s1, 0, 0, 0);
+          s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kr4[cc][2], qr[t][cc][2], s0, 0, 0, 0);
+          s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kr4[cc][3], qr[t][cc][3], s1, 0, 0, 0);
+        }
+        st[t] = s0 + s1;
+      }
+      if (k == 0) {
+        if (prev_unit >= 0) store_prev();              // a whole chunk of MFMAs before the next counted wait
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+          mx[t] = -INFINITY; ls[t] = 0.f; prev_qi[t] = qi[t];
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) acc[t][h][c4] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        prev_unit = u;
+      }
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {                   // online softmax: lane (query lo, quarter g) holds keys 4 g + r
+        float cm = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float sv = (k * 16 + 4 * g + r) < a.Tk ? st[t][r] * a.scale : -INFINITY;
+          st[t][r] = sv;
+          cm = fmaxf(cm, sv);
+        }
+#if defined(MDT_TUNING) && defined(MDT_ABL_CTX_NOSM)     // timing only: no running maximum, no exponentials, no rescale
+        ls[t] += st[t][0]; continue;
+#endif
+        cm = xg32_max(xg16_max(cm));
+        const float mn = fmaxf(mx[t], cm);             // finite: every chunk holds at least one key
+        const float sc = __expf(mx[t] - mn);
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = __expf(st[t][r] - mn);
+          st[t][r] = e;
+          sum += e;
+        }
+        ls[t] = ls[t] * sc + sum;
+        mx[t] = mn;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int c4 = 0; c4 < 4; ++c4) acc[t][h][c4] *= sc;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the value rows of half 0 (issued with the key rows)
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) lds_read_f4(vr[1][s_], cur + aV[s_] + 256);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        if (half == 1) {
+          __builtin_amdgcn_sched_barrier(0);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+          for (int s_ = 0; s_ < 4; ++s_) {
+            const float pr = st[t][s_];
+#if defined(MDT_TUNING) && defined(MDT_ABL_CTX_NOPV)     // timing only: a quarter of the output MFMAs
+            if (s_) { acc[t][half][0][0] += vr[half][s_][0] * pr; continue; }
+#endif
+            acc[t][half][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[half][s_][0], pr, acc[t][half][0], 0, 0, 0);
+            acc[t][half][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[half][s_][1], pr, acc[t][half][1], 0, 0, 0);
+            acc[t][half][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[half][s_][2], pr, acc[t][half][2], 0, 0, 0);
+            acc[t][half][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[half][s_][3], pr, acc[t][half][3], 0, 0, 0);
+          }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // (every read of this slot has returned: the last wait above) -- refill it
+      issue_next();
+    }
+  }
+  store_prev();
 }
 
 hipError_t launch_attn_ctx(const AttnArgs& a, hipStream_t s) {
   if (a.batch <= 0) return hipSuccess;
   if (a.Tk <= 0 || a.Tk > 64 || a.ldkv % 4 || a.T <= 0 || a.heads <= 0) return hipErrorInvalidValue;
-  if (a.T * a.heads > 16) launch_attn_ctx_rt<2>(a, s);     // two row tiles of a sample share the context loads
-  else launch_attn_ctx_rt<1>(a, s);
+  static int wgs = 0;                                  // two workgroups (8 waves, 128 KB of rings) per CU
+  if (!wgs) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    wgs = 2 * cus;
+#if defined(MDT_TUNING) && defined(MDT_ABL_CTX_OCC1)
+    wgs = cus;
+#endif
+  }
+  const int R = a.T * a.heads;
+  if (R > 16) {                                        // two row tiles of a sample share the context stream
+    const int units = a.batch * ((R + 31) / 32);
+    hipLaunchKernelGGL((k_attn_ctx<2>), dim3((unsigned)std::min(wgs, (units + 3) / 4)), dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL((k_attn_ctx<1>), dim3((unsigned)std::min(wgs, (a.batch + 3) / 4)), dim3(256), 0, s, a);
+  }
   return hipGetLastError();
 }
 

@@ -174,9 +174,12 @@ def test_attention(B, T, Tk, shared):
 
 
 @pytest.mark.parametrize("B,T,Tk,shared", [(3, 16, 64, False), (2, 32, 64, True), (5, 4, 40, False), (2, 1, 33, False),
-                                           (1, 64, 64, False), (3, 8, 16, True), (2, 3, 20, False), (3, 5, 64, True)])
+                                           (1, 64, 64, False), (3, 8, 16, True), (2, 3, 20, False), (3, 5, 64, True),
+                                           (2100, 1, 33, False), (1100, 4, 64, False), (650, 16, 20, True), (2500, 2, 9, False)])
 def test_attention_on_normalised_context(B, T, Tk, shared):
-    """MDT_OP_ATTN_CTX: softmax(q' c^T scale) c with keys = values = the context rows, against the interpreter and torch."""
+    """MDT_OP_ATTN_CTX: softmax(q' c^T scale) c with keys = values = the context rows, against the interpreter and torch.
+    The large batches give every wave of the (persistent) launch several work units: the stream of context chunks then runs
+    across unit boundaries (query rows reloaded, previous unit stored from the accumulators, 1 / 2 / 3 / 4 chunks per unit)."""
     H, F_ = 8, 128
     R = T * H
     act = torch.cat([rnd(B * R * F_, seed=1) * 0.3, rnd(B * Tk * F_, seed=2), torch.zeros(B * R * F_)])

@@ -312,7 +312,7 @@ def test_lowering_matches_reference_golden(case, mode, monkeypatch):
     assert abs(cu.flops_per_sample_eval - {"cfg1": 388.7e6}.get(case, cu.flops_per_sample_eval)) < 1e6
 
 
-_RING_UNITS = ("k_tblock32", "k_rconv", "k_tf128", "k_tf256", "k_rconv_f32", "k_tf128_f32", "k_tf256_f32")
+_RING_UNITS = ("k_tblock32", "k_rconv", "k_tf128", "k_tf256", "k_rconv_f32", "k_tf128_f32", "k_tf256_f32", "k_attn")
 
 
 @pytest.fixture(scope="module")
@@ -347,10 +347,13 @@ def test_ring_kernels_keep_their_arrays_in_registers(ring_kernel_reports):
     # The exact-fp32 instantiations (round 4: *_f32 units) are all at ZERO: k_tf256's fp32 phase needs two fragment sets instead
     # of three (a unit is 512 MFMA-pipe cycles, one unit of read-ahead covers the LDS latency), which is what the split form lacks.
     limits = {"k_tblock32": 24, "k_rconv": 0, "k_tf128": 0, "k_tf256": 16,      # bytes per lane
-              "k_rconv_f32": 0, "k_tf128_f32": 0, "k_tf256_f32": 0}
+              "k_rconv_f32": 0, "k_tf128_f32": 0, "k_tf256_f32": 0,
+              "k_attn": 0}        # k_attn_ctx (round 4: context streamed through a per-wave LDS ring, inline-asm fragment reads)
     for name, limit in limits.items():
         assert res[name], name
         for fn, v in res[name]:
+            if name == "k_attn" and "k_attn_ctx" not in fn:
+                continue
             if name.startswith("k_rconv") and re.search(r"ELi2ELi[01]ELb[01]EEEvNS_9RConvArgsE$", fn):
                 # two-source instantiations <..., NSRC = 2, PRO, F32>: only the 1x1 form without a prologue (PRO = 0) is on the
                 # default path (the concatenated inputs' residual convolution; C = 128, or C = 256 with the output channels
@@ -388,7 +391,7 @@ def test_no_instruction_touches_an_in_flight_fragment_read(ring_kernel_reports):
     assert isa_lint.lint_kernel([gl, "global_load_dword v9, v[2:3], off offset:128", "s_waitcnt vmcnt(0)", "v_mov_b32_e32 v1, v9"]) == []
     _, lint = ring_kernel_reports
     for name, (report, n_reads) in lint.items():
-        assert n_reads > 100, (name, n_reads)
+        assert n_reads > (50 if name == "k_attn" else 100), (name, n_reads)
         for kernel, violations in report.items():
             assert not violations, (name, kernel, violations[:3])
 

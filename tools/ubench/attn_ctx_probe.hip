@@ -1,0 +1,36 @@
+// Where does a launch of k_attn_ctx (csrc/k_attn.hip, the LDS-streamed form of round 4) spend its time?  The product kernel, compiled
+// here with its timing-only switches (-DMDT_TUNING -DMDT_ABL_CTX_*: WRONG results), at configs[2]'s shapes.
+//
+//   for v in "" -DMDT_ABL_CTX_NOSM -DMDT_ABL_CTX_NODMA -DMDT_ABL_CTX_OCC1 -DMDT_ABL_CTX_NOS -DMDT_ABL_CTX_NOPV; do
+//     hipcc -O3 -std=c++17 --offload-arch=gfx950 -DMDT_TUNING $v -Imoleculediffusiontransformer_amd/csrc -Iinclude \
+//         tools/ubench/attn_ctx_probe.hip -o /tmp/attn_ctx_probe && /tmp/attn_ctx_probe; done
+#include "../../moleculediffusiontransformer_amd/csrc/k_attn.hip"
+
+#include <vector>
+
+int main() {
+  const int B = 4096, H = 8, Tk = 64, F = 128;
+  for (int T : {4, 1}) {
+    const size_t nq = (size_t)B * T * H * F, nc = (size_t)B * Tk * F;
+    float *q, *c, *o;
+    (void)hipMalloc(&q, nq * 4); (void)hipMalloc(&c, nc * 4); (void)hipMalloc(&o, nq * 4);
+    std::vector<float> hq(nq), hc(nc);
+    for (size_t i = 0; i < nq; ++i) hq[i] = 0.3f * (float)((i * 2654435761u >> 8) % 2001 - 1000) / 1000.f;
+    for (size_t i = 0; i < nc; ++i) hc[i] = (float)((i * 40503u >> 4) % 2001 - 1000) / 1000.f;
+    (void)hipMemcpy(q, hq.data(), nq * 4, hipMemcpyHostToDevice); (void)hipMemcpy(c, hc.data(), nc * 4, hipMemcpyHostToDevice);
+    mdt::AttnArgs a{};
+    a.q = q; a.k = c; a.out = o; a.batch = B; a.T = T; a.Tk = Tk; a.heads = H; a.ldq = F; a.ldkv = F; a.ldo = F; a.kv_bstride = Tk;
+    a.scale = 0.125f;
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i) (void)mdt::launch_attn_ctx(a, 0);
+    (void)hipEventRecord(e0, 0);
+    const int reps = 50;
+    for (int i = 0; i < reps; ++i) (void)mdt::launch_attn_ctx(a, 0);
+    (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    const double bytes = (double)(nc + 2 * nq) * 4;
+    printf("T=%d: %.1f us per launch, %.2f TB/s algorithmic\n", T, ms * 1000 / reps, bytes / (ms / reps * 1e-3) / 1e12);
+    (void)hipFree(q); (void)hipFree(c); (void)hipFree(o);
+  }
+  return 0;
+}
