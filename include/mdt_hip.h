@@ -90,7 +90,7 @@ enum mdt_op_kind {
                           a, w = weight tiles, bias | none, out, res | none, p0 = gain, p1 = bias of the GroupNorm | none,
                           p3 = [scale | shift] | none (modules.py:117-121, :193-205)                             */
   MDT_OP_RESBLOCK = 10, /* a whole ResnetBlock1d with one GroupNorm group on a 64-token level (the U-Net's Patcher / Unpatcher,
-                          modules.py:145-205, 208-257) in one launch, (cin, cout) = (16, 64) | (64, 16):
+                          modules.py:145-205, 208-257) in one launch, padded (cin, cout) = (16, 64) | (64, 16) | (16, 16), see MDT_K_CIN_REAL:
                           out = conv3(silu(gn(conv3(silu(gn(a))) + b1) (scale + 1) + shift)) + b2 + to_out(a);
                           a [B][64][cin], w = bf16 hi/lo MFMA fragments (conv1 | conv2 | to_out k-steps),
                           bias = gamma1 | beta1 | b1 | gamma2 | beta2 | (b2 + to_out bias), out [B][64][cout],
@@ -195,7 +195,10 @@ enum mdt_rconv_i { MDT_R_T = 0, MDT_R_C = 1, MDT_R_LDA = 2, MDT_R_LDC = 3, MDT_R
 enum mdt_rconv_f { MDT_RF_EPS = 0, MDT_RF_IN_SCALE = 1, MDT_RF_IN_SCALE2 = 2 };
 enum mdt_resblock_i { MDT_K_T = 0, MDT_K_CIN = 1, MDT_K_COUT = 2, MDT_K_FILM_LD = 3,
                       MDT_K_WF32 = 4 /* 1: w = fp32 MFMA fragments [step][row tile][half lo][64 lanes][4] (lane (i, g) float r =
-                                        W[16 rt + i][the step's pair 8 g + 4 lo + r]), exact fp32 MFMA products */ };
+                                        W[16 rt + i][the step's pair 8 g + 4 lo + r]), exact fp32 MFMA products */,
+                      MDT_K_CIN_REAL = 5, MDT_K_COUT_REAL = 6 /* CIN / COUT are channel counts padded to 16; the GroupNorm
+                                        statistics run over the first CIN_REAL / COUT_REAL channels (0 = all of them); padded
+                                        gains, biases, weights -- hence outputs -- are zero */ };
 enum mdt_resblock_f { MDT_KF_EPS = 0 };
 
 enum mdt_attn_i {

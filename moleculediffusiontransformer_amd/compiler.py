@@ -566,22 +566,37 @@ class UNetCompiler:
         return frags
 
     def resblock_ok(self, rows: int, cin: int, cout: int, groups: int, p: str) -> bool:
+        # (padded channel counts: QMDiffusionForward's Patcher has 2 real input channels, its Unpatcher 1 real output channel)
         return (self.use_resblock and self.ring_mode and self.fuse_blocks and groups == 1 and rows == 64
-                and (cin, cout) in ((16, 64), (64, 16)) and (p + "to_out.weight") in self.sd)
+                and (pad16(cin), pad16(cout)) in ((16, 64), (64, 16), (16, 16)) and (p + "to_out.weight") in self.sd)
 
     def resblock(self, x: Ten, p: str, cin: int, cout: int, free_input: bool) -> Ten:
-        """ResnetBlock1d with one GroupNorm group on the 64-token level as ONE launch (MDT_OP_RESBLOCK)."""
+        """ResnetBlock1d with one GroupNorm group on the 64-token level as ONE launch (MDT_OP_RESBLOCK); cin / cout are the real
+        channel counts, the op works on the padded ones (zero gains / biases / weights on the padding)."""
         sd = self.sd
-        y = self._new(x.rows, cout, cout)
-        frags = (self._resblock_frags(sd[p + "block1.project.weight"].float(), self.wf32)
-                 + self._resblock_frags(sd[p + "block2.project.weight"].float(), self.wf32)
-                 + self._resblock_frags(sd[p + "to_out.weight"].float(), self.wf32))
-        vec = torch.cat([sd[p + "block1.groupnorm.weight"], sd[p + "block1.groupnorm.bias"], sd[p + "block1.project.bias"],
-                         sd[p + "block2.groupnorm.weight"], sd[p + "block2.groupnorm.bias"],
-                         sd[p + "block2.project.bias"] + sd[p + "to_out.bias"]]).float()
+        cin_p, cout_p = pad16(cin), pad16(cout)
+        y = self._new(x.rows, cout_p, cout)
+
+        def wpad(name, ci, co):
+            w = sd[p + name].float()
+            out = torch.zeros(pad16(co), pad16(ci), w.shape[2])
+            out[:co, :ci] = w
+            return out
+
+        def vpad(v, c):
+            out = torch.zeros(pad16(c))
+            out[:c] = v.float()
+            return out
+        frags = (self._resblock_frags(wpad("block1.project.weight", cin, cout), self.wf32)
+                 + self._resblock_frags(wpad("block2.project.weight", cout, cout), self.wf32)
+                 + self._resblock_frags(wpad("to_out.weight", cin, cout), self.wf32))
+        vec = torch.cat([vpad(sd[p + "block1.groupnorm.weight"], cin), vpad(sd[p + "block1.groupnorm.bias"], cin),
+                         vpad(sd[p + "block1.project.bias"], cout),
+                         vpad(sd[p + "block2.groupnorm.weight"], cout), vpad(sd[p + "block2.groupnorm.bias"], cout),
+                         vpad(sd[p + "block2.project.bias"] + sd[p + "to_out.bias"], cout)])
         ss_off = self.ss_total                       # FiLM vectors of this block inside the shared (scale | shift) row
         self.ss_offsets[p] = ss_off
-        self.ss_total += 2 * cout
+        self.ss_total += 2 * cout_p
         op = rt.MdtOp()
         op.kind = rt.OP_RESBLOCK
         op.a, op.out = x.ref(), y.ref()
@@ -589,10 +604,11 @@ class UNetCompiler:
         op.bias = _ref(rt.SP_WEIGHT, self.W.add(p + "resblock.vec", vec))
         op._film = ("ss", ss_off)
         i = op.i
-        i[rt.K_T], i[rt.K_CIN], i[rt.K_COUT], i[rt.K_FILM_LD], i[rt.K_WF32] = x.rows, cin, cout, cout, int(self.wf32)
+        i[rt.K_T], i[rt.K_CIN], i[rt.K_COUT], i[rt.K_FILM_LD], i[rt.K_WF32] = x.rows, cin_p, cout_p, cout_p, int(self.wf32)
+        i[rt.K_CIN_REAL], i[rt.K_COUT_REAL] = cin, cout
         op.f[0] = 1e-5
         self._emit(op)
-        self.flops += 2 * x.rows * (3 * cin * cout + 3 * cout * cout + cin * cout)
+        self.flops += 2 * x.rows * (3 * cin_p * cout_p + 3 * cout_p * cout_p + cin_p * cout_p)
         if free_input:
             self._free(x)
         return y

@@ -2,7 +2,10 @@
 // 208-257) in one launch:
 //     a1 = silu(GroupNorm_1group(x))                       h = conv_k3(a1) + b1
 //     a2 = silu(GroupNorm_1group(h) (scale + 1) + shift)   y = conv_k3(a2) + b2 + to_out_1x1(x) + b_out
-// for (CIN, COUT) = (16, 64) | (64, 16).  As separate launches (two GroupNorm-apply passes, three GEMMs) the five ops
+// for (CIN, COUT) = (16, 64) | (64, 16) | (16, 16); round 4: the channel counts are the PADDED ones (multiples of 16), the
+// GroupNorm statistics run over the first cin_real / cout_real channels only (QMDiffusionForward's Patcher takes 2 real
+// channels in 16, its Unpatcher leaves 1 in 16: padded gains, biases and weights are zero, so are the padded outputs).
+// As separate launches (two GroupNorm-apply passes, three GEMMs) the five ops
 // move 16 MB tensors through HBM between launches of 10-20 us each: 76 + 72 us per U-Net evaluation at batch 1024.
 //
 // One sample (64 tokens) per group of 4 waves, two samples in flight per workgroup (8 waves = 2 per SIMD: while one
@@ -196,15 +199,17 @@ __global__ __launch_bounds__(512) void k_resblock(ResBlockArgs a) {
 
   // mean and 1 / sqrt(var + eps) over the sample (4 waves x 64 lanes x N values): two-pass inside the wave, then the
   // waves' (mean, M2) pairs merged through LDS with ONE barrier (Chan et al.: M2 = sum M2_k + n sum (mean_k - mean)^2)
-  auto sample_stats = [&](auto&& value, auto nc, int slot, float& mean, float& rstd) {
+  // (`real(k)`: the value belongs to a real channel; `cnt`: real values per wave -- the same for the four waves of a sample)
+  auto sample_stats = [&](auto&& value, auto&& real, auto nc, float cnt, int slot, float& mean, float& rstd) {
     constexpr int N = decltype(nc)::value;
+    const float icnt = 1.0f / cnt;
     float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < N; ++k) s += value(k);
-    const float mw = wave_sum(s) * (1.0f / (64 * N));
+    for (int k = 0; k < N; ++k) s += real(k) ? value(k) : 0.f;
+    const float mw = wave_sum(s) * icnt;
     float m2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < N; ++k) { const float d = value(k) - mw; m2 += d * d; }
+    for (int k = 0; k < N; ++k) { const float d = real(k) ? value(k) - mw : 0.f; m2 += d * d; }
     m2 = wave_sum(m2);
     if (lane == 0) reinterpret_cast<float2*>(red)[(half * 2 + slot) * 4 + w] = make_float2(mw, m2);
     __syncthreads();
@@ -212,9 +217,10 @@ __global__ __launch_bounds__(512) void k_resblock(ResBlockArgs a) {
     const float4 p23 = reinterpret_cast<const float4*>(red)[(half * 2 + slot) * 2 + 1];
     mean = 0.25f * ((p01.x + p01.z) + (p23.x + p23.z));
     const float d0 = p01.x - mean, d1 = p01.z - mean, d2 = p23.x - mean, d3 = p23.z - mean;
-    const float M2 = ((p01.y + p01.w) + (p23.y + p23.w)) + (64 * N) * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
-    rstd = __builtin_amdgcn_rsqf(M2 * (1.0f / (256 * N)) + a.eps);
+    const float M2 = ((p01.y + p01.w) + (p23.y + p23.w)) + cnt * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+    rstd = __builtin_amdgcn_rsqf(M2 * (0.25f * icnt) + a.eps);
   };
+  const float cnt1 = 16.0f * (float)a.cin_real, cnt2 = 16.0f * (float)a.cout_real;   // a wave holds 16 tokens of its sample
 
   __syncthreads();
   const int step = 2 * gridDim.x;
@@ -235,7 +241,8 @@ __global__ __launch_bounds__(512) void k_resblock(ResBlockArgs a) {
 #pragma unroll
     for (int j = 0; j < NV; ++j) { xv[j][0] = xn[j].x; xv[j][1] = xn[j].y; xv[j][2] = xn[j].z; xv[j][3] = xn[j].w; }
     float mean1, rstd1;
-    sample_stats([&](int k) { return xv[k >> 2][k & 3]; }, std::integral_constant<int, 4 * NV>{}, 0, mean1, rstd1);
+    sample_stats([&](int k) { return xv[k >> 2][k & 3]; }, [&](int k) { return 4 * c4 + (k & 3) < a.cin_real; },
+                 std::integral_constant<int, 4 * NV>{}, cnt1, 0, mean1, rstd1);
     {
       const float ga[4] = {g1.x, g1.y, g1.z, g1.w}, be[4] = {be1.x, be1.y, be1.z, be1.w};
 #pragma unroll
@@ -315,7 +322,8 @@ __global__ __launch_bounds__(512) void k_resblock(ResBlockArgs a) {
     fold_acc2();
     // ---- GroupNorm 2 + FiLM + SiLU on the accumulators, split -> a2 planes ----
     float mean2, rstd2;
-    sample_stats([&](int k) { return acc[k >> 2][k & 3]; }, std::integral_constant<int, 4 * RT>{}, 1, mean2, rstd2);
+    sample_stats([&](int k) { return acc[k >> 2][k & 3]; }, [&](int k) { return 16 * (k >> 2) + 4 * g + (k & 3) < a.cout_real; },
+                 std::integral_constant<int, 4 * RT>{}, cnt2, 1, mean2, rstd2);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       const float fav[4] = {fa[rt].x, fa[rt].y, fa[rt].z, fa[rt].w}, fbv[4] = {fb[rt].x, fb[rt].y, fb[rt].z, fb[rt].w};
@@ -352,7 +360,7 @@ __global__ __launch_bounds__(512) void k_resblock(ResBlockArgs a) {
 }
 
 bool resblock_supported(int T_, int cin, int cout) {
-  return T_ == T && ((cin == 16 && cout == 64) || (cin == 64 && cout == 16));
+  return T_ == T && ((cin == 16 && cout == 64) || (cin == 64 && cout == 16) || (cin == 16 && cout == 16));
 }
 
 template <int CIN, int COUT, bool F32>
@@ -375,6 +383,8 @@ static hipError_t launch_rb(const ResBlockArgs& a, hipStream_t s) {
 hipError_t launch_resblock(const ResBlockArgs& a, hipStream_t s) {
   if (a.B <= 0) return hipSuccess;
   if (!resblock_supported(a.T, a.cin, a.cout)) return hipErrorInvalidValue;
+  if (a.cin_real <= 0 || a.cin_real > a.cin || a.cout_real <= 0 || a.cout_real > a.cout) return hipErrorInvalidValue;
+  if (a.cin == 16 && a.cout == 16) return a.wf32 ? launch_rb<16, 16, true>(a, s) : launch_rb<16, 16, false>(a, s);
   if (a.wf32) return a.cin == 16 ? launch_rb<16, 64, true>(a, s) : launch_rb<64, 16, true>(a, s);
   return a.cin == 16 ? launch_rb<16, 64, false>(a, s) : launch_rb<64, 16, false>(a, s);
 }

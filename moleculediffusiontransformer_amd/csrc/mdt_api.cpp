@@ -148,6 +148,8 @@ static const char* validate(const mdt_op& o, int idx, char* buf, size_t nbuf) {
         return bad("shape not supported by the fused ResNet block");
       if (!o.a.space || !o.w.space || !o.bias.space || !o.out.space) return bad("missing operand");
       if (o.i[MDT_K_WF32] != 0 && o.i[MDT_K_WF32] != 1) return bad("WF32 must be 0 (split-bf16 fragments) or 1 (fp32 fragments)");
+      if (o.i[MDT_K_CIN_REAL] < 0 || o.i[MDT_K_CIN_REAL] > o.i[MDT_K_CIN] || o.i[MDT_K_COUT_REAL] < 0 || o.i[MDT_K_COUT_REAL] > o.i[MDT_K_COUT])
+        return bad("CIN_REAL / COUT_REAL must be 0 (= CIN / COUT) or a channel count inside the padded one");
       break;
     case MDT_OP_ATTN:
       if (o.i[MDT_A_T] <= 0 || o.i[MDT_A_T] > 8192 || o.i[MDT_A_TK] <= 0 || o.i[MDT_A_TK] > 8192)
@@ -375,6 +377,8 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
         a.x = ptr(o.a); a.out = ptr(o.out); a.w = ptr(o.w); a.vec = ptr(o.bias); a.film = ptr(o.p3);
         a.B = B; a.T = o.i[MDT_K_T]; a.cin = o.i[MDT_K_CIN]; a.cout = o.i[MDT_K_COUT]; a.film_ld = o.i[MDT_K_FILM_LD];
         a.eps = o.f[MDT_KF_EPS]; a.wf32 = o.i[MDT_K_WF32];
+        a.cin_real = o.i[MDT_K_CIN_REAL] > 0 ? o.i[MDT_K_CIN_REAL] : a.cin;
+        a.cout_real = o.i[MDT_K_COUT_REAL] > 0 ? o.i[MDT_K_COUT_REAL] : a.cout;
         if (!missing) e = mdt::launch_resblock(a, stream);
         break;
       }

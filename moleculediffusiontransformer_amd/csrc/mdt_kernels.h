@@ -161,6 +161,7 @@ struct ResBlockArgs {
   int B, T, cin, cout, film_ld;
   float eps;
   int wf32;            // 1: w = fp32 MFMA fragments [step][row tile][half][64 lanes][4], exact fp32 products (MDT_K_WF32)
+  int cin_real, cout_real;   // channels the GroupNorm statistics run over (<= cin / cout: the rest is zero padding)
 };
 bool resblock_supported(int T, int cin, int cout);
 hipError_t launch_resblock(const ResBlockArgs& a, hipStream_t s);

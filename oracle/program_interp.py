@@ -307,14 +307,18 @@ def _resblock(op, bufs: Buffers, B: int) -> None:
     g1, be1, b1 = vec[:cin], vec[cin: 2 * cin], vec[2 * cin: 2 * cin + cout]
     g2, be2, bo = (vec[2 * cin + cout: 2 * cin + 2 * cout], vec[2 * cin + 2 * cout: 2 * cin + 3 * cout],
                    vec[2 * cin + 3 * cout:])
-    x = bufs.view(op.a, B, B * T * cin).view(B, T, cin).transpose(1, 2)
-    h = F.conv1d(_silu(F.group_norm(x, 1, g1, be1, float(f[0]))), ws[0], b1, padding=1)
-    h = F.group_norm(h, 1, g2, be2, float(f[0]))
+    # cin / cout are padded channel counts; the block itself has ci / co channels (MDT_K_CIN_REAL / MDT_K_COUT_REAL, 0 = all)
+    ci, co = (i[rt.K_CIN_REAL] or cin), (i[rt.K_COUT_REAL] or cout)
+    x = bufs.view(op.a, B, B * T * cin).view(B, T, cin).transpose(1, 2)[:, :ci]
+    h = F.conv1d(_silu(F.group_norm(x, 1, g1[:ci], be1[:ci], float(f[0]))), ws[0][:co, :ci], b1[:co], padding=1)
+    h = F.group_norm(h, 1, g2[:co], be2[:co], float(f[0]))
     if op.p3.space != rt.SP_NONE:
         ss = bufs.view(op.p3, B, fld + cout)
-        h = h * (ss[:cout, None] + 1.0) + ss[fld: fld + cout, None]
-    y = F.conv1d(_silu(h), ws[1], bo, padding=1) + F.conv1d(x, ws[2])
-    bufs.view(op.out, B, B * T * cout).view(B, T, cout)[:] = y.transpose(1, 2)
+        h = h * (ss[:co, None] + 1.0) + ss[fld: fld + co, None]
+    y = F.conv1d(_silu(h), ws[1][:co, :co], bo[:co], padding=1) + F.conv1d(x, ws[2][:co, :ci])
+    out = bufs.view(op.out, B, B * T * cout).view(B, T, cout)
+    out.zero_()
+    out[:, :, :co] = y.transpose(1, 2)
 
 
 def _tblock(op, bufs: Buffers, B: int) -> None:

@@ -683,14 +683,16 @@ def _resblock_case(cin, cout, film):
           p + "block2.project.bias": 0.1 * rnd(cout, seed=8),
           p + "to_out.weight": rnd(cout, cin, 1, seed=9, scale=cin ** -0.5), p + "to_out.bias": 0.1 * rnd(cout, seed=10)}
     comp = UNetCompiler(inverse_unet_config(16, 64, 128, 12), 64, 12, sd)
-    x = Ten(A, 0, 64, cin)
+    cin_p, cout_p = (cin + 15) // 16 * 16, (cout + 15) // 16 * 16        # the op works on channel counts padded to 16
+    x = Ten(A, 0, 64, cin_p, cin)
     assert comp.resblock_ok(64, cin, cout, 1, p)
     y = comp.resnet(x, p, cin, cout, 1, free_input=False)
     assert len(comp.ops) == 1 and comp.ops[0].kind == rt.OP_RESBLOCK
     op = comp.ops[0]
-    op.out = ref(A, 64 * cin)
+    op.out = ref(A, 64 * cin_p)
     op.p3 = ref(S, 0) if film else ref(0, 0)
-    shr = 0.3 * rnd(2 * cout, seed=11)
+    shr = torch.zeros(2 * cout_p)                      # [scale(cout_p) | shift(cout_p)], zero on the padding
+    shr[:cout], shr[cout_p: cout_p + cout] = 0.3 * rnd(cout, seed=11), 0.3 * rnd(cout, seed=12)
 
     def closed_form(xin):                              # xin [B, 64, cin]
         F = torch.nn.functional
@@ -699,27 +701,33 @@ def _resblock_case(cin, cout, film):
                      sd[p + "block1.project.weight"], sd[p + "block1.project.bias"], padding=1)
         h = F.group_norm(h, 1, sd[p + "block2.groupnorm.weight"], sd[p + "block2.groupnorm.bias"], 1e-5)
         if film:
-            h = h * (shr[:cout].view(1, cout, 1) + 1) + shr[cout:].view(1, cout, 1)
+            h = h * (shr[:cout].view(1, cout, 1) + 1) + shr[cout_p: cout_p + cout].view(1, cout, 1)
         yt = F.conv1d(F.silu(h), sd[p + "block2.project.weight"], sd[p + "block2.project.bias"], padding=1)
         return (yt + F.conv1d(xt, sd[p + "to_out.weight"], sd[p + "to_out.bias"])).transpose(1, 2)
     return comp, op, shr, closed_form
 
 
-@pytest.mark.parametrize("cin,cout", [(16, 64), (64, 16)])
+@pytest.mark.parametrize("cin,cout", [(16, 64), (64, 16), (16, 16), (2, 16), (16, 1), (8, 16), (16, 8), (5, 50)])
 @pytest.mark.parametrize("B,film", [(1, True), (2, False), (7, True), (1030, True)])
 def test_fused_resnet_block(cin, cout, B, film, prod):
     """k_resblock (the Patcher / Unpatcher ResnetBlock1d in one launch; odd batches leave half a workgroup idle, 1030
-    samples wrap the persistent loop) against the interpreter and against torch's group_norm / conv1d."""
+    samples wrap the persistent loop) against the interpreter and against torch's group_norm / conv1d.  Channel counts that
+    are not multiples of 16 (QMDiffusionForward: 2 -> 16 and 16 -> 1; AnalogDiffusionFull: 8 -> 16, 16 -> 8) run padded, with
+    the GroupNorm statistics over the real channels only and exact zeros on the padding of the output."""
     comp, op, shr, closed_form = _resblock_case(cin, cout, film)
-    n_in, n_out = B * 64 * cin, B * 64 * cout
-    act = torch.cat([rnd(n_in, seed=12) * 1.5 + 0.3, torch.zeros(n_out)])
+    cin_p, cout_p = (cin + 15) // 16 * 16, (cout + 15) // 16 * 16
+    n_in, n_out = B * 64 * cin_p, B * 64 * cout_p
+    xin = torch.zeros(B, 64, cin_p)
+    xin[:, :, :cin] = (rnd(B * 64 * cin, seed=12) * 1.5 + 0.3).view(B, 64, cin)
+    act = torch.cat([xin.view(-1), torch.full((n_out,), 7.0)])
     (ga, _, _), (ca, _, _) = run_both([op], comp.W.pack(), act, shr, {}, B)
     og, oc = ga[n_in:], ca[n_in:]
     scale = max(1.0, oc.abs().max().item())
     assert torch.isfinite(og).all() and (og - oc).abs().max() < 1e-4 * scale, (og - oc).abs().max().item()
     assert torch.equal(ga[:n_in], ca[:n_in])
-    y = closed_form(act[:n_in].view(B, 64, cin))
-    assert (og.view(B, 64, cout) - y).abs().max() < 1e-4 * scale
+    y = closed_form(xin[:, :, :cin])
+    assert (og.view(B, 64, cout_p)[:, :, :cout] - y).abs().max() < 1e-4 * scale
+    assert (og.view(B, 64, cout_p)[:, :, cout:] == 0).all()
 
 
 @pytest.mark.parametrize("mode,split,with_pin", [(rt.TB_SELF, True, False), (rt.TB_SELF, True, True), (rt.TB_CROSS, True, True),
