@@ -321,9 +321,17 @@ __device__ __forceinline__ unsigned lds_addr(const unsigned char* p) {
 //   LDS image of a chunk: 16 rows x 512 B, the 16-byte slots of a row XOR-swizzled with the row number THROUGH THE SOURCE ADDRESS
 //   of the DMA (its LDS side is lane-linear): the S-side reads (16 lanes = 16 rows, one slot) and the O-side reads (16 lanes =
 //   16 slots of one row) are both conflict-free.
+#if defined(MDT_TUNING) && defined(MDT_ABL_CTX_CLOCK)   // probe only: shader-clock and 100 MHz stamps of workgroup 0, wave 0
+__device__ unsigned long long g_ctx_stamp[4 + 2 * 1024];   // [0..1]: workgroup 0's ticks; then (start, end) of every workgroup on the 100 MHz clock
+#endif
+
 template <int RT>
 __global__ __launch_bounds__(256, 2) void k_attn_ctx(AttnArgs a) {
   constexpr int D = 128, CH = 8192;
+#if defined(MDT_TUNING) && defined(MDT_ABL_CTX_CLOCK)
+  unsigned long long t0c, t0r;
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0c), "=s"(t0r)::"memory");
+#endif
   __shared__ __attribute__((aligned(1024))) unsigned char lds_all[4 * 2 * CH];
   typedef __attribute__((address_space(3))) void* lds_ptr;
   const int lane = threadIdx.x & 63;
@@ -522,6 +530,12 @@ __global__ __launch_bounds__(256, 2) void k_attn_ctx(AttnArgs a) {
     }
   }
   store_prev();
+#if defined(MDT_TUNING) && defined(MDT_ABL_CTX_CLOCK)
+  unsigned long long t1c, t1r;
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1c), "=s"(t1r)::"memory");
+  if (blockIdx.x == 0 && threadIdx.x == 0) { g_ctx_stamp[0] = t1c - t0c; g_ctx_stamp[1] = t1r - t0r; }
+  if (threadIdx.x == 0 && blockIdx.x < 1024) { g_ctx_stamp[4 + 2 * blockIdx.x] = t0r; g_ctx_stamp[5 + 2 * blockIdx.x] = t1r; }
+#endif
 }
 
 hipError_t launch_attn_ctx(const AttnArgs& a, hipStream_t s) {

@@ -30,6 +30,24 @@ int main() {
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     const double bytes = (double)(nc + 2 * nq) * 4;
     printf("T=%d: %.1f us per launch, %.2f TB/s algorithmic\n", T, ms * 1000 / reps, bytes / (ms / reps * 1e-3) / 1e12);
+#ifdef MDT_ABL_CTX_CLOCK
+    static unsigned long long st[4 + 2048];
+    (void)hipMemcpyFromSymbol(st, HIP_SYMBOL(mdt::g_ctx_stamp), sizeof(st));
+    {
+      unsigned long long lo = ~0ull, hi = 0, smax = 0, emin = ~0ull;
+      const int nwg = 512;
+      for (int w = 0; w < nwg; ++w) {
+        lo = std::min(lo, st[4 + 2 * w]); hi = std::max(hi, st[5 + 2 * w]);
+        smax = std::max(smax, st[4 + 2 * w]); emin = std::min(emin, st[5 + 2 * w]);
+      }
+      double life = 0;
+      for (int w = 0; w < nwg; ++w) life += (double)(st[5 + 2 * w] - st[4 + 2 * w]);
+      printf("      all workgroups (100 MHz clock): first start -> last end %.2f us, last start +%.2f us, first end +%.2f us, mean lifetime %.2f us\n",
+             (hi - lo) / 100.0, (smax - lo) / 100.0, (emin - lo) / 100.0, life / nwg / 100.0);
+    }
+    printf("      workgroup 0: %llu shader-clock ticks in %llu ticks of the 100 MHz clock = %.2f us -> %.3f GHz\n", st[0], st[1], st[1] / 100.0,
+           st[0] / (st[1] * 10.0));
+#endif
     (void)hipFree(q); (void)hipFree(c); (void)hipFree(o);
   }
   return 0;
