@@ -530,6 +530,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_ctx(AttnArgs a) {
     }
   }
   store_prev();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the look-ahead past the last element has landed before the ring is given back
 #if defined(MDT_TUNING) && defined(MDT_ABL_CTX_CLOCK)
   unsigned long long t1c, t1r;
   asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1c), "=s"(t1r)::"memory");
