@@ -146,6 +146,7 @@ class UNetCompiler:
         self.tb_chain = os.environ.get("MDT_TB_CHAIN", "1") == "1"
         self.use_rconv = os.environ.get("MDT_RCONV", "1") == "1"     # row-stationary convs (k_rconv) at C = 128 / 256
         self.use_resblock = os.environ.get("MDT_RESBLOCK", "1") == "1"   # Patcher / Unpatcher ResNets as ONE launch (k_resblock)
+        self.t1_fold = os.environ.get("MDT_T1_FOLD", "1") == "1"   # self-attention over one token per sample as one folded GEMM
         self.convt_merge = os.environ.get("MDT_CONVT_MERGE", "1") == "1"   # ConvTranspose phases in one launch
         # Transformer1d's closing 1x1 convolution folded into its last feed-forward block (ring kernels only)
         self.fold_out = os.environ.get("MDT_FOLD_OUT", "1") == "1"
@@ -1195,6 +1196,25 @@ class UNetCompiler:
                   bias_off=self._vec(p + "attention.to_out.bias", c), res=t, copy16=copy16 if ao.b16 else None)
         self._free(ao)
 
+    def attention_single_token(self, t: Ten, p: str) -> Ten:
+        """Self-attention over ONE token per sample (configs[2]'s 256-channel level): the softmax of a single score is 1 for
+        every head, so the block is x + Wo (Wv LN_ctx(x)) + bo (modules.py:401-410, :350-364 with n = 1) -- the query / key
+        projections and the attention core drop out exactly.  One GEMM with the LayerNorm prologue and the residual instead of
+        four projections, the core and a reduce launch: W' = Wo Wv diag(g_ctx), b' = Wo (Wv b_ctx) + bo, folded in fp64.
+        Returns the new residual stream (the GEMM's column tiles all read the whole input row: not in place)."""
+        sd, c, mid = self.sd, t.ld, self.cfg.mid_features
+        wv = sd[p + "to_kv.weight"].double()[mid:]                                 # [mid, C]
+        gc, bc = sd[p + "norm_context.weight"].double(), sd[p + "norm_context.bias"].double()
+        wo, bo = sd[p + "attention.to_out.weight"].double(), sd[p + "attention.to_out.bias"].double()   # [C, mid]
+        w = (wo @ (wv * gc.unsqueeze(0))).float()
+        bias = (wo @ (wv @ bc) + bo).float()
+        out = self._new(t.rows, c)
+        self.gemm(t, (p + "single_token.folded", w), c, out, cin=c, pro=rt.PRO_LAYERNORM,
+                  gain=self._ones(c), nbias=self._zeros(c), eps=1e-5,
+                  bias_off=self.W.add(p + "single_token.folded.bias", bias), res=t)
+        self._free(t)
+        return out
+
     def fold_ok(self) -> bool:
         """Fold a layer-by-layer cross-attention onto the normalised context?  Worth it when the hoisted K / V rows are the
         launch's main traffic (many keys); with few keys the doubled projections cost more than they save."""
@@ -1307,7 +1327,10 @@ class UNetCompiler:
                     t, pend = nxt, po
                 continue
             if fused:
-                self.tblock(t, rt.TB_SELF, bp + "attention.", variant=split)
+                if t.rows == 1 and self.t1_fold:
+                    t = self.attention_single_token(t, bp + "attention.")
+                else:
+                    self.tblock(t, rt.TB_SELF, bp + "attention.", variant=split)
                 if cross:
                     self.cross_layers.append(bp + "cross_attention.")
                     xv = split
@@ -1334,7 +1357,10 @@ class UNetCompiler:
             folded = cross and self.fold_ok()
             # plain-bf16 mode: the attention block in front of the feed-forward block hands it x as bf16 (no conversion pass)
             t16 = self._new16(t.rows, c) if (ff16 and not folded) else None
-            self.attention_layer(t, bp + "attention.", None, copy16=None if cross else t16)
+            if t.rows == 1 and self.t1_fold and t16 is None:
+                t = self.attention_single_token(t, bp + "attention.")
+            else:
+                self.attention_layer(t, bp + "attention.", None, copy16=None if cross else t16)
             if folded:
                 self.attention_layer_folded(t, bp + "cross_attention.")
             elif cross:
