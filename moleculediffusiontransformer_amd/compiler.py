@@ -1432,9 +1432,18 @@ class UNetCompiler:
             dp = f"downsamples.{i}."
             ci, co, f = cfg.level_channels(i), cfg.level_channels(i + 1), cfg.factors[i]
             y = self._new(x.rows // f, co)
-            self.gemm(x, self._conv_w(dp + "downsample.weight", ci, co), co, y, cin=ci,
-                      bias_off=self._vec(dp + "downsample.bias", co), taps=2 * f + 1, t_stride=f, t_dj=1, t_off=-f,
-                      r_out=x.rows // f)
+            if x.rows == f:
+                # ONE output token per sample (configs[2]'s last level): taps 0 .. f - 1 and 2 f of the strided convolution
+                # (modules.py:62-75: kernel 2 f + 1, stride f, padding f) only ever see padding -- taps f .. 2 f - 1 on inputs
+                # 0 .. f - 1 are the whole sum, exactly
+                name, wfull = self._conv_w(dp + "downsample.weight", ci, co)
+                wcut = wfull.view(co, 2 * f + 1, ci)[:, f: 2 * f].reshape(co, f * ci).contiguous()
+                self.gemm(x, (name + "/live_taps", wcut), co, y, cin=ci, bias_off=self._vec(dp + "downsample.bias", co),
+                          taps=f, t_stride=f, t_dj=1, t_off=0, r_out=1)
+            else:
+                self.gemm(x, self._conv_w(dp + "downsample.weight", ci, co), co, y, cin=ci,
+                          bias_off=self._vec(dp + "downsample.bias", co), taps=2 * f + 1, t_stride=f, t_dj=1, t_off=-f,
+                          r_out=x.rows // f)
             x = y                         # the block input stays alive as a skip of the previous level
             skips: List[Ten] = []
             x_is_skip = False
