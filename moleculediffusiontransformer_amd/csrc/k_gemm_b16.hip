@@ -37,6 +37,10 @@ __device__ __forceinline__ float gelu16(float x) {
   return 0.5f * x * (1.0f + copysignf(erfa, x));
 }
 
+#ifndef MDT_B16_EPI_GROUPS
+#define MDT_B16_EPI_GROUPS 8      // (4: the residual of half a 32-row block in flight per wave -- the epilogue was bound by bytes in flight)
+#endif
+
 template <int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(64 * WM * WN) void k_gemm_b16(Gemm16Args g) {
   constexpr int NW = WM * WN, BM = 32 * TM * WM, BN = 32 * TN * WN, BK = 64;
@@ -170,12 +174,13 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_b16(Gemm16Args g) {
     const bool cok = ec < CW && ncol < g.N;                       // (N is a multiple of 16: a float4 never straddles it)
     float4 bia = make_float4(0.f, 0.f, 0.f, 0.f);
     if (g.bias && cok) bia = *reinterpret_cast<const float4*>(g.bias + ncol);
+    constexpr int NB = MDT_B16_EPI_GROUPS;                          // row groups per batch: their residual loads fly together
 #pragma unroll
-    for (int p0 = 0; p0 < 32; p0 += 4 * RPP) {                    // 4 row groups per batch: their residual loads fly together
-      float4 v[4], rs[4];
-      bool ok[4];
+    for (int p0 = 0; p0 < 32; p0 += NB * RPP) {
+      float4 v[NB], rs[NB];
+      bool ok[NB];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < NB; ++u) {
         const int row = p0 + u * RPP + er, m = mrow0 + row;
         ok[u] = cok && m < g.M;
         v[u] = *reinterpret_cast<const float4*>(ws + row * EP + ec);
@@ -183,7 +188,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_b16(Gemm16Args g) {
         if (g.res && ok[u]) rs[u] = *reinterpret_cast<const float4*>(g.res + (int64_t)m * g.ldr + ncol);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < NB; ++u) {
         const int m = mrow0 + p0 + u * RPP + er;
         float x[4] = {v[u].x + bia.x, v[u].y + bia.y, v[u].z + bia.z, v[u].w + bia.w};
         if (g.act == 1) {
