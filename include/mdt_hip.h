@@ -206,7 +206,8 @@ enum mdt_attn_i {
   MDT_A_KV_BSTRIDE = 6, /* rows between consecutive samples' K/V (TK, or 0 for a batch-invariant context) */
   MDT_A_OUT16 = 7,      /* MDT_OP_ATTN: 1 = out is bf16 (LDO in bf16 elements), read by a bf16 x bf16 GEMM */
   MDT_A_QCOL = 8,       /* MDT_OP_ATTN: first float of q inside its rows (q | k | v projected by ONE GEMM into one tensor) */
-  MDT_A_KCOL = 9        /* ... and of k inside the a2 rows (v follows heads * 64 floats later)                          */
+  MDT_A_KCOL = 9,       /* ... and of k inside the a2 rows (v follows heads * 64 floats later)                          */
+  MDT_A_SPLIT = 10      /* MDT_OP_ATTN_CTX: 1 = the scores q' c^T as split-bf16 products (the default mode's arithmetic), 0 = exact fp32 */
 };
 enum mdt_attn_f { MDT_AF_SCALE = 0 };
 

@@ -147,6 +147,7 @@ class UNetCompiler:
         self.use_rconv = os.environ.get("MDT_RCONV", "1") == "1"     # row-stationary convs (k_rconv) at C = 128 / 256
         self.use_resblock = os.environ.get("MDT_RESBLOCK", "1") == "1"   # Patcher / Unpatcher ResNets as ONE launch (k_resblock)
         self.t1_fold = os.environ.get("MDT_T1_FOLD", "1") == "1"   # self-attention over one token per sample as one folded GEMM
+        self.ctx_split = os.environ.get("MDT_CTX_SPLIT", "1") == "1"   # k_attn_ctx: split-bf16 scores in the split-bf16 mode
         self.convt_merge = os.environ.get("MDT_CONVT_MERGE", "1") == "1"   # ConvTranspose phases in one launch
         # Transformer1d's closing 1x1 convolution folded into its last feed-forward block (ring kernels only)
         self.fold_out = os.environ.get("MDT_FOLD_OUT", "1") == "1"
@@ -1249,6 +1250,7 @@ class UNetCompiler:
         i = op.i
         i[rt.A_T], i[rt.A_TK], i[rt.A_HEADS] = t.rows, self.n_ctx, H
         i[rt.A_LDQ], i[rt.A_LDKV], i[rt.A_LDO], i[rt.A_KV_BSTRIDE] = F_, F_, F_, self.n_ctx
+        i[rt.A_SPLIT] = int(self.gemm_mode == "bf16x3" and self.ctx_split)      # scores in the mode's own arithmetic
         op.f[0] = float(cfg.head_features) ** -0.5
         self._emit(op)
         self.flops += 2 * 2 * t.rows * H * self.n_ctx * F_

@@ -18,6 +18,7 @@
 namespace mdt {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 template <int KTM>   // key tiles held in registers: 1 (Tk <= 16) or 4 (Tk <= 64)
 __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
@@ -325,7 +326,11 @@ __device__ __forceinline__ unsigned lds_addr(const unsigned char* p) {
 __device__ unsigned long long g_ctx_stamp[4 + 2 * 1024];   // [0..1]: workgroup 0's ticks; then (start, end) of every workgroup on the 100 MHz clock
 #endif
 
-template <int RT>
+// SPLIT: the scores S = q' c^T as split-bf16 products (hi hi + hi lo + lo hi on v_mfma_f32_16x16x32_bf16: 12 MFMAs of 16 cycles per
+// row tile and chunk instead of 32 of 32 cycles; the default mode's arithmetic, like every other GEMM of that mode); the output
+// side P c stays exact fp32 (its contraction runs over keys: the bf16 form would need the context tile transposed).  The operand
+// registers ARE the fp32 fragments: k-slot e of step s is feature 16 (2 s + (e >> 2)) + 4 g + (e & 3) for q' and c alike.
+template <int RT, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void k_attn_ctx(AttnArgs a) {
   constexpr int D = 128, CH = 8192;
 #if defined(MDT_TUNING) && defined(MDT_ABL_CTX_CLOCK)
@@ -386,8 +391,18 @@ __global__ __launch_bounds__(256, 2) void k_attn_ctx(AttnArgs a) {
     const int jr = 4 * g + c;
     aV[c] = jr * 512 + ((lo ^ jr) << 4);
   }
-  f32x4 qr[RT][8];                                     // qr[t][cc][e] = q'[row lo of tile t][16 cc + 4 g + e]
+  f32x4 qr[SPLIT ? 1 : RT][8];                         // qr[t][cc][e] = q'[row lo of tile t][16 cc + 4 g + e]   (exact form)
+  bf16x8 qh[SPLIT ? RT : 1][4], ql[SPLIT ? RT : 1][4]; // the same values as bf16 hi / lo planes, one register pair per 32-wide step
   int qi[RT];
+  auto split8 = [](const f32x4& u, const f32x4& v, bf16x8& hi, bf16x8& lo) __attribute__((always_inline)) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float x = e < 4 ? u[e & 3] : v[e & 3];
+      const __bf16 h = (__bf16)x;
+      hi[e] = h;
+      lo[e] = (__bf16)(x - (float)h);
+    }
+  };
 
   f32x4 acc[RT][2][4];
   float mx[RT], ls[RT];
@@ -422,9 +437,13 @@ __global__ __launch_bounds__(256, 2) void k_attn_ctx(AttnArgs a) {
         const unsigned cur = lds_addr(ring + (j & 1) * CH);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int cc = 0; cc < 8; ++cc) lds_read_f4(qr[t][cc], cur + aS[cc & 3] + (cc & 4) * 64);
+        for (int cc = 0; cc < 8; ++cc) lds_read_f4(qr[SPLIT ? 0 : t][cc], cur + aS[cc & 3] + (cc & 4) * 64);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (SPLIT) {
+#pragma unroll
+          for (int st = 0; st < 4; ++st) split8(qr[0][2 * st], qr[0][2 * st + 1], qh[t][st], ql[t][st]);
+        }
         issue_next();
       }
     }
@@ -442,9 +461,22 @@ __global__ __launch_bounds__(256, 2) void k_attn_ctx(AttnArgs a) {
       for (int s_ = 0; s_ < 4; ++s_) lds_read_f4(vr[0][s_], cur + aV[s_]);
       asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
+      bf16x8 kh[SPLIT ? 4 : 1], kl[SPLIT ? 4 : 1];
+      if constexpr (SPLIT) {
+#pragma unroll
+        for (int st = 0; st < 4; ++st) split8(kr4[2 * st], kr4[2 * st + 1], kh[st], kl[st]);
+      }
 #pragma unroll
       for (int t = 0; t < RT; ++t) {
         f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0;
+        if constexpr (SPLIT) {
+#pragma unroll
+          for (int st = 0; st < 4; ++st) {
+            s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl[st], qh[t][st], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh[st], ql[t][st], s1, 0, 0, 0);
+            s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh[st], qh[t][st], s0, 0, 0, 0);
+          }
+        } else
 #pragma unroll
         for (int cc = 0; cc < 8; ++cc) {
 #if defined(MDT_TUNING) && defined(MDT_ABL_CTX_NOS)      // timing only: one of the 32 score MFMAs
@@ -554,10 +586,13 @@ hipError_t launch_attn_ctx(const AttnArgs& a, hipStream_t s) {
   }
   const int R = a.T * a.heads;
   if (R > 16) {                                        // two row tiles of a sample share the context stream
-    const int units = a.batch * ((R + 31) / 32);
-    hipLaunchKernelGGL((k_attn_ctx<2>), dim3((unsigned)std::min(wgs, (units + 3) / 4)), dim3(256), 0, s, a);
+    const dim3 grid((unsigned)std::min(wgs, (a.batch * ((R + 31) / 32) + 3) / 4));
+    if (a.split_scores) hipLaunchKernelGGL((k_attn_ctx<2, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_attn_ctx<2, false>), grid, dim3(256), 0, s, a);
   } else {
-    hipLaunchKernelGGL((k_attn_ctx<1>), dim3((unsigned)std::min(wgs, (a.batch + 3) / 4)), dim3(256), 0, s, a);
+    const dim3 grid((unsigned)std::min(wgs, (a.batch + 3) / 4));
+    if (a.split_scores) hipLaunchKernelGGL((k_attn_ctx<1, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_attn_ctx<1, false>), grid, dim3(256), 0, s, a);
   }
   return hipGetLastError();
 }

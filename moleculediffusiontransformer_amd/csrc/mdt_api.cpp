@@ -161,6 +161,7 @@ static const char* validate(const mdt_op& o, int idx, char* buf, size_t nbuf) {
       if (o.i[MDT_A_T] <= 0 || o.i[MDT_A_HEADS] <= 0 || o.i[MDT_A_TK] <= 0 || o.i[MDT_A_TK] > 64 || o.i[MDT_A_LDKV] < 128 || o.i[MDT_A_LDKV] % 4)
         return bad("context attention supports 1..64 keys of 128 features");
       if (!o.a.space || !o.a2.space || !o.out.space) return bad("missing operand");
+      if (o.i[MDT_A_SPLIT] != 0 && o.i[MDT_A_SPLIT] != 1) return bad("SPLIT must be 0 (exact fp32 scores) or 1 (split-bf16 scores)");
       break;
     case MDT_OP_CONCAT:
       if (o.i[MDT_C_CA] % 4 || o.i[MDT_C_CB] % 4 || o.i[MDT_C_ROWS] <= 0) return bad("bad dims");
@@ -396,7 +397,7 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
         mdt::AttnArgs a;
         a.q = ptr(o.a); a.k = ptr(o.a2); a.out = ptr(o.out); a.batch = B; a.T = o.i[MDT_A_T]; a.Tk = o.i[MDT_A_TK];
         a.heads = o.i[MDT_A_HEADS]; a.ldq = 128; a.ldkv = o.i[MDT_A_LDKV]; a.ldo = 128;
-        a.kv_bstride = o.i[MDT_A_KV_BSTRIDE]; a.scale = o.f[MDT_AF_SCALE]; a.out16 = 0;
+        a.kv_bstride = o.i[MDT_A_KV_BSTRIDE]; a.scale = o.f[MDT_AF_SCALE]; a.out16 = 0; a.split_scores = o.i[MDT_A_SPLIT];
         if (!missing) e = mdt::launch_attn_ctx(a, stream);
         break;
       }

@@ -176,7 +176,8 @@ def test_attention(B, T, Tk, shared):
 @pytest.mark.parametrize("B,T,Tk,shared", [(3, 16, 64, False), (2, 32, 64, True), (5, 4, 40, False), (2, 1, 33, False),
                                            (1, 64, 64, False), (3, 8, 16, True), (2, 3, 20, False), (3, 5, 64, True),
                                            (2100, 1, 33, False), (1100, 4, 64, False), (650, 16, 20, True), (2500, 2, 9, False)])
-def test_attention_on_normalised_context(B, T, Tk, shared):
+@pytest.mark.parametrize("split", [0, 1])
+def test_attention_on_normalised_context(B, T, Tk, shared, split):
     """MDT_OP_ATTN_CTX: softmax(q' c^T scale) c with keys = values = the context rows, against the interpreter and torch.
     The large batches give every wave of the (persistent) launch several work units: the stream of context chunks then runs
     across unit boundaries (query rows reloaded, previous unit stored from the accumulators, 1 / 2 / 3 / 4 chunks per unit)."""
@@ -191,6 +192,7 @@ def test_attention_on_normalised_context(B, T, Tk, shared):
     i = op.i
     i[rt.A_T], i[rt.A_TK], i[rt.A_HEADS], i[rt.A_LDQ], i[rt.A_LDKV], i[rt.A_LDO] = T, Tk, H, F_, F_, F_
     i[rt.A_KV_BSTRIDE] = 0 if shared else Tk
+    i[rt.A_SPLIT] = split           # 1: the scores as split-bf16 products (2^-17 per product), 0: exact fp32 MFMA
     op.f[0] = 0.125
     (ga, _, _), (ca, _, _) = run_both([op], torch.zeros(4), act, shr, {}, B)
     assert (ga - ca).abs().max() < 1e-5

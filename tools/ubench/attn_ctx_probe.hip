@@ -21,6 +21,9 @@ int main() {
     mdt::AttnArgs a{};
     a.q = q; a.k = c; a.out = o; a.batch = B; a.T = T; a.Tk = Tk; a.heads = H; a.ldq = F; a.ldkv = F; a.ldo = F; a.kv_bstride = Tk;
     a.scale = 0.125f;
+#ifdef CTXP_SPLIT
+    a.split_scores = 1;           // the default mode's form: split-bf16 scores
+#endif
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     for (int i = 0; i < 3; ++i) (void)mdt::launch_attn_ctx(a, 0);
     (void)hipEventRecord(e0, 0);
