@@ -39,7 +39,11 @@ __global__ __launch_bounds__(256) void k_gemm_as(GemmArgs g, int nsplit, int dbg
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* As = smem;
   unsigned char* Ws = smem + AS_BM * AROWB;
-  float* Cs = reinterpret_cast<float*>(smem + AS_BM * AROWB + 2 * WSTAGE);   // epilogue staging [64][68] fp32
+  // epilogue staging [64][68] fp32; K = 128 leaves room for TWO of them: the tile of step j is written out while step j + 1 parks
+  // into the other, and the barrier that only protected the staging buffer goes away
+  constexpr int NCS = KC == 1 ? 2 : 1;
+  constexpr int CSF = AS_BM * (AS_BN + 4);
+  float* Cs0 = reinterpret_cast<float*>(smem + AS_BM * AROWB + 2 * WSTAGE);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int mtile = blockIdx.x / nsplit, split = blockIdx.x % nsplit;
@@ -187,6 +191,7 @@ __global__ __launch_bounds__(256) void k_gemm_as(GemmArgs g, int nsplit, int dbg
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
     }
     const bool last_k = c == KC - 1;
+    float* Cs = Cs0 + (NCS == 2 ? (j & 1) * CSF : 0);
     if (last_k && !(dbg & 1)) {
       // park the finished 64x64 tile in LDS (32x32 C/D layout: col = lane&31, row = (reg&3)+8*(reg>>2)+4*(lane>>5))
 #pragma unroll
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(256) void k_gemm_as(GemmArgs g, int nsplit, int dbg
     __syncthreads();
     if (last_k && !(dbg & 1)) {
       store_tile_coalesced<AS_BM, AS_BN>(Cs, g, m0, (step0 + j) * AS_BN);
-      __syncthreads();      // Cs is rewritten by the next step
+      if constexpr (NCS == 1) __syncthreads();      // Cs is rewritten by the next step (two buffers: by the step after next, behind its barrier)
     }
   }
 }
@@ -205,7 +210,7 @@ __global__ __launch_bounds__(256) void k_gemm_as(GemmArgs g, int nsplit, int dbg
 template <int PRO, int KC>
 static hipError_t launch_as(const GemmArgs& g, hipStream_t s) {
   constexpr int K = AS_BKW * KC;
-  const size_t smem = (size_t)AS_BM * (4 * K + 16) + 2 * (size_t)AS_BN * AS_WROWB + (size_t)AS_BM * (AS_BN + 4) * 4;
+  const size_t smem = (size_t)AS_BM * (4 * K + 16) + 2 * (size_t)AS_BN * AS_WROWB + (size_t)(KC == 1 ? 2 : 1) * AS_BM * (AS_BN + 4) * 4;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_as<PRO, KC>),
