@@ -146,15 +146,17 @@ def kernel_breakdown(eng, rt, B):
     return out
 
 
-def pmc_summary():
+def pmc_summary(variant=""):
     """Rows of the newest committed PMC traffic summary (profiles/r*_pmc_hbm_traffic.csv: FETCH_SIZE x2 gfx950
     correction + WRITE_SIZE, separate rocprofv3 passes of THIS workload at batch 1024): (kernel name, launches in the
     profiled run, MB per launch)."""
     import glob
     import re
     # the headline workload's summary of the newest round: profiles/r<N>_pmc_hbm_traffic.csv (NOT r<N>_<other config>_pmc_...)
-    files = [f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.csv"))
-             if re.fullmatch(r"r\d+_pmc_hbm_traffic\.csv", os.path.basename(f))]
+    # variant "f32": r<N>_f32_pmc_hbm_traffic.csv, the same workload in the exact-fp32 mode
+    mid = (variant + "_") if variant else ""
+    files = [f for f in glob.glob(os.path.join(ROOT, "profiles", f"r*_{mid}pmc_hbm_traffic.csv"))
+             if re.fullmatch(rf"r\d+_{mid}pmc_hbm_traffic\.csv", os.path.basename(f))]
     files.sort(key=lambda f: int(re.match(r"r(\d+)_", os.path.basename(f)).group(1)))
     if not files:
         return None, []
@@ -167,9 +169,9 @@ def pmc_summary():
     return os.path.basename(files[-1]), rows
 
 
-def pmc_traffic(kernel_class):
+def pmc_traffic(kernel_class, variant=""):
     """HBM bytes per launch of one kernel class from the committed PMC summary, or (None, None)."""
-    fname, rows = pmc_summary()
+    fname, rows = pmc_summary(variant)
     prefixes = ("mdt::k_tblock", "mdt::k_tf128", "mdt::k_tf256") if kernel_class == "k_tblock" else ("mdt::" + kernel_class,)
     n = sum(r[1] for r in rows if r[0].startswith(prefixes))
     if not n:
@@ -503,6 +505,7 @@ def main():
             dom32 = max((k for k in bd32 if bd32[k][2] > 0), key=lambda k: bd32[k][1])
             n32, ms32, fl32 = bd32[dom32]
             alg32 = fl32 / (ms32 * 1e-3) / 1e12
+            f32_traffic = pmc_traffic(dom32, variant="f32") if B == 1024 else (None, None)
             result["exact_f32"] = {
                 "value": round(B * f32_steps / dt32, 2), "unit": "molecules/s", "steps": f32_steps,
                 "ms_per_step": round(1e3 * dt32 / f32_steps, 2), "dtype": "f32 (every product an exact fp32 MFMA, v_mfma_f32_16x16x4_f32)",
@@ -512,7 +515,8 @@ def main():
                 "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": FP32_MFMA_PEAK_TFLOPS, "mfma_dtype": "f32",
                              "kernel": dom32 + " (all launches of the dominant kernel class in one U-Net eval)",
                              "achieved": round(alg32, 2), "frac": round(alg32 / FP32_MFMA_PEAK_TFLOPS, 4),
-                             "launches_per_eval": n32, "avg_launch_us": round(1e3 * ms32 / n32, 2), "traffic": None},
+                             "launches_per_eval": n32, "avg_launch_us": round(1e3 * ms32 / n32, 2),
+                             "traffic": f32_traffic[0], "traffic_source": f32_traffic[1]},
                 "unet_eval": {"ms_avg_graph_replay": round(avg32, 4), "evals_timed": len(ev32),
                               "tflops_executed": round(flops_exec * B / (avg32 * 1e-3) / 1e12, 2),
                               "fp32_mfma_fraction_executed": round(flops_exec * B / (avg32 * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)},
@@ -522,9 +526,11 @@ def main():
         if not a.no_other_configs and world == 1 and a.workload == "cfg1" and a.cond_scale == 1.0:
             # the other single-GPU configurations of BASELINE.json with the same binary, few steps each (informational:
             # the headline `value` above is configs[1])
-            def quick(tag, case, batch, tsteps, cscale, nsteps=2, gemm_mode=None, warm_timesteps=None):
+            def quick(tag, case, batch, tsteps, cscale, nsteps=3, gemm_mode=None, warm_timesteps=None):
+                """One BASELINE configuration with the same binary: >= 3 timed sample() calls and the roofline fraction of ITS
+                dominant kernel class (HIP-event time of every launch of one evaluation at this batch, as the headline's)."""
                 with contextlib.redirect_stdout(sys.stderr):
-                    mm = model if case == "cfg1" else make_synth_model(case, device)
+                    mm = model if (case == "cfg1" and not gemm_mode) else make_synth_model(case, device)
                 if gemm_mode:
                     mm.gemm_mode = gemm_mode
                 sq = synth_normal(f"bench/other/{tag}", (batch, mm.unet.config.ctx_max_length)).to(device)
@@ -537,13 +543,32 @@ def main():
                 dt = (time.perf_counter() - c0) / nsteps
                 assert torch.isfinite(o).all()
                 r = {"molecules_per_s": round(batch / dt, 1), "ms_per_step": round(1e3 * dt, 2), "batch": batch,
-                     "timesteps": tsteps, "cond_scale": cscale}
-                if gemm_mode:
-                    # whole sample() call (sampler updates, conditioning prelude and hoisted programs included) over the
-                    # U-Net's executed FLOPs; bf16 mode: one MFMA per product
-                    fl = mm._engine.c.flops_per_sample_eval * batch * 2 * (tsteps - 1)
-                    r.update({"gemm_mode": gemm_mode, "tflops_executed": round(fl / dt / 1e12, 1),
-                              "bf16_mfma_fraction": round(fl / dt / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4)})
+                     "timesteps": tsteps, "cond_scale": cscale, "steps": nsteps}
+                e = mm._engine
+                mode = e.c.gemm_mode
+                pk = FP32_MFMA_PEAK_TFLOPS if mode == "f32" else BF16_MFMA_PEAK_TFLOPS
+                mu = 3.0 if mode == "bf16x3" else 1.0
+                if mode != "bf16x3":
+                    r["gemm_mode"] = mode
+                # whole sample() call (sampler updates, conditioning prelude and hoisted programs included) over the U-Net's
+                # executed FLOPs (guidance: two passes per evaluation); split-bf16: three MFMAs per product
+                fl = e.c.flops_per_sample_eval * batch * 2 * (tsteps - 1) * (2 if cscale != 1.0 else 1)
+                r["tflops_executed"] = round(mu * fl / dt / 1e12, 1)
+                r["mfma_fraction_whole_call"] = round(mu * fl / dt / 1e12 / pk, 4)
+                try:
+                    eb = e.B                                  # (guidance: the engine runs the doubled batch)
+                    bd_ = kernel_breakdown(e, rt, eb)
+                    dom_ = max((k for k in bd_ if bd_[k][2] > 0), key=lambda k: bd_[k][1])
+                    n_, ms_, fl_ = bd_[dom_]
+                    tot_ = sum(v[1] for v in bd_.values())
+                    r["roofline"] = {"bound": "mfma", "unit": "TFLOP/s", "peak": pk, "kernel": dom_, "launches_per_eval": n_,
+                                     "avg_launch_us": round(1e3 * ms_ / n_, 2), "achieved": round(mu * fl_ / (ms_ * 1e-3) / 1e12, 2),
+                                     "frac": round(mu * fl_ / (ms_ * 1e-3) / 1e12 / pk, 4),
+                                     "share_of_eval_time": round(ms_ / tot_, 3), "launches_in_eval": sum(v[0] for v in bd_.values())}
+                except Exception as ex:                     # never lose the line over a diagnostic
+                    r["roofline"] = {"error": repr(ex)}
+                if mm is not model:
+                    del mm
                 return r
             def sampler_update_rate(batch):
                 """The genuinely HBM-bound kernel class: the two halves of the ADPM2 update at the configs[3] shard
@@ -577,11 +602,14 @@ def main():
                 "configs[2] QMDiffusionForward": quick("cfg3", "cfg3", 4096, 100, 1.0),
                 "configs[3] per-GPU shard (batch 8192)": quick("shard", "cfg1", 8192, 64, 1.0),
                 "configs[1] with guidance (cond_scale 7.5)": quick("cfg", "cfg1", 1024, 64, 7.5),
-                "configs[4] architecture (channels 256, fp32-class products)": quick("cfg5", "cfg5", 128, 16, 1.0, nsteps=1),
+                "configs[4] architecture (channels 256, fp32-class products)": quick("cfg5", "cfg5", 128, 16, 1.0),
                 "configs[4] architecture in its bf16 mode (plain bf16 products, bf16 GEMM operands)":
-                    quick("cfg5b", "cfg5", 1024, 16, 1.0, nsteps=1, gemm_mode="bf16"),
+                    quick("cfg5b", "cfg5", 1024, 16, 1.0, gemm_mode="bf16"),
                 "configs[4] in its bf16 mode at its stated length (256 timesteps = 510 U-Net evaluations)":
-                    quick("cfg5c", "cfg5", 512, 256, 1.0, nsteps=1, gemm_mode="bf16", warm_timesteps=4),
+                    quick("cfg5c", "cfg5", 512, 256, 1.0, gemm_mode="bf16", warm_timesteps=4),
+                # strict-fp32 numbers beyond configs[1] (exact fp32 MFMA products; `exact_f32` above is configs[1])
+                "configs[2] QMDiffusionForward, exact fp32 products": quick("cfg3f", "cfg3", 4096, 100, 1.0, gemm_mode="f32"),
+                "configs[3] per-GPU shard (batch 8192), exact fp32 products": quick("shardf", "cfg1", 8192, 64, 1.0, gemm_mode="f32"),
                 "sampler update kernels at the configs[3] shard size (HBM-bound class)": sampler_update_rate(8192),
             }
 

@@ -32,7 +32,7 @@ extern "C" {
  * bit 30 on top -- the Python binding refuses such a library for sampling. */
 int mdt_abi_version(void);
 const char *mdt_last_error(void);
-/* Process-wide tuning / test hooks (not needed for correct results): "pair_stride" = v > 0 places the two workgroups of
+/* Process-wide tuning / test hooks (NOT part of the stable ABI; not needed for correct results): "pair_stride" = v > 0 places the two workgroups of
  * every pair-split MDT_OP_TF256 v workgroup ids apart whatever the op says (1: neighbours, i.e. different XCDs; 0: back to
  * the ops' own value); "tile16" = 0 | 1 | 2 forces a tile of the bf16 x bf16 GEMM (-1: automatic); "pair_capacity": see
  * mdt_pair_capacity.  Returns 0, or 1 for an unknown key. */
@@ -42,11 +42,14 @@ int mdt_set_tuning(const char *key, int32_t value);
  * unknown.  The two workgroups of a pair wait for each other inside the launch, so mdt_program_run never puts more than this
  * many into one launch: a larger batch runs as several launches over consecutive row-block ranges (same results).  The host
  * reads it to choose between the pair-split and the whole-workgroup form by batch size (generative.py::_wide).
- * mdt_set_tuning("pair_capacity", v > 0) replaces it (tests: force chunking on a small batch; 0 = back to the device's). */
+ * mdt_set_tuning("pair_capacity", v > 0) replaces it (tests: force chunking on a small batch; 0 = back to the device's); the
+ * override is a TEST HOOK: it is refused unless the process has MDT_TEST_HOOKS=1 in its environment. */
 int32_t mdt_pair_capacity(void);
 /* Test hook: enqueue a kernel of n_workgroups workgroups that only HOLD compute units -- each allocates lds_bytes of LDS (<= 160
  * KiB: nothing else fits next to it) and spins for `ticks` of the 100 MHz real-time counter.  Used to break the co-residency
- * of pair-split launches on purpose (another stream holding most of the device) and check that the failure is reported. */
+ * of pair-split launches on purpose (another stream holding most of the device) and check that the failure is reported.
+ * NOT part of the stable ABI: refused unless the process has MDT_TEST_HOOKS=1 in its environment; at most 4096 workgroups and
+ * 3 s (3e8 ticks). */
 int mdt_test_occupy(int32_t n_workgroups, int32_t lds_bytes, uint64_t ticks, void *stream);
 
 /* ------------------------------------------------------------------ */
@@ -179,7 +182,9 @@ enum mdt_gemm_i {
                         operands stream through LDS-DMA; no prologue, stride, phases or output row mapping, cin % 64 == 0;
                         6 = as 2 and the OUTPUT is bf16 too (LDC / O_COL in bf16 elements): a tensor whose only reader is the next
                         bf16 x bf16 GEMM (feed-forward hidden layer); 10 = as 2 and ALSO a bf16 copy [rows][N] of the fp32 output
-                        into p0 (the residual stream as the A operand of the next GEMM, written where it is produced)        */
+                        into p0 (the residual stream as the A operand of the next GEMM, written where it is produced).
+                        Formats 2 / 6 / 10 end in a float4 epilogue: N, LDC, O_COL and LDR must be multiples of 4 and bias /
+                        residual / out 16-byte aligned (bf16 out / copy: 8), otherwise the op is rejected                    */
 };
 enum mdt_gemm_f { MDT_GF_EPS = 0 };
 

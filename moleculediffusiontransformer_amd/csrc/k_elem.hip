@@ -464,7 +464,7 @@ hipError_t launch_time_embed(const float* cn, const float* w, float* out, int ro
 // ------------------------------------------------------------------------------------------------
 // C ABI entry points of this translation unit (declared in include/mdt_hip.h)
 // ------------------------------------------------------------------------------------------------
-extern "C" void mdt_set_error(const char* msg);  // mdt_api.cpp
+extern "C" __attribute__((visibility("hidden"))) void mdt_set_error(const char* msg);  // mdt_api.cpp (not exported)
 
 namespace {
 inline int finish(const char* what) {
@@ -506,18 +506,16 @@ int mdt_cond_embed_add(const float* seq, const float* fc1_w, const float* fc1_b,
 }
 
 // the sampler kernels stage one sample's (L x Cp) tile in LDS: up to the CU's 160 KiB (the default limit of a launch is 64 KiB:
-// raised once per kernel).  max_length = 1024 (the reference constructors' default) at 16 padded channels is 68 KiB.
+// raised once per kernel and device).  max_length = 1024 (the reference constructors' default) at 16 padded channels is 68 KiB.
 #define MDT_CHECK_TILE(name)                                                                   \
   if (B <= 0) return 0;                                                                        \
   if (L % 4 || Cp % 16 || Cp < C) return bad(name ": need L % 4 == 0, Cp % 16 == 0, Cp >= C"); \
   if (tile_bytes(L, Cp) > 160 * 1024) return bad(name ": (L, Cp) tile exceeds the 160 KiB of LDS of a compute unit");
 #define MDT_BIG_LDS(kernel)                                                                                          \
   do {                                                                                                                \
-    static bool set_ = false;                                                                                         \
-    if (!set_) {                                                                                                      \
+    static mdt::DevOnce once_;                                    /* per device, not per process (mdt_kernels.h) */     \
+    if (once_.first())                                                                                                \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-      set_ = true;                                                                                                    \
-    }                                                                                                                 \
   } while (0)
 
 int mdt_precond_in(const float* x, float* xin, float c_in, int32_t B, int32_t C, int32_t L, int32_t Cp,

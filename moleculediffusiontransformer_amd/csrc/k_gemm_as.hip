@@ -211,11 +211,10 @@ template <int PRO, int KC>
 static hipError_t launch_as(const GemmArgs& g, hipStream_t s) {
   constexpr int K = AS_BKW * KC;
   const size_t smem = (size_t)AS_BM * (4 * K + 16) + 2 * (size_t)AS_BN * AS_WROWB + (size_t)(KC == 1 ? 2 : 1) * AS_BM * (AS_BN + 4) * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DevOnce attr_once;                          // per device (mdt_kernels.h)
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_as<PRO, KC>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
   }
   const int mt = (g.M + AS_BM - 1) / AS_BM;
   const int nsteps = (g.N + AS_BN - 1) / AS_BN;

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_b16(Gemm16Args g) {
     constexpr int CW = 32 * TN;                                   // columns of the block (64)
     constexpr int RPP = 64 / (CW / 4);                            // rows per pass of the wave (4)
     const int mrow0 = m0 + wr * 32 * TM + a * 32, ncol = n0 + wc * CW + ec;
-    const bool cok = ec < CW && ncol < g.N;                       // (N is a multiple of 16: a float4 never straddles it)
+    const bool cok = ec < CW && ncol < g.N;                       // (N % 4 == 0, gemm_b16_epilogue_ok: a float4 never straddles it)
     float4 bia = make_float4(0.f, 0.f, 0.f, 0.f);
     if (g.bias && cok) bia = *reinterpret_cast<const float4*>(g.bias + ncol);
     constexpr int NB = MDT_B16_EPI_GROUPS;                          // row groups per batch: their residual loads fly together
@@ -217,11 +217,10 @@ static hipError_t launch16(const Gemm16Args& g, hipStream_t s) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   const int mt = (g.M + BM - 1) / BM, nt = (g.N + BN - 1) / BN;
   const size_t smem = 2 * (size_t)(BM + BN) * 128;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DevOnce attr_once;                          // per device (mdt_kernels.h)
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_b16<WM, WN, TM, TN>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
   }
   hipLaunchKernelGGL((k_gemm_b16<WM, WN, TM, TN>), dim3((unsigned)(mt * nt)), dim3(64 * WM * WN), smem, s, g);
   return hipGetLastError();
@@ -231,13 +230,25 @@ bool gemm_b16_supported(int cin, int taps, int lda, int a_col) {
   return cin > 0 && cin % 64 == 0 && taps >= 1 && lda % 8 == 0 && a_col % 8 == 0;
 }
 
+// The epilogue walks the parked accumulators 4 columns per lane: float4 bias / residual loads, float4 (fp32) or 8-byte (bf16)
+// stores at column n0 + 4 k.  So N, the output pitch and column offset and the residual pitch must be multiples of 4, the
+// tensors 16-byte aligned (8 for a bf16 output / copy) -- otherwise the accesses are misaligned and a float4 reaches past column N.
+bool gemm_b16_epilogue_ok(const Gemm16Args& g) {
+  auto al = [](const void* p, size_t a) { return (reinterpret_cast<size_t>(p) & (a - 1)) == 0; };
+  if (g.N <= 0 || g.N % 4 || g.ldc % 4 || g.o_col % 4) return false;
+  if (g.res && (g.ldr % 4 || !al(g.res, 16))) return false;
+  if (g.bias && !al(g.bias, 16)) return false;
+  if (!al(g.out, g.out16 ? 8 : 16) || (g.copy16 && !al(g.copy16, 8))) return false;
+  return true;
+}
+
 // MDT_TILE16 = 0 (256 x 256), 1 (256 x 128), 2 (128 x 128) forces a tile (tuning aid, read once); mdt_set_tuning("tile16", v)
 // does the same at run time (tests walk the configurations in one process; -1 = automatic)
 static int g_force_tile16 = -1;
 void set_tile16(int v) { g_force_tile16 = v; }
 hipError_t launch_gemm_b16(const Gemm16Args& g, hipStream_t s) {
   if (g.M <= 0) return hipSuccess;
-  if (!gemm_b16_supported(g.cin, g.taps, g.lda, g.a_col)) return hipErrorInvalidValue;
+  if (!gemm_b16_supported(g.cin, g.taps, g.lda, g.a_col) || !gemm_b16_epilogue_ok(g)) return hipErrorInvalidValue;
   static int force0 = -2;
   if (force0 == -2) {
     force0 = -1;

@@ -314,11 +314,10 @@ static hipError_t launch3(const GemmArgs& g, hipStream_t s) {
   size_t smem = STAGES * (size_t)(BM + BN) * ROWB + (PRO == 1 ? BM * 2 * sizeof(float) : 0);
   const size_t ctile = (size_t)BM * (BN + 4) * sizeof(float);     // epilogue staging reuses the same memory
   if (smem < ctile) smem = ctile;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DevOnce attr_once;                          // per device (mdt_kernels.h)
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm3<PRO, TM, TN, BKT, STAGES, NPROD>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
   }
   hipLaunchKernelGGL((k_gemm3<PRO, TM, TN, BKT, STAGES, NPROD>), dim3((unsigned)(mt * nt), 1, (unsigned)(g.phases > 1 ? g.phases : 1)), dim3(256), smem, s, g);
   return hipGetLastError();

@@ -633,11 +633,10 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
 template <int RTW, int C, int TAPS, int NSPLIT, int NSRC, int PRO>
 static hipError_t launch_rc2(const RConvArgs& a, hipStream_t s) {
   const size_t smem = (size_t)NS * SLOT + (RTW == 2 ? SLOT : 0);      // ring (+ operand exchange area)
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DevOnce attr_once;                          // per device (mdt_kernels.h)
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rconv<RTW, C, TAPS, NSPLIT, NSRC, PRO, F32>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
-    attr_set = true;
   }
   const int rows = 16 * RTW;
   hipLaunchKernelGGL((k_rconv<RTW, C, TAPS, NSPLIT, NSRC, PRO, F32>), dim3((unsigned)((a.M + rows - 1) / rows), NSPLIT), dim3(512), smem, s, a);

@@ -369,11 +369,10 @@ static hipError_t launch_rb(const ResBlockArgs& a, hipStream_t s) {
   constexpr int WBYTES = (ksteps_of(CIN) + ksteps_of(COUT) + rsteps_of(CIN)) * RT * 2 * 1024;
   constexpr int SAMPLE = F32 ? 2 * ROWS * pitch32_of(CIN) + ROWS * pitch32_of(COUT) : 4 * ROWS * pitch_of(CIN) + 2 * ROWS * pitch_of(COUT);
   const size_t smem = (size_t)WBYTES + 2 * SAMPLE + 2 * 4 * 4 * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DevOnce attr_once;                          // per device (mdt_kernels.h)
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resblock<CIN, COUT, F32>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(160 * 1024));
-    attr_set = true;
   }
   const int pairs = (a.B + 1) / 2;
   hipLaunchKernelGGL((k_resblock<CIN, COUT, F32>), dim3((unsigned)(pairs < 256 ? pairs : 256)), dim3(512), smem, s, a);

@@ -893,11 +893,10 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
 template <int MODE, int NPW, bool CHAIN>
 static hipError_t launch_32c(const TBlockArgs& a, hipStream_t s) {
   const size_t smem = (size_t)NS * SLOT + (MODE == TB_CROSS ? 3 : 1) * 4 * 64 * 16 + (size_t)64 * a.nchunk * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DevOnce attr_once;                          // per device (mdt_kernels.h)
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tblock32<MODE, NPW, CHAIN>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
-    attr_set = true;
   }
   const int nsplit = a.nsplit > 1 ? a.nsplit : 1;
   hipLaunchKernelGGL((k_tblock32<MODE, NPW, CHAIN>), dim3((unsigned)((a.M + 31) / 32), (unsigned)nsplit), dim3(512), smem, s, a);

@@ -653,11 +653,10 @@ __global__ __launch_bounds__(512) void k_tblock_lw(TBlockArgs a) {
 template <int MODE, int NPW = 0>
 static hipError_t launch_lw(const TBlockArgs& a, hipStream_t s) {
   const size_t smem = (size_t)NS * SLOT + (size_t)64 * a.nchunk * sizeof(float);   // ring + per-chunk bias vectors
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DevOnce attr_once;                          // per device (mdt_kernels.h)
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tblock_lw<MODE, NPW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
-    attr_set = true;
   }
   hipLaunchKernelGGL((k_tblock_lw<MODE, NPW>), dim3((unsigned)((a.M + 63) / 64)), dim3(512), smem, s, a);
   return hipGetLastError();

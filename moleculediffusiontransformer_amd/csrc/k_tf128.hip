@@ -974,11 +974,10 @@ __global__ __launch_bounds__(512) void k_tf128(TFArgs a) {
 template <int NPW, int RES, bool F32>
 static hipError_t launch_tf(const TFArgs& a, hipStream_t s) {
   const size_t smem = (size_t)NS * SLOT + (size_t)(a.nvec + (RES > 0 ? a.nfilm : 0)) * sizeof(float);   // ring + vectors [+ FiLM rows]
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DevOnce attr_once;                          // per device (mdt_kernels.h)
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tf128<NPW, RES, F32>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(160 * 1024));
-    attr_set = true;
   }
   hipLaunchKernelGGL((k_tf128<NPW, RES, F32>), dim3((unsigned)((a.M + 63) / 64)), dim3(512), smem, s, a);
   return hipGetLastError();

@@ -1242,11 +1242,10 @@ int g_pair_capacity_override = 0;     // tests (mdt_set_tuning("pair_capacity", 
 template <int NPW, int NSPLIT, bool F32>
 static hipError_t launch_tf2(const TFArgs& a, hipStream_t s) {
   const size_t smem = (size_t)NS * SLOT + RED_BYTES + 2 * VEC_BYTES + 1024;   // ring, S^T exchange, vectors, prefetch sink
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DevOnce attr_once;                          // per device (mdt_kernels.h)
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tf256<NPW, NSPLIT, F32>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(160 * 1024));
-    attr_set = true;
   }
   const int nrb = (a.M + 31) / 32;
   if constexpr (NSPLIT == 1) {

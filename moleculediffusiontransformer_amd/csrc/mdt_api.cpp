@@ -49,19 +49,32 @@ extern "C" {
 
 static int g_pair_stride = 0;    // mdt_set_tuning("pair_stride", v): overrides MDT_F_PAIR_STRIDE of every pair-split op (tests)
 
-void mdt_set_error(const char* msg) { g_err = msg ? msg : ""; }
+// (library-internal: k_elem.hip reports its launch errors through it; hidden, so it is not part of the exported C ABI)
+__attribute__((visibility("hidden"))) void mdt_set_error(const char* msg) { g_err = msg ? msg : ""; }
+// Test hooks (mdt_test_occupy, the "pair_capacity" override) can stall the device or make pair-split launches refuse: they act
+// only in a process that has MDT_TEST_HOOKS=1 in its environment (tests/conftest.py sets it), never for an ordinary ABI caller.
+static bool test_hooks_enabled() {
+  const char* e = getenv("MDT_TEST_HOOKS");
+  return e && e[0] == '1';
+}
 int mdt_set_tuning(const char* key, int32_t value) {
   const std::string k = key ? key : "";
   if (k == "pair_stride") { g_pair_stride = value; return 0; }
   if (k == "tile16") { mdt::set_tile16(value); return 0; }
-  if (k == "pair_capacity") { mdt::g_pair_capacity_override = value > 0 ? value : 0; return 0; }
+  if (k == "pair_capacity") {
+    if (value > 0 && !test_hooks_enabled()) return fail("mdt_set_tuning(pair_capacity): a test hook, needs MDT_TEST_HOOKS=1");
+    mdt::g_pair_capacity_override = value > 0 ? value : 0;
+    return 0;
+  }
   g_err = "mdt_set_tuning: unknown key '" + k + "'";
   return 1;
 }
 const char* mdt_last_error(void) { return g_err.c_str(); }
 int32_t mdt_pair_capacity(void) { return mdt::tf256_pair_capacity(); }
 int mdt_test_occupy(int32_t n_workgroups, int32_t lds_bytes, uint64_t ticks, void* stream) {
-  if (n_workgroups <= 0 || lds_bytes < 0 || lds_bytes > 160 * 1024) return fail("mdt_test_occupy: bad arguments");
+  if (!test_hooks_enabled()) return fail("mdt_test_occupy: a test hook, needs MDT_TEST_HOOKS=1 in the environment");
+  if (n_workgroups <= 0 || n_workgroups > 4096 || lds_bytes < 0 || lds_bytes > 160 * 1024) return fail("mdt_test_occupy: bad arguments");
+  if (ticks > 300000000ull) return fail("mdt_test_occupy: at most 3 s (3e8 ticks of the 100 MHz counter)");
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_test_occupy), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipLaunchKernelGGL(k_test_occupy, dim3((unsigned)n_workgroups), dim3(64), (size_t)lds_bytes, (hipStream_t)stream, (unsigned long long)ticks);
   const hipError_t e = hipGetLastError();
@@ -108,6 +121,8 @@ static const char* validate(const mdt_op& o, int idx, char* buf, size_t nbuf) {
       if (i[MDT_G_WFMT] & 2) {
         if (!mdt::gemm_b16_supported(i[MDT_G_CIN], i[MDT_G_TAPS], i[MDT_G_LDA], i[MDT_G_A_COL]) || o.a2.space)
           return bad("bf16 x bf16 GEMM needs cin % 64 == 0 and 16-byte aligned bf16 rows");
+        if (i[MDT_G_N] % 4 || i[MDT_G_LDC] % 4 || i[MDT_G_O_COL] % 4 || (o.res.space && i[MDT_G_LDR] % 4))
+          return bad("bf16 x bf16 GEMM: N, ldc, o_col and ldr must be multiples of 4 (float4 epilogue)");
         if (i[MDT_G_PRO] || i[MDT_G_T_STRIDE] != 1 || i[MDT_G_PHASES] > 1 || i[MDT_G_O_STRIDE] != 1 || i[MDT_G_O_OFF] ||
             i[MDT_G_R_OUT] != i[MDT_G_R_IN] || i[MDT_G_O_ROWS] != i[MDT_G_R_OUT] || i[MDT_G_M_MODE])
           return bad("bf16 x bf16 GEMM: no prologue / stride / phases / output row mapping (use MDT_OP_PREP16 + WFMT 1 forms)");

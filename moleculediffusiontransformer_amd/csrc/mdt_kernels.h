@@ -74,6 +74,7 @@ struct Gemm16Args {
   unsigned short* copy16;     // fp32 output: also a bf16 copy [M][N] of it (the next GEMM's A operand), or nullptr
 };
 bool gemm_b16_supported(int cin, int taps, int lda, int a_col);
+bool gemm_b16_epilogue_ok(const Gemm16Args& g);   // N / ldc / o_col / ldr % 4 == 0 and 16-byte aligned tensors (float4 epilogue)
 hipError_t launch_gemm_b16(const Gemm16Args& g, hipStream_t s);
 void set_tile16(int v);          // tuning hook behind mdt_set_tuning("tile16", v)
 struct Prep16Args {
@@ -86,6 +87,20 @@ struct Prep16Args {
 hipError_t launch_prep16(const Prep16Args& g, hipStream_t s);
 bool gemm_as_eligible(const GemmArgs& g);                           // wide-N / small-K layers
 hipError_t launch_gemm_as(const GemmArgs& g, hipStream_t s);       // A-stationary split-bf16 (k_gemm_as.hip)
+
+// "Done once" state that belongs to the DEVICE, not the process: hipFuncSetAttribute(MaxDynamicSharedMemorySize) and values read
+// from hipDeviceGetAttribute are per (function, device), so a process that drives a second GPU has to repeat them there (ADVICE
+// r4).  One bit per device ordinal; first() is true the first time it is called with that device current.
+struct DevOnce {
+  unsigned long long mask = 0;
+  bool first() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return true;      // unknown: repeat the (cheap, idempotent) call
+    if ((mask >> d) & 1ull) return false;
+    mask |= 1ull << d;
+    return true;
+  }
+};
 
 #ifdef __HIPCC__
 // Loader waves of a ring kernel, after their last tile: pull the NEXT launch's weight stream into this XCD's L2 -- one dword per

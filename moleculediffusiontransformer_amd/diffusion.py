@@ -168,7 +168,7 @@ def scale_weights(sigma: Tensor, sigma_data: float) -> ScaleWeights:
                         float(c_noise[0]))
 
 
-@dataclass
+@dataclass(frozen=True)
 class StepScalars:
     """Everything one ADPM2 step needs, as fp32-exact Python floats."""
     sigma: float
@@ -194,7 +194,7 @@ def adpm2_plan(num_steps: int, schedule, sampler: ADPM2Sampler, sigma_data: floa
     key = (num_steps, sigmas.numpy().tobytes(), type(sampler), float(getattr(sampler, "rho", 0.0)), float(sigma_data))
     hit = _PLAN_CACHE.get(key)
     if hit is not None:
-        return sigmas, hit
+        return sigmas, hit                               # (a tuple: every caller shares it)
     steps: List[StepScalars] = []
     for i in range(num_steps - 1):
         sigma, sigma_next = sigmas[i], sigmas[i + 1]
@@ -208,8 +208,8 @@ def adpm2_plan(num_steps: int, schedule, sampler: ADPM2Sampler, sigma_data: floa
                                  float(torch.tensor(renoise, dtype=torch.float32))))
     if len(_PLAN_CACHE) >= 16:
         _PLAN_CACHE.pop(next(iter(_PLAN_CACHE)))
-    _PLAN_CACHE[key] = steps
-    return sigmas, steps
+    _PLAN_CACHE[key] = tuple(steps)
+    return sigmas, _PLAN_CACHE[key]
 
 
 class NoiseSource:

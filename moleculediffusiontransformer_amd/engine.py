@@ -98,8 +98,10 @@ class UNetEngine:
     # units held by another stream or process, or a CU mask, are invisible to it) raises bit 0 of the diagnostic word on the
     # device and the launch's rows are garbage.  Every sampling loop and every net() evaluation copies that word to pinned host
     # memory behind its last launch (note_handoff) and -- by default -- WAITS for the copy and raises before any result is
-    # returned (sync_handoff_check: one event wait per call; VERDICT r3 #9 / ADVICE r3).  Pipelined callers may defer the look
-    # to the next call or to an explicit handoff_check(wait=True) (model.defer_handoff_check).
+    # returned (sync_handoff_check: one event wait per call, i.e. ONE HOST SYNCHRONISATION per sample() and per
+    # torch.ops.mdt.unet_eval / denoise evaluation; VERDICT r3 #9 / ADVICE r3).  Pipelined callers (user sampler loops built on
+    # denoise_fn) defer the look to the next call or to an explicit handoff_check(wait=True) with model.defer_handoff_check;
+    # under a stream capture nothing is waited for (see note_handoff).
     sync_handoff_check = True
 
     def note_handoff(self) -> None:
@@ -108,6 +110,11 @@ class UNetEngine:
         if getattr(self, "_xstat_host", None) is None:
             self._xstat_host = torch.zeros(1, dtype=torch.int32).pin_memory()
             self._xstat_event = torch.cuda.Event()
+        if torch.cuda.is_current_stream_capturing():
+            # inside a user's graph capture (torch.ops.mdt.unet_eval in a captured region): a host wait would invalidate the
+            # capture, and the copy would be replayed into stale pinned memory.  The status word stays on the device; the next
+            # un-captured call -- or handoff_status() -- reports a time-out of the replays.
+            return
         self._xstat_host.copy_(self.xflags[:1], non_blocking=True)
         self._xstat_event.record()
         self._xstat_pending = True

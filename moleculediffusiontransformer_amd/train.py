@@ -168,6 +168,16 @@ def unet_cfg_forward(unet, x, time, embedding, embedding_scale: float = 1.0, emb
     return unet_forward(unet, x, time, embedding)
 
 
+def _clip(x: Tensor, dynamic_threshold: float = 0.0) -> Tensor:
+    """clip(), diffusion.py:75-88, as the training objective sees it (denoise_fn :814): clamp to [-1, 1], or -- with
+    ``dynamic_threshold`` > 0 -- clamp to the per-sample quantile of |x| (at least 1) and divide by it."""
+    if dynamic_threshold == 0.0:
+        return x.clamp(-1.0, 1.0)
+    scale = torch.quantile(x.flatten(1).abs(), dynamic_threshold, dim=-1).clamp(min=1.0)
+    scale = scale.view(-1, *((1,) * (x.ndim - 1)))
+    return x.clamp(-scale, scale) / scale
+
+
 def kdiffusion_loss(model, x: Tensor, noise: Optional[Tensor], embedding: Tensor, sigmas: Optional[Tensor] = None,
                     **kwargs) -> Tensor:
     """KDiffusion_mod.forward (diffusion.py:820-844): per-sample log-normal sigma, noised input, one denoise, weighted MSE.
@@ -185,7 +195,7 @@ def kdiffusion_loss(model, x: Tensor, noise: Optional[Tensor], embedding: Tensor
     c_out = sp * sd * (sd ** 2 + sp ** 2) ** -0.5
     c_in = (sp ** 2 + sd ** 2) ** -0.5
     pred = unet_cfg_forward(model.unet, c_in * x_noisy, c_noise, embedding, **kwargs)
-    x_denoised = (c_skip * x_noisy + c_out * pred).clamp(-1.0, 1.0)     # clip, dynamic_threshold = 0 (diffusion.py:75-77)
+    x_denoised = _clip(c_skip * x_noisy + c_out * pred, float(kd.dynamic_threshold))
     losses = F.mse_loss(x_denoised, x, reduction="none").flatten(1).mean(dim=1)
     losses = losses * ((sigmas ** 2 + sd ** 2) * (sigmas * sd) ** -2)    # loss_weight, diffusion.py:816-818
     return losses.mean()

@@ -9,6 +9,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# libmdt_hip.so's test hooks (mdt_test_occupy, the "pair_capacity" override) act only in a process that asks for them
+os.environ.setdefault("MDT_TEST_HOOKS", "1")
 
 
 def pytest_configure(config):

@@ -1,6 +1,6 @@
 """Round-4 fixtures from the REAL reference (build container only):
 
-    python tests/golden/make_golden_r4.py
+    python tests/golden/make_golden_r4.py          (writes all four files)
 
   analog_forward.npz   what AnalogDiffusionSparse.forward / AnalogDiffusionFull.forward (graphmodel.py:316-353 / :497-545) hand to
                        self.diffusion -- the training target sliced / padded from the packed `output` rows and the conditioning
@@ -12,7 +12,12 @@
                        tiny inverse model with KDiffusion_mod.dynamic_threshold = 0.9 (every class hard-codes 0.0; the attribute is
                        read at denoise time, diffusion.py:814)
 
-Only inputs and outputs are stored.
+  train_loss.npz       QMDiffusion.forward (generative.py:812-833 -> KDiffusion_mod.forward, diffusion.py:820-844) of the tiny
+                       inverse model with KDiffusion_mod.dynamic_threshold = 0.0 and 0.9 on fixed sigmas / noise: the training
+                       objective applies clip() inside denoise_fn (:814), so it depends on the threshold
+
+Only inputs and outputs are stored.  Every array is a function of named synthetic draws (synth.py), so re-running the script
+reproduces the files bit for bit.
 """
 import os
 import sys
@@ -44,6 +49,9 @@ def main():
     for pn in (False, True):
         sp = AnalogDiffusionSparse(max_length=16, channels=32, pred_dim=8 if pn else 3, context_embedding_max_length=12,
                                    unet_type="cfg", text_embed_dim=64, embed_dim_position=64, predict_neighbors=pn)
+        with torch.no_grad():       # the recorded embedding goes through fc1: synthetic weights, not the constructor's random ones
+            sp.fc1.weight.copy_(synth_normal("r4/analog/fc1_w", tuple(sp.fc1.weight.shape)))
+            sp.fc1.bias.copy_(synth_normal("r4/analog/fc1_b", tuple(sp.fc1.bias.shape)))
         sp.diffusion = _Rec()
         sp.forward(seq, packed)
         out[f"sparse_pn{int(pn)}_target"] = sp.diffusion.output.numpy()
@@ -84,8 +92,28 @@ def dynthr():
     G.save("dynthr.npz", **out)
 
 
+def train_loss():
+    out = {}
+    m = G.build("inverse", max_length=32, pred_dim=16, channels=16, context_embedding_max_length=12, text_embed_dim=64,
+                embed_dim_position=64)
+    B = 3
+    seq = synth_normal("tiny/seq", (B, 12))
+    x0 = synth_normal("r4/train/x0", (B, 16, 32)) * 1.5          # heavy enough that the 0.9 quantile of |x_denoised| exceeds 1
+    noise = synth_normal("r4/train/noise", (B, 16, 32))
+    sigmas = (-1.2 + 1.2 * synth_normal("r4/train/sig", (B,))).exp()
+    kd = m.diffusion.diffusion
+    kd.sigma_distribution = lambda num_samples, device: sigmas.clone()       # the draw of diffusion.py:824, fixed
+    out.update(seq=seq.numpy(), x0=x0.numpy(), noise=noise.numpy(), sigmas=sigmas.numpy())
+    for q in (0.0, 0.9):
+        kd.dynamic_threshold = q
+        inj = G.NoiseInjector("unused")
+        inj._draw = lambda shape: noise.clone()                              # randn_like of diffusion.py:828
+        with inj, torch.no_grad():
+            out[f"loss_q{q}"] = m(seq, x0).numpy()
+    G.save("train_loss.npz", **out)
+
+
 if __name__ == "__main__":
-    if "dynthr" in sys.argv:
-        dynthr()
-        sys.exit(0)
-    main()
+    only = [a for a in sys.argv[1:] if a in ("main", "dynthr", "train_loss")]
+    for name in (only or ["main", "dynthr", "train_loss"]):
+        {"main": main, "dynthr": dynthr, "train_loss": train_loss}[name]()

@@ -204,6 +204,39 @@ def test_training_loss_matches_reference_formula():
     assert a.requires_grad and torch.equal(a.detach(), b.detach())
 
 
+def test_training_loss_honours_dynamic_threshold_like_the_reference():
+    """the training objective goes through denoise_fn, whose clip() reads KDiffusion_mod.dynamic_threshold
+    (diffusion.py:814, :75-88).  QMDiffusion.forward of the tiny model against the loss the REAL reference returned on the same
+    sigmas / noise with the threshold at 0.0 and 0.9 (tests/golden/make_golden_r4.py train_loss); the analog wrappers' recorded
+    conditioning embeddings (now from synthetic fc1 weights: reproducible) ride along."""
+    from moleculediffusiontransformer_amd.synth import make_synth_model
+    from moleculediffusiontransformer_amd.train import conditioning_embedding, kdiffusion_loss
+    g = load_golden("train_loss.npz")
+    m = make_synth_model("tiny")
+    seq, x0 = torch.from_numpy(g["seq"]), torch.from_numpy(g["x0"])
+    noise, sigmas = torch.from_numpy(g["noise"]), torch.from_numpy(g["sigmas"])
+    emb = conditioning_embedding(m, seq)
+    got = {}
+    for q in (0.0, 0.9):
+        m.diffusion.diffusion.dynamic_threshold = q
+        got[q] = float(kdiffusion_loss(m, x0, noise, emb, sigmas=sigmas).detach())
+        ref = float(g[f"loss_q{q}"])
+        assert abs(got[q] - ref) < 2e-5 * abs(ref), (q, got[q], ref)
+    assert abs(got[0.9] - got[0.0]) > 1.0              # the fixture really exercises the quantile branch
+    from moleculediffusiontransformer_amd.graphmodel import AnalogDiffusionSparse
+    from moleculediffusiontransformer_amd.synth import synth_normal
+    a = load_golden("analog_forward.npz")
+    for pn in (False, True):
+        sp = AnalogDiffusionSparse(max_length=16, channels=32, pred_dim=8 if pn else 3, context_embedding_max_length=12,
+                                   text_embed_dim=64, embed_dim_position=64, predict_neighbors=pn)
+        with torch.no_grad():
+            sp.fc1.weight.copy_(synth_normal("r4/analog/fc1_w", tuple(sp.fc1.weight.shape)))
+            sp.fc1.bias.copy_(synth_normal("r4/analog/fc1_b", tuple(sp.fc1.bias.shape)))
+        sp.diffusion = _Rec()
+        sp.forward(torch.from_numpy(a["seq"]), torch.from_numpy(a["packed"]))
+        assert (sp.diffusion.embedding - torch.from_numpy(a[f"sparse_pn{int(pn)}_emb"])).abs().max() < 1e-6
+
+
 def test_sampler_seams_exist_with_reference_signatures():
     """diffusion.py:347-366 (Sampler), :486-549 (ADPM2Sampler), :554-591 (DiffusionSampler), :594-625 (DiffusionInpainter),
     :724-767 (XDiffusion_x.sample / inpaint): the mix-and-match seams of SURVEY section 8(b)."""
