@@ -131,6 +131,22 @@ enum mdt_op_kind {
                           the per-layer key / value projections are folded into the query / output projections by the host):
                           a = q' [B][T * heads][128] (rows (token, head)), a2 = c [B | 1][Tk <= 64][LDKV], out [B][T * heads][128]
                           = softmax(q' c^T * scale) c; ints as MDT_OP_ATTN (LDQ / LDO unused)                              */
+  MDT_OP_RES256 = 15,  /* a CHAIN of ResnetBlock1d blocks (modules.py:145-205) of a 256-channel level in ONE launch, 32-row workgroups that
+                          keep their rows in registers from the first block to the last (csrc/k_res256.hip): kind 1: x = Block(x)
+                          N_RES times, every block's output also stored as a skip tensor (DownsampleBlock1d / BottleneckBlock1d,
+                          modules.py:680-721, :865-928); kind 2: x = Block(cat([x, s * skip[rb]])) (UpsampleBlock1d, :828-862).
+                          a = x, out, res = skip tensors (addressed as MDT_OP_TF128's), w = weight sub-tile stream, bias = the blocks'
+                          vectors, p0 = tile descriptors, p3 = the blocks' FiLM rows; ints: enum mdt_tf128_i with C = 256, the ResNet
+                          fields, NT, NVEC = N_RES x (6 C | 9 C), and NPOST = taps of the block convolutions (3, or 1 when T = 1: only
+                          the centre tap of a k = 3 convolution sees data); RES_PAIR1 / RES_PAIR2 are implied (GroupNorm groups of
+                          64 channels on a 2C-channel input, 32 otherwise).  Stream: sub-tiles [64 features][128 k] in (tap, K half,
+                          chunk) order per convolution; rows 0..31 of chunk c are output channels 32 c .., rows 32..63 channels
+                          128 + 32 c ..; K columns in accumulator order (k-slot 32 st + 8 g + e = channel 16 (2 st + (e >> 2)) + 4 g +
+                          (e & 3)).  Descriptors: kind (2 bits: 0 weight sub-tile, 1 skip rows of block aux, 2 scratch, 3 scratch + the
+                          vectors of block aux) | aux << 2; sequence: [3 (block 0)], then per block, kind 1: X nt X nt, kind 2: X nt X
+                          8 S X 8 S X nt X nt (block1 on x, to_out on x, to_out on the skip, block1 on the skip, block2; X = 2, or 3 with aux = next block at a block's first X; nt = 8 taps; S = 1).  Vectors
+                          per block: kind 1 [g1 | b1 | bias1 | g2 | b2 | bias2], kind 2 [g1 (2C) | b1 (2C) | bias1 | bias_to_out | g2 |
+                          b2 | bias2].  WF32 as MDT_OP_TF256 (fp32 fragment sub-tiles)                                                  */
   MDT_OP_TBLOCK = 7    /* fused transformer sub-block, in place on x (TransformerBlock.forward, modules.py:456-461):
                           x += Attention(x) | x += Attention(x, context) | x += FeedForward(x); LayerNorm affine
                           folded into the projection weights, q/k/v/probabilities/hidden never leave registers */

@@ -162,6 +162,12 @@ class UNetCompiler:
         # projections into the query / output projections and attend to the normalised context itself
         # ResNet blocks of a 128-channel level inside the transformer launch that follows them (k_tf128 RES = 1 / 2)
         self.res128 = os.environ.get("MDT_RES128", "1") == "1"
+        # MDT_RES256: the 256-channel level's ResNet blocks as chained launches (MDT_OP_RES256, csrc/k_res256.hip) -- 1 always, 0 never
+        # (one k_rconv launch per convolution), auto (default) = where it measured faster: in the wide program (batches whose
+        # 256-channel level does not fit one pair-split launch: +2.1 ... +3.3 % same-box at B = 2048 / 8192 / guidance) and on a
+        # one-token level (configs[2]: +0.7 %); at BASELINE configs[1]'s B = 1024 the per-convolution launches, which split the
+        # output channels over two workgroups, are 0.4 % faster than the chain on half the compute units (profiles/r5_res256_ab.txt)
+        self.res256_mode = os.environ.get("MDT_RES256", "auto")
         self.b16 = os.environ.get("MDT_B16", "1") == "1"
         self.qkv_merge = os.environ.get("MDT_QKV_MERGE", "1") == "1"   # ... and self-attention's q | k | v as one GEMM     # bf16 mode: regular layers as PREP16 + bf16 x bf16 GEMM
         self.fold_ctx = os.environ.get("MDT_FOLD_CTX", "1") == "1"
@@ -621,6 +627,9 @@ class UNetCompiler:
         assert x.ld == cin_p, (p, x.ld, cin_p)
         if self.resblock_ok(x.rows, cin, cout, groups, p):
             return self.resblock(x, p, cin, cout, free_input)
+        if cin == cout and x.ld == cin and self.res256_ok(p, cin, x.rows, groups, False):
+            y = self._new(x.rows, cin)                        # a chain of one block (its "skip" store is the output itself)
+            return self.resnet_chain256(x, [p], 1, [y], 1.0, y, free_input)
         if cin == cout and x.ld == cin and (p + "to_out.weight") not in self.sd and groups > 0 and cin % groups == 0 \
                 and self.rconv_ok(x.rows, cin, 3, cin // groups):
             return self._resnet_rconv(x, None, 1.0, p, cin, groups, free_input)
@@ -1021,7 +1030,8 @@ class UNetCompiler:
             return False
         return not (cross and (16 // rows) * self.n_ctx > 48)
 
-    def transformer_fused256(self, x: Ten, p: str, c: int, layers: int, cross: bool, free_input: bool) -> Ten:
+    def transformer_fused256(self, x: Ten, p: str, c: int, layers: int, cross: bool, free_input: bool,
+                             y: Optional[Ten] = None) -> Ten:
         """Transformer1d.forward (modules.py:519-524) of a 256-channel level as ONE MDT_OP_TF256 (csrc/k_tf256.hip): 32 KB
         sub-tiles in consumption order, two scratch descriptors behind every sub-block (the wave pairs' partial sums meet
         there; the first one carries the next sub-block's vectors), K columns of residual-stream consumers in accumulator
@@ -1127,7 +1137,8 @@ class UNetCompiler:
             self.flops += 2 * 2 * rows * c * w1.shape[0]
         assert all(len(d) == len(descs[0]) for d in descs)
         desc = [v for d in descs for v in d]
-        y = self._new(rows, c)
+        if y is None:
+            y = self._new(rows, c)
         op = rt.MdtOp()
         op.kind = rt.OP_TF256
         op.a, op.out = x.ref(), y.ref()
@@ -1149,6 +1160,105 @@ class UNetCompiler:
         if cross:
             op._kv = ("kv", cross0)
             op.a2 = _ref(rt.SP_ACT, 0)
+        self._emit(op)
+        if free_input:
+            self._free(x)
+        return y
+
+    # ------------------------------------------------------------------ a chain of ResNet blocks of a 256-channel level
+    def res256_ok(self, p: str, c: int, rows: int, groups: int, two_source: bool) -> bool:
+        """Can the ResnetBlock1d at prefix p be a link of an MDT_OP_RES256 chain (csrc/k_res256.hip)?  256 channels, GroupNorm
+        groups of 32 channels (64 on the 2C-channel input of an up-path block), C -> C or 2C -> C with to_out."""
+        if not (self.use_rconv and self.ring_mode and self.fuse_blocks) or self.res256_mode == "0":
+            return False
+        if c != 256 or rows > 16 or 16 % rows or groups <= 0:
+            return False
+        if self.res256_mode != "1" and not (self.tf256 or rows == 1):
+            return False
+        cin = 2 * c if two_source else c
+        if cin % groups or c % groups or cin // groups != (64 if two_source else 32) or c // groups != 32:
+            return False
+        w1 = self.sd.get(p + "block1.project.weight")
+        if w1 is None or tuple(w1.shape) != (c, cin, 3) or tuple(self.sd[p + "block2.project.weight"].shape) != (c, c, 3):
+            return False
+        return ((p + "to_out.weight") in self.sd) == two_source
+
+    def resnet_chain256(self, x: Ten, blocks: List[str], kind: int, skips: List[Ten], scale_b: float, y: Ten,
+                        free_input: bool) -> Ten:
+        """ResnetBlock1d.forward (modules.py:193-205) for every prefix in `blocks`, ONE MDT_OP_RES256 launch.  kind 1: x = Block(x),
+        block rb's output also stored to skips[rb] (whole tensors apart, ascending); kind 2: x = Block(cat([x, scale_b * skips[rb]]))
+        (modules.py:828-829; skips descending, in order of consumption).  Sub-tiles [64][128]: rows 0..31 = output channels 32 ch ..,
+        rows 32..63 = channels 128 + 32 ch .. (a wave of the kernel owns a contiguous half of the channels); K columns in
+        accumulator order; one token per sample: only the centre tap of the k = 3 convolutions is streamed."""
+        sd, c, rows = self.sd, 256, x.rows
+        taps = 1 if rows == 1 else 3
+        acc = torch.tensor([16 * (2 * (k >> 5) + ((k & 7) >> 2)) + 4 * ((k >> 3) & 3) + (k & 3) for k in range(c)])
+        W_, S_, X_, XV_ = 0, 1, 2, 3
+        tiles: List[torch.Tensor] = []
+        desc: List[int] = [XV_ | (0 << 2)]                        # the vectors of block 0
+        vec: List[torch.Tensor] = []
+        n = len(blocks)
+
+        def conv_tiles(w: torch.Tensor) -> None:                   # [c][c][k] -> (tap, K half, chunk) sub-tiles
+            k = w.shape[2]
+            tp = [k // 2] if (k == 3 and taps == 1) else list(range(k))
+            for tap in tp:
+                wt = w[:, :, tap][:, acc]
+                for kh in range(2):
+                    for ch in range(4):
+                        rws = torch.cat([torch.arange(32 * ch, 32 * ch + 32), torch.arange(128 + 32 * ch, 128 + 32 * ch + 32)])
+                        desc.append(W_ | (len(tiles) << 2))
+                        tiles.append(self._wtile(wt[rws][:, 128 * kh: 128 * kh + 128].contiguous()))
+
+        film0 = None
+        for rb, bp in enumerate(blocks):
+            ss_off = self.ss_total                                  # FiLM vectors inside the shared (scale | shift) row
+            self.ss_offsets[bp] = ss_off
+            self.ss_total += 2 * c
+            film0 = ss_off if film0 is None else film0
+            w1, w2 = sd[bp + "block1.project.weight"].float(), sd[bp + "block2.project.weight"].float()
+            g1, b1 = sd[bp + "block1.groupnorm.weight"].float(), sd[bp + "block1.groupnorm.bias"].float()
+            g2, b2 = sd[bp + "block2.groupnorm.weight"].float(), sd[bp + "block2.groupnorm.bias"].float()
+            bias1, bias2 = sd[bp + "block1.project.bias"].float(), sd[bp + "block2.project.bias"].float()
+            first_x = XV_ | ((rb + 1) << 2) if rb + 1 < n else X_    # a block's first exchange carries the NEXT block's vectors
+            if kind == 1:
+                desc.append(first_x)
+                conv_tiles(w1)
+                desc.append(X_)
+                conv_tiles(w2)
+                vec += [g1, b1, bias1, g2, b2, bias2]
+                self.flops += 2 * rows * taps * c * c * 2
+            else:
+                wr, br = sd[bp + "to_out.weight"].float(), sd[bp + "to_out.bias"].float()      # [c, 2c, 1]
+                desc.append(first_x)
+                conv_tiles(w1[:, :c])                               # block1 on x
+                desc.append(X_)
+                conv_tiles(wr[:, :c])                               # to_out on x
+                desc += [S_ | (rb << 2), X_]
+                conv_tiles(wr[:, c:])                               # to_out on the skip
+                desc += [S_ | (rb << 2), X_]
+                conv_tiles(w1[:, c:])                               # block1 on the skip
+                desc.append(X_)
+                conv_tiles(w2)
+                vec += [g1, b1, bias1, br, g2, b2, bias2]
+                self.flops += 2 * rows * (taps * 2 * c * c + taps * c * c + 2 * c * c)
+        v = torch.cat([t.reshape(-1) for t in vec])
+        assert v.numel() == n * (6 if kind == 1 else 9) * c
+        for k in range(1, len(skips)):                              # whole tensors apart (ascending produced / descending consumed)
+            step = rows * c if kind == 1 else -rows * c
+            assert skips[k].off == skips[0].off + k * step and skips[k].space == rt.SP_ACT
+        op = rt.MdtOp()
+        op.kind = rt.OP_RES256
+        op.a, op.out, op.res = x.ref(), y.ref(), skips[0].ref()
+        op._film = ("ss", film0)
+        op.w = _ref(rt.SP_WEIGHT, self.W.add(blocks[0] + "res256.tiles", torch.cat(tiles)))
+        op.i[rt.W_KB] = min(sum(t.numel() for t in tiles) * 4 // 1024, 4096)
+        op.bias = _ref(rt.SP_WEIGHT, self.W.add(blocks[0] + "res256.vec", v))
+        op.p0 = _ref(rt.SP_WEIGHT, self.W.add(blocks[0] + "res256.desc", torch.tensor(desc, dtype=torch.int32).view(torch.float32)))
+        i = op.i
+        i[rt.F_C], i[rt.F_T], i[rt.F_NT], i[rt.F_NVEC], i[rt.F_NPOST] = c, rows, len(desc), v.numel(), taps
+        i[rt.F_RES_KIND], i[rt.F_N_RES], i[rt.F_NFILM], i[rt.F_WF32] = kind, n, 2 * c * n, int(self.wf32)
+        op.f[rt.FF_EPS_RES], op.f[rt.FF_SKIP_SCALE] = 1e-5, float(scale_b if kind == 2 else 1.0)
         self._emit(op)
         if free_input:
             self._free(x)
@@ -1268,7 +1378,7 @@ class UNetCompiler:
         if self.tf128_ok(c, x.rows, layers, cross):
             return self.transformer_fused128(x, p, c, layers, cross, free_input, y=y_out)
         if self.tf256_ok(c, x.rows, layers, cross):
-            return self.transformer_fused256(x, p, c, layers, cross, free_input)
+            return self.transformer_fused256(x, p, c, layers, cross, free_input, y=y_out)
         t = self._new(x.rows, c)
         gi, bi = self._vec(p + "to_in.0.weight", c), self._vec(p + "to_in.0.bias", c)
         wi, bias_i = self._conv_w(p + "to_in.1.weight", c, c), self._vec(p + "to_in.1.bias", c)
@@ -1478,6 +1588,20 @@ class UNetCompiler:
                             outs[nb] = yy
                 skips += outs
                 x = outs[-1]
+            elif nb > 0 and x.ld == co and all(self.res256_ok(bp, co, x.rows, g, False) for bp in blocks):
+                # 256-channel level: the blocks as ONE chained launch (MDT_OP_RES256); outputs whole tensors apart in one allocation
+                # (with the transformer's behind them), so that the up path's chain addresses its skips by index
+                n_out = nb + (1 if nat > 0 else 0)
+                base = self.arena.alloc(n_out * x.rows * co)
+                outs = [Ten(rt.SP_ACT, base + k * x.rows * co, x.rows, co, co) for k in range(n_out)]
+                self.resnet_chain256(x, blocks, 1, outs[:nb], 1.0, outs[nb - 1], free_input=not x_is_skip)
+                if nat > 0:
+                    yy = self.transformer(outs[nb - 1], dp + "transformer.", co, nat, True, free_input=False, y_out=outs[nb])
+                    if yy is not outs[nb]:
+                        self._free(outs[nb])
+                        outs[nb] = yy
+                skips += outs
+                x = outs[-1]
             else:
                 for bp in blocks:
                     x = self.resnet(x, bp, co, co, g, free_input=not x_is_skip)
@@ -1519,6 +1643,13 @@ class UNetCompiler:
                     tfs = tfs[1:]
                 else:                     # the blocks alone (the transformer behind them is not a k_tf128 launch)
                     x = self.transformer_fused128(x, "", ci, 0, False, True, res=(2, blocks, g, cons, 2 ** -0.5))
+                for sk in cons:
+                    self._free(sk)
+            elif (bool(cons) and x.ld == ci and all(self.res256_ok(bp, ci, x.rows, g, True) for bp in blocks)
+                  and all(sk.space == rt.SP_ACT and sk.rows == x.rows and sk.ld == ci
+                          and sk.off == cons[0].off - k * x.rows * ci for k, sk in enumerate(cons))):
+                del skips[len(skips) - n_res:]
+                x = self.resnet_chain256(x, blocks, 2, cons, 2 ** -0.5, self._new(x.rows, ci), True)
                 for sk in cons:
                     self._free(sk)
             else:
@@ -1602,7 +1733,7 @@ class UNetCompiler:
             for op in ops:
                 o = rt.MdtOp()
                 C_memmove(o, op)
-                if op.kind in (rt.OP_GEMM, rt.OP_GN_ACT, rt.OP_RCONV, rt.OP_RESBLOCK, rt.OP_PREP16, rt.OP_TF128) and isinstance(getattr(op, "_film", None), tuple):
+                if op.kind in (rt.OP_GEMM, rt.OP_GN_ACT, rt.OP_RCONV, rt.OP_RESBLOCK, rt.OP_PREP16, rt.OP_TF128, rt.OP_RES256) and isinstance(getattr(op, "_film", None), tuple):
                     o.p3 = _ref(rt.SP_SHR, ss_cur + op._film[1])
                 if op.kind == rt.OP_ATTN_CTX:
                     if fixed:

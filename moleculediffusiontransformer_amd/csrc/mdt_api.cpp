@@ -245,6 +245,18 @@ static const char* validate(const mdt_op& o, int idx, char* buf, size_t nbuf) {
         return bad("the pair-split form needs the hand-off flags (p2), the hand-off blocks (p3) and a pair stride of 1..64");
       break;
     }
+    case MDT_OP_RES256: {
+      const int32_t* i = o.i;
+      if (i[MDT_F_C] != 256) return bad("the ResNet chain needs C = 256");
+      if (!mdt::res256_supported(i[MDT_F_T], i[MDT_F_RES_KIND], i[MDT_F_N_RES], i[MDT_F_NPOST]))
+        return bad("ResNet chain: tokens per sample must divide 16, kind 1 | 2, 1..255 blocks, taps 3 (or 1 with one token per sample)");
+      if (i[MDT_F_NT] <= 0 || i[MDT_F_NBLOCKS] || i[MDT_F_HAS_IN] || i[MDT_F_CROSS]) return bad("ResNet chain: bad tile count / stray transformer fields");
+      if (i[MDT_F_WF32] != 0 && i[MDT_F_WF32] != 1) return bad("WF32 must be 0 (split-bf16 tiles) or 1 (fp32 fragment tiles)");
+      if (i[MDT_F_NVEC] != i[MDT_F_N_RES] * (i[MDT_F_RES_KIND] == 1 ? 6 : 9) * 256 || i[MDT_F_NFILM] < 512 * i[MDT_F_N_RES])
+        return bad("ResNet chain: NVEC must be N_RES x (6 | 9) x 256 floats and NFILM >= 512 N_RES");
+      if (!o.a.space || !o.out.space || !o.w.space || !o.bias.space || !o.p0.space || !o.res.space || !o.p3.space) return bad("missing operand");
+      break;
+    }
     default:
       return bad("unknown op kind");
   }
@@ -312,7 +324,7 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
     int pf_lines = 0;
     if (!no_prefetch && idx + 1 < last) {
       const mdt_op& nx = p->ops[idx + 1];
-      if ((nx.kind == MDT_OP_TBLOCK || nx.kind == MDT_OP_RCONV || nx.kind == MDT_OP_TF128 || nx.kind == MDT_OP_TF256) &&
+      if ((nx.kind == MDT_OP_TBLOCK || nx.kind == MDT_OP_RCONV || nx.kind == MDT_OP_TF128 || nx.kind == MDT_OP_TF256 || nx.kind == MDT_OP_RES256) &&
           nx.i[MDT_W_KB] > 0 && nx.w.space == MDT_SP_WEIGHT && bd->weights) {
         pf_ptr = bd->weights + nx.w.off;
         // at most the first 2 MB: an XCD's L2 holds 4 MB, the long streams of the whole-transformer launches are pulled in from
@@ -493,6 +505,23 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
             return fail("mdt_program_run: a dual-batch fused transformer needs the shared K/V rows and B = 2 x (a multiple of the samples per workgroup)");
         }
         if (!missing) e = wide ? mdt::launch_tf256(a, stream) : mdt::launch_tf128(a, stream);
+        break;
+      }
+      case MDT_OP_RES256: {
+        const int32_t* i = o.i;
+        mdt::TFArgs a = {};
+        a.x = ptr(o.a); a.out = ptr(o.out); a.w = ptr(o.w); a.vec = ptr(o.bias);
+        a.tiles = reinterpret_cast<const unsigned*>(ptr(o.p0));
+        a.T = i[MDT_F_T]; a.M = B * a.T; a.NT = i[MDT_F_NT]; a.nvec = i[MDT_F_NVEC]; a.nsamples = B;
+        a.npost = i[MDT_F_NPOST];                        // taps of the block convolutions
+        a.res_kind = i[MDT_F_RES_KIND]; a.n_res = i[MDT_F_N_RES]; a.nfilm = i[MDT_F_NFILM];
+        a.film = ptr(o.p3); a.skip = ptr(o.res);
+        a.skip_stride = (int64_t)B * a.T * 256 * (a.res_kind == 2 ? -1 : 1);
+        a.skip_scale = o.f[MDT_FF_SKIP_SCALE]; a.eps_res = o.f[MDT_FF_EPS_RES];
+        a.pf_ptr = pf_ptr; a.pf_lines = pf_lines;
+        a.nsplit = 1; a.wf32 = i[MDT_F_WF32];
+        a.dbgbuf = ptr(o.p2);                            // (tuning builds with -DMDT_STAMPS: clock stamps of workgroup 0; else unused)
+        if (!missing) e = mdt::launch_res256(a, stream);
         break;
       }
       case MDT_OP_TIME_EMBED: {

@@ -270,6 +270,10 @@ hipError_t launch_tf128_f32(const TFArgs& a, hipStream_t s);    // the exact-fp3
 bool tf256_supported(int T, int Tk, int nheads, int nff, bool cross);
 hipError_t launch_tf256(const TFArgs& a, hipStream_t s);
 hipError_t launch_tf256_f32(const TFArgs& a, hipStream_t s);
+// MDT_OP_RES256 (k_res256.hip): a chain of ResnetBlock1d blocks of a 256-channel level in one launch; TFArgs fields as the ResNet
+// part of MDT_OP_TF128 (res_kind, n_res, skip, skip_stride, skip_scale, film, eps_res) with npost = taps of the block convolutions
+bool res256_supported(int T, int kind, int n_res, int taps);
+hipError_t launch_res256(const TFArgs& a, hipStream_t s);
 int tf256_pair_capacity();              // workgroups of a pair-split launch resident at once on the current device
 extern int g_pair_capacity_override;    // tests: > 0 replaces the device's capacity    // (k_tf256_f32.hip); reached through launch_tf256
 

@@ -19,12 +19,13 @@ OP_GEMM, OP_GN_STATS, OP_ATTN, OP_CONCAT, OP_PATCH, OP_TIME_EMBED, OP_TBLOCK, OP
 OP_RESBLOCK = 10
 OP_TF128 = 11
 OP_TF256 = 12
+OP_RES256 = 15
 OP_ATTN_CTX = 13
 OP_PREP16 = 14
 W_KB = 23          # ring-kernel ops: KB of the weight stream (prefetched into the L2s by the previous launch)
 OP_NAMES = {OP_GEMM: "k_gemm", OP_GN_STATS: "k_gn_stats", OP_ATTN: "k_attn", OP_CONCAT: "k_concat", OP_PATCH: "k_patch",
             OP_TIME_EMBED: "k_time_embed", OP_TBLOCK: "k_tblock", OP_GN_ACT: "k_gn_act", OP_RCONV: "k_rconv",
-            OP_RESBLOCK: "k_resblock", OP_TF128: "k_tf128", OP_TF256: "k_tf256", OP_ATTN_CTX: "k_attn_ctx", OP_PREP16: "k_prep16"}
+            OP_RESBLOCK: "k_resblock", OP_TF128: "k_tf128", OP_TF256: "k_tf256", OP_RES256: "k_res256", OP_ATTN_CTX: "k_attn_ctx", OP_PREP16: "k_prep16"}
 TB_SELF, TB_CROSS, TB_FF = 0, 1, 2
 PRO_NONE, PRO_LAYERNORM, PRO_GROUPNORM, PRO_SILU = 0, 1, 2, 3
 

@@ -207,6 +207,8 @@ def run_program(ops, bufs: Buffers, B: int, n_shared_rows: int = 0) -> None:
             _tf128(op, bufs, B)
         elif op.kind == rt.OP_TF256:
             _tf256(op, bufs, B)
+        elif op.kind == rt.OP_RES256:
+            _res256(op, bufs, B)
         else:
             raise ValueError(f"unknown op kind {op.kind}")
 
@@ -673,4 +675,103 @@ def _tf256(op, bufs: Buffers, B: int) -> None:
             x = x + hdn @ torch.cat(w2, dim=1).T + b2
         end_subblock(last=last)
     assert all(t == NT for t in cur["t"]), (cur["t"], NT)
+    bufs.view(op.out, B, B * T * C).view(B, T, C)[:] = x
+
+
+def _res256(op, bufs: Buffers, B: int) -> None:
+    """MDT_OP_RES256 semantics (include/mdt_hip.h): a chain of ResnetBlock1d blocks (reference modules.py:145-205, :828-829) of a
+    256-channel level, reconstructed from the sub-tile stream by following the tile descriptors: sub-tiles [64][128] in (tap, K half,
+    chunk) order, rows 0..31 = output channels 32 ch .., rows 32..63 = channels 128 + 32 ch .., K columns in accumulator order."""
+    i, f = op.i, op.f
+    C, T, NT, taps = i[rt.F_C], i[rt.F_T], i[rt.F_NT], i[rt.F_NPOST]
+    kind, n_res = i[rt.F_RES_KIND], i[rt.F_N_RES]
+    assert C == 256 and kind in (1, 2) and taps in (1, 3)
+    desc = bufs.view(op.p0, B, NT).contiguous().view(torch.int32).tolist()
+    nw = sum(1 for d in desc if (d & 3) == 0)
+    stream = bufs.view(op.w, B, nw * 64 * 128)
+    vec = bufs.view(op.bias, B, i[rt.F_NVEC])
+    film = bufs.view(op.p3, B, i[rt.F_NFILM])
+    acc = torch.tensor([16 * (2 * (k >> 5) + ((k & 7) >> 2)) + 4 * ((k >> 3) & 3) + (k & 3) for k in range(C)])
+    inv_acc = torch.empty(C, dtype=torch.long)
+    inv_acc[acc] = torch.arange(C)
+    eps_r, s_b = float(f[rt.FF_EPS_RES]), float(f[rt.FF_SKIP_SCALE])
+    wf32 = bool(i[rt.F_WF32])          # fp32 fragment sub-tiles (exact-fp32 products) instead of bf16 hi / lo planes
+    cur = {"t": 0, "v": 0}
+
+    def expect(kind_, aux=None):
+        d = desc[cur["t"]]
+        cur["t"] += 1
+        assert d & 3 == kind_ and (aux is None or (d >> 2) == aux), (cur["t"] - 1, d, kind_, aux)
+        return d >> 2
+
+    def X(first_of_block=None):                 # an exchange tile: scratch, or scratch + the NEXT block's vectors at a block's first
+        d = desc[cur["t"]]
+        cur["t"] += 1
+        if first_of_block is not None and first_of_block + 1 < n_res:
+            assert d & 3 == 3 and (d >> 2) == first_of_block + 1, "a block's first exchange carries the next block's vectors"
+        else:
+            assert d & 3 == 2, (cur["t"] - 1, d)
+
+    def conv_w(k):                               # k taps of sub-tiles -> [C, C, k] in natural channel order
+        w = torch.zeros(C, C, k)
+        for tap in range(k):
+            for kh in range(2):
+                for ch in range(4):
+                    t = _untile(stream, expect(0), 64, 128, wf32)
+                    rows = torch.cat([torch.arange(32 * ch, 32 * ch + 32), torch.arange(128 + 32 * ch, 128 + 32 * ch + 32)])
+                    w[rows[:, None], acc[128 * kh: 128 * kh + 128][None, :], tap] = t
+        return w
+
+    def V(n):
+        out = vec[cur["v"]: cur["v"] + n]
+        cur["v"] += n
+        return out
+
+    def gn_silu(t, gsize, gam, bet, fl=None):
+        cc = t.shape[2]
+        y = F.group_norm(t.transpose(1, 2), cc // gsize, gam, bet, eps_r).transpose(1, 2)
+        if fl is not None:
+            y = y * (fl[:cc] + 1.0) + fl[cc:]
+        return _silu(y)
+
+    def conv(t, w):                              # Conv1d with `taps` live taps (one token per sample: the centre tap alone)
+        if w.shape[2] == 1:
+            return t @ w[:, :, 0].T
+        return F.conv1d(t.transpose(1, 2), w, None, padding=1).transpose(1, 2)
+
+    x = bufs.view(op.a, B, B * T * C).view(B, T, C).clone()
+    expect(3, 0)                                 # the vector tile of block 0
+    for rb in range(n_res):
+        fl = film[rb * 2 * C: (rb + 1) * 2 * C]
+        if kind == 1:
+            X(rb)
+            w1 = conv_w(taps)
+            X()
+            w2 = conv_w(taps)
+            g1, b1, bias1, g2, b2, bias2 = (V(C) for _ in range(6))
+            h = conv(gn_silu(x, 32, g1, b1), w1) + bias1
+            x = conv(gn_silu(h, 32, g2, b2, fl), w2) + bias2 + x
+            sk = rt.MdtRef(op.res.space, 0, op.res.off + rb * T * C)
+            bufs.view(sk, B, B * T * C).view(B, T, C)[:] = x
+        else:
+            sk = rt.MdtRef(op.res.space, 0, op.res.off - rb * T * C)
+            xb = bufs.view(sk, B, B * T * C).view(B, T, C) * s_b
+            X(rb)
+            w1a = conv_w(taps)
+            X()
+            wra = conv_w(1)
+            expect(1, rb)
+            X()
+            wrb = conv_w(1)
+            expect(1, rb)
+            X()
+            w1b = conv_w(taps)
+            X()
+            w2 = conv_w(taps)
+            g1, b1, bias1, br, g2, b2, bias2 = V(2 * C), V(2 * C), V(C), V(C), V(C), V(C), V(C)
+            xc = gn_silu(torch.cat([x, xb], dim=2), 64, g1, b1)
+            h = conv(xc[:, :, :C], w1a) + conv(xc[:, :, C:], w1b) + bias1
+            r = x @ wra[:, :, 0].T + xb @ wrb[:, :, 0].T + br
+            x = conv(gn_silu(h, 32, g2, b2, fl), w2) + bias2 + r
+    assert cur["t"] == NT and cur["v"] == vec.numel(), (cur, NT, vec.numel())
     bufs.view(op.out, B, B * T * C).view(B, T, C)[:] = x

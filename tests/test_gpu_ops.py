@@ -1044,3 +1044,79 @@ def test_resnet_blocks_inside_the_transformer_launch(kind, T, B, n_res, layers, 
             if kind == 1:
                 assert (ga[(2 + k) * n: (3 + k) * n].view(B, T, C).double() - h.transpose(1, 2)).abs().max() < tol
         assert (yg.double() - h.transpose(1, 2)).abs().max() < tol
+
+
+@pytest.mark.parametrize("kind,T,B,n_res", [
+    (1, 4, 8, 3),        # down path of configs[1]: three blocks, every output stored as a skip
+    (1, 4, 70, 1),       # bottleneck block; ragged last workgroup (280 rows)
+    (1, 1, 37, 2),       # one token per sample (configs[2]): only the centre tap is streamed
+    (1, 16, 3, 1),       # a whole 16-lane row per sample
+    (2, 4, 8, 4),        # up path of configs[1]: four two-source blocks, skips consumed downwards
+    (2, 4, 1030, 1),     # many workgroups, ragged last one
+    (2, 1, 50, 2),
+    (2, 8, 5, 2),
+])
+def test_resnet_chain_256(kind, T, B, n_res, prod, monkeypatch):
+    """MDT_OP_RES256 (k_res256.hip): a chain of ResnetBlock1d blocks of a 256-channel level in one launch, against (i) the CPU
+    interpreter of the op and (ii) the reference's module arithmetic (modules.py:145-205: GroupNorm -> [FiLM] -> SiLU -> Conv1d(k =
+    3), twice, + to_out(x) | x; :828-829: cat with the scaled skip).  Kind 1 also stores every block's output; kind 2 reads its
+    skips in reverse order.  Both product types."""
+    from moleculediffusiontransformer_amd.compiler import Ten, UNetCompiler
+    from moleculediffusiontransformer_amd.netspec import inverse_unet_config
+    import torch.nn.functional as F
+    monkeypatch.setenv("MDT_RES256", "1")
+    C, G = 256, 8
+    cfg = inverse_unet_config(16, 64, 128, 12)
+    blocks = [f"res{k}." for k in range(n_res)]
+    sd = {}
+    for k, bp in enumerate(blocks):
+        sd.update(_resnet_sd(bp, C, C if kind == 1 else 2 * C, 100 * (k + 1)))
+    comp = UNetCompiler(cfg, 64, 12, sd, gemm_mode="f32" if prod == "f32" else "bf16x3")
+    assert all(comp.res256_ok(bp, C, T, G, kind == 2) for bp in blocks)
+    # per-sample arena: [x | y | skip 0 .. n_res-1]
+    x, y = Ten(A, 0, T, C), Ten(A, T * C, T, C)
+    skips = [Ten(A, (2 + k) * T * C, T, C) for k in range(n_res)]
+    if kind == 2:
+        skips = skips[::-1]                  # consumed from the highest address downwards
+    comp.resnet_chain256(x, blocks, kind, skips, 2 ** -0.5, y, False)
+    op = comp.ops[0]
+    assert op.kind == rt.OP_RES256 and len(comp.ops) == 1 and op.i[rt.F_NPOST] == (1 if T == 1 else 3)
+    film_off = 64
+    op.p3 = ref(S, film_off)
+    act_x = rnd(B * T * C, seed=13) * 1.5 + 0.3
+    sk_in = rnd(n_res * B * T * C, seed=16) * 1.2 - 0.1 if kind == 2 else torch.zeros(n_res * B * T * C)
+    act = torch.cat([act_x, torch.zeros(B * T * C), sk_in])
+    shr = torch.cat([torch.zeros(film_off), 0.3 * rnd(n_res * 2 * C, seed=15), torch.zeros(256)])
+    (ga, _, _), (ca, _, _) = run_both([op], comp.W.pack(), act, shr, {}, B)
+    n = B * T * C
+    yg, yc = ga[n: 2 * n].view(B, T, C), ca[n: 2 * n].view(B, T, C)
+    assert torch.isfinite(yg).all()
+    tol = 2e-4 * max(1.0, yc.abs().max().item())
+    assert (yg - yc).abs().max() < tol, (yg - yc).abs().max().item()
+    assert torch.equal(ga[:n], act_x)
+    if kind == 1:                            # every block's output stored as a skip tensor
+        sg, sc = ga[2 * n: (2 + n_res) * n], ca[2 * n: (2 + n_res) * n]
+        assert (sg - sc).abs().max() < tol
+    else:
+        assert torch.equal(ga[2 * n: (2 + n_res) * n], sk_in)
+    # repeated launches return the same bits
+    (gb, _, _), _ = run_both([op], comp.W.pack(), act, shr, {}, B)
+    assert torch.equal(ga, gb)
+    # ---- the reference's arithmetic ----
+    h = act_x.view(B, T, C).transpose(1, 2).double()
+    for k, bp in enumerate(blocks):
+        fl = shr[film_off + k * 2 * C: film_off + (k + 1) * 2 * C].double()
+        xin = h
+        if kind == 2:
+            sk = sk_in.view(n_res, B, T, C)[n_res - 1 - k].transpose(1, 2).double() * 2 ** -0.5
+            xin = torch.cat([h, sk], dim=1)
+        g = lambda key: sd[bp + key].double()   # noqa: E731
+        t1 = F.conv1d(F.silu(F.group_norm(xin, G, g("block1.groupnorm.weight"), g("block1.groupnorm.bias"), 1e-5)),
+                      g("block1.project.weight"), g("block1.project.bias"), padding=1)
+        t2 = F.group_norm(t1, G, g("block2.groupnorm.weight"), g("block2.groupnorm.bias"), 1e-5)
+        t2 = F.silu(t2 * (fl[:C].view(1, C, 1) + 1) + fl[C:].view(1, C, 1))
+        t2 = F.conv1d(t2, g("block2.project.weight"), g("block2.project.bias"), padding=1)
+        h = t2 + (F.conv1d(xin, g("to_out.weight"), g("to_out.bias")) if kind == 2 else xin)
+        if kind == 1:
+            assert (ga[(2 + k) * n: (3 + k) * n].view(B, T, C).double() - h.transpose(1, 2)).abs().max() < tol
+    assert (yg.double() - h.transpose(1, 2)).abs().max() < tol

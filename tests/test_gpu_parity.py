@@ -83,6 +83,29 @@ def test_sample_matches_reference(models, name, case, want):
     assert (out.cpu() - out_ref).abs().max() < TOL
 
 
+@pytest.mark.parametrize("mode", ["bf16x3", "f32"])
+def test_chained_resnet_blocks_match_the_reference_sample(mode, monkeypatch):
+    """MDT_OP_RES256 forced on (MDT_RES256=1) in the NARROW program of configs[1] -- the automatic policy uses it in the wide program
+    and on one-token levels only -- against the reference's 64-step golden sample with its intermediate sampler states, both
+    product types; 20 launches per evaluation."""
+    from moleculediffusiontransformer_amd import runtime as rt
+    monkeypatch.setenv("MDT_RES256", "1")
+    monkeypatch.setenv("MDT_F32_FUSED", "1")
+    g = load_golden("cfg1_b4_t64_sample.npz")
+    m = make_model("cfg1")
+    m.gemm_mode = mode
+    out_ref = to_t(g["out"])
+    init, step = noise_fns("cfg1_b4_t64", tuple(out_ref.shape))
+    trace = {"want": (1, 2, 32, 63)}
+    out = m.sample(to_t(g["seq"]), DEV, cond_scale=1.0, timesteps=64, clamp=False,
+                   noise=NoiseSource(init=init, steps=lambda i: step(i, init)), trace=trace)
+    kinds = [op.kind for op in m._engine.c.programs["eval"]]
+    assert kinds.count(rt.OP_RES256) == 4 and rt.OP_RCONV not in kinds and len(kinds) == 20
+    for s_ in (1, 2, 32, 63):
+        assert (trace[s_].cpu() - to_t(g[f"x_step{s_}"])).abs().max() < TOL, s_
+    assert (out.cpu() - out_ref).abs().max() < TOL
+
+
 def test_wide_batch_kernel_choice_matches_reference():
     """The 256-channel transformers run pair-split (k_tf256 NSPLIT = 2) at small batches and as whole-transformer launches without the
     split above 4096 rows at that level, 1024 samples here (generative.py::_wide).  Both forms against the reference's golden sample, the automatic
@@ -98,6 +121,9 @@ def test_wide_batch_kernel_choice_matches_reference():
         outs[choice] = m.sample(seq, DEV, cond_scale=7.5, timesteps=T, noise=NoiseSource(init=init, steps=lambda i: step(i, init))).cpu()
         forms = {op.i[rt.F_NSPLIT] for op in m._engine.c.programs["eval"] if op.kind == rt.OP_TF256}
         assert forms == ({1} if choice == "wide" else {2}) and m._engine.c.tf256 == (choice == "wide")
+        # round 5: the wide program chains the 256-channel level's ResNet blocks (MDT_OP_RES256: 4 launches instead of 26)
+        kinds = [op.kind for op in m._engine.c.programs["eval"]]
+        assert (rt.OP_RES256 in kinds) == (choice == "wide") and len(kinds) == (20 if choice == "wide" else 42)
         assert m._engine.handoff_status() == 0
         assert (outs[choice] - to_t(g["out"])).abs().max() < TOL
     m.kernel_choice = "auto"
@@ -334,7 +360,7 @@ def test_repeated_sampling_is_bitwise_stable(B, cs, mode, monkeypatch):
     assert m._engine.handoff_status() == 0
     from moleculediffusiontransformer_amd import runtime as rt
     ev = m._engine.c.programs["eval"]
-    assert len(ev) == 42 and all(op.i[rt.F_WF32] == int(mode == "f32") for op in ev if op.kind in (rt.OP_TF128, rt.OP_TF256))
+    assert len(ev) == 42 and all(op.i[rt.F_WF32] == int(mode == "f32") for op in ev if op.kind in (rt.OP_TF128, rt.OP_TF256, rt.OP_RES256))
 
 
 def test_handoff_timeout_is_reported_before_the_call_returns():

@@ -305,7 +305,7 @@ def test_lowering_matches_reference_golden(case, mode, monkeypatch):
     elif mode == "f32" and case == "cfg1":
         # the fused program of the default mode, op for op, with fp32 fragment tiles
         ref = compile_unet(ucfg, kw["max_length"], kw["context_embedding_max_length"], usd, max_time_rows=4, gemm_mode="bf16x3", tf256=wide)
-        assert [op.kind for op in cu.programs["eval"]] == [op.kind for op in ref.programs["eval"]] and len(cu.programs["eval"]) == 42
+        assert [op.kind for op in cu.programs["eval"]] == [op.kind for op in ref.programs["eval"]] and len(cu.programs["eval"]) == (20 if wide else 42)
         wf = {rt.OP_TF128: rt.F_WF32, rt.OP_TF256: rt.F_WF32, rt.OP_RCONV: rt.R_WF32, rt.OP_RESBLOCK: rt.K_WF32}
         assert all(op.i[wf[op.kind]] == 1 for op in cu.programs["eval"] if op.kind in wf)
         assert all(op.i[wf[op.kind]] == 0 for op in ref.programs["eval"] if op.kind in wf)
@@ -345,7 +345,7 @@ def test_lowering_matches_reference_golden(case, mode, monkeypatch):
     assert abs(cu.flops_per_sample_eval - {"cfg1": 388.7e6}.get(case, cu.flops_per_sample_eval)) < 1e6
 
 
-_RING_UNITS = ("k_tblock32", "k_rconv", "k_tf128", "k_tf256", "k_rconv_f32", "k_tf128_f32", "k_tf256_f32", "k_attn")
+_RING_UNITS = ("k_tblock32", "k_rconv", "k_tf128", "k_tf256", "k_rconv_f32", "k_tf128_f32", "k_tf256_f32", "k_attn", "k_res256")
 
 
 @pytest.fixture(scope="module")
@@ -381,7 +381,8 @@ def test_ring_kernels_keep_their_arrays_in_registers(ring_kernel_reports):
     # of three (a unit is 512 MFMA-pipe cycles, one unit of read-ahead covers the LDS latency), which is what the split form lacks.
     limits = {"k_tblock32": 24, "k_rconv": 0, "k_tf128": 0, "k_tf256": 16,      # bytes per lane
               "k_rconv_f32": 0, "k_tf128_f32": 0, "k_tf256_f32": 0,
-              "k_attn": 0}        # k_attn_ctx (round 4: context streamed through a per-wave LDS ring, inline-asm fragment reads)
+              "k_attn": 0,        # k_attn_ctx (round 4: context streamed through a per-wave LDS ring, inline-asm fragment reads)
+              "k_res256": 0}      # round 5: the chained ResNet blocks of the 256-channel level (all 8 instantiations)
     for name, limit in limits.items():
         assert res[name], name
         for fn, v in res[name]:
