@@ -142,8 +142,9 @@ enum mdt_op_kind {
                           64 channels on a 2C-channel input, 32 otherwise).  Stream: sub-tiles [64 features][128 k] in (tap, K half,
                           chunk) order per convolution; rows 0..31 of chunk c are output channels 32 c .., rows 32..63 channels
                           128 + 32 c ..; K columns in accumulator order (k-slot 32 st + 8 g + e = channel 16 (2 st + (e >> 2)) + 4 g +
-                          (e & 3)).  Descriptors: kind (2 bits: 0 weight sub-tile, 1 skip rows of block aux, 2 scratch, 3 scratch + the
-                          vectors of block aux) | aux << 2; sequence: [3 (block 0)], then per block, kind 1: X nt X nt, kind 2: X nt X
+                          (e & 3)).  Descriptors (HEADS of them, NT tiles in all) are SEGMENTS: kind (2 bits: 0 = a RUN of aux consecutive sub-tiles
+                          of the weight stream, which is stored in consumption order, 1 skip rows of block aux, 2 scratch, 3 scratch + the
+                          vectors of block aux) | aux << 2; tile sequence: [3 (block 0)], then per block, kind 1: X nt X nt, kind 2: X nt X
                           8 S X 8 S X nt X nt (block1 on x, to_out on x, to_out on the skip, block1 on the skip, block2; X = 2, or 3 with aux = next block at a block's first X; nt = 8 taps; S = 1).  Vectors
                           per block: kind 1 [g1 | b1 | bias1 | g2 | b2 | bias2], kind 2 [g1 (2C) | b1 (2C) | bias1 | bias_to_out | g2 |
                           b2 | bias2].  WF32 as MDT_OP_TF256 (fp32 fragment sub-tiles)                                                  */

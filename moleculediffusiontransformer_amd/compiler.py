@@ -1195,7 +1195,8 @@ class UNetCompiler:
         acc = torch.tensor([16 * (2 * (k >> 5) + ((k & 7) >> 2)) + 4 * ((k >> 3) & 3) + (k & 3) for k in range(c)])
         W_, S_, X_, XV_ = 0, 1, 2, 3
         tiles: List[torch.Tensor] = []
-        desc: List[int] = [XV_ | (0 << 2)]                        # the vectors of block 0
+        desc: List[int] = [XV_ | (0 << 2)]                        # the vectors of block 0 (descriptors = SEGMENTS: a weight
+                                                                    # descriptor stands for a run of consecutive sub-tiles)
         vec: List[torch.Tensor] = []
         n = len(blocks)
 
@@ -1207,7 +1208,10 @@ class UNetCompiler:
                 for kh in range(2):
                     for ch in range(4):
                         rws = torch.cat([torch.arange(32 * ch, 32 * ch + 32), torch.arange(128 + 32 * ch, 128 + 32 * ch + 32)])
-                        desc.append(W_ | (len(tiles) << 2))
+                        if desc and (desc[-1] & 3) == W_ and len(desc) > 1:
+                            desc[-1] += 1 << 2                  # run-length: one descriptor per RUN of weight sub-tiles
+                        else:
+                            desc.append(W_ | (1 << 2))
                         tiles.append(self._wtile(wt[rws][:, 128 * kh: 128 * kh + 128].contiguous()))
 
         film0 = None
@@ -1256,7 +1260,8 @@ class UNetCompiler:
         op.bias = _ref(rt.SP_WEIGHT, self.W.add(blocks[0] + "res256.vec", v))
         op.p0 = _ref(rt.SP_WEIGHT, self.W.add(blocks[0] + "res256.desc", torch.tensor(desc, dtype=torch.int32).view(torch.float32)))
         i = op.i
-        i[rt.F_C], i[rt.F_T], i[rt.F_NT], i[rt.F_NVEC], i[rt.F_NPOST] = c, rows, len(desc), v.numel(), taps
+        ntiles = sum((d >> 2) if (d & 3) == W_ else 1 for d in desc)
+        i[rt.F_C], i[rt.F_T], i[rt.F_NT], i[rt.F_NVEC], i[rt.F_NPOST], i[rt.F_HEADS] = c, rows, ntiles, v.numel(), taps, len(desc)
         i[rt.F_RES_KIND], i[rt.F_N_RES], i[rt.F_NFILM], i[rt.F_WF32] = kind, n, 2 * c * n, int(self.wf32)
         op.f[rt.FF_EPS_RES], op.f[rt.FF_SKIP_SCALE] = 1e-5, float(scale_b if kind == 2 else 1.0)
         self._emit(op)

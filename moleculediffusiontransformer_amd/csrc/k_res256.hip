@@ -167,10 +167,9 @@ __global__ __launch_bounds__(512) void k_res256(TFArgs a) {
     };
     auto issue_w = [&](unsigned char* slot, const unsigned char* tile) {       // tile: wave-uniform
       // The per-lane offsets pass through an empty asm so that their zero-extension stays in THIS basic block: hoisted out of the
-      // tile loop (as 64-bit register pairs) the address becomes a 64-bit VALU add per piece and the instruction takes the
-      // vector-address form -- every piece then waits for the previous one to release the address registers: 1050-1150 cycles per
-      // sub-tile instead of ~650 (in-kernel stamps, tools/res256_bench.py).  With a 32-bit offset next to a scalar base hipcc selects
-      // global_load_lds_dwordx4 v, s[base] and the eight pieces issue back to back.
+      // tile loop as 64-bit register pairs, the address became a 64-bit VALU add per piece and the instruction took the
+      // vector-address form with ONE register pair rewritten between the pieces.  With a 32-bit offset next to a scalar base hipcc
+      // selects global_load_lds_dwordx4 v, s[base] (k_rconv.hip's form).
       unsigned off[IPT];                                 // (all eight first: one register each, no piece waits for the previous
 #pragma unroll                                           //  one to release its address register)
       for (int q = 0; q < IPT; ++q) {
@@ -224,43 +223,88 @@ __global__ __launch_bounds__(512) void k_res256(TFArgs a) {
         default: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
       }
     };
-    const unsigned d0 = tiles[0], d1 = NT > 1 ? tiles[1] : 0u;
+    // The stream is described by SEGMENTS (a.nheads of them): a weight segment stands for `aux` consecutive sub-tiles of the weight
+    // stream (which is stored in consumption order), every other descriptor for one tile.  Two cursors walk the list: tile k + 1
+    // (what may stay in flight at the wait of turn k) and tile k + 2 (what is issued behind B(k)).  While both are inside weight
+    // segments a turn is `s_waitcnt vmcnt(8); s_barrier; eight pieces` and some scalar arithmetic -- no descriptor load, no decode:
+    // k_rconv.hip's turn.  (First version: one descriptor per tile, loaded and decoded every turn, the wait dispatched by a switch on
+    // the piece count: 1100 cycles per sub-tile in the in-kernel stamps of tools/res256_bench.py, of which 548 are the LDS-DMA issue
+    // itself -- the CU's 64 B/clk vector-memory path; 890 with the switch gone.)
+    const int NSEG = a.nheads;
+    struct Cur { int seg, rem; unsigned kind, aux; };
+    auto load_seg = [&](Cur& c) {
+      if (c.seg < NSEG) {
+        const unsigned d = tiles[c.seg];
+        c.kind = d & 3u;
+        c.aux = d >> 2;
+        c.rem = c.kind == D_W ? (int)c.aux : 1;
+      } else {
+        c.kind = D_X;                                  // past the end: nothing to issue, nothing in flight
+        c.aux = 0;
+        c.rem = 1 << 30;
+      }
+    };
+    auto advance = [&](Cur& c) {
+      if (--c.rem == 0) {
+        ++c.seg;
+        load_seg(c);
+      }
+    };
+    unsigned wnext = 0;                                // next sub-tile of the weight stream to issue
+    auto issue_cur = [&](int tau, const Cur& c) {      // the tile under the issue cursor -> slot of tile tau
+      if (c.kind == D_W) {
+        issue_w(smem + MDT_SLOT_IDX(tau) * SLOT + iw * 1024, wsrc + (int64_t)wnext * SLOT);
+        ++wnext;
+      } else {
+        issue_tile(tau, c.kind | (c.aux << 2));
+      }
+    };
+    Cur ci = {0, 0, 0u, 0u}, cw;
+    load_seg(ci);
     __builtin_amdgcn_s_barrier();   // P: the compute waves' row loads are queued ahead of the stream
-    issue_tile(0, d0);
-    if (NT > 1) issue_tile(1, d1);
-    // (An in-launch L2 prefetch of the stream as in k_tf256.hip was built and measured here: no effect, with the weights L2-resident
-    //  or not -- what a loader turn costs is its own instruction stream: 8 pieces x ~72 cycles of issue, and the wait's dispatch.
-    //  As an 11-way switch on the piece count the dispatch alone was 420 cycles of scalar branches per turn, 1100 cycles per sub-tile
-    //  in all (in-kernel stamps, tools/res256_bench.py); with the common case -- a weight or skip tile next, 8 pieces -- tested first
-    //  it is a compare and a branch.)
-    // Software-pipelined turn: the descriptor of tile k + 3 is requested one turn early, and everything tile k + 2's pieces need
-    // (kind, source pointer, slot) is formed BEFORE the wait and the barrier, so that the pieces follow B(k) at once.
-    unsigned dn = d1;                                                    // descriptor of tile k + 1
-    unsigned d2 = NT > 2 ? tiles[2] : 0u;                                // ... of tile k + 2
+    issue_cur(0, ci);
+    advance(ci);
+    cw = ci;                                           // tile 1
+    if (NT > 1) {
+      issue_cur(1, ci);
+      advance(ci);                                     // tile 2
+    }
     for (int k = 0; k < NT; ++k) {
-      const unsigned d3 = k + 3 < NT ? tiles[k + 3] : 0u;
-      const bool w2 = k + 2 < NT && (d2 & 3u) == D_W;
-      const unsigned char* tile2 = wsrc + (int64_t)(d2 >> 2) * SLOT;
-      unsigned char* slot2 = smem + MDT_SLOT_IDX(k + 2) * SLOT + iw * 1024;
 #ifdef MDT_STAMPS   // loader wave 4 of workgroup 0: (turn start, tile landed, barrier passed, pieces issued) for tiles 24..47
       unsigned long long ls0 = 0, ls1 = 0, ls2 = 0, ls3 = 0;
       const bool lst = a.dbgbuf && blockIdx.x == 0 && iw == 0 && k >= 24 && k < 48;
       if (lst) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ls0)::"memory");
 #endif
-      // tile k landed; tile k + 1 may be in flight
-      const unsigned kn = dn & 3u;
-      if (k + 1 < NT && kn <= D_SKIP) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (k + 1 < NT && kn == D_XV) wait_vm(pieces_of(dn));
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (cw.kind == D_W && ci.kind == D_W && cw.rem > 1 && ci.rem > 1 && k + 2 < NT) {
+        // ---- the common turn: weight sub-tiles on both cursors ----
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                 // tile k landed; tile k + 1 (8 pieces) may be in flight
 #ifdef MDT_STAMPS
-      if (lst) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ls1)::"memory");
+        if (lst) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ls1)::"memory");
 #endif
-      __builtin_amdgcn_s_barrier();                                      // B(k)
+        __builtin_amdgcn_s_barrier();                                    // B(k)
 #ifdef MDT_STAMPS
-      if (lst) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ls2)::"memory");
+        if (lst) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ls2)::"memory");
 #endif
-      if (w2) issue_w(slot2, tile2);
-      else if (k + 2 < NT) issue_tile(k + 2, d2);
+        issue_w(smem + MDT_SLOT_IDX(k + 2) * SLOT + iw * 1024, wsrc + (int64_t)wnext * SLOT);
+        ++wnext;
+        --cw.rem;
+        --ci.rem;
+      } else {
+        // ---- a segment boundary, a scratch / vector / skip tile, or the end of the stream ----
+        if (k + 1 < NT && (cw.kind == D_W || cw.kind == D_SKIP)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (k + 1 < NT && cw.kind == D_XV) wait_vm(pieces_of(D_XV));
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef MDT_STAMPS
+        if (lst) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ls1)::"memory");
+#endif
+        __builtin_amdgcn_s_barrier();                                    // B(k)
+#ifdef MDT_STAMPS
+        if (lst) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ls2)::"memory");
+#endif
+        if (k + 2 < NT) issue_cur(k + 2, ci);
+        advance(cw);
+        advance(ci);
+      }
 #ifdef MDT_STAMPS
       if (lst) {
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ls3)::"memory");
@@ -268,8 +312,6 @@ __global__ __launch_bounds__(512) void k_res256(TFArgs a) {
         if (lane == 0) { lo_[0] = ls0; lo_[1] = ls1; lo_[2] = ls2; lo_[3] = ls3; }
       }
 #endif
-      dn = d2;
-      d2 = d3;
     }
     prefetch_next_weights(a.pf_ptr, a.pf_lines, iw * 64 + lane);
     return;
@@ -721,7 +763,7 @@ bool res256_supported(int T, int kind, int n_res, int taps) {
 hipError_t launch_res256(const TFArgs& a, hipStream_t s) {
   if (a.M <= 0) return hipSuccess;
   const int taps = a.npost;
-  if (!res256_supported(a.T, a.res_kind, a.n_res, taps) || a.NT <= 0 || !a.skip || !a.film || !a.vec || !a.tiles) return hipErrorInvalidValue;
+  if (!res256_supported(a.T, a.res_kind, a.n_res, taps) || a.NT <= 0 || a.nheads <= 0 || !a.skip || !a.film || !a.vec || !a.tiles) return hipErrorInvalidValue;
   if (a.wf32) {                                       // exact fp32 products on fp32 fragment sub-tiles (MDT_F_WF32)
     if (a.res_kind == 1) return taps == 3 ? launch_rs<1, 3, true>(a, s) : launch_rs<1, 1, true>(a, s);
     return taps == 3 ? launch_rs<2, 3, true>(a, s) : launch_rs<2, 1, true>(a, s);

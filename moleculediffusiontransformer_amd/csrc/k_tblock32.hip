@@ -242,7 +242,9 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
       __builtin_amdgcn_s_barrier();   // S2: operand planes exchanged (compute waves' prologue; the feed-forward kernel keeps the plain one)
     }
     for (int k = 0; k < NT; ++k) {
-      wait_vm(k + 1 < NT ? (is_kv(k + 1) ? NPW : IPT) : 0);              // tile k landed; tile k+1 may be in flight
+      // tile k landed; tile k + 1 may be in flight (the weight-tile case first: the switch is a cascade of scalar branches, k_tf256.hip)
+      if (k + 1 < NT && !is_kv(k + 1)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else wait_vm(k + 1 < NT ? NPW : 0);
       __builtin_amdgcn_s_barrier();                                      // B(k)
       if (k + 2 < NT) issue_tile(k + 2);
     }

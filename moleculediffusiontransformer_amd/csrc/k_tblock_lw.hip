@@ -239,7 +239,9 @@ __global__ __launch_bounds__(512) void k_tblock_lw(TBlockArgs a) {
 #endif
     for (int k = 0; k < NT; ++k) {
       MDT_LSTAMP();
-      wait_vm(k + 1 < NT ? pieces_of(k + 1) : 0);                        // tile k landed; tile k+1 may be in flight
+      // tile k landed; tile k + 1 may be in flight (the weight-tile case first: the switch is a cascade of scalar branches, k_tf256.hip)
+      if (k + 1 < NT && pieces_of(k + 1) == IPT) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else wait_vm(k + 1 < NT ? pieces_of(k + 1) : 0);
       MDT_LSTAMP();
       __builtin_amdgcn_s_barrier();                                      // B(k)
       MDT_LSTAMP();

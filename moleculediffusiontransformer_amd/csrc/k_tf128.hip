@@ -283,7 +283,11 @@ __global__ __launch_bounds__(512) void k_tf128(TFArgs a) {
     unsigned dn = d1;                                                    // descriptor of tile k + 1
     for (int k = 0; k < NT; ++k) {
       const unsigned d2 = k + 2 < NT ? tiles[k + 2] : 0u;
-      wait_vm(k + 1 < NT ? pieces_of(dn) : 0);                           // tile k landed; tile k+1 may be in flight
+      // tile k landed; tile k + 1 may be in flight (the common case -- a weight tile next: 8 pieces -- first: as compiled the
+      // switch of wait_vm is a cascade of scalar branches, k_tf256.hip)
+      if (k + 1 < NT && pieces_of(dn) == IPT) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (NPW > 0 && k + 1 < NT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW > 0 ? NPW : 1) : "memory");          // a K / V tile next
+      else wait_vm(k + 1 < NT ? pieces_of(dn) : 0);
       __builtin_amdgcn_s_barrier();                                      // B(k)
       if (k + 2 < NT) issue_tile(k + 2, d2);
       dn = d2;

@@ -329,7 +329,14 @@ __global__ __launch_bounds__(512) void k_tf256(TFArgs a) {
 #pragma unroll
       for (int j = 0; j < AHEAD - 1; ++j) allow += k + 1 + j < NT ? pieces_of(dq[j]) : 0;
       if (PF_ON && k + 1 < NT) allow += pf1 + pf2;
-      wait_vm(allow);                                                    // tile k landed; tiles k + 1 .. may be in flight
+      // tile k landed; tiles k + 1 .. may be in flight.  Round 5: the common cases -- a weight sub-tile or a K / V tile next, no
+      // touch of this workgroup in flight -- are tested first: as compiled, the 17-way switch of wait_vm is a cascade of ~27
+      // scalar branches, ~300 cycles of a loader turn (stamps of the same loader in k_res256.hip, where the loader IS what a
+      // sub-tile waits for: 1100 -> 890 cycles per sub-tile).  Here the compute waves arrive at the barrier last: same-box A/B of
+      // this change on the headline 4506 / 4487 -> 4519 / 4526 molecules/s, evaluation 1.766 ms either way (profiles/r5_res256_ab.txt)
+      if (allow == IPT) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (NPW > 0 && allow == NPW) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW > 0 ? NPW : 1) : "memory");      // a K / V tile next
+      else wait_vm(allow);
       MDT_BARRIER();                                      // B(k)
       if (k + AHEAD < NT) issue_tile(k + AHEAD, dnew);
       if constexpr (PF_ON) {

@@ -250,7 +250,8 @@ static const char* validate(const mdt_op& o, int idx, char* buf, size_t nbuf) {
       if (i[MDT_F_C] != 256) return bad("the ResNet chain needs C = 256");
       if (!mdt::res256_supported(i[MDT_F_T], i[MDT_F_RES_KIND], i[MDT_F_N_RES], i[MDT_F_NPOST]))
         return bad("ResNet chain: tokens per sample must divide 16, kind 1 | 2, 1..255 blocks, taps 3 (or 1 with one token per sample)");
-      if (i[MDT_F_NT] <= 0 || i[MDT_F_NBLOCKS] || i[MDT_F_HAS_IN] || i[MDT_F_CROSS]) return bad("ResNet chain: bad tile count / stray transformer fields");
+      if (i[MDT_F_NT] <= 0 || i[MDT_F_HEADS] <= 0 || i[MDT_F_HEADS] > i[MDT_F_NT] || i[MDT_F_NBLOCKS] || i[MDT_F_HAS_IN] || i[MDT_F_CROSS])
+        return bad("ResNet chain: bad tile / segment count or stray transformer fields");
       if (i[MDT_F_WF32] != 0 && i[MDT_F_WF32] != 1) return bad("WF32 must be 0 (split-bf16 tiles) or 1 (fp32 fragment tiles)");
       if (i[MDT_F_NVEC] != i[MDT_F_N_RES] * (i[MDT_F_RES_KIND] == 1 ? 6 : 9) * 256 || i[MDT_F_NFILM] < 512 * i[MDT_F_N_RES])
         return bad("ResNet chain: NVEC must be N_RES x (6 | 9) x 256 floats and NFILM >= 512 N_RES");
@@ -513,6 +514,7 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
         a.x = ptr(o.a); a.out = ptr(o.out); a.w = ptr(o.w); a.vec = ptr(o.bias);
         a.tiles = reinterpret_cast<const unsigned*>(ptr(o.p0));
         a.T = i[MDT_F_T]; a.M = B * a.T; a.NT = i[MDT_F_NT]; a.nvec = i[MDT_F_NVEC]; a.nsamples = B;
+        a.nheads = i[MDT_F_HEADS];                       // descriptors (segments) behind p0
         a.npost = i[MDT_F_NPOST];                        // taps of the block convolutions
         a.res_kind = i[MDT_F_RES_KIND]; a.n_res = i[MDT_F_N_RES]; a.nfilm = i[MDT_F_NFILM];
         a.film = ptr(o.p3); a.skip = ptr(o.res);

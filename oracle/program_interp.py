@@ -686,8 +686,15 @@ def _res256(op, bufs: Buffers, B: int) -> None:
     C, T, NT, taps = i[rt.F_C], i[rt.F_T], i[rt.F_NT], i[rt.F_NPOST]
     kind, n_res = i[rt.F_RES_KIND], i[rt.F_N_RES]
     assert C == 256 and kind in (1, 2) and taps in (1, 3)
-    desc = bufs.view(op.p0, B, NT).contiguous().view(torch.int32).tolist()
-    nw = sum(1 for d in desc if (d & 3) == 0)
+    segs = bufs.view(op.p0, B, i[rt.F_HEADS]).contiguous().view(torch.int32).tolist()    # SEGMENTS: a weight descriptor = a run
+    desc, nw = [], 0
+    for d in segs:
+        if d & 3 == 0:
+            desc += [0 | ((nw + k) << 2) for k in range(d >> 2)]
+            nw += d >> 2
+        else:
+            desc.append(d)
+    assert len(desc) == NT, (len(desc), NT)
     stream = bufs.view(op.w, B, nw * 64 * 128)
     vec = bufs.view(op.bias, B, i[rt.F_NVEC])
     film = bufs.view(op.p3, B, i[rt.F_NFILM])

@@ -37,11 +37,6 @@ for B in (8, 1024, int(os.environ.get("MDT_BIG", "4096"))):
         if os.environ.get("MDT_DBG", "0") == "8":
             op.p2 = ref(rt.SP_EXT0, 0)
         W = comp.W.pack()
-        if os.environ.get("MDT_WARM_TILES"):         # timing experiment (wrong results): every weight sub-tile is one of the first n
-            nwarm = int(os.environ["MDT_WARM_TILES"])
-            d = W[op.p0.off: op.p0.off + op.i[rt.F_NT]].view(torch.int32)
-            wt = (d & 3) == 0
-            d[wt] = ((d[wt] >> 2) % nwarm) << 2
         W = W.to(dev)
         act = torch.randn(B * (2 + n) * T * C, device=dev)
         shr = torch.randn(2 * C * n, device=dev) * 0.1
