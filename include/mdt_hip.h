@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MDT_ABI_VERSION 4
+#define MDT_ABI_VERSION 5
 
 /* MDT_ABI_VERSION; a library built with -DMDT_TUNING (timing-only switches that may give WRONG results, csrc/mdt_kernels.h) sets
  * bit 30 on top -- the Python binding refuses such a library for sampling. */

@@ -12,7 +12,7 @@ from typing import Optional
 from . import build as _build
 
 N_EXT = 8
-ABI_VERSION = 4        # MDT_ABI_VERSION of include/mdt_hip.h this binding was written against
+ABI_VERSION = 5        # MDT_ABI_VERSION of include/mdt_hip.h this binding was written against
 ABI_TUNING_BIT = 0x40000000   # set in mdt_abi_version() by a -DMDT_TUNING build (csrc/mdt_kernels.h)
 SP_NONE, SP_WEIGHT, SP_ACT, SP_SHR, SP_EXT0 = 0, 1, 2, 3, 4
 OP_GEMM, OP_GN_STATS, OP_ATTN, OP_CONCAT, OP_PATCH, OP_TIME_EMBED, OP_TBLOCK, OP_GN_ACT, OP_RCONV = 1, 2, 3, 4, 5, 6, 7, 8, 9
