@@ -297,6 +297,30 @@ def test_bench_two_rank_logic_on_one_gpu():
     assert mg["shard_invariance"]["bitwise_equal_to_1_rank_run"] is True and mg["shard_invariance"]["rank"] == 1
 
 
+def test_bench_eight_rank_logic_on_one_gpu():
+    """the same self-launch path with EIGHT ranks (`python bench.py --gpus 8`), sharing cuda:0 over gloo at a small
+    batch: eight children, one JSON line, eight ranks seen by the all-gather, 8 x 32 gathered rows, and the bitwise shard-invariance
+    check on the LAST rank's rows (global sample indices 224..255 against a 1-rank run)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MDT_BENCH_SHARE_GPU="1", OMP_NUM_THREADS="2")
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1",
+                        "--batch", "32", "--timesteps", "3", "--no-breakdown", "--master-port", "29541"],
+                       capture_output=True, text=True, timeout=1500, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 256 and d["scaling"] == "weak" and d["value"] > 0
+    mg = d["multi_gpu"]
+    assert mg["rccl_ranks_seen"] == 8 and mg["gathered_rows"] == 256 and mg["collectives_per_step"] == 1
+    assert mg["shard_invariance"]["bitwise_equal_to_1_rank_run"] is True and mg["shard_invariance"]["rank"] == 7
+
+
 def test_rccl_all_gather_runs_on_one_gpu():
     """the RCCL path had never executed anywhere.  On a one-GPU box: (i) backend "nccl" (= RCCL) at world size 1
     with all_gather_into_tensor FORCED through all_gather_samples / all_gather_tokens on device tensors; (ii) bench.py as one

@@ -15,7 +15,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int C = 128, SLOT = 256 * C, NS = 4, IPT = 8;   // 32 KB tiles, 8 DMA pieces per wave per tile (4 issuing waves)
 
-template <int DMA, int RT>
+// ACC4 (RT = 1 only): the six MFMAs of a unit go to FOUR accumulators instead of two (the lo x hi product of each feature tile to a
+// second accumulator): is the unit's dependent accumulation (every other MFMA on the same registers) what the one-row-tile form waits for?
+template <int DMA, int RT, int ACC4 = 0>
 __global__ __launch_bounds__(DMA == 0 ? 512 : 256) void kpipe_rt(const unsigned char* w, float* out, unsigned long long* cyc,
                                                               int ntiles, int wtiles, const unsigned* desc) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -61,8 +63,9 @@ __global__ __launch_bounds__(DMA == 0 ? 512 : 256) void kpipe_rt(const unsigned 
       asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr) : "memory");
     };
     f32x4 acc[RT][4];
+    f32x4 accb[4];
     for (int t = 0; t < RT; ++t)
-      for (int n = 0; n < 4; ++n) acc[t][n] = f32x4{0, 0, 0, 0};
+      for (int n = 0; n < 4; ++n) { acc[t][n] = f32x4{0, 0, 0, 0}; accb[n] = f32x4{0, 0, 0, 0}; }
     bf16x8 fh[3][2], fl[3][2];
     unsigned dcur = 2u % (unsigned)wtiles;                 // descriptor of the tile being issued (k + 2)
     unsigned dnext = 3u % (unsigned)wtiles;
@@ -117,11 +120,13 @@ __global__ __launch_bounds__(DMA == 0 ? 512 : 256) void kpipe_rt(const unsigned 
         if (last && u == 7) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         const int st = u >> 1, f0 = 2 * (u & 1);
-        for (int t = 0; t < RT; ++t) acc[t][f0] = MFMA(fl[s0][0], xh[t][st], acc[t][f0], 0, 0, 0);
+        if (ACC4) accb[f0] = MFMA(fl[s0][0], xh[0][st], accb[f0], 0, 0, 0);
+        else for (int t = 0; t < RT; ++t) acc[t][f0] = MFMA(fl[s0][0], xh[t][st], acc[t][f0], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         if (pre) lds_read(fh[s2][0], base + ((2 * (un & 1)) * 16 * 4 * C));
         __builtin_amdgcn_sched_barrier(0);
-        for (int t = 0; t < RT; ++t) acc[t][f0 + 1] = MFMA(fl[s0][1], xh[t][st], acc[t][f0 + 1], 0, 0, 0);
+        if (ACC4) accb[f0 + 1] = MFMA(fl[s0][1], xh[0][st], accb[f0 + 1], 0, 0, 0);
+        else for (int t = 0; t < RT; ++t) acc[t][f0 + 1] = MFMA(fl[s0][1], xh[t][st], acc[t][f0 + 1], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         if (pre) lds_read(fl[s2][0], base + ((2 * (un & 1)) * 16 * 4 * C + 2 * C));
         __builtin_amdgcn_sched_barrier(0);
@@ -154,6 +159,7 @@ __global__ __launch_bounds__(DMA == 0 ? 512 : 256) void kpipe_rt(const unsigned 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     f32x4 s = f32x4{0, 0, 0, 0};
     for (int t = 0; t < RT; ++t) s += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
+    s += accb[0] + accb[1] + accb[2] + accb[3];
     out[blockIdx.x * 256 + (tid & 255)] = s[0] + s[1] + s[2] + s[3];
   }
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
@@ -309,6 +315,7 @@ int main() {
   };
   for (int blocks : {1, 256}) {
     report("4 compute + 4 loader waves, 1 row tile / wave (shipped)", kpipe_rt<0, 1>, 512, blocks, 510, 64);
+    report("  ... 1 row tile, four accumulators per unit instead of two", kpipe_rt<0, 1, 1>, 512, blocks, 510, 64);
     report("4 compute + 4 loader waves, 2 row tiles / wave", kpipe_rt<0, 2>, 512, blocks, 510, 128);
     report("4 compute waves, own DMA as a burst behind the barrier, 1 tile", kpipe_rt<1, 1>, 256, blocks, 510, 64);
     report("4 compute waves, own DMA as a burst behind the barrier, 2 tiles", kpipe_rt<1, 2>, 256, blocks, 510, 128);
