@@ -26,7 +26,7 @@ def test_c_abi_exports_every_declared_symbol():
     assert declared == set(rt.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.mdt_abi_version() == rt.ABI_VERSION == 4      # (no MDT_ABI_TUNING_BIT: not a timing-only build)
+    assert lib.mdt_abi_version() == rt.ABI_VERSION == 5      # (no MDT_ABI_TUNING_BIT: not a timing-only build)
     assert ctypes.sizeof(rt.MdtOp) == 8 + 10 * 16 + 24 * 4 + 8 * 4
     bad = rt.MdtOp()
     bad.kind = 1   # GEMM with cin == 0
