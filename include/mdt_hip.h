@@ -229,7 +229,9 @@ enum mdt_attn_i {
   MDT_A_OUT16 = 7,      /* MDT_OP_ATTN: 1 = out is bf16 (LDO in bf16 elements), read by a bf16 x bf16 GEMM */
   MDT_A_QCOL = 8,       /* MDT_OP_ATTN: first float of q inside its rows (q | k | v projected by ONE GEMM into one tensor) */
   MDT_A_KCOL = 9,       /* ... and of k inside the a2 rows (v follows heads * 64 floats later)                          */
-  MDT_A_SPLIT = 10      /* MDT_OP_ATTN_CTX: 1 = the scores q' c^T as split-bf16 products (the default mode's arithmetic), 0 = exact fp32 */
+  MDT_A_SPLIT = 10,     /* MDT_OP_ATTN_CTX: 1 = the scores q' c^T as split-bf16 products (the default mode's arithmetic), 0 = exact fp32 */
+  MDT_A_IN16 = 11       /* MDT_OP_ATTN: mask, 1 = q is bf16 (LDQ / QCOL in bf16 elements, multiples of 8), 2 = k | v are bf16 (LDKV / KCOL
+                           likewise): the plain-bf16 mode's q | k | v GEMM writes bf16; widened exactly to fp32 in registers */
 };
 enum mdt_attn_f { MDT_AF_SCALE = 0 };
 

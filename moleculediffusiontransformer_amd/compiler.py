@@ -410,7 +410,8 @@ class UNetCompiler:
         self._emit(op)
         return y
 
-    def attn(self, q: Ten, kv: rt.MdtRef, tk: int, kv_bstride: int, out: Ten, ldkv: Optional[int] = None, kcol: int = 0) -> None:
+    def attn(self, q: Ten, kv: rt.MdtRef, tk: int, kv_bstride: int, out: Ten, ldkv: Optional[int] = None, kcol: int = 0,
+             kv16: bool = False) -> None:
         cfg = self.cfg
         op = rt.MdtOp()
         op.kind = rt.OP_ATTN
@@ -424,6 +425,7 @@ class UNetCompiler:
         i[rt.A_T], i[rt.A_TK], i[rt.A_HEADS] = q.rows, tk, cfg.heads
         i[rt.A_LDQ], i[rt.A_LDKV], i[rt.A_LDO], i[rt.A_KV_BSTRIDE] = q.ld, ldkv or 2 * cfg.mid_features, out.ld, kv_bstride
         i[rt.A_OUT16], i[rt.A_KCOL] = int(out.b16), kcol
+        i[rt.A_IN16] = (1 if q.b16 else 0) | (2 if kv16 else 0)     # plain-bf16 mode: q | k | v as their GEMM wrote them
         op.f[0] = float(cfg.head_features) ** -0.5
         self._emit(op)
         self.flops += 2 * 2 * q.rows * tk * cfg.mid_features
@@ -1283,27 +1285,28 @@ class UNetCompiler:
             gc, bc = sd[p + "norm_context.weight"].double(), sd[p + "norm_context.bias"].double()
             w = torch.cat([wq * gq.unsqueeze(0), wkv * gc.unsqueeze(0)]).float()
             bias = torch.cat([wq @ bq, wkv @ bc]).float()
-            qkv = self._new(t.rows, 3 * mid)
+            qkv = self._new16(t.rows, 3 * mid)          # bf16 out of the GEMM's epilogue: half the bytes of the attention core
             self.gemm(t, (p + "qkv.folded", w), 3 * mid, qkv, cin=c, pro=rt.PRO_LAYERNORM,
                       gain=self._ones(c), nbias=self._zeros(c), eps=1e-5,
                       bias_off=self.W.add(p + "qkv.folded.bias", bias))
             ao = self._new16(t.rows, mid)
-            self.attn(qkv, qkv.ref(), t.rows, t.rows, ao, ldkv=3 * mid, kcol=mid)
+            self.attn(qkv, qkv.ref(), t.rows, t.rows, ao, ldkv=3 * mid, kcol=mid, kv16=True)
             self._free(qkv)
             self.gemm(ao, self._lin_w(p + "attention.to_out.weight"), c, t, cin=mid,
                       bias_off=self._vec(p + "attention.to_out.bias", c), res=t, copy16=copy16)
             self._free(ao)
             return
-        q = self._new(t.rows, mid)
+        b16 = self.b16_ok(c) and self.b16_ok(mid)
+        q = self._new16(t.rows, mid) if b16 else self._new(t.rows, mid)
         self.gemm(t, self._lin_w(p + "to_q.weight"), mid, q, cin=c, pro=rt.PRO_LAYERNORM,
                   gain=self._vec(p + "norm.weight", c), nbias=self._vec(p + "norm.bias", c), eps=1e-5)
         ao = self._new16(t.rows, mid) if self.b16_ok(mid) else self._new(t.rows, mid)
         if cross_index is None:
-            kv = self._new(t.rows, 2 * mid)
+            kv = self._new16(t.rows, 2 * mid) if b16 else self._new(t.rows, 2 * mid)
             self.gemm(t, self._lin_w(p + "to_kv.weight"), 2 * mid, kv, cin=c, pro=rt.PRO_LAYERNORM,
                       gain=self._vec(p + "norm_context.weight", c), nbias=self._vec(p + "norm_context.bias", c),
                       eps=1e-5)
-            self.attn(q, kv.ref(), t.rows, t.rows, ao)
+            self.attn(q, kv.ref(), t.rows, t.rows, ao, kv16=b16)
             self._free(kv)
         else:
             self.attn(q, ("kv", cross_index), self.n_ctx, self.n_ctx, ao)

@@ -20,54 +20,102 @@ namespace mdt {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int KTM>   // key tiles held in registers: 1 (Tk <= 16) or 4 (Tk <= 64)
+// ---- operand loads.  H = the tensor is bf16 (plain-bf16 mode: q | k | v come out of a bf16 x bf16 GEMM as bf16, MDT_A_IN16;
+// the values are widened to fp32 in registers -- exact -- and both contractions stay fp32 MFMAs): half the bytes of the launch,
+// which is HBM-bound (3.3 TB/s with fp32 rows at B = 2048, profiles/r5_cfg4_op_profile_b2048.txt).
+template <bool H>
+__device__ __forceinline__ void ld_row16(const unsigned char* base, int64_t elem, float (&d)[16]) {   // 16 consecutive features
+  if constexpr (H) {
+    const uint4* p = reinterpret_cast<const uint4*>(base + elem * 2);
+    const uint4 u0 = p[0], u1 = p[1];
+    const unsigned w[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      d[2 * c] = __builtin_bit_cast(float, w[c] << 16);
+      d[2 * c + 1] = __builtin_bit_cast(float, w[c] & 0xffff0000u);
+    }
+  } else {
+    const float4* p = reinterpret_cast<const float4*>(base + elem * 4);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float4 t = p[c];
+      d[4 * c] = t.x; d[4 * c + 1] = t.y; d[4 * c + 2] = t.z; d[4 * c + 3] = t.w;
+    }
+  }
+}
+template <bool H>
+__device__ __forceinline__ void ld_row4(const unsigned char* base, int64_t elem, float* d, bool live) {   // 4 consecutive features
+  if (!live) { d[0] = d[1] = d[2] = d[3] = 0.f; return; }
+  if constexpr (H) {
+    const uint2 u = *reinterpret_cast<const uint2*>(base + elem * 2);
+    d[0] = __builtin_bit_cast(float, u.x << 16); d[1] = __builtin_bit_cast(float, u.x & 0xffff0000u);
+    d[2] = __builtin_bit_cast(float, u.y << 16); d[3] = __builtin_bit_cast(float, u.y & 0xffff0000u);
+  } else {
+    const float4 t = *reinterpret_cast<const float4*>(base + elem * 4);
+    d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w;
+  }
+}
+// O^T tile dt, row 4 g + r of lane (query lo, quarter g) is feature 16 g + 4 r + dt (the PV contraction leaves the output-row
+// order free: with "row i of tile dt = feature 4 i + dt" the A operand of the four tiles at one k-step is ONE 16-byte piece of the
+// value row -- round 5; it used to be four 4-byte loads 64 bytes apart): 16 consecutive features per lane.
+__device__ __forceinline__ void st_out16(const AttnArgs& a, int b, int h, int i, int g, const f32x4 (&acc)[4], float inv) {
+  constexpr int D = 64;
+  if (a.out16) {
+    unsigned short* o16 = reinterpret_cast<unsigned short*>(a.out) + ((int64_t)b * a.T + i) * a.ldo + h * D + 16 * g;
+#pragma unroll
+    for (int rp = 0; rp < 2; ++rp) {
+      unsigned w[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int r = 2 * rp + (c >> 1), dt = 2 * (c & 1);
+        const unsigned short h0 = __builtin_bit_cast(unsigned short, (__bf16)(acc[dt][r] * inv));
+        const unsigned short h1 = __builtin_bit_cast(unsigned short, (__bf16)(acc[dt + 1][r] * inv));
+        w[c] = h0 | ((unsigned)h1 << 16);
+      }
+      *reinterpret_cast<uint4*>(o16 + 8 * rp) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+  } else {
+    float* o = a.out + ((int64_t)b * a.T + i) * a.ldo + h * D + 16 * g;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      *reinterpret_cast<float4*>(o + 4 * r) = make_float4(acc[0][r] * inv, acc[1][r] * inv, acc[2][r] * inv, acc[3][r] * inv);
+  }
+}
+
+template <int KTM, int IN16>   // key tiles held in registers: 1 (Tk <= 16) or 4 (Tk <= 64); IN16: bit 0 = q is bf16, bit 1 = k | v are
 __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
   constexpr int D = 64;
+  constexpr bool HQ = IN16 & 1, HK = (IN16 & 2) != 0;
   const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (wid >= a.batch * a.heads) return;
   const int b = wid / a.heads, h = wid % a.heads;
   const int lane = threadIdx.x & 63;
   const int lo = lane & 15, g = lane >> 4;
-  const float* q = a.q + (int64_t)b * a.T * a.ldq + h * D;
-  const float* k = a.k + (int64_t)b * a.kv_bstride * a.ldkv + h * D;
-  const float* v = k + a.heads * D;
-  float* o = a.out + (int64_t)b * a.T * a.ldo + h * D;
+  const unsigned char* qb = reinterpret_cast<const unsigned char*>(a.q);
+  const unsigned char* kb = reinterpret_cast<const unsigned char*>(a.k);
+  const int64_t q0 = (int64_t)b * a.T * a.ldq + h * D, k0e = (int64_t)b * a.kv_bstride * a.ldkv + h * D, v0e = k0e + a.heads * D;
   const int KT = (a.Tk + 15) >> 4, QT = (a.T + 15) >> 4;
 
+  // K rows (A operand of S^T) and V pieces (A operand of O^T) of every key tile: fetched ONCE per (sample, head) -- they do not
+  // depend on the query tile -- and up-front, so that all global loads of the head are in flight together.
+  float kr[KTM][16], vr[KTM][16];
+#pragma unroll
+  for (int kt = 0; kt < KTM; ++kt) {
+    if (kt < KT) {
+      const int j = kt * 16 + lo;
+      ld_row16<HK>(kb, k0e + (int64_t)(j < a.Tk ? j : 0) * a.ldkv + 16 * g, kr[kt]);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int jj = kt * 16 + 4 * g + s;           // key row this lane quarter feeds at PV step s
+        ld_row4<HK>(kb, v0e + (int64_t)(jj < a.Tk ? jj : 0) * a.ldkv + 4 * lo, &vr[kt][4 * s], jj < a.Tk);
+      }
+    }
+  }
   for (int qt = 0; qt < QT; ++qt) {
     // B operand of S^T: this lane's 16 features of query row i
     const int i = qt * 16 + lo;
     float qr[16];
-    {
-      const float4* p = reinterpret_cast<const float4*>(q + (int64_t)(i < a.T ? i : 0) * a.ldq + 16 * g);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float4 t = p[c];
-        qr[4 * c] = t.x; qr[4 * c + 1] = t.y; qr[4 * c + 2] = t.z; qr[4 * c + 3] = t.w;
-      }
-    }
-    // K rows (A operand of S^T) and V columns (A operand of O^T) of every key tile are fetched up-front so
-    // that all global loads of the head are in flight together.
-    float kr[KTM][16], vr[KTM][16];
-#pragma unroll
-    for (int kt = 0; kt < KTM; ++kt) {
-      if (kt < KT) {
-        const int j = kt * 16 + lo;
-        const float4* p = reinterpret_cast<const float4*>(k + (int64_t)(j < a.Tk ? j : 0) * a.ldkv + 16 * g);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const float4 t = p[c];
-          kr[kt][4 * c] = t.x; kr[kt][4 * c + 1] = t.y; kr[kt][4 * c + 2] = t.z; kr[kt][4 * c + 3] = t.w;
-        }
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const int jj = kt * 16 + 4 * g + s;           // key row this lane quarter feeds at PV step s
-          const float* vrow = v + (int64_t)(jj < a.Tk ? jj : 0) * a.ldkv + lo;
-#pragma unroll
-          for (int dt = 0; dt < 4; ++dt) vr[kt][4 * s + dt] = jj < a.Tk ? vrow[16 * dt] : 0.f;
-        }
-      }
-    }
+    ld_row16<HQ>(qb, q0 + (int64_t)(i < a.T ? i : 0) * a.ldq + 16 * g, qr);
     f32x4 st[KTM];
     float mx = -INFINITY;
 #pragma unroll
@@ -120,22 +168,7 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
         }
       }
     }
-    if (i < a.T && a.out16) {
-      unsigned short* o16 = reinterpret_cast<unsigned short*>(a.out) + (int64_t)b * a.T * a.ldo + h * D;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        unsigned short hh[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) hh[r] = __builtin_bit_cast(unsigned short, (__bf16)acc[dt][r]);
-        *reinterpret_cast<uint2*>(o16 + (int64_t)i * a.ldo + 16 * dt + 4 * g) =
-            make_uint2(hh[0] | ((unsigned)hh[1] << 16), hh[2] | ((unsigned)hh[3] << 16));
-      }
-    } else if (i < a.T) {
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-        *reinterpret_cast<float4*>(o + (int64_t)i * a.ldo + 16 * dt + 4 * g) =
-            make_float4(acc[dt][0], acc[dt][1], acc[dt][2], acc[dt][3]);
-    }
+    if (i < a.T) st_out16(a, b, h, i, g, acc, 1.0f);
   }
 }
 
@@ -145,8 +178,10 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
 // maximum, the accumulated O^T and sum are rescaled when it moves; the result is divided by the sum once at the end.  Layouts,
 // MFMA operand maps and exactness (fp32 MFMA, expf) as k_attn above; mathematically the same softmax, rounding differs from
 // the two-pass form by a few ulp.
+template <int IN16>
 __global__ __launch_bounds__(256) void k_attn_long(AttnArgs a) {
   constexpr int D = 64, KTM = 4;
+  constexpr bool HQ = IN16 & 1, HK = (IN16 & 2) != 0;
   const int QT = (a.T + 15) >> 4;
   const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (wid >= (int64_t)a.batch * a.heads * QT) return;
@@ -155,19 +190,12 @@ __global__ __launch_bounds__(256) void k_attn_long(AttnArgs a) {
   const int b = bh / a.heads, h = bh % a.heads;
   const int lane = threadIdx.x & 63;
   const int lo = lane & 15, g = lane >> 4;
-  const float* q = a.q + (int64_t)b * a.T * a.ldq + h * D;
-  const float* k = a.k + (int64_t)b * a.kv_bstride * a.ldkv + h * D;
-  const float* v = k + a.heads * D;
+  const unsigned char* qb = reinterpret_cast<const unsigned char*>(a.q);
+  const unsigned char* kb = reinterpret_cast<const unsigned char*>(a.k);
+  const int64_t q0 = (int64_t)b * a.T * a.ldq + h * D, k0e = (int64_t)b * a.kv_bstride * a.ldkv + h * D, v0e = k0e + a.heads * D;
   const int i = qt * 16 + lo;
   float qr[16];
-  {
-    const float4* p = reinterpret_cast<const float4*>(q + (int64_t)(i < a.T ? i : 0) * a.ldq + 16 * g);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const float4 t = p[c];
-      qr[4 * c] = t.x; qr[4 * c + 1] = t.y; qr[4 * c + 2] = t.z; qr[4 * c + 3] = t.w;
-    }
-  }
+  ld_row16<HQ>(qb, q0 + (int64_t)(i < a.T ? i : 0) * a.ldq + 16 * g, qr);
   f32x4 acc[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -177,18 +205,11 @@ __global__ __launch_bounds__(256) void k_attn_long(AttnArgs a) {
 #pragma unroll
     for (int kt = 0; kt < KTM; ++kt) {
       const int j = k0 + kt * 16 + lo;
-      const float4* p = reinterpret_cast<const float4*>(k + (int64_t)(j < a.Tk ? j : 0) * a.ldkv + 16 * g);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float4 t = p[c];
-        kr[kt][4 * c] = t.x; kr[kt][4 * c + 1] = t.y; kr[kt][4 * c + 2] = t.z; kr[kt][4 * c + 3] = t.w;
-      }
+      ld_row16<HK>(kb, k0e + (int64_t)(j < a.Tk ? j : 0) * a.ldkv + 16 * g, kr[kt]);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const int jj = k0 + kt * 16 + 4 * g + s;
-        const float* vrow = v + (int64_t)(jj < a.Tk ? jj : 0) * a.ldkv + lo;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) vr[kt][4 * s + dt] = jj < a.Tk ? vrow[16 * dt] : 0.f;
+        ld_row4<HK>(kb, v0e + (int64_t)(jj < a.Tk ? jj : 0) * a.ldkv + 4 * lo, &vr[kt][4 * s], jj < a.Tk);
       }
     }
     f32x4 st[KTM];
@@ -237,41 +258,37 @@ __global__ __launch_bounds__(256) void k_attn_long(AttnArgs a) {
           acc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[kt][4 * s + dt], st[kt][s], acc[dt], 0, 0, 0);
   }
   if (i >= a.T) return;
-  const float inv = 1.0f / l_run;
-  if (a.out16) {
-    unsigned short* o16 = reinterpret_cast<unsigned short*>(a.out) + (int64_t)b * a.T * a.ldo + h * D;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      unsigned short hh[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) hh[r] = __builtin_bit_cast(unsigned short, (__bf16)(acc[dt][r] * inv));
-      *reinterpret_cast<uint2*>(o16 + (int64_t)i * a.ldo + 16 * dt + 4 * g) =
-          make_uint2(hh[0] | ((unsigned)hh[1] << 16), hh[2] | ((unsigned)hh[3] << 16));
-    }
-  } else {
-    float* o = a.out + (int64_t)b * a.T * a.ldo + h * D;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-      *reinterpret_cast<float4*>(o + (int64_t)i * a.ldo + 16 * dt + 4 * g) =
-          make_float4(acc[dt][0] * inv, acc[dt][1] * inv, acc[dt][2] * inv, acc[dt][3] * inv);
-  }
+  st_out16(a, b, h, i, g, acc, 1.0f / l_run);
 }
 
-hipError_t launch_attn(const AttnArgs& a, hipStream_t s) {
-  if (a.batch <= 0) return hipSuccess;
-  if (a.T <= 0 || a.Tk <= 0 || a.T > 8192 || a.Tk > 8192 || a.ldq % 4 || a.ldkv % 4 || a.ldo % 4) return hipErrorInvalidValue;
+template <int IN16>
+static hipError_t launch_attn_in(const AttnArgs& a, hipStream_t s) {
   if (a.T > 64 || a.Tk > 64) {
     const int64_t w = (int64_t)a.batch * a.heads * ((a.T + 15) / 16);
     if ((w + 3) / 4 > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_attn_long, dim3((unsigned)((w + 3) / 4)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_attn_long<IN16>, dim3((unsigned)((w + 3) / 4)), dim3(256), 0, s, a);
     return hipGetLastError();
   }
   const int waves = a.batch * a.heads;
   if (a.Tk <= 16)
-    hipLaunchKernelGGL(k_attn<1>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((k_attn<1, IN16>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a);
   else
-    hipLaunchKernelGGL(k_attn<4>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((k_attn<4, IN16>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a);
   return hipGetLastError();
+}
+
+hipError_t launch_attn(const AttnArgs& a, hipStream_t s) {
+  if (a.batch <= 0) return hipSuccess;
+  if (a.T <= 0 || a.Tk <= 0 || a.T > 8192 || a.Tk > 8192 || a.ldo % 4) return hipErrorInvalidValue;
+  if (a.in16 < 0 || a.in16 > 3) return hipErrorInvalidValue;
+  if (a.ldq % ((a.in16 & 1) ? 8 : 4) || a.ldkv % ((a.in16 & 2) ? 8 : 4)) return hipErrorInvalidValue;   // 16-byte row pieces
+  if (a.out16 && a.ldo % 8) return hipErrorInvalidValue;
+  switch (a.in16) {
+    case 0: return launch_attn_in<0>(a, s);
+    case 1: return launch_attn_in<1>(a, s);
+    case 2: return launch_attn_in<2>(a, s);
+    default: return launch_attn_in<3>(a, s);
+  }
 }
 
 

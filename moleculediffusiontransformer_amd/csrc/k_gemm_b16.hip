@@ -64,10 +64,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_b16(Gemm16Args g) {
 
   // ---- per-lane DMA sources (lane l of an instruction: LDS row R0 + l / 8, physical slot l % 8) ----
   // (fixed bounds: hipcc's host pass silently drops the kernel stub when a lambda captures an array of dependent size)
-  static_assert(NA <= 4 && NB <= 4, "at most 4 DMA instructions per wave and operand");
-  const unsigned char* abase[4];
-  int arow[4];                   // row inside the sample, or a large negative number for rows past M
-  const unsigned char* wsrc[4];
+  static_assert(NA <= 8 && NB <= 8, "at most 8 DMA instructions per wave and operand");
+  const unsigned char* abase[8];
+  int arow[8];                   // row inside the sample, or a large negative number for rows past M
+  const unsigned char* wsrc[8];
 #pragma unroll
   for (int j = 0; j < NA; ++j) {
     const int R = (j * NW + wave) * 8 + (lane >> 3);
@@ -155,12 +155,13 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_b16(Gemm16Args g) {
   // by row: 16 lanes per row, float4 each -- bias, GELU, residual (float4 loads, all requested before the first store of the
   // pass) and the fp32 store and / or the bf16 store as 16- / 8-byte accesses of 256- / 128-byte row segments.
   __syncthreads();                                  // every wave is done reading the last stage
-  constexpr int EP = 72;                            // floats per parked row
+  constexpr int EP = 32 * TN + 8;                   // floats per parked row (72 / 136: pitch = 8 mod 32 banks)
   float* ws = reinterpret_cast<float*>(smem) + wave * (32 * EP);
   static_assert(NW * 32 * EP * 4 <= 2 * STAGE, "parking area inside the staging buffers");
   unsigned short* o16 = g.out16 ? reinterpret_cast<unsigned short*>(g.out) : g.copy16;
   const int ld16 = g.out16 ? g.ldc : g.N, oc16 = g.out16 ? g.o_col : 0;
-  const int er = lane >> 4, ec = (lane & 15) * 4;   // this lane's row inside a group of 4 rows, its first column
+  constexpr int LPR = 8 * TN;                       // lanes per parked row (float4 each)
+  const int er = lane / LPR, ec = (lane % LPR) * 4; // this lane's row inside a group of 64 / LPR rows, its first column
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
 #pragma unroll
@@ -259,6 +260,9 @@ hipError_t launch_gemm_b16(const Gemm16Args& g, hipStream_t s) {
   int cfg = tiles(256, 256) >= 256 ? 0 : (tiles(256, 128) >= 256 ? 1 : 2);     // the largest tile that still fills 256 CUs
   if (force >= 0) cfg = force;
   switch (cfg) {
+    // (256 x 256 on FOUR waves of 128 x 128 -- launch16<2, 2, 4, 4>, 16 MFMAs per 8 KB of fragment reads, 256 accumulator
+    //  registers -- measured 5-30 % SLOWER than the eight-wave form on every configs[4] shape, round 5: one wave per SIMD
+    //  leaves nothing to run under its fragment reads)
     case 0: return launch16<2, 4, 4, 2>(g, s);
     case 1: return launch16<4, 2, 2, 2>(g, s);
     default: return launch16<2, 2, 2, 2>(g, s);

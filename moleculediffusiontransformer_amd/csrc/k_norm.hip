@@ -61,12 +61,15 @@ __global__ __launch_bounds__(NT) void k_gn_stats(GnStatsArgs g) {
 // elements in registers (two-pass variance, shuffle reduction in a fixed order: deterministic).
 // TB threads per workgroup: 256, or 1024 for the large samples of the deep U-Net (16 K - 32 K elements: a quarter of the
 // registers per thread, four times the loads in flight per sample)
-template <int NF4, int TB = 256>
+// SPLIT (round 5): one workgroup per (sample, GROUP) instead of per sample -- the deep U-Net's samples are 64-128 KB, a
+// workgroup of 1024 threads loaded all of it, reduced, then stored (two such workgroups per CU: 2.6-3.1 TB/s, the phases of a
+// workgroup do not overlap); with a group per 256-thread workgroup eight of them share a CU and one's stores run under another's loads.
+template <int NF4, int TB = 256, bool SPLIT = false>
 __global__ __launch_bounds__(TB) void k_gn_act(GnActArgs a) {
   __shared__ float red[TB / 64];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const int tpg = TB / a.groups;                   // threads per group (power of two)
-  const int grp = tid / tpg, u = tid % tpg;
+  const int b = SPLIT ? blockIdx.x / a.groups : blockIdx.x, tid = threadIdx.x;
+  const int tpg = SPLIT ? TB : TB / a.groups;      // threads per group (power of two)
+  const int grp = SPLIT ? blockIdx.x % a.groups : tid / tpg, u = SPLIT ? tid : tid % tpg;
   const int q4 = a.gsize / 4;                      // float4 per row of the group's channel span
   const int nf4 = a.rows * q4;                     // float4 per group
   const float* xb = a.x + (int64_t)b * a.rows * a.ld + grp * a.gsize;
@@ -165,6 +168,15 @@ hipError_t launch_gn_act(const GnActArgs& a, hipStream_t s) {
   if (a.batch <= 0) return hipSuccess;
   if (!gn_act_eligible(a.rows, a.ld, a.groups, a.gsize)) return hipErrorInvalidValue;
   const int tpg = 256 / a.groups, per = (a.rows * (a.gsize / 4) + tpg - 1) / tpg;
+  const int nf4 = a.rows * (a.gsize / 4);
+  if (a.groups > 1 && nf4 >= 256 && nf4 <= 2048 && (int64_t)a.batch * a.groups < 0x7fffffffLL) {
+    const dim3 grid((unsigned)(a.batch * a.groups));
+    if (nf4 <= 256) hipLaunchKernelGGL((k_gn_act<1, 256, true>), grid, dim3(256), 0, s, a);
+    else if (nf4 <= 512) hipLaunchKernelGGL((k_gn_act<2, 256, true>), grid, dim3(256), 0, s, a);
+    else if (nf4 <= 1024) hipLaunchKernelGGL((k_gn_act<4, 256, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_gn_act<8, 256, true>), grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+  }
   if (per <= 1) hipLaunchKernelGGL((k_gn_act<1>), dim3(a.batch), dim3(256), 0, s, a);
   else if (per <= 2) hipLaunchKernelGGL((k_gn_act<2>), dim3(a.batch), dim3(256), 0, s, a);
   else if (per <= 4) hipLaunchKernelGGL((k_gn_act<4>), dim3(a.batch), dim3(256), 0, s, a);

@@ -170,6 +170,11 @@ static const char* validate(const mdt_op& o, int idx, char* buf, size_t nbuf) {
       if (o.i[MDT_A_T] <= 0 || o.i[MDT_A_T] > 8192 || o.i[MDT_A_TK] <= 0 || o.i[MDT_A_TK] > 8192)
         return bad("attention supports 1..8192 queries and keys per sample (more than 64 of either: the online-softmax kernel)");
       if (o.i[MDT_A_QCOL] < 0 || o.i[MDT_A_KCOL] < 0 || o.i[MDT_A_QCOL] % 4 || o.i[MDT_A_KCOL] % 4) return bad("bad q / k column offset");
+      if (o.i[MDT_A_IN16] < 0 || o.i[MDT_A_IN16] > 3) return bad("IN16 is a mask: 1 = q is bf16, 2 = k | v are bf16");
+      if (((o.i[MDT_A_IN16] & 1) && (o.i[MDT_A_QCOL] % 8 || o.i[MDT_A_LDQ] % 8)) ||
+          ((o.i[MDT_A_IN16] & 2) && (o.i[MDT_A_KCOL] % 8 || o.i[MDT_A_LDKV] % 8)))
+        return bad("bf16 q / k | v rows are read in 16-byte pieces: pitch and column offset must be multiples of 8 elements");
+      if (o.i[MDT_A_OUT16] && o.i[MDT_A_LDO] % 8) return bad("a bf16 attention output is written in 16-byte pieces: LDO % 8");
       if (!o.a.space || !o.a2.space || !o.out.space) return bad("missing operand");
       break;
     case MDT_OP_ATTN_CTX:
@@ -414,8 +419,9 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
       case MDT_OP_ATTN: {
         mdt::AttnArgs a;
         a.q = ptr(o.a); a.k = ptr(o.a2); a.out = ptr(o.out); a.batch = B; a.T = o.i[MDT_A_T]; a.Tk = o.i[MDT_A_TK];
-        if (a.q) a.q += o.i[MDT_A_QCOL];
-        if (a.k) a.k += o.i[MDT_A_KCOL];
+        a.in16 = o.i[MDT_A_IN16]; a.split_scores = 0;
+        if (a.q) a.q = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.q) + (size_t)o.i[MDT_A_QCOL] * ((a.in16 & 1) ? 2 : 4));
+        if (a.k) a.k = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.k) + (size_t)o.i[MDT_A_KCOL] * ((a.in16 & 2) ? 2 : 4));
         a.heads = o.i[MDT_A_HEADS]; a.ldq = o.i[MDT_A_LDQ]; a.ldkv = o.i[MDT_A_LDKV]; a.ldo = o.i[MDT_A_LDO];
         a.kv_bstride = o.i[MDT_A_KV_BSTRIDE]; a.scale = o.f[MDT_AF_SCALE]; a.out16 = o.i[MDT_A_OUT16];
         if (!missing) e = mdt::launch_attn(a, stream);
@@ -425,7 +431,7 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
         mdt::AttnArgs a;
         a.q = ptr(o.a); a.k = ptr(o.a2); a.out = ptr(o.out); a.batch = B; a.T = o.i[MDT_A_T]; a.Tk = o.i[MDT_A_TK];
         a.heads = o.i[MDT_A_HEADS]; a.ldq = 128; a.ldkv = o.i[MDT_A_LDKV]; a.ldo = 128;
-        a.kv_bstride = o.i[MDT_A_KV_BSTRIDE]; a.scale = o.f[MDT_AF_SCALE]; a.out16 = 0; a.split_scores = o.i[MDT_A_SPLIT];
+        a.kv_bstride = o.i[MDT_A_KV_BSTRIDE]; a.scale = o.f[MDT_AF_SCALE]; a.out16 = 0; a.split_scores = o.i[MDT_A_SPLIT]; a.in16 = 0;
         if (!missing) e = mdt::launch_attn_ctx(a, stream);
         break;
       }

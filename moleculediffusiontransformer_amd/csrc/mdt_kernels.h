@@ -189,6 +189,7 @@ struct AttnArgs {
   float scale;
   int out16;   // MDT_OP_ATTN: 1 = out is bf16 (ldo in bf16 elements)
   int split_scores;   // MDT_OP_ATTN_CTX: 1 = scores as split-bf16 products (MDT_A_SPLIT), 0 = exact fp32 MFMA
+  int in16;    // MDT_OP_ATTN: bit 0 = q is bf16, bit 1 = k | v are bf16 (ldq / ldkv in bf16 elements; q / k point at bf16 data)
 };
 hipError_t launch_attn(const AttnArgs& a, hipStream_t s);
 // MDT_OP_ATTN_CTX: rows q [batch][T * heads][128] against the normalised context k [batch | 1][Tk][ldkv >= 128] (K = V)

@@ -147,12 +147,18 @@ def run_program(ops, bufs: Buffers, B: int, n_shared_rows: int = 0) -> None:
             ldq, ldkv, ldo, bs = i[rt.A_LDQ], i[rt.A_LDKV], i[rt.A_LDO], i[rt.A_KV_BSTRIDE]
             D = 64
             qc, kc = i[rt.A_QCOL], i[rt.A_KCOL]
-            q = bufs.view(op.a, B, B * T * ldq).view(B, T, ldq)[:, :, qc: qc + H * D].reshape(B, T, H, D).transpose(1, 2)
+            in16 = i[rt.A_IN16]                 # mask: 1 = q is bf16, 2 = k | v are bf16 (pitches / columns in bf16 elements)
+
+            def rows(ref, n, ld, half):
+                if half:
+                    return bufs.view(ref, B, n * ld // 2).view(torch.bfloat16).float().view(n, ld)
+                return bufs.view(ref, B, n * ld).view(n, ld)
+            q = rows(op.a, B * T, ldq, in16 & 1).view(B, T, ldq)[:, :, qc: qc + H * D].reshape(B, T, H, D).transpose(1, 2)
             if bs == 0:
-                kv = bufs.view(op.a2, B, Tk * ldkv).view(1, Tk, ldkv).expand(B, -1, -1)
+                kv = rows(op.a2, Tk, ldkv, in16 & 2).view(1, Tk, ldkv).expand(B, -1, -1)
             else:
                 assert bs == Tk
-                kv = bufs.view(op.a2, B, B * Tk * ldkv).view(B, Tk, ldkv)
+                kv = rows(op.a2, B * Tk, ldkv, in16 & 2).view(B, Tk, ldkv)
             k = kv[:, :, kc: kc + H * D].reshape(B, Tk, H, D).transpose(1, 2)
             v = kv[:, :, kc + H * D: kc + 2 * H * D].reshape(B, Tk, H, D).transpose(1, 2)
             sim = (q @ k.transpose(-1, -2)) * float(f[0])

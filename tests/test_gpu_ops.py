@@ -173,6 +173,56 @@ def test_attention(B, T, Tk, shared):
     assert (ga - ca).abs().max() < 1e-5
 
 
+@pytest.mark.parametrize("B,T,Tk,shared", [(3, 32, 32, False), (2, 8, 8, False), (3, 32, 12, True), (2, 8, 12, True), (1, 100, 70, False)])
+@pytest.mark.parametrize("in16", [1, 2, 3])
+@pytest.mark.parametrize("out16", [0, 1])
+def test_attention_with_bf16_operands(B, T, Tk, shared, in16, out16):
+    """MDT_A_IN16 (plain-bf16 mode): q and / or k | v arrive as bf16 (written so by their GEMM), are widened exactly and contracted in
+    fp32; the merged q | k | v tensor of a self-attention layer (one pitch, column offsets) when all three are bf16."""
+    H, D = 8, 64
+    merged = in16 == 3 and not shared and T == Tk
+    qf, kvf = rnd(B * T * H * D, seed=1), rnd((1 if shared else B) * Tk * 2 * H * D, seed=2)
+
+    def pack(x, half):
+        return x.to(torch.bfloat16).view(torch.float32) if half else x
+    if merged:
+        qkv = torch.cat([qf.view(B * T, H * D), kvf.view(B * Tk, 2 * H * D)], 1)
+        regions = [pack(qkv.reshape(-1), True)]
+    else:
+        regions = [pack(qf, in16 & 1)] + ([] if shared else [pack(kvf, in16 & 2)])
+    n_in = sum(r.numel() for r in regions)
+    n_out = B * T * H * D // (2 if out16 else 1)
+    act = torch.cat(regions + [torch.zeros(n_out)])
+    shr = pack(kvf, in16 & 2) if shared else torch.zeros(4)
+    op = rt.MdtOp()
+    op.kind = rt.OP_ATTN
+    op.a, op.out = ref(A, 0), ref(A, n_in // B)
+    i = op.i
+    if merged:
+        op.a2 = ref(A, 0)
+        i[rt.A_LDQ], i[rt.A_LDKV], i[rt.A_KCOL] = 3 * H * D, 3 * H * D, H * D
+    else:
+        op.a2 = ref(S, 0) if shared else ref(A, regions[0].numel() // B)
+        i[rt.A_LDQ], i[rt.A_LDKV] = H * D, 2 * H * D
+    i[rt.A_T], i[rt.A_TK], i[rt.A_HEADS], i[rt.A_LDO] = T, Tk, H, H * D
+    i[rt.A_KV_BSTRIDE] = 0 if shared else Tk
+    i[rt.A_IN16], i[rt.A_OUT16] = in16, out16
+    op.f[0] = D ** -0.5
+    (ga, _, _), (ca, _, _) = run_both([op], torch.zeros(4), act, shr, {}, B)
+    go, co = ga[n_in:], ca[n_in:]
+    if out16:
+        go, co = go.view(torch.bfloat16).float(), co.view(torch.bfloat16).float()
+        assert (go - co).abs().max() < 2e-2 and ((go - co).abs() > 1e-5).float().mean() < 1e-3      # a rounding boundary, rarely
+    else:
+        assert (go - co).abs().max() < 1e-5
+    # and against torch on the widened values
+    q = (qf.to(torch.bfloat16).float() if in16 & 1 else qf).view(B, T, H, D).transpose(1, 2)
+    kv = (kvf.to(torch.bfloat16).float() if in16 & 2 else kvf).view(-1, Tk, 2, H, D)
+    k, v = kv[:, :, 0].transpose(1, 2), kv[:, :, 1].transpose(1, 2)
+    o = ((q @ k.transpose(-1, -2) * D ** -0.5).softmax(-1) @ v).transpose(1, 2).reshape(-1)
+    assert (go - (o.to(torch.bfloat16).float() if out16 else o)).abs().max() < (2e-2 if out16 else 1e-5)
+
+
 @pytest.mark.parametrize("B,T,Tk,shared", [(3, 16, 64, False), (2, 32, 64, True), (5, 4, 40, False), (2, 1, 33, False),
                                            (1, 64, 64, False), (3, 8, 16, True), (2, 3, 20, False), (3, 5, 64, True),
                                            (2100, 1, 33, False), (1100, 4, 64, False), (650, 16, 20, True), (2500, 2, 9, False)])

@@ -2,7 +2,7 @@
 """Micro-benchmark of the plain-bf16 GEMM forms on the deep-UNet (configs[4]) layer shapes through the C ABI (GPU box):
   reg   = MDT_G_WFMT 1: fp32 A, prologue in the kernel, register staging (k_gemm3<NPROD = 1>)
   dma   = MDT_OP_PREP16 + MDT_G_WFMT 2: bf16 A written once, both operands by LDS-DMA (k_gemm_b16); prep and GEMM timed apart
-MDT_TILE16_LIVE = 0 / 1 / 2 forces the 256x256 / 256x128 / 128x128 tile.  BATCH=<B> (default 512)."""
+MDT_TILE16 = 0 / 1 / 2 / 3 forces the 256x256 / 256x128 / 128x128 / 256x256-on-four-waves tile.  BATCH=<B> (default 512)."""
 import os
 import sys
 
