@@ -608,8 +608,8 @@ def main():
                 "configs[4] in its bf16 mode at its stated length (256 timesteps = 510 U-Net evaluations)":
                     # batch 2048 per GPU: the layer-by-layer bf16 program is HBM-bound by its fp32 residual stream and its GEMMs
                     # reach their rate from M = 16384 rows on the 1024-channel level (tools/cfg4_probe.py: 110 / 140 / 152 / 153
-                    # molecules/s at batch 512 / 1024 / 2048 / 4096); 2 timed calls of ~14 s each
-                    quick("cfg5c", "cfg5", 2048, 256, 1.0, nsteps=2, gemm_mode="bf16", warm_timesteps=4),
+                    # molecules/s at batch 512 / 1024 / 2048 / 4096); 3 timed calls of ~14 s each
+                    quick("cfg5c", "cfg5", 2048, 256, 1.0, gemm_mode="bf16", warm_timesteps=4),
                 # strict-fp32 numbers beyond configs[1] (exact fp32 MFMA products; `exact_f32` above is configs[1])
                 "configs[2] QMDiffusionForward, exact fp32 products": quick("cfg3f", "cfg3", 4096, 100, 1.0, gemm_mode="f32"),
                 "configs[3] per-GPU shard (batch 8192), exact fp32 products": quick("shardf", "cfg1", 8192, 64, 1.0, gemm_mode="f32"),
