@@ -201,7 +201,12 @@ enum mdt_gemm_i {
                         bf16 x bf16 GEMM (feed-forward hidden layer); 10 = as 2 and ALSO a bf16 copy [rows][N] of the fp32 output
                         into p0 (the residual stream as the A operand of the next GEMM, written where it is produced).
                         Formats 2 / 6 / 10 end in a float4 epilogue: N, LDC, O_COL and LDR must be multiples of 4 and bias /
-                        residual / out 16-byte aligned (bf16 out / copy: 8), otherwise the op is rejected                    */
+                        residual / out 16-byte aligned (bf16 out / copy: 8), otherwise the op is rejected;
+                        16 = RING TILES (k_proj.hip, round 5): w holds N / 64 * CIN / 128 tiles of 32 KB, tile (chunk c, K half h)
+                        at index c * (CIN / 128) + h = W[64 c .. 64 c + 64)[128 h .. 128 h + 128) as a bf16 hi plane [64][128]
+                        followed by the lo plane (split-bf16 products); CIN in {128, 256}, N % 64 == 0, prologue none or
+                        LayerNorm (p0 / p1 both unbound = LayerNorm WITHOUT affine: the caller folded gain into the weights and
+                        bias into the bias), one tap, bias / residual optional (the residual may alias out), no activation / row mapping */
 };
 enum mdt_gemm_f { MDT_GF_EPS = 0 };
 

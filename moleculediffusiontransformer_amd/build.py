@@ -35,6 +35,7 @@ SOURCES = [
     ("k_tf256_f32.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("k_rconv.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("k_rconv_f32.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
+    ("k_proj.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("k_res256.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("k_resblock.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("k_norm.hip", []),

@@ -91,12 +91,20 @@ class _Weights:
         self.chunks: List[torch.Tensor] = []
         self.n = 0
         self.index: Dict[str, int] = {}
+        self.starts: Dict[int, torch.Tensor] = {}      # offset -> the tensor added there
+
+    def read(self, off: int, n: int) -> torch.Tensor:
+        """The first n floats of the tensor that was added at offset `off`."""
+        t = self.starts[off]
+        assert t.numel() >= n, (off, n, t.numel())
+        return t[:n].clone()
 
     def add(self, name: str, t: torch.Tensor) -> int:
         t = t.detach().to(torch.float32).contiguous().reshape(-1).cpu()
         off = self.n
         pad = (-t.numel()) % 64
         self.chunks.append(t)
+        self.starts[off] = t
         if pad:
             self.chunks.append(torch.zeros(pad))
         self.n += t.numel() + pad
@@ -168,6 +176,7 @@ class UNetCompiler:
         # one-token level (configs[2]: +0.7 %); at BASELINE configs[1]'s B = 1024 the per-convolution launches, which split the
         # output channels over two workgroups, are 0.4 % faster than the chain on half the compute units (profiles/r5_res256_ab.txt)
         self.res256_mode = os.environ.get("MDT_RES256", "auto")
+        self.use_proj = os.environ.get("MDT_PROJ", "1") != "0"      # K = 128 / 256 projections on ring tiles (k_proj.hip)
         self.b16 = os.environ.get("MDT_B16", "1") == "1"
         self.qkv_merge = os.environ.get("MDT_QKV_MERGE", "1") == "1"   # ... and self-attention's q | k | v as one GEMM     # bf16 mode: regular layers as PREP16 + bf16 x bf16 GEMM
         self.fold_ctx = os.environ.get("MDT_FOLD_CTX", "1") == "1"
@@ -334,7 +343,35 @@ class UNetCompiler:
             pro, gain, nbias, stats, film, groups, gsize, pro_silu, a_col = rt.PRO_NONE, None, None, None, None, 0, 0, 0, 0
         op = rt.MdtOp()
         op.kind = rt.OP_GEMM
-        w_off, wlo_off, *wfmt = self._pack_w(wt, cin)
+        # row-stationary projection on ring tiles (k_proj.hip, MDT_G_WFMT = 16): the K = 128 / 256 layers between the fused kernels
+        ring = (self.use_proj and self.gemm_mode == "bf16x3" and not self.wf32 and cin in (128, 256) and n % 64 == 0 and taps == 1
+                and t_stride == 1 and t_off == 0 and phases <= 1 and o_stride == 1 and o_off == 0 and r_out_ == a.rows
+                and out.rows == r_out_ and act == 0 and pro in (rt.PRO_NONE, rt.PRO_LAYERNORM) and not a.b16 and not out.b16
+                and copy16 is None and a.ld % 4 == 0 and a_col % 4 == 0 and o_col % 4 == 0 and out.ld % 4 == 0
+                and (res is None or res.ld % 4 == 0) and tuple(wt[1].shape) == (n, cin))
+        if ring:
+            # LayerNorm's gain folds into the weights and its bias into the bias (W (g xn + b) = (W g) xn + W b, fp64 on the host): the
+            # kernel normalises without per-channel vectors (48 float4 per lane ahead of its first barrier at K = 256 otherwise)
+            fold = pro == rt.PRO_LAYERNORM
+            key = (wt[0], "ring", gain if fold else None, nbias if fold else None, bias_off if fold else None)
+            if key not in self._packed:
+                w = wt[1].double()
+                fb = None
+                if fold:
+                    gv = self.W.read(gain, cin).double()
+                    bv = self.W.read(nbias, cin).double()
+                    b0 = self.W.read(bias_off, n).double() if bias_off is not None else torch.zeros(n, dtype=torch.float64)
+                    fb = self.W.add(wt[0] + "/ring.bias", (b0 + w @ bv).float())
+                    w = w * gv.unsqueeze(0)
+                w = w.float()
+                tiles = [self._tile(w[64 * c: 64 * c + 64, 128 * h: 128 * h + 128]) for c in range(n // 64) for h in range(cin // 128)]
+                self._packed[key] = (self.W.add(wt[0] + "/ring.tiles", torch.cat(tiles)), None, 16, fb)
+            w_off, wlo_off, fmt16, fb = self._packed[key]
+            wfmt = [fmt16]
+            if fold:
+                bias_off, gain, nbias = fb, None, None
+        else:
+            w_off, wlo_off, *wfmt = self._pack_w(wt, cin)
         op.a, op.w, op.out = a.ref(), _ref(rt.SP_WEIGHT, w_off), out.ref()
         op.i[rt.G_WFMT] = ((2 | (4 if out.b16 else 0) | (8 if copy16 is not None else 0)) if a.b16 else wfmt[0]) if wfmt else 0
         if copy16 is not None:               # a bf16 copy of the fp32 output, written by the epilogue (MDT_G_WFMT 10)

@@ -162,6 +162,22 @@ struct RConvArgs {
   int pf_lines;        // ... its size in 128-byte lines
   int wf32;            // 1: fp32 fragment tiles, exact fp32 MFMA products (MDT_R_WF32)
 };
+// MDT_OP_GEMM with MDT_G_WFMT = 16 (k_proj.hip): row-stationary projection, weights as ring tiles
+struct ProjArgs {
+  const float* x;      // [M][lda] (A_COL applied)
+  const float* w;      // 32 KB tiles [64 features][128 k] (bf16 hi plane | lo plane), order (64-feature chunk, K half)
+  const float* bias;   // [N] or nullptr
+  const float* res;    // [M][ldr] added to the result, or nullptr (may alias out)
+  const float* gamma;  // LayerNorm gain / bias over the K input channels (ln = 1)
+  const float* beta;
+  float* out;          // [M][ldc] (O_COL applied)
+  int M, N, K, lda, ldc, ldr, ln;
+  float eps;
+  int nch;             // (set by the launcher) 64-feature chunks per workgroup
+};
+bool proj_supported(int K, int N, int lda, int ldc, int ldr);
+hipError_t launch_proj(const ProjArgs& a, hipStream_t s);
+
 bool rconv_supported(int C, int T, int taps, int gsize);
 hipError_t launch_rconv(const RConvArgs& a, hipStream_t s);
 hipError_t launch_rconv_f32(const RConvArgs& a, hipStream_t s);   // (k_rconv_f32.hip); reached through launch_rconv

@@ -54,7 +54,9 @@ def run_program(ops, bufs: Buffers, B: int, n_shared_rows: int = 0) -> None:
                 a = bufs.view(op.a, B, batches * r_in * lda).view(batches, r_in, lda)
             a = a[:, :, i[rt.G_A_COL]: i[rt.G_A_COL] + cin]
             pro = i[rt.G_PRO]
-            if pro == rt.PRO_LAYERNORM:
+            if pro == rt.PRO_LAYERNORM and op.p0.space == rt.SP_NONE:      # (ring-tile projection: no affine, folded into W / bias)
+                a = F.layer_norm(a, (cin,), eps=float(f[0]))
+            elif pro == rt.PRO_LAYERNORM:
                 g, b = bufs.view(op.p0, B, cin), bufs.view(op.p1, B, cin)
                 a = F.layer_norm(a, (cin,), g, b, eps=float(f[0]))
             elif pro == rt.PRO_GROUPNORM:
@@ -80,6 +82,14 @@ def run_program(ops, bufs: Buffers, B: int, n_shared_rows: int = 0) -> None:
                 half = nph * n * taps * cin // 2
                 w_all = bufs.view(op.w, B, half).view(torch.bfloat16).float().view(nph, n, taps, cin)
                 a = a.to(torch.bfloat16).float()
+            elif i[rt.G_WFMT] == 16:             # ring tiles (k_proj.hip): [64 features][128 k] hi | lo planes, order (chunk, K half)
+                khn = cin // 128
+                stream = bufs.view(op.w, B, (n // 64) * khn * 64 * 128)
+                w_all = torch.zeros(n, cin)
+                for c_ in range(n // 64):
+                    for h_ in range(khn):
+                        w_all[64 * c_: 64 * c_ + 64, 128 * h_: 128 * h_ + 128] = _untile(stream, c_ * khn + h_, 64, 128)
+                w_all = w_all.view(1, n, 1, cin)
             elif op.a2.space != rt.SP_NONE:      # split-bf16 weights: two bf16 planes stored as raw bits
                 half = nph * n * taps * cin // 2
                 hi = bufs.view(op.w, B, half).view(torch.bfloat16).float()

@@ -62,6 +62,44 @@ def test_gemm_plain_bias_gelu_residual(B, R, cin, N, taps):
     assert (ga - ca).abs().max() < 2e-5
 
 
+@pytest.mark.parametrize("B,R,cin,N", [(37, 1, 256, 1024), (70, 1, 256, 256), (129, 4, 128, 1024), (5, 4, 128, 64), (33, 16, 128, 192),
+                                       (300, 1, 256, 64), (1100, 4, 128, 512), (2100, 1, 256, 1024)])
+@pytest.mark.parametrize("ln,res", [("plain", False), (False, True), ("plain", True), ("affine", False), ("affine", True)])
+def test_row_stationary_projection_on_ring_tiles(B, R, cin, N, ln, res):
+    """k_proj (MDT_G_WFMT = 16): LayerNorm prologue (without affine -- what the compiler emits, gain / bias folded into W / bias -- and
+    with gain / bias vectors), bias, residual IN PLACE on the output, row counts that are no multiple of the workgroup's rows, one to
+    several workgroups per row block; against the interpreter (split-bf16 weights) and the exact fp32 product."""
+    from moleculediffusiontransformer_amd.compiler import UNetCompiler
+    w = rnd(N, cin, seed=1, scale=cin ** -0.5)
+    tiles = [UNetCompiler._tile(w[64 * c: 64 * c + 64, 128 * h: 128 * h + 128]) for c in range(N // 64) for h in range(cin // 128)]
+    wt = torch.cat(tiles)
+    weights = torch.cat([wt, rnd(N, seed=2), 1 + 0.1 * rnd(cin, seed=5), 0.1 * rnd(cin, seed=6)])
+    nb = wt.numel()
+    x = rnd(B * R * cin, seed=3) * 1.3 + 0.2
+    out0 = rnd(B * R * N, seed=4)
+    act = torch.cat([x, out0])
+    op = gemm_op(a=ref(A, 0), w=ref(W, 0), bias=ref(W, nb), out=ref(A, R * cin), r_out=R, r_in=R, lda=cin, cin=cin, taps=1, n=N,
+                 ldc=N, o_rows=R, eps=1e-5)
+    if ln:
+        op.i[rt.G_PRO] = rt.PRO_LAYERNORM
+        if ln == "affine":
+            op.p0, op.p1 = ref(W, nb + N), ref(W, nb + N + cin)
+    if res:
+        op.res = ref(A, R * cin)
+        op.i[rt.G_LDR] = N
+    op.i[rt.G_WFMT] = 16
+    (ga, _, _), (ca, _, _) = run_both([op], weights, act, torch.zeros(4), {}, B)
+    assert torch.equal(ga[: B * R * cin], x)
+    assert (ga - ca).abs().max() < 5e-5              # (summation order; the split planes carry ~2^-17 relative rounding)
+    a = x.view(B * R, cin)
+    if ln == "affine":
+        a = torch.nn.functional.layer_norm(a, (cin,), weights[nb + N: nb + N + cin], weights[nb + N + cin:], 1e-5)
+    elif ln:
+        a = torch.nn.functional.layer_norm(a, (cin,), eps=1e-5)
+    y = a.double() @ w.double().T + weights[nb: nb + N].double() + (out0.view(B * R, N).double() if res else 0)
+    assert (ga[B * R * cin:].view(B * R, N).double() - y).abs().max() < 1e-4
+
+
 def test_gemm_strided_conv_and_transposed_phases():
     B, Lin, cin, N, f = 3, 16, 64, 128, 4
     # Conv1d k=9 s=4 p=4 (modules.py:40-51)

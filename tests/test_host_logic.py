@@ -345,7 +345,7 @@ def test_lowering_matches_reference_golden(case, mode, monkeypatch):
     assert abs(cu.flops_per_sample_eval - {"cfg1": 388.7e6}.get(case, cu.flops_per_sample_eval)) < 1e6
 
 
-_RING_UNITS = ("k_tblock32", "k_rconv", "k_tf128", "k_tf256", "k_rconv_f32", "k_tf128_f32", "k_tf256_f32", "k_attn", "k_res256")
+_RING_UNITS = ("k_tblock32", "k_rconv", "k_tf128", "k_tf256", "k_rconv_f32", "k_tf128_f32", "k_tf256_f32", "k_attn", "k_res256", "k_proj")
 
 
 @pytest.fixture(scope="module")
@@ -382,7 +382,8 @@ def test_ring_kernels_keep_their_arrays_in_registers(ring_kernel_reports):
     limits = {"k_tblock32": 24, "k_rconv": 0, "k_tf128": 0, "k_tf256": 16,      # bytes per lane
               "k_rconv_f32": 0, "k_tf128_f32": 0, "k_tf256_f32": 0,
               "k_attn": 0,        # k_attn_ctx (round 4: context streamed through a per-wave LDS ring, inline-asm fragment reads)
-              "k_res256": 0}      # round 5: the chained ResNet blocks of the 256-channel level (all 8 instantiations)
+              "k_res256": 0,      # round 5: the chained ResNet blocks of the 256-channel level (all 8 instantiations)
+              "k_proj": 0}        # round 5: the row-stationary projection on ring tiles (all 12 instantiations)
     for name, limit in limits.items():
         assert res[name], name
         for fn, v in res[name]:
