@@ -51,7 +51,9 @@ def test_unet_eval_and_denoise_match_reference(models, case):
         y = m.unet(x[b:b + 1], t[b:b + 1], embedding=emb[b:b + 1], embedding_scale=1.0)
         assert (y.cpu() - to_t(g["y_scale1"])[b:b + 1]).abs().max() < 5e-5, (case, b)
         y = m.unet(x[b:b + 1], t[b:b + 1], embedding=emb[b:b + 1], embedding_scale=7.5)
-        assert (y.cpu() - to_t(g["y_scale7p5"])[b:b + 1]).abs().max() < 2e-4, (case, b)
+        # guidance multiplies the difference of two passes by 7.5: the bound is 7.5 x (error of either pass, < 5e-5 above), measured
+        # 0.4e-4 .. 2.7e-4 over the seven models (rounding noise: 1.8e-4 / 2.7e-4 for the same row with the round-4 / round-5 projections)
+        assert (y.cpu() - to_t(g["y_scale7p5"])[b:b + 1]).abs().max() < 4e-4, (case, b)
     d = m.diffusion.diffusion.denoise_fn(x * 2.5, sigma=torch.tensor(2.5), embedding=emb, embedding_scale=1.0)
     assert (d.cpu() - to_t(g["denoise_sigma2p5"])).abs().max() < 5e-5
 
