@@ -218,7 +218,10 @@ enum mdt_rconv_i { MDT_R_T = 0, MDT_R_C = 1, MDT_R_LDA = 2, MDT_R_LDC = 3, MDT_R
                    MDT_R_GSIZE = 6 /* channels per GroupNorm group, 0 = no normalisation */, MDT_R_SILU = 7,
                    MDT_R_FILM_LD = 8 /* floats between the scale and the shift row */,
                    MDT_R_LDA2 = 9 /* floats per row of the second source (a2), if any */,
-                   MDT_R_WF32 = 10 /* 1: w = fp32 fragment tiles, exact fp32 MFMA products (see MDT_F_WF32) */ };
+                   MDT_R_WF32 = 10 /* 1: w = fp32 fragment tiles, exact fp32 MFMA products (see MDT_F_WF32) */,
+                   MDT_R_KSRC = 11 /* > 1 (round 5): a is [rows][KSRC * C] and its KSRC blocks of C channels accumulate into the C outputs,
+                                      i.e. out = a W^T + bias (+ res) with K = KSRC * C == 1024 (tiles in the order source block /
+                                      K half / feature chunk); one tap, no GroupNorm / FiLM / second source */ };
 enum mdt_rconv_f { MDT_RF_EPS = 0, MDT_RF_IN_SCALE = 1, MDT_RF_IN_SCALE2 = 2 };
 enum mdt_resblock_i { MDT_K_T = 0, MDT_K_CIN = 1, MDT_K_COUT = 2, MDT_K_FILM_LD = 3,
                       MDT_K_WF32 = 4 /* 1: w = fp32 MFMA fragments [step][row tile][half lo][64 lanes][4] (lane (i, g) float r =

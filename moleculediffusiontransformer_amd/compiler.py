@@ -341,6 +341,38 @@ class UNetCompiler:
             self._emit(pre)
             a = a16
             pro, gain, nbias, stats, film, groups, gsize, pro_silu, a_col = rt.PRO_NONE, None, None, None, None, 0, 0, 0, 0
+        # K = 1024 -> C outputs (configs[2]'s output projections behind the 8 x 128 attention rows): k_rconv with the input's 1024 / C
+        # channel blocks as sources accumulating into one output (MDT_R_KSRC)
+        if (self.use_proj and self.use_rconv and self.ring_mode and self.fuse_blocks and (self.gemm_mode == "bf16x3" or self.wf32)
+                and n in (128, 256) and cin == 1024 and taps == 1 and t_stride == 1 and t_off == 0 and phases <= 1 and o_stride == 1
+                and o_off == 0 and r_out_ == a.rows and out.rows == r_out_ and act == 0 and pro == rt.PRO_NONE and m_mode == 0
+                and not a.b16 and not out.b16 and copy16 is None and a_col == 0 and o_col == 0 and a.ld % 4 == 0 and out.ld % 4 == 0
+                and a.rows in (1, 2, 4, 8, 16) and (res is None or res.ld % 4 == 0) and tuple(wt[1].shape) == (n, cin)):
+            ksrc = cin // n
+            key = (wt[0], "kblocks", self.wf32)
+            if key not in self._packed:
+                w = wt[1]
+                tiles = [self._wtile(w[64 * ch: 64 * ch + 64, s_ * n + 128 * kh: s_ * n + 128 * kh + 128])
+                         for s_ in range(ksrc) for kh in range(n // 128) for ch in range(n // 64)]
+                self._packed[key] = (self.W.add(wt[0] + "/kblocks.tiles", torch.cat(tiles)), sum(t.numel() for t in tiles) * 4 // 1024)
+            w_off, kb = self._packed[key]
+            op = rt.MdtOp()
+            op.kind = rt.OP_RCONV
+            op.a, op.out, op.w = a.ref(), out.ref(), _ref(rt.SP_WEIGHT, w_off)
+            op.i[rt.W_KB] = kb
+            if bias_off is not None:
+                op.bias = _ref(rt.SP_WEIGHT, bias_off)
+            if res is not None:
+                op.res = res.ref()
+            i = op.i
+            i[rt.R_T], i[rt.R_C], i[rt.R_LDA], i[rt.R_LDC], i[rt.R_TAPS] = a.rows, n, a.ld, out.ld, 1
+            i[rt.R_LDR] = res.ld if res is not None else 0
+            i[rt.R_FILM_LD], i[rt.R_WF32], i[rt.R_KSRC] = n, int(self.wf32), ksrc
+            op.f[0], op.f[1] = 1e-5, 1.0
+            self._emit(op)
+            if count_flops:
+                self.flops += 2 * a.rows * n * cin
+            return
         op = rt.MdtOp()
         op.kind = rt.OP_GEMM
         # row-stationary projection on ring tiles (k_proj.hip, MDT_G_WFMT = 16): the K = 128 / 256 layers between the fused kernels

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                                      // B(k)
       if (k + 2 < TT) issue_tile(k + 2);
-      if (RTW == 2 && k == NT && nsrc == 2) __builtin_amdgcn_s_barrier();   // X of the second source (follows B(NT))
+      if (RTW == 2 && nsrc >= 2 && k > 0 && k % NT == 0) __builtin_amdgcn_s_barrier();   // X of the next source (follows its first B)
     }
     prefetch_next_weights(a.pf_ptr, a.pf_lines, iw * 64 + lane);
     return;
@@ -248,13 +248,17 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
   // two sources without a GroupNorm prologue: the second source's rows are requested together with the first's (in
   // front of barrier P) and wait in registers while the first source's tiles run
   constexpr bool GN = PRO > 0;
-  constexpr bool EARLY2 = NSRC == 2 && !GN;
+  // NSRC = 4 | 8 (round 5, MDT_R_KSRC): the sources are consecutive C-channel BLOCKS of one tensor [M][NSRC C] -- a K = NSRC C projection
+  // onto C outputs (configs[2]'s output projections behind the 8 x 128 attention rows), no prologue; NSRC = 2 stays the concatenation
+  constexpr bool KSRC = NSRC > 2;
+  static_assert(!KSRC || (PRO == 0 && TAPS == 1), "K blocks: a plain projection");
+  constexpr bool EARLY2 = NSRC >= 2 && !GN;          // the NEXT source's rows are requested while this one's tiles run
   float4 xu2[EARLY2 ? NSTW : 1], xw2[EARLY2 ? NSTW : 1];
 #pragma unroll 1
   for (int src = 0; src < nsrc; ++src) {
-  const float* xsrc = src ? a.x2 : a.x;
-  const int lda = src ? a.lda2 : a.lda;
-  const float in_scale = src ? a.in_scale2 : a.in_scale;
+  const float* xsrc = KSRC ? a.x + src * C : (src ? a.x2 : a.x);
+  const int lda = (src && !KSRC) ? a.lda2 : a.lda;
+  const float in_scale = (src && !KSRC) ? a.in_scale2 : a.in_scale;
   const float* gamma = a.gamma + src * C;            // source b's gain / bias follow source a's
   const float* beta = a.beta + src * C;
   // ---- the wave's 16 rows: load, (GroupNorm + FiLM + SiLU), split into bf16 hi/lo MFMA operands ----
@@ -267,7 +271,7 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
     float xr[NSTW][8];
     const float* xp = xsrc + (int64_t)mc * lda + 32 * st0 + 8 * g;
     float4 xu[NSTW], xw[NSTW];
-    if (EARLY2 && src == 1) {
+    if (EARLY2 && src >= 1) {
 #pragma unroll
       for (int st = 0; st < NSTW; ++st) { xu[st] = xu2[EARLY2 ? st : 0]; xw[st] = xw2[EARLY2 ? st : 0]; }
     } else {
@@ -276,8 +280,10 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
         xu[st] = *reinterpret_cast<const float4*>(xp + 32 * st);
         xw[st] = *reinterpret_cast<const float4*>(xp + 32 * st + 4);
       }
-      if constexpr (EARLY2) {
-        const float* xq = a.x2 + (int64_t)mc * a.lda2 + 32 * st0 + 8 * g;
+    }
+    if constexpr (EARLY2) {
+      if (src + 1 < nsrc) {
+        const float* xq = (KSRC ? a.x + (int64_t)mc * a.lda + (src + 1) * C : a.x2 + (int64_t)mc * a.lda2) + 32 * st0 + 8 * g;
 #pragma unroll
         for (int st = 0; st < NSTW; ++st) {
           xu2[st] = *reinterpret_cast<const float4*>(xq + 32 * st);
@@ -665,6 +671,11 @@ hipError_t launch_rconv(const RConvArgs& a, hipStream_t s) {
   if (a.M <= 0) return hipSuccess;
   if (!rconv_supported(a.C, a.T, a.taps, a.gsize) || (a.gsize > 0 && (!a.gamma || !a.beta))) return hipErrorInvalidValue;
   if (a.x2 && a.film) return hipErrorInvalidValue;   // FiLM only ever precedes a single-source convolution
+  if (a.ksrc > 1) {                                  // K = ksrc C input channels in consecutive C-channel blocks (MDT_R_KSRC)
+    if (a.x2 || a.film || a.gsize > 0 || a.taps != 1 || a.ksrc * a.C != 1024) return hipErrorInvalidValue;
+    if (a.C == 128) return launch_rc2<4, 128, 1, 1, 8, 0>(a, s);
+    return launch_rc2<2, 256, 1, 2, 4, 0>(a, s);     // (always two workgroups per row block: the unsplit form spills 68 bytes)
+  }
   // C = 128: 64-row workgroups (wave = row tile); C = 256: 32-row workgroups, features split over wave pairs (the
   // 64-row form needs 64 operand + 64 accumulator + 32 shifted-operand registers per lane and spills)
   if (a.C == 128) return a.taps == 3 ? launch_rc<4, 128, 3, 1>(a, s) : launch_rc<4, 128, 1, 1>(a, s);

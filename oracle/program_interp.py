@@ -251,8 +251,13 @@ def _rconv(op, bufs: Buffers, B: int) -> None:
     i, f = op.i, op.f
     T, C, lda, ldc, ldr, taps, gs = (i[rt.R_T], i[rt.R_C], i[rt.R_LDA], i[rt.R_LDC], i[rt.R_LDR], i[rt.R_TAPS],
                                      i[rt.R_GSIZE])
-    srcs = [(bufs.view(op.a, B, B * T * lda).view(B, T, lda)[:, :, :C] * float(f[1]))]
-    if op.a2.space != rt.SP_NONE:                       # second half of a concatenated input
+    ksrc = i[rt.R_KSRC]
+    if ksrc > 1:                                        # K = ksrc C projection: consecutive C-channel blocks of ONE tensor
+        xa = bufs.view(op.a, B, B * T * lda).view(B, T, lda)
+        srcs = [xa[:, :, s_ * C: (s_ + 1) * C] for s_ in range(ksrc)]
+    else:
+        srcs = [(bufs.view(op.a, B, B * T * lda).view(B, T, lda)[:, :, :C] * float(f[1]))]
+    if ksrc <= 1 and op.a2.space != rt.SP_NONE:         # second half of a concatenated input
         lda2 = i[rt.R_LDA2]
         srcs.append(bufs.view(op.a2, B, B * T * lda2).view(B, T, lda2)[:, :, :C] * float(f[2]))
     nsrc = len(srcs)

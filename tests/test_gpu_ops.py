@@ -100,6 +100,39 @@ def test_row_stationary_projection_on_ring_tiles(B, R, cin, N, ln, res):
     assert (ga[B * R * cin:].view(B * R, N).double() - y).abs().max() < 1e-4
 
 
+@pytest.mark.parametrize("B,T,C", [(70, 1, 256), (2100, 1, 256), (4100, 1, 256), (129, 4, 128), (1100, 4, 128), (5, 16, 128), (37, 2, 256)])
+@pytest.mark.parametrize("res", [False, True])
+def test_row_stationary_conv_as_a_k1024_projection(B, T, C, res, prod):
+    """MDT_R_KSRC: the 1024 / C channel blocks of one input tensor as the sources of k_rconv (the next block's rows requested while
+    the current block's tiles run) = out = x W^T + b (+ res in place), K = 1024; against the interpreter and the exact product."""
+    from moleculediffusiontransformer_amd.compiler import UNetCompiler
+    K, ks = 1024, 1024 // C
+    f32 = prod == "f32"
+    tile = UNetCompiler._tile_f32 if f32 else UNetCompiler._tile
+    w = rnd(C, K, seed=1, scale=K ** -0.5)
+    tiles = [tile(w[64 * ch: 64 * ch + 64, s_ * C + 128 * kh: s_ * C + 128 * kh + 128])
+             for s_ in range(ks) for kh in range(C // 128) for ch in range(C // 64)]
+    wt = torch.cat(tiles)
+    weights = torch.cat([wt, rnd(C, seed=2)])
+    x = rnd(B * T * K, seed=3)
+    out0 = rnd(B * T * C, seed=4)
+    act = torch.cat([x, out0])
+    op = rt.MdtOp()
+    op.kind = rt.OP_RCONV
+    op.a, op.out, op.w, op.bias = ref(A, 0), ref(A, T * K), ref(W, 0), ref(W, wt.numel())
+    if res:
+        op.res = ref(A, T * K)
+    i = op.i
+    i[rt.R_T], i[rt.R_C], i[rt.R_LDA], i[rt.R_LDC], i[rt.R_TAPS], i[rt.R_LDR] = T, C, K, C, 1, (C if res else 0)
+    i[rt.R_FILM_LD], i[rt.R_WF32], i[rt.R_KSRC] = C, int(f32), ks
+    op.f[0], op.f[1] = 1e-5, 1.0
+    (ga, _, _), (ca, _, _) = run_both([op], weights, act, torch.zeros(4), {}, B)
+    assert torch.equal(ga[: B * T * K], x)
+    assert (ga - ca).abs().max() < 5e-5
+    y = x.view(B * T, K).double() @ w.double().T + weights[wt.numel():].double() + (out0.view(B * T, C).double() if res else 0)
+    assert (ga[B * T * K:].view(B * T, C).double() - y).abs().max() < (2e-5 if f32 else 1e-4)
+
+
 def test_gemm_strided_conv_and_transposed_phases():
     B, Lin, cin, N, f = 3, 16, 64, 128, 4
     # Conv1d k=9 s=4 p=4 (modules.py:40-51)
