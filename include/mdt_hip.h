@@ -228,7 +228,10 @@ enum mdt_resblock_i { MDT_K_T = 0, MDT_K_CIN = 1, MDT_K_COUT = 2, MDT_K_FILM_LD 
                                         W[16 rt + i][the step's pair 8 g + 4 lo + r]), exact fp32 MFMA products */,
                       MDT_K_CIN_REAL = 5, MDT_K_COUT_REAL = 6 /* CIN / COUT are channel counts padded to 16; the GroupNorm
                                         statistics run over the first CIN_REAL / COUT_REAL channels (0 = all of them); padded
-                                        gains, biases, weights -- hence outputs -- are zero */ };
+                                        gains, biases, weights -- hence outputs -- are zero */,
+                      MDT_K_PATCH_IN = 7, MDT_K_PATCH_OUT = 8 /* p > 1 (round 5): the Patcher / Unpatcher rearrange folded into the
+                                        block -- PATCH_IN: a is still patched, [T / p][CIN p] with a[l][c p + q] = x[l p + q][c];
+                                        PATCH_OUT: out is written patched, [T / p][COUT p]; 0 / 1 = plain [T][C] */ };
 enum mdt_resblock_f { MDT_KF_EPS = 0 };
 
 enum mdt_attn_i {

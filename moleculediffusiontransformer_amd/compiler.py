@@ -176,6 +176,7 @@ class UNetCompiler:
         # one-token level (configs[2]: +0.7 %); at BASELINE configs[1]'s B = 1024 the per-convolution launches, which split the
         # output channels over two workgroups, are 0.4 % faster than the chain on half the compute units (profiles/r5_res256_ab.txt)
         self.res256_mode = os.environ.get("MDT_RES256", "auto")
+        self.fold_patch = os.environ.get("MDT_FOLD_PATCH", "1") != "0"   # Patcher / Unpatcher rearranges folded into k_resblock
         self.use_proj = os.environ.get("MDT_PROJ", "1") != "0"      # K = 128 / 256 projections on ring tiles (k_proj.hip)
         self.b16 = os.environ.get("MDT_B16", "1") == "1"
         self.qkv_merge = os.environ.get("MDT_QKV_MERGE", "1") == "1"   # ... and self-attention's q | k | v as one GEMM     # bf16 mode: regular layers as PREP16 + bf16 x bf16 GEMM
@@ -1613,8 +1614,13 @@ class UNetCompiler:
         if ps > 1:
             if (c0 // ps) % 16:
                 raise ValueError("channels // patch_size must be a multiple of 16")
-            y = self.patch(x, ps, inverse=False)
-            self._free(x)
+            if self.fold_patch and self.ops[-1].kind == rt.OP_RESBLOCK and x.rows % ps == 0:
+                # the Patcher's rearrange as the store pattern of the block that feeds it (MDT_K_PATCH_OUT): one launch less
+                y = Ten(x.space, x.off, x.rows // ps, x.ld * ps, x.ld * ps)
+                self.ops[-1].i[rt.K_PATCH_OUT] = ps
+            else:
+                y = self.patch(x, ps, inverse=False)
+                self._free(x)
             x = y
         skips_list = [[x]]
         for i in range(cfg.num_layers):
@@ -1762,12 +1768,20 @@ class UNetCompiler:
             self._free(x)
             x = y
         self._free(skips_list.pop()[0])
-        if ps > 1:
+        fold_in = (ps > 1 and self.fold_patch and x.ld % ps == 0
+                   and self.resblock_ok(x.rows * ps, c0 // ps, cin, 1, "to_out.block.") and x.ld // ps == pad16(c0 // ps))
+        if fold_in:
+            # ... and the Unpatcher's as the load pattern of the block behind it (MDT_K_PATCH_IN)
+            x = Ten(x.space, x.off, x.rows * ps, x.ld // ps, x.ld // ps)
+        elif ps > 1:
             y = self.patch(x, ps, inverse=True)
             self._free(x)
             x = y
         out = Ten(rt.SP_EXT0 + EXT_OUT, 0, L, self.in_pad, cin)
         y = self.resnet(x, "to_out.block.", c0 // ps, cin, 1)
+        if fold_in:
+            assert self.ops[-1].kind == rt.OP_RESBLOCK
+            self.ops[-1].i[rt.K_PATCH_IN] = ps
         # the final resnet wrote into an arena buffer; retarget its last GEMM to the bound output tensor
         last_op = self.ops[-1]
         assert last_op.kind in (rt.OP_GEMM, rt.OP_RESBLOCK)

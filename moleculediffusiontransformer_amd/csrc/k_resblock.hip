@@ -228,9 +228,22 @@ __global__ __launch_bounds__(512) void k_resblock(ResBlockArgs a) {
   float4 xn[NV];                                     // the next pass's input rows
   auto request_rows = [&](int it) {
     const int b = 2 * blockIdx.x + it * step + half;
-    const float4* xp = reinterpret_cast<const float4*>(a.x + (int64_t)(b < a.B ? b : a.B - 1) * T * CIN);
+    const float* xb = a.x + (int64_t)(b < a.B ? b : a.B - 1) * T * CIN;
+    if (a.patch_in > 1) {
+      // the input is still PATCHED (MDT_K_PATCH_IN = p: [T / p][CIN p], y[l][c p + q] = x[l p + q][c]; the Unpatcher's rearrange,
+      // modules.py / a_unet Patcher): the four channels of a float4 are p floats apart -- four 4-byte loads instead of a launch
+      const int p_ = a.patch_in;
 #pragma unroll
-    for (int j = 0; j < NV; ++j) xn[j] = xp[t + 256 * j];
+      for (int j = 0; j < NV; ++j) {
+        const int e = t + 256 * j, tok = e / (CIN / 4), cc = 4 * (e % (CIN / 4));
+        const float* s_ = xb + (tok / p_) * (p_ * CIN) + cc * p_ + tok % p_;
+        xn[j] = make_float4(s_[0], s_[p_], s_[2 * p_], s_[3 * p_]);
+      }
+    } else {
+      const float4* xp = reinterpret_cast<const float4*>(xb);
+#pragma unroll
+      for (int j = 0; j < NV; ++j) xn[j] = xp[t + 256 * j];
+    }
   };
   request_rows(0);
   for (int it = 0; it < niter; ++it) {
@@ -349,7 +362,16 @@ __global__ __launch_bounds__(512) void k_resblock(ResBlockArgs a) {
       else kstep(xh, xl, orr[s2 < K2 ? 0 : s2 - K2], K1 + s2);
     }
     fold_acc2();
-    if (live) {
+    if (live && a.patch_out > 1) {
+      // the output goes out PATCHED (MDT_K_PATCH_OUT = p: [T / p][COUT p], the Patcher's rearrange): token 16 w + i, channel c at
+      // [(token / p)][c p + token % p]
+      const int p_ = a.patch_out, tok = 16 * w + i;
+      float* yo = a.out + (int64_t)b * T * COUT + (tok / p_) * (p_ * COUT) + (4 * g) * p_ + tok % p_;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) yo[(16 * rt + r) * p_] = acc[rt][r];
+    } else if (live) {
       float* yo = a.out + ((int64_t)b * T + 16 * w + i) * COUT + 4 * g;
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)

@@ -176,6 +176,8 @@ static const char* validate(const mdt_op& o, int idx, char* buf, size_t nbuf) {
       if (o.i[MDT_K_WF32] != 0 && o.i[MDT_K_WF32] != 1) return bad("WF32 must be 0 (split-bf16 fragments) or 1 (fp32 fragments)");
       if (o.i[MDT_K_CIN_REAL] < 0 || o.i[MDT_K_CIN_REAL] > o.i[MDT_K_CIN] || o.i[MDT_K_COUT_REAL] < 0 || o.i[MDT_K_COUT_REAL] > o.i[MDT_K_COUT])
         return bad("CIN_REAL / COUT_REAL must be 0 (= CIN / COUT) or a channel count inside the padded one");
+      for (int k : {MDT_K_PATCH_IN, MDT_K_PATCH_OUT})
+        if (o.i[k] < 0 || (o.i[k] > 1 && o.i[MDT_K_T] % o.i[k])) return bad("PATCH_IN / PATCH_OUT must be 0 / 1 (none) or a divisor of T");
       break;
     case MDT_OP_ATTN:
       if (o.i[MDT_A_T] <= 0 || o.i[MDT_A_T] > 8192 || o.i[MDT_A_TK] <= 0 || o.i[MDT_A_TK] > 8192)
@@ -430,6 +432,7 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
         a.eps = o.f[MDT_KF_EPS]; a.wf32 = o.i[MDT_K_WF32];
         a.cin_real = o.i[MDT_K_CIN_REAL] > 0 ? o.i[MDT_K_CIN_REAL] : a.cin;
         a.cout_real = o.i[MDT_K_COUT_REAL] > 0 ? o.i[MDT_K_COUT_REAL] : a.cout;
+        a.patch_in = o.i[MDT_K_PATCH_IN]; a.patch_out = o.i[MDT_K_PATCH_OUT];
         if (!missing) e = mdt::launch_resblock(a, stream);
         break;
       }

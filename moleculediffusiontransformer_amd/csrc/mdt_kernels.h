@@ -194,6 +194,7 @@ struct ResBlockArgs {
   float eps;
   int wf32;            // 1: w = fp32 MFMA fragments [step][row tile][half][64 lanes][4], exact fp32 products (MDT_K_WF32)
   int cin_real, cout_real;   // channels the GroupNorm statistics run over (<= cin / cout: the rest is zero padding)
+  int patch_in, patch_out;   // > 1: the input is still patched / the output leaves patched ([T / p][C p]; MDT_K_PATCH_IN / _OUT)
 };
 bool resblock_supported(int T, int cin, int cout);
 hipError_t launch_resblock(const ResBlockArgs& a, hipStream_t s);

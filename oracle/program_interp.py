@@ -332,16 +332,22 @@ def _resblock(op, bufs: Buffers, B: int) -> None:
                    vec[2 * cin + 3 * cout:])
     # cin / cout are padded channel counts; the block itself has ci / co channels (MDT_K_CIN_REAL / MDT_K_COUT_REAL, 0 = all)
     ci, co = (i[rt.K_CIN_REAL] or cin), (i[rt.K_COUT_REAL] or cout)
-    x = bufs.view(op.a, B, B * T * cin).view(B, T, cin).transpose(1, 2)[:, :ci]
+    pin, pout = i[rt.K_PATCH_IN], i[rt.K_PATCH_OUT]
+    xin = bufs.view(op.a, B, B * T * cin)
+    if pin > 1:          # still patched: a[l][c p + q] = x[l p + q][c]
+        xin = xin.view(B, T // pin, cin, pin).permute(0, 1, 3, 2).reshape(B, T, cin)
+    x = xin.view(B, T, cin).transpose(1, 2)[:, :ci]
     h = F.conv1d(_silu(F.group_norm(x, 1, g1[:ci], be1[:ci], float(f[0]))), ws[0][:co, :ci], b1[:co], padding=1)
     h = F.group_norm(h, 1, g2[:co], be2[:co], float(f[0]))
     if op.p3.space != rt.SP_NONE:
         ss = bufs.view(op.p3, B, fld + cout)
         h = h * (ss[:co, None] + 1.0) + ss[fld: fld + co, None]
     y = F.conv1d(_silu(h), ws[1][:co, :co], bo[:co], padding=1) + F.conv1d(x, ws[2][:co, :ci])
-    out = bufs.view(op.out, B, B * T * cout).view(B, T, cout)
-    out.zero_()
-    out[:, :, :co] = y.transpose(1, 2)
+    o = torch.zeros(B, T, cout)
+    o[:, :, :co] = y.transpose(1, 2)
+    if pout > 1:         # written patched: out[l][c p + q] = y[l p + q][c]
+        o = o.view(B, T // pout, pout, cout).permute(0, 1, 3, 2)
+    bufs.view(op.out, B, B * T * cout)[:] = o.reshape(-1)
 
 
 def _tblock(op, bufs: Buffers, B: int) -> None:
