@@ -206,7 +206,8 @@ enum mdt_gemm_i {
                         at index c * (CIN / 128) + h = W[64 c .. 64 c + 64)[128 h .. 128 h + 128) as a bf16 hi plane [64][128]
                         followed by the lo plane (split-bf16 products); CIN in {128, 256}, N % 64 == 0, prologue none or
                         LayerNorm (p0 / p1 both unbound = LayerNorm WITHOUT affine: the caller folded gain into the weights and
-                        bias into the bias), one tap, bias / residual optional (the residual may alias out), no activation / row mapping */
+                        bias into the bias), one tap, bias / residual optional (the residual may alias out), no activation / row mapping;
+                        17 = as 16 with fp32 FRAGMENT tiles (the layout of MDT_F_WF32) and exact fp32 MFMA products */
 };
 enum mdt_gemm_f { MDT_GF_EPS = 0 };
 

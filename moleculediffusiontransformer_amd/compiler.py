@@ -377,7 +377,7 @@ class UNetCompiler:
         op = rt.MdtOp()
         op.kind = rt.OP_GEMM
         # row-stationary projection on ring tiles (k_proj.hip, MDT_G_WFMT = 16): the K = 128 / 256 layers between the fused kernels
-        ring = (self.use_proj and self.gemm_mode == "bf16x3" and not self.wf32 and cin in (128, 256) and n % 64 == 0 and taps == 1
+        ring = (self.use_proj and (self.gemm_mode == "bf16x3" or self.wf32) and cin in (128, 256) and n % 64 == 0 and taps == 1
                 and t_stride == 1 and t_off == 0 and phases <= 1 and o_stride == 1 and o_off == 0 and r_out_ == a.rows
                 and out.rows == r_out_ and act == 0 and pro in (rt.PRO_NONE, rt.PRO_LAYERNORM) and not a.b16 and not out.b16
                 and copy16 is None and a.ld % 4 == 0 and a_col % 4 == 0 and o_col % 4 == 0 and out.ld % 4 == 0
@@ -386,7 +386,7 @@ class UNetCompiler:
             # LayerNorm's gain folds into the weights and its bias into the bias (W (g xn + b) = (W g) xn + W b, fp64 on the host): the
             # kernel normalises without per-channel vectors (48 float4 per lane ahead of its first barrier at K = 256 otherwise)
             fold = pro == rt.PRO_LAYERNORM
-            key = (wt[0], "ring", gain if fold else None, nbias if fold else None, bias_off if fold else None)
+            key = (wt[0], "ring", self.wf32, gain if fold else None, nbias if fold else None, bias_off if fold else None)
             if key not in self._packed:
                 w = wt[1].double()
                 fb = None
@@ -397,8 +397,8 @@ class UNetCompiler:
                     fb = self.W.add(wt[0] + "/ring.bias", (b0 + w @ bv).float())
                     w = w * gv.unsqueeze(0)
                 w = w.float()
-                tiles = [self._tile(w[64 * c: 64 * c + 64, 128 * h: 128 * h + 128]) for c in range(n // 64) for h in range(cin // 128)]
-                self._packed[key] = (self.W.add(wt[0] + "/ring.tiles", torch.cat(tiles)), None, 16, fb)
+                tiles = [self._wtile(w[64 * c: 64 * c + 64, 128 * h: 128 * h + 128]) for c in range(n // 64) for h in range(cin // 128)]
+                self._packed[key] = (self.W.add(wt[0] + "/ring.tiles", torch.cat(tiles)), None, 17 if self.wf32 else 16, fb)
             w_off, wlo_off, fmt16, fb = self._packed[key]
             wfmt = [fmt16]
             if fold:

@@ -45,12 +45,20 @@ constexpr int NS = 4;           // ring slots
 constexpr int IPT = CS / 16;    // DMA pieces per tile per loader wave
 constexpr int PJ_BIAS_PASSES = 8;   // bias slice of a workgroup in LDS: up to 8 x 256 floats = 32 chunks
 
+// 8 values of one k-step -> its two 128-bit operand registers: bf16 hi / lo planes, or (F32) the values themselves, slots 0..3 in
+// `hi`, 4..7 in `lo` (k_rconv.hip / k_tf128.hip)
+template <bool F32>
 __device__ __forceinline__ void pj_split8(const float v[8], bf16x8& hi, bf16x8& lo) {
+  if constexpr (F32) {
+    hi = __builtin_bit_cast(bf16x8, f32x4{v[0], v[1], v[2], v[3]});
+    lo = __builtin_bit_cast(bf16x8, f32x4{v[4], v[5], v[6], v[7]});
+  } else {
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const __bf16 h = (__bf16)v[e];
-    hi[e] = h;
-    lo[e] = (__bf16)(v[e] - (float)h);
+    for (int e = 0; e < 8; ++e) {
+      const __bf16 h = (__bf16)v[e];
+      hi[e] = h;
+      lo[e] = (__bf16)(v[e] - (float)h);
+    }
   }
 }
 
@@ -73,7 +81,7 @@ __device__ __forceinline__ void pj_lgkm_wait() {
 
 }  // namespace
 
-template <int RTW, int KH, int LN, bool HASR>
+template <int RTW, int KH, int LN, bool HASR, bool F32>
 __global__ __launch_bounds__(512) void k_proj(ProjArgs a) {
   constexpr int NST = 4 * KH;               // k-steps of the input channels
   constexpr int NFT = (RTW == 4) ? 4 : 2;   // feature tiles per chunk per wave
@@ -98,7 +106,8 @@ __global__ __launch_bounds__(512) void k_proj(ProjArgs a) {
 #pragma unroll
     for (int q = 0; q < IPT; ++q) {
       const int U = 2 * (iw + 4 * q);
-      voffP[q] = (unsigned)(U * (2 * CS) + ((xP ^ (U & 15)) << 4) + baseP);
+      // (F32: fp32 fragment tiles are stored in LDS order, a linear copy)
+      voffP[q] = F32 ? (unsigned)((iw + 4 * q) * 1024 + lane * 16) : (unsigned)(U * (2 * CS) + ((xP ^ (U & 15)) << 4) + baseP);
     }
     const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(a.w) + (int64_t)c0 * KH * SLOT;
     auto issue_tile = [&](int tau) {
@@ -142,12 +151,14 @@ __global__ __launch_bounds__(512) void k_proj(ProjArgs a) {
   // fragment addressing inside a tile: row = 16 ft + i, 16-byte chunk = 4 st + g, XOR-swizzled with i (k_rconv.hip)
   int aP[4];
 #pragma unroll
-  for (int st = 0; st < 4; ++st) aP[st] = fh * (2 * 16 * 4 * CS) + i * (4 * CS) + (((4 * st + g) ^ i) << 4);
+  for (int st = 0; st < 4; ++st)      // F32: fragment (feature tile ft, k-step st, half lo) at ft * 8192 + st * 2048 + lo * 1024, the lane's 16 bytes inside
+    aP[st] = F32 ? lane * 16 + fh * 16384 + st * 2048 : fh * (2 * 16 * 4 * CS) + i * (4 * CS) + (((4 * st + g) ^ i) << 4);
   bf16x8 frh[4][2], frl[4][2];
   auto frag_read = [&](unsigned base, auto uc, int set, auto jc) {
     constexpr int u = decltype(uc)::value, j = decltype(jc)::value;
     constexpr int q = j >> 1, lo = j & 1;
-    constexpr int off = (RTW == 4) ? ((2 * (u & 1) + q) * 16 * 4 * CS + lo * (2 * CS)) : (q * 16 * 4 * CS + lo * (2 * CS));
+    constexpr int off = F32 ? ((RTW == 4) ? ((2 * (u & 1) + q) * 8192 + lo * 1024) : (q * 8192 + lo * 1024))
+                            : ((RTW == 4) ? ((2 * (u & 1) + q) * 16 * 4 * CS + lo * (2 * CS)) : (q * 16 * 4 * CS + lo * (2 * CS)));
     pj_lds_read16<off>(lo ? frl[set][q] : frh[set][q], base);
   };
   using J0 = std::integral_constant<int, 0>;
@@ -226,7 +237,7 @@ __global__ __launch_bounds__(512) void k_proj(ProjArgs a) {
       }
     }
 #pragma unroll
-    for (int st = 0; st < NST; ++st) pj_split8(xr[st], xh[st], xl[st]);
+    for (int st = 0; st < NST; ++st) pj_split8<F32>(xr[st], xh[st], xl[st]);
   }
 
   __builtin_amdgcn_s_barrier();                      // B(0): tile 0 has landed, the bias slice is in LDS (loader waves)
@@ -302,12 +313,29 @@ __global__ __launch_bounds__(512) void k_proj(ProjArgs a) {
         auto mm = [&](const bf16x8& w, const bf16x8& x, int q) {
           acc[ia + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, acc[ia + q], 0, 0, 0);
         };
-        mm(frl[s0][0], oph, 0); rd(J0{});
-        mm(frl[s0][1], oph, 1); rd(J1{});
-        mm(frh[s0][0], opl, 0); rd(J2{});
-        mm(frh[s0][1], opl, 1); rd(J3{});
-        mm(frh[s0][0], oph, 0);
-        mm(frh[s0][1], oph, 1);
+        if constexpr (F32) {
+          // exact fp32: fragment (q, half) x operand half, four 16x16x4 MFMAs each, the two accumulators alternating (k_rconv.hip)
+          auto mm4 = [&](const bf16x8& w0, const bf16x8& w1, const bf16x8& x, auto r0c) {
+            constexpr int r0 = decltype(r0c)::value;
+            const f32x4 a0 = __builtin_bit_cast(f32x4, w0), a1 = __builtin_bit_cast(f32x4, w1), xb = __builtin_bit_cast(f32x4, x);
+#pragma unroll
+            for (int r = r0; r < r0 + 2; ++r) {
+              acc[ia] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[r], xb[r], acc[ia], 0, 0, 0);
+              acc[ia + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[r], xb[r], acc[ia + 1], 0, 0, 0);
+            }
+          };
+          mm4(frh[s0][0], frh[s0][1], oph, J0{}); rd(J0{});
+          mm4(frh[s0][0], frh[s0][1], oph, J2{}); rd(J1{});
+          mm4(frl[s0][0], frl[s0][1], opl, J0{}); rd(J2{});
+          mm4(frl[s0][0], frl[s0][1], opl, J2{}); rd(J3{});
+        } else {
+          mm(frl[s0][0], oph, 0); rd(J0{});
+          mm(frl[s0][1], oph, 1); rd(J1{});
+          mm(frh[s0][0], opl, 0); rd(J2{});
+          mm(frh[s0][1], opl, 1); rd(J3{});
+          mm(frh[s0][0], oph, 0);
+          mm(frh[s0][1], oph, 1);
+        }
         __builtin_amdgcn_sched_barrier(0);
       };
       unit(std::integral_constant<int, 0>{}); unit(std::integral_constant<int, 1>{});
@@ -353,13 +381,13 @@ __global__ __launch_bounds__(512) void k_proj(ProjArgs a) {
   }
 }
 
-template <int RTW, int KH, int LN, bool HASR>
+template <int RTW, int KH, int LN, bool HASR, bool F32>
 static hipError_t launch_pj(const ProjArgs& a0, hipStream_t s) {
   ProjArgs a = a0;
   static DevOnce attr_once;                          // per device (mdt_kernels.h)
   constexpr int SMEM = NS * SLOT + PJ_BIAS_PASSES * 256 * 4;
   if (attr_once.first()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj<RTW, KH, LN, HASR>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj<RTW, KH, LN, HASR, F32>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
   }
   const int rows = 16 * RTW, rb = (a.M + rows - 1) / rows, nchunks = a.N / 64;
   int nsplit = 1;                                    // workgroups per row block while the row blocks alone leave CUs idle
@@ -368,15 +396,15 @@ static hipError_t launch_pj(const ProjArgs& a0, hipStream_t s) {
     nsplit *= 2;
   }
   a.nch = nchunks / nsplit;
-  hipLaunchKernelGGL((k_proj<RTW, KH, LN, HASR>), dim3((unsigned)rb, (unsigned)nsplit), dim3(512), (size_t)SMEM, s, a);
+  hipLaunchKernelGGL((k_proj<RTW, KH, LN, HASR, F32>), dim3((unsigned)rb, (unsigned)nsplit), dim3(512), (size_t)SMEM, s, a);
   return hipGetLastError();
 }
 
-template <int RTW, int KH>
+template <int RTW, int KH, bool F32>
 static hipError_t launch_pj2(const ProjArgs& a, hipStream_t s) {
-  if (a.ln && a.gamma) return a.res ? launch_pj<RTW, KH, 2, true>(a, s) : launch_pj<RTW, KH, 2, false>(a, s);
-  if (a.ln) return a.res ? launch_pj<RTW, KH, 1, true>(a, s) : launch_pj<RTW, KH, 1, false>(a, s);
-  return a.res ? launch_pj<RTW, KH, 0, true>(a, s) : launch_pj<RTW, KH, 0, false>(a, s);
+  if (a.ln && a.gamma) return a.res ? launch_pj<RTW, KH, 2, true, F32>(a, s) : launch_pj<RTW, KH, 2, false, F32>(a, s);
+  if (a.ln) return a.res ? launch_pj<RTW, KH, 1, true, F32>(a, s) : launch_pj<RTW, KH, 1, false, F32>(a, s);
+  return a.res ? launch_pj<RTW, KH, 0, true, F32>(a, s) : launch_pj<RTW, KH, 0, false, F32>(a, s);
 }
 
 bool proj_supported(int K, int N, int lda, int ldc, int ldr) {
@@ -388,7 +416,8 @@ hipError_t launch_proj(const ProjArgs& a, hipStream_t s) {
   if (!proj_supported(a.K, a.N, a.lda, a.ldc, a.ldr) || (a.ln && (!a.gamma != !a.beta))) return hipErrorInvalidValue;
   auto al16 = [](const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; };
   if (!al16(a.x) || !al16(a.out) || !al16(a.w) || (a.bias && !al16(a.bias)) || (a.res && !al16(a.res))) return hipErrorInvalidValue;
-  return a.K == 128 ? launch_pj2<4, 1>(a, s) : launch_pj2<2, 2>(a, s);
+  if (a.wf32) return a.K == 128 ? launch_pj2<4, 1, true>(a, s) : launch_pj2<2, 2, true>(a, s);   // fp32 fragment tiles, exact fp32 products
+  return a.K == 128 ? launch_pj2<4, 1, false>(a, s) : launch_pj2<2, 2, false>(a, s);
 }
 
 }  // namespace mdt

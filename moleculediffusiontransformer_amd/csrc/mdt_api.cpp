@@ -107,7 +107,7 @@ static const char* validate(const mdt_op& o, int idx, char* buf, size_t nbuf) {
       if (i[MDT_G_PRO] == MDT_PRO_LAYERNORM) {
         if (i[MDT_G_TAPS] != 1) return bad("LayerNorm prologue needs taps == 1");
         if (i[MDT_G_CIN] > 2048) return bad("LayerNorm prologue supports <= 2048 features");
-        if (i[MDT_G_WFMT] == 16 ? (!o.p0.space != !o.p1.space) : (!o.p0.space || !o.p1.space))
+        if ((i[MDT_G_WFMT] == 16 || i[MDT_G_WFMT] == 17) ? (!o.p0.space != !o.p1.space) : (!o.p0.space || !o.p1.space))
           return bad("LayerNorm prologue needs gain and bias (ring-tile projection: both or neither -- neither = no affine)");
       }
       if (i[MDT_G_PRO] == MDT_PRO_GROUPNORM) {
@@ -117,8 +117,8 @@ static const char* validate(const mdt_op& o, int idx, char* buf, size_t nbuf) {
       if (i[MDT_G_M_MODE] < 0 || i[MDT_G_M_MODE] > 2) return bad("bad m_mode");
       if (o.res.space && i[MDT_G_LDR] <= 0) return bad("residual without ldr");
       if (o.a2.space && i[MDT_G_CIN] % 32) return bad("split-bf16 weights need cin % 32 == 0");
-      if (i[MDT_G_WFMT] < 0 || (i[MDT_G_WFMT] > 2 && i[MDT_G_WFMT] != 6 && i[MDT_G_WFMT] != 10 && i[MDT_G_WFMT] != 16)) return bad("bad weight format");
-      if (i[MDT_G_WFMT] == 16) {
+      if (i[MDT_G_WFMT] < 0 || (i[MDT_G_WFMT] > 2 && i[MDT_G_WFMT] != 6 && i[MDT_G_WFMT] != 10 && i[MDT_G_WFMT] != 16 && i[MDT_G_WFMT] != 17)) return bad("bad weight format");
+      if (i[MDT_G_WFMT] == 16 || i[MDT_G_WFMT] == 17) {
         if (!mdt::proj_supported(i[MDT_G_CIN], i[MDT_G_N], i[MDT_G_LDA], i[MDT_G_LDC], o.res.space ? i[MDT_G_LDR] : 0) || o.a2.space)
           return bad("ring-tile projection needs cin in {128, 256}, N % 64 == 0, 16-byte aligned rows and no lo plane (the tiles hold both)");
         if (i[MDT_G_PRO] > 1 || i[MDT_G_TAPS] != 1 || i[MDT_G_T_STRIDE] != 1 || i[MDT_G_T_OFF] || i[MDT_G_PHASES] > 1 || i[MDT_G_O_STRIDE] != 1 ||
@@ -365,11 +365,11 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
         g.o_off = i[MDT_G_O_OFF]; g.ldr = i[MDT_G_LDR]; g.pro = i[MDT_G_PRO]; g.groups = i[MDT_G_GROUPS];
         g.gsize = i[MDT_G_GSIZE]; g.pro_silu = i[MDT_G_PRO_SILU]; g.act = i[MDT_G_ACT]; g.a_col = i[MDT_G_A_COL];
         g.o_col = i[MDT_G_O_COL]; g.eps = o.f[MDT_GF_EPS]; g.phases = i[MDT_G_PHASES]; g.wfmt = i[MDT_G_WFMT];
-        if (!missing && i[MDT_G_WFMT] == 16) {
+        if (!missing && (i[MDT_G_WFMT] == 16 || i[MDT_G_WFMT] == 17)) {
           mdt::ProjArgs h;
           h.x = g.A + g.a_col; h.w = g.W; h.bias = g.bias; h.res = g.res; h.gamma = g.p0; h.beta = g.p1; h.out = g.out + g.o_col;
           h.M = g.M; h.N = g.N; h.K = g.cin; h.lda = g.lda; h.ldc = g.ldc; h.ldr = g.res ? g.ldr : 0; h.ln = g.pro == MDT_PRO_LAYERNORM;
-          h.eps = g.eps; h.nch = 0;
+          h.eps = g.eps; h.nch = 0; h.wf32 = i[MDT_G_WFMT] == 17;
           e = mdt::launch_proj(h, stream);
         } else if (!missing && (i[MDT_G_WFMT] & 2)) {
           mdt::Gemm16Args h;

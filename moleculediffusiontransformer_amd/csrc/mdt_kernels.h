@@ -175,6 +175,7 @@ struct ProjArgs {
   int M, N, K, lda, ldc, ldr, ln;
   float eps;
   int nch;             // (set by the launcher) 64-feature chunks per workgroup
+  int wf32;            // 1: fp32 fragment tiles, exact fp32 MFMA products (MDT_G_WFMT = 17)
 };
 bool proj_supported(int K, int N, int lda, int ldc, int ldr);
 hipError_t launch_proj(const ProjArgs& a, hipStream_t s);

@@ -82,13 +82,13 @@ def run_program(ops, bufs: Buffers, B: int, n_shared_rows: int = 0) -> None:
                 half = nph * n * taps * cin // 2
                 w_all = bufs.view(op.w, B, half).view(torch.bfloat16).float().view(nph, n, taps, cin)
                 a = a.to(torch.bfloat16).float()
-            elif i[rt.G_WFMT] == 16:             # ring tiles (k_proj.hip): [64 features][128 k] hi | lo planes, order (chunk, K half)
+            elif i[rt.G_WFMT] in (16, 17):       # ring tiles (k_proj.hip): [64 features][128 k] hi | lo planes (17: fp32 fragments), order (chunk, K half)
                 khn = cin // 128
                 stream = bufs.view(op.w, B, (n // 64) * khn * 64 * 128)
                 w_all = torch.zeros(n, cin)
                 for c_ in range(n // 64):
                     for h_ in range(khn):
-                        w_all[64 * c_: 64 * c_ + 64, 128 * h_: 128 * h_ + 128] = _untile(stream, c_ * khn + h_, 64, 128)
+                        w_all[64 * c_: 64 * c_ + 64, 128 * h_: 128 * h_ + 128] = _untile(stream, c_ * khn + h_, 64, 128, i[rt.G_WFMT] == 17)
                 w_all = w_all.view(1, n, 1, cin)
             elif op.a2.space != rt.SP_NONE:      # split-bf16 weights: two bf16 planes stored as raw bits
                 half = nph * n * taps * cin // 2
