@@ -63,7 +63,9 @@ def test_gemm_plain_bias_gelu_residual(B, R, cin, N, taps):
 
 
 @pytest.mark.parametrize("B,R,cin,N", [(37, 1, 256, 1024), (70, 1, 256, 256), (129, 4, 128, 1024), (5, 4, 128, 64), (33, 16, 128, 192),
-                                       (300, 1, 256, 64), (1100, 4, 128, 512), (2100, 1, 256, 1024)])
+                                       (300, 1, 256, 64), (1100, 4, 128, 512), (2100, 1, 256, 1024),
+                                       # enough row blocks to fill the chip alone: ONE workgroup per row block walks all 16 chunks
+                                       (4200, 4, 128, 1024), (8200, 1, 256, 1024)])
 @pytest.mark.parametrize("ln,res", [("plain", False), (False, True), ("plain", True), ("affine", False), ("affine", True)])
 def test_row_stationary_projection_on_ring_tiles(B, R, cin, N, ln, res, prod):
     """k_proj (MDT_G_WFMT = 16): LayerNorm prologue (without affine -- what the compiler emits, gain / bias folded into W / bias -- and
