@@ -222,7 +222,15 @@ enum mdt_rconv_i { MDT_R_T = 0, MDT_R_C = 1, MDT_R_LDA = 2, MDT_R_LDC = 3, MDT_R
                    MDT_R_WF32 = 10 /* 1: w = fp32 fragment tiles, exact fp32 MFMA products (see MDT_F_WF32) */,
                    MDT_R_KSRC = 11 /* > 1 (round 5): a is [rows][KSRC * C] and its KSRC blocks of C channels accumulate into the C outputs,
                                       i.e. out = a W^T + bias (+ res) with K = KSRC * C == 1024 (tiles in the order source block /
-                                      K half / feature chunk); one tap, no GroupNorm / FiLM / second source */ };
+                                      K half / feature chunk); one tap, no GroupNorm / FiLM / second source.  KSRC = 2 (C = 256): the two
+                                      256-channel blocks of one tensor with 1 or 3 taps -- a strided Conv1d(k = 2 f + 1, stride f) in
+                                      PATCH form: f consecutive tokens are one row of f * channels values and the convolution is k = 3
+                                      over those rows */,
+                   MDT_R_HALF_OUT = 12 /* 1 (C = 256, one source, no prologue): only output channels 0 .. 127 exist (LDC >= 128); the
+                                      tile stream keeps the layout of all four 64-feature chunks, chunks 2 / 3 are never read */,
+                   MDT_R_NB = 13 /* > 1 (one source, no prologue): NB * C output channels = NB convolutions of the same rows in one launch
+                                      (tile streams, bias, residual and output columns of the blocks follow each other): a
+                                      ConvTranspose1d(k = 2 f, stride f) in patch form writes f tokens x channels per input token */ };
 enum mdt_rconv_f { MDT_RF_EPS = 0, MDT_RF_IN_SCALE = 1, MDT_RF_IN_SCALE2 = 2 };
 enum mdt_resblock_i { MDT_K_T = 0, MDT_K_CIN = 1, MDT_K_COUT = 2, MDT_K_FILM_LD = 3,
                       MDT_K_WF32 = 4 /* 1: w = fp32 MFMA fragments [step][row tile][half lo][64 lanes][4] (lane (i, g) float r =

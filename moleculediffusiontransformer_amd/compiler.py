@@ -176,6 +176,7 @@ class UNetCompiler:
         # one-token level (configs[2]: +0.7 %); at BASELINE configs[1]'s B = 1024 the per-convolution launches, which split the
         # output channels over two workgroups, are 0.4 % faster than the chain on half the compute units (profiles/r5_res256_ab.txt)
         self.res256_mode = os.environ.get("MDT_RES256", "auto")
+        self.patch_conv = os.environ.get("MDT_PATCH_CONV", "1") != "0"   # resampling convolutions in patch form on k_rconv
         self.fold_patch = os.environ.get("MDT_FOLD_PATCH", "1") != "0"   # Patcher / Unpatcher rearranges folded into k_resblock
         self.use_proj = os.environ.get("MDT_PROJ", "1") != "0"      # K = 128 / 256 projections on ring tiles (k_proj.hip)
         self.b16 = os.environ.get("MDT_B16", "1") == "1"
@@ -509,21 +510,27 @@ class UNetCompiler:
 
     def rconv(self, x: Ten, w: torch.Tensor, name: str, out: Ten, *, taps: int, bias_off: Optional[int] = None,
               res: Optional[Ten] = None, gn=None, film=None, in_scale: float = 1.0, x2: Optional[Ten] = None,
-              in_scale2: float = 1.0) -> None:
+              in_scale2: float = 1.0, ksrc: int = 0, half_out: bool = False, flops: Optional[int] = None, nb: int = 1) -> None:
         """out = bias + conv_k(silu(gn(in_scale * x) * (scale + 1) + shift)) (+ res); w is [C][C][taps] (a slice of
         the reference Conv1d weight), gn = (gain offset, bias offset, gsize, eps, silu) in the packed weights.
         With x2 the input is cat([in_scale * x, in_scale2 * x2]) and w is [C][2C][taps]; the GroupNorm vectors at the
         gain / bias offsets then hold 2C entries."""
-        c = x.ld
-        nsrc = 2 if x2 is not None else 1
+        # ksrc = 2: x is [rows][2 C], its two C-channel blocks are the sources (MDT_R_KSRC); half_out: w is [C / 2][C][taps] and only
+        # output channels 0 .. C / 2 - 1 exist (MDT_R_HALF_OUT; the tile stream keeps all four chunks of a (tap, K half), two unused)
+        c = x.ld // ksrc if ksrc else x.ld
+        nsrc = ksrc if ksrc else (2 if x2 is not None else 1)
+        if half_out:
+            w = torch.cat([w, torch.zeros_like(w)])
         if taps == 3 and x.rows == 1:
             # ONE token per sample (configs[2]'s 256-channel level): both neighbours of a k = 3 convolution are zero padding
             # (modules.py:105-112: padding = 1), their products are exactly 0 -- only the centre tap is streamed and multiplied
             w, taps = w[:, :, 1:2], 1
-        assert w.shape == (c, nsrc * c, taps) and out.ld == c and out.rows == x.rows, (name, tuple(w.shape), c, taps)
+        # nb > 1: w is [nb C][C][taps] -- nb convolutions of the same rows, output channels block after block (MDT_R_NB)
+        assert w.shape == (nb * c, nsrc * c, taps) and out.ld == (c // 2 if half_out else nb * c) and out.rows == x.rows, \
+            (name, tuple(w.shape), c, taps)
         assert x2 is None or (x2.ld == c and x2.rows == x.rows and film is None)
-        tiles = [self._wtile(w[64 * ch: 64 * ch + 64, s * c + 128 * kh: s * c + 128 * kh + 128, tap])
-                 for s in range(nsrc) for tap in range(taps) for kh in range(c // 128) for ch in range(c // 64)]
+        tiles = [self._wtile(w[b_ * c + 64 * ch: b_ * c + 64 * ch + 64, s * c + 128 * kh: s * c + 128 * kh + 128, tap])
+                 for b_ in range(nb) for s in range(nsrc) for tap in range(taps) for kh in range(c // 128) for ch in range(c // 64)]
         op = rt.MdtOp()
         op.kind = rt.OP_RCONV
         op.a, op.out = x.ref(), out.ref()
@@ -541,6 +548,7 @@ class UNetCompiler:
         i[rt.R_T], i[rt.R_C], i[rt.R_LDA], i[rt.R_LDC], i[rt.R_TAPS] = x.rows, c, x.ld, out.ld, taps
         i[rt.R_LDR] = res.ld if res is not None else 0
         i[rt.R_FILM_LD], i[rt.R_WF32] = c, int(self.wf32)
+        i[rt.R_KSRC], i[rt.R_HALF_OUT], i[rt.R_NB] = ksrc, int(half_out), (nb if nb > 1 else 0)
         op.f[0], op.f[1] = 1e-5, in_scale
         if gn is not None:
             gain, nbias, gsize, eps, silu = gn
@@ -550,7 +558,65 @@ class UNetCompiler:
         if isinstance(film, tuple):
             op._film = film
         self._emit(op)
-        self.flops += 2 * x.rows * c * c * taps * nsrc            # executed (the skipped padding products are not counted)
+        # executed products (skipped padding is not counted; `flops`: the caller's count where the weights hold structural zeros)
+        self.flops += flops if flops is not None else 2 * x.rows * c * c * taps * nsrc
+
+    def down_patch_ok(self, x: Ten, ci: int, co: int, f: int) -> bool:
+        """The strided convolution of a DownsampleBlock1d in PATCH form on the row-stationary kernel (down_patch)."""
+        return (self.patch_conv and self.use_rconv and self.ring_mode and self.fuse_blocks and (self.gemm_mode == "bf16x3" or self.wf32)
+                and x.ld == ci and x.rows % f == 0 and (x.rows // f) in (1, 2, 4, 8, 16)
+                and ((ci * f == 256 and co == 128) or (ci * f == 512 and co == 256)))
+
+    def down_patch(self, x: Ten, dp: str, ci: int, co: int, f: int, y: Ten) -> None:
+        """Conv1d(ci -> co, kernel 2 f + 1, stride f, padding f) (modules.py:62-75) as a k = 3 convolution over PATCHES: f consecutive
+        tokens are one row of f ci contiguous values, output token t reads patch t - 1 (taps 0 .. f - 1), patch t (taps f .. 2 f - 1)
+        and the first token of patch t + 1 (tap 2 f); the zero padding of the patch convolution is the zero padding of the original.
+        f ci = 256 -> 128 channels: the 256-channel kernel producing its lower half of the outputs; f ci = 512 -> 256: the two
+        256-value halves of a patch as the kernel's two sources.  (The tiled GEMM ran these at 16 - 25 us, latency-bound.)"""
+        w = self.sd[dp + "downsample.weight"].float()            # [co][ci][2 f + 1]
+        cp = ci * f
+        w3 = torch.zeros(co, cp, 3)
+        for q in range(f):
+            w3[:, q * ci: (q + 1) * ci, 0] = w[:, :, q]
+            w3[:, q * ci: (q + 1) * ci, 1] = w[:, :, f + q]
+        w3[:, :ci, 2] = w[:, :, 2 * f]
+        xp = Ten(x.space, x.off, x.rows // f, cp, cp)
+        bias = self._vec(dp + "downsample.bias", co)
+        fl = 2 * xp.rows * co * ci * ((2 * f + 1) if xp.rows > 1 else f)      # the convolution's own products (as the GEMM lowering counts)
+        if cp == 256:
+            self.rconv(xp, w3, dp + "downsample.weight/patch", y, taps=3, bias_off=bias, half_out=True, flops=fl)
+        else:
+            self.rconv(xp, w3, dp + "downsample.weight/patch", y, taps=3, bias_off=bias, ksrc=2, flops=fl)
+
+    def up_patch_ok(self, x: Ten, ci: int, co: int, f: int, res: Optional[Ten]) -> bool:
+        """The ConvTranspose1d of an UpsampleBlock1d in PATCH form on the row-stationary kernel (up_patch)."""
+        return (self.patch_conv and self.use_rconv and self.ring_mode and self.fuse_blocks and (self.gemm_mode == "bf16x3" or self.wf32)
+                and f % 2 == 0 and x.ld == ci and ci in (128, 256) and (f * co) % ci == 0 and 1 < f * co // ci <= 8
+                and x.rows in (1, 2, 4, 8, 16) and (res is None or res.ld == co))
+
+    def up_patch(self, x: Ten, up: str, ci: int, co: int, f: int, y: Ten, res: Optional[Ten]) -> None:
+        """ConvTranspose1d(ci -> co, kernel 2 f, stride f, padding f / 2) (modules.py:74-81) as a k = 3 convolution that writes
+        PATCHES: input token t produces the f output tokens f t .. f t + f - 1 = one row of f co contiguous values.  With the phase
+        weights W(ph, 0) = w[:, :, ph]^T, W(ph, 1) = w[:, :, ph + f]^T of the GEMM lowering: output token f t + j is
+        W(j + f/2, 1) x[t - 1] + W(j + f/2, 0) x[t] for j < f/2 and W(j - f/2, 1) x[t] + W(j - f/2, 0) x[t + 1] otherwise; zero padding
+        of the patch convolution = the rows the transposed convolution never reads.  f co = NB ci output channels: NB blocks of one
+        MDT_OP_RCONV launch (the GEMM form ran the f phases as one latency-bound launch of 17 - 22 us)."""
+        wt = self.sd[up + "upsample.weight"].float()             # [ci][co][2 f]
+        w3 = torch.zeros(f * co, ci, 3)
+        h = f // 2
+        for j in range(f):
+            rows = slice(j * co, (j + 1) * co)
+            if j < h:
+                w3[rows, :, 0] = wt[:, :, j + h + f].T
+                w3[rows, :, 1] = wt[:, :, j + h].T
+            else:
+                w3[rows, :, 1] = wt[:, :, j - h + f].T
+                w3[rows, :, 2] = wt[:, :, j - h].T
+        bias = self.W.add(up + "upsample.bias/patch", self.sd[up + "upsample.bias"].float().repeat(f))
+        yp = Ten(y.space, y.off, x.rows, f * co, f * co)
+        rp = Ten(res.space, res.off, x.rows, f * co, f * co) if res is not None else None
+        self.rconv(x, w3, up + "upsample.weight/patch", yp, taps=3, bias_off=bias, res=rp, nb=f * co // ci,
+                   flops=2 * x.rows * f * co * 2 * ci)
 
     def _resnet_rconv(self, xa: Ten, xb: Optional[Ten], scale_b: float, p: str, c: int, groups: int,
                       free_input: bool) -> Ten:
@@ -1627,7 +1693,9 @@ class UNetCompiler:
             dp = f"downsamples.{i}."
             ci, co, f = cfg.level_channels(i), cfg.level_channels(i + 1), cfg.factors[i]
             y = self._new(x.rows // f, co)
-            if x.rows == f:
+            if self.down_patch_ok(x, ci, co, f):
+                self.down_patch(x, dp, ci, co, f, y)
+            elif x.rows == f:
                 # ONE output token per sample (configs[2]'s last level): taps 0 .. f - 1 and 2 f of the strided convolution
                 # (modules.py:62-75: kernel 2 f + 1, stride f, padding f) only ever see padding -- taps f .. 2 f - 1 on inputs
                 # 0 .. f - 1 are the whole sum, exactly
@@ -1751,7 +1819,9 @@ class UNetCompiler:
             y = self._new(x.rows * f, co)
             last = u == cfg.num_layers - 1
             res = skips_list[0][0] if last else None       # `x += skips_list.pop()` (modules.py:1176)
-            if self.convt_merge:
+            if self.up_patch_ok(x, ci, co, f, res):
+                self.up_patch(x, up, ci, co, f, y, res)
+            elif self.convt_merge:
                 # all f phases in ONE launch (grid.z = phase): each phase alone is a 64..256-workgroup GEMM that runs
                 # at launch latency, and the phases are independent
                 wall = torch.cat([torch.stack((wt[:, :, ph], wt[:, :, ph + f]), dim=0).permute(2, 0, 1).reshape(co, 2 * ci)

@@ -165,7 +165,8 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
     auto issue_tile = [&](int tau) {
       // stream order (tap, K half, chunk): this workgroup's chunks are NCH consecutive ones of every (tap, K half)
       const int tl = tau % NT;
-      const int ts = (tau / NT) * NTF + (tl / NCH) * NCHT + (int)blockIdx.y * NCH + tl % NCH;
+      // (a.nb > 1: blockIdx.y = output block x NSPLIT + split; the blocks' tile streams follow each other)
+      const int ts = ((int)blockIdx.y / NSPLIT) * (nsrc * NTF) + (tau / NT) * NTF + (tl / NCH) * NCHT + ((int)blockIdx.y % NSPLIT) * NCH + tl % NCH;
       const unsigned char* tile = wsrc + (int64_t)ts * SLOT;
       unsigned char* slot = smem + (tau % NS) * SLOT + iw * 1024;
 #pragma unroll
@@ -188,6 +189,8 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
   }
 
   // ================= compute waves =================
+  // first output channel of this workgroup: output block (MDT_R_NB: blockIdx.y / NSPLIT, C channels each), then its split's chunks
+  const int ocol0 = ((int)blockIdx.y / NSPLIT) * C + ((int)blockIdx.y % NSPLIT) * (64 * NCH);
 #ifdef MDT_STAMPS   // tuning build: wave 0 of workgroup 0 records the shader clock into the film buffer's tail (never in a real run)
   unsigned long long* stamps = reinterpret_cast<unsigned long long*>(const_cast<float*>(a.dbgbuf));
   int nstamp = 0;
@@ -252,13 +255,16 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
   // onto C outputs (configs[2]'s output projections behind the 8 x 128 attention rows), no prologue; NSRC = 2 stays the concatenation
   constexpr bool KSRC = NSRC > 2;
   static_assert(!KSRC || (PRO == 0 && TAPS == 1), "K blocks: a plain projection");
+  // NSRC = 2 serves both: x | x2 (the concatenations of the up path), or -- a.ksrc == 2 -- the two C-channel blocks of one tensor
+  // (a strided convolution in patch form: 2 C = factor x channels, see compiler.py::down_patch)
+  const bool ks = KSRC || (NSRC == 2 && a.ksrc == 2);
   constexpr bool EARLY2 = NSRC >= 2 && !GN;          // the NEXT source's rows are requested while this one's tiles run
   float4 xu2[EARLY2 ? NSTW : 1], xw2[EARLY2 ? NSTW : 1];
 #pragma unroll 1
   for (int src = 0; src < nsrc; ++src) {
-  const float* xsrc = KSRC ? a.x + src * C : (src ? a.x2 : a.x);
-  const int lda = (src && !KSRC) ? a.lda2 : a.lda;
-  const float in_scale = (src && !KSRC) ? a.in_scale2 : a.in_scale;
+  const float* xsrc = ks ? a.x + src * C : (src ? a.x2 : a.x);
+  const int lda = (src && !ks) ? a.lda2 : a.lda;
+  const float in_scale = (src && !ks) ? a.in_scale2 : a.in_scale;
   const float* gamma = a.gamma + src * C;            // source b's gain / bias follow source a's
   const float* beta = a.beta + src * C;
   // ---- the wave's 16 rows: load, (GroupNorm + FiLM + SiLU), split into bf16 hi/lo MFMA operands ----
@@ -283,7 +289,7 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
     }
     if constexpr (EARLY2) {
       if (src + 1 < nsrc) {
-        const float* xq = (KSRC ? a.x + (int64_t)mc * a.lda + (src + 1) * C : a.x2 + (int64_t)mc * a.lda2) + 32 * st0 + 8 * g;
+        const float* xq = (ks ? a.x + (int64_t)mc * a.lda + (src + 1) * C : a.x2 + (int64_t)mc * a.lda2) + 32 * st0 + 8 * g;
 #pragma unroll
         for (int st = 0; st < NSTW; ++st) {
           xu2[st] = *reinterpret_cast<const float4*>(xq + 32 * st);
@@ -323,15 +329,14 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
         for (int c = 0; c < NCH; ++c)
 #pragma unroll
           for (int q = 0; q < NFT; ++q)
-            ib[c][q] = *reinterpret_cast<const float4*>(a.bias + 64 * ((int)blockIdx.y * NCH + c) + 16 * (NFT * fh + q) + 4 * g);
+            ib[c][q] = *reinterpret_cast<const float4*>(a.bias + ocol0 + 64 * c + 16 * (NFT * fh + q) + 4 * g);
       }
       if (a.res) {
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
 #pragma unroll
           for (int q = 0; q < NFT; ++q)
-            ir[c][q] = *reinterpret_cast<const float4*>(a.res + (int64_t)mc * a.ldr + 64 * ((int)blockIdx.y * NCH + c) +
-                                                        16 * (NFT * fh + q) + 4 * g);
+            ir[c][q] = *reinterpret_cast<const float4*>(a.res + (int64_t)mc * a.ldr + ocol0 + 64 * c + 16 * (NFT * fh + q) + 4 * g);
       }
     }
     // P: the loader waves start the weight stream only now, behind this wave's requests (a row load queued behind the
@@ -630,7 +635,7 @@ __global__ __launch_bounds__(512) void k_rconv(RConvArgs a) {
     for (int c = 0; c < NCH; ++c)
 #pragma unroll
       for (int q = 0; q < NFT; ++q) {
-        const int f = 64 * ((int)blockIdx.y * NCH + c) + 16 * (NFT * fh + q) + 4 * g;
+        const int f = ocol0 + 64 * c + 16 * (NFT * fh + q) + 4 * g;
         store_nt(a.out + (int64_t)m * a.ldc + f, make_float4(acc[c][q][0], acc[c][q][1], acc[c][q][2], acc[c][q][3]));
       }
   }
@@ -645,7 +650,9 @@ static hipError_t launch_rc2(const RConvArgs& a, hipStream_t s) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
   }
   const int rows = 16 * RTW;
-  hipLaunchKernelGGL((k_rconv<RTW, C, TAPS, NSPLIT, NSRC, PRO, F32>), dim3((unsigned)((a.M + rows - 1) / rows), NSPLIT), dim3(512), smem, s, a);
+  // half_out (NSPLIT = 2 forms only): ONE workgroup per row block, the one that produces output channels 0 .. C / 2 - 1
+  hipLaunchKernelGGL((k_rconv<RTW, C, TAPS, NSPLIT, NSRC, PRO, F32>), dim3((unsigned)((a.M + rows - 1) / rows), a.half_out ? 1 : NSPLIT * (a.nb > 1 ? a.nb : 1)),
+                     dim3(512), smem, s, a);
   return hipGetLastError();
 }
 
@@ -671,6 +678,17 @@ hipError_t launch_rconv(const RConvArgs& a, hipStream_t s) {
   if (a.M <= 0) return hipSuccess;
   if (!rconv_supported(a.C, a.T, a.taps, a.gsize) || (a.gsize > 0 && (!a.gamma || !a.beta))) return hipErrorInvalidValue;
   if (a.x2 && a.film) return hipErrorInvalidValue;   // FiLM only ever precedes a single-source convolution
+  if (a.nb > 1 && (a.nb > 8 || a.half_out || a.ksrc > 1 || a.x2 || a.film || a.gsize > 0)) return hipErrorInvalidValue;
+  if (a.nb > 1) {                                    // NB x C output channels: NB convolutions of the same rows, no prologue
+    if (a.C == 128) return a.taps == 3 ? launch_rc2<4, 128, 3, 1, 1, 0>(a, s) : launch_rc2<4, 128, 1, 1, 1, 0>(a, s);
+    return a.taps == 3 ? launch_rc2<2, 256, 3, 2, 1, 0>(a, s) : launch_rc2<2, 256, 1, 2, 1, 0>(a, s);
+  }
+  if (a.half_out && (a.C != 256 || a.x2 || a.film || a.gsize > 0 || a.ksrc > 1)) return hipErrorInvalidValue;
+  if (a.half_out) return a.taps == 3 ? launch_rc2<2, 256, 3, 2, 1, 0>(a, s) : launch_rc2<2, 256, 1, 2, 1, 0>(a, s);
+  if (a.ksrc == 2) {                                 // two C-channel blocks of one tensor, taps as usual, no prologue
+    if (a.x2 || a.film || a.gsize > 0 || a.C != 256) return hipErrorInvalidValue;
+    return a.taps == 3 ? launch_rc2<2, 256, 3, 2, 2, 0>(a, s) : launch_rc2<2, 256, 1, 2, 2, 0>(a, s);   // (the unsplit forms spill)
+  }
   if (a.ksrc > 1) {                                  // K = ksrc C input channels in consecutive C-channel blocks (MDT_R_KSRC)
     if (a.x2 || a.film || a.gsize > 0 || a.taps != 1 || a.ksrc * a.C != 1024) return hipErrorInvalidValue;
     if (a.C == 128) return launch_rc2<4, 128, 1, 1, 8, 0>(a, s);

@@ -165,9 +165,18 @@ static const char* validate(const mdt_op& o, int idx, char* buf, size_t nbuf) {
       if (!o.a.space || !o.w.space || !o.out.space) return bad("missing operand");
       if (o.i[MDT_R_GSIZE] > 0 && (!o.p0.space || !o.p1.space)) return bad("GroupNorm prologue needs gain and bias");
       if (o.i[MDT_R_WF32] != 0 && o.i[MDT_R_WF32] != 1) return bad("WF32 must be 0 (split-bf16 tiles) or 1 (fp32 fragment tiles)");
-      if (o.i[MDT_R_KSRC] < 0 || (o.i[MDT_R_KSRC] > 1 && (o.i[MDT_R_KSRC] * o.i[MDT_R_C] != 1024 || o.i[MDT_R_TAPS] != 1 || o.i[MDT_R_GSIZE] ||
-                                                        o.a2.space || o.p3.space || o.i[MDT_R_LDA] < 1024)))
-        return bad("KSRC > 1 is a plain K = 1024 projection: KSRC * C == 1024, one tap, no GroupNorm / FiLM / second source");
+      if (o.i[MDT_R_KSRC] == 2) {
+        if (o.i[MDT_R_C] != 256 || o.i[MDT_R_GSIZE] || o.a2.space || o.p3.space || o.i[MDT_R_LDA] < 512)
+          return bad("KSRC = 2: two 256-channel blocks of one tensor, no GroupNorm / FiLM / second source");
+      } else if (o.i[MDT_R_KSRC] < 0 || (o.i[MDT_R_KSRC] > 1 && (o.i[MDT_R_KSRC] * o.i[MDT_R_C] != 1024 || o.i[MDT_R_TAPS] != 1 || o.i[MDT_R_GSIZE] ||
+                                                               o.a2.space || o.p3.space || o.i[MDT_R_LDA] < 1024)))
+        return bad("KSRC > 2 is a plain K = 1024 projection: KSRC * C == 1024, one tap, no GroupNorm / FiLM / second source");
+      if (o.i[MDT_R_HALF_OUT] != 0 && (o.i[MDT_R_HALF_OUT] != 1 || o.i[MDT_R_C] != 256 || o.i[MDT_R_GSIZE] || o.a2.space || o.p3.space ||
+                                       o.i[MDT_R_KSRC] > 1 || o.i[MDT_R_LDC] < 128))
+        return bad("HALF_OUT: a 256 -> 128 channel convolution without prologue (C = 256, one source)");
+      if (o.i[MDT_R_NB] < 0 || o.i[MDT_R_NB] > 8 || (o.i[MDT_R_NB] > 1 && (o.i[MDT_R_GSIZE] || o.a2.space || o.p3.space || o.i[MDT_R_KSRC] > 1 ||
+                                                                         o.i[MDT_R_HALF_OUT] || o.i[MDT_R_LDC] < o.i[MDT_R_NB] * o.i[MDT_R_C])))
+        return bad("NB > 1: NB x C output channels of one source without prologue, LDC >= NB * C");
       break;
     case MDT_OP_RESBLOCK:
       if (!mdt::resblock_supported(o.i[MDT_K_T], o.i[MDT_K_CIN], o.i[MDT_K_COUT]))
@@ -421,7 +430,7 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
         a.ldr = o.i[MDT_R_LDR]; a.taps = o.i[MDT_R_TAPS]; a.gsize = o.i[MDT_R_GSIZE]; a.silu = o.i[MDT_R_SILU];
         a.film_ld = o.i[MDT_R_FILM_LD]; a.eps = o.f[MDT_RF_EPS]; a.in_scale = o.f[MDT_RF_IN_SCALE];
         a.lda2 = o.i[MDT_R_LDA2]; a.in_scale2 = o.f[MDT_RF_IN_SCALE2];
-        a.pf_ptr = pf_ptr; a.pf_lines = pf_lines; a.wf32 = o.i[MDT_R_WF32]; a.ksrc = o.i[MDT_R_KSRC];
+        a.pf_ptr = pf_ptr; a.pf_lines = pf_lines; a.wf32 = o.i[MDT_R_WF32]; a.ksrc = o.i[MDT_R_KSRC]; a.half_out = o.i[MDT_R_HALF_OUT]; a.nb = o.i[MDT_R_NB];
         if (!missing) e = mdt::launch_rconv(a, stream);
         break;
       }

@@ -161,7 +161,9 @@ struct RConvArgs {
   const void* pf_ptr;  // weight stream of the NEXT launch (pulled into the L2s by the idle loader waves), or nullptr
   int pf_lines;        // ... its size in 128-byte lines
   int wf32;            // 1: fp32 fragment tiles, exact fp32 MFMA products (MDT_R_WF32)
-  int ksrc;            // > 1: x is [M][ksrc C]: ksrc blocks of C channels accumulate into the C outputs (MDT_R_KSRC; ksrc C == 1024)
+  int ksrc;            // > 1: x is [M][ksrc C]: ksrc blocks of C channels accumulate into the C outputs (MDT_R_KSRC; 2, or ksrc C == 1024)
+  int half_out;        // 1: only output channels 0 .. C / 2 - 1 exist (C = 256; ldc >= 128; MDT_R_HALF_OUT)
+  int nb;              // > 1: NB x C output channels -- NB convolutions of the same input, blocks of weights / bias / out consecutive (MDT_R_NB)
 };
 // MDT_OP_GEMM with MDT_G_WFMT = 16 (k_proj.hip): row-stationary projection, weights as ring tiles
 struct ProjArgs {

@@ -37,7 +37,7 @@ A_T, A_TK, A_HEADS, A_LDQ, A_LDKV, A_LDO, A_KV_BSTRIDE, A_OUT16, A_QCOL, A_KCOL,
 C_ROWS, C_CA, C_CB = range(3)
 P_ROWS_IN, P_C_IN, P_LD_IN, P_LD_OUT, P_PATCH, P_INVERSE = range(6)
 T_HALF, T_LD = range(2)
-R_T, R_C, R_LDA, R_LDC, R_LDR, R_TAPS, R_GSIZE, R_SILU, R_FILM_LD, R_LDA2, R_WF32, R_KSRC = range(12)
+R_T, R_C, R_LDA, R_LDC, R_LDR, R_TAPS, R_GSIZE, R_SILU, R_FILM_LD, R_LDA2, R_WF32, R_KSRC, R_HALF_OUT, R_NB = range(14)
 K_T, K_CIN, K_COUT, K_FILM_LD, K_WF32, K_CIN_REAL, K_COUT_REAL, K_PATCH_IN, K_PATCH_OUT = range(9)
 B_MODE, B_C, B_T, B_NCHUNK, B_NBIAS, B_TK, B_KV_BSTRIDE, B_LDKV, B_HEADS, B_VARIANT, B_POST = range(11)
 B_KV2 = 11

@@ -277,20 +277,24 @@ def _rconv(op, bufs: Buffers, B: int) -> None:
         ys.append(y)
     y = torch.cat(ys, dim=2)
     nkh, nch = C // 128, C // 64
-    stream = bufs.view(op.w, B, nsrc * taps * C * C)
-    w = torch.empty(C, nsrc * C, taps)
+    nb = max(int(i[rt.R_NB]), 1)                        # NB x C output channels: NB convolutions of the same rows
+    stream = bufs.view(op.w, B, nb * nsrc * taps * C * C)
+    w = torch.empty(nb * C, nsrc * C, taps)
     k = 0
-    for s_ in range(nsrc):
-        for tap in range(taps):
-            for kh in range(nkh):
-                for ch in range(nch):
-                    w[64 * ch: 64 * ch + 64, s_ * C + 128 * kh: s_ * C + 128 * kh + 128, tap] = _untile(stream, k, 64, 128, bool(i[rt.R_WF32]))
-                    k += 1
-    bias = bufs.view(op.bias, B, C) if op.bias.space != rt.SP_NONE else None
-    o = F.conv1d(y.transpose(1, 2), w, bias, padding=taps // 2).transpose(1, 2)
+    for b_ in range(nb):
+        for s_ in range(nsrc):
+            for tap in range(taps):
+                for kh in range(nkh):
+                    for ch in range(nch):
+                        w[b_ * C + 64 * ch: b_ * C + 64 * ch + 64, s_ * C + 128 * kh: s_ * C + 128 * kh + 128, tap] = \
+                            _untile(stream, k, 64, 128, bool(i[rt.R_WF32]))
+                        k += 1
+    co = C // 2 if i[rt.R_HALF_OUT] else nb * C         # HALF_OUT: only output channels 0 .. C / 2 - 1 exist
+    bias = bufs.view(op.bias, B, co) if op.bias.space != rt.SP_NONE else None
+    o = F.conv1d(y.transpose(1, 2), w[:co], bias, padding=taps // 2).transpose(1, 2)
     if op.res.space != rt.SP_NONE:
-        o = o + bufs.view(op.res, B, B * T * ldr).view(B, T, ldr)[:, :, :C]
-    bufs.view(op.out, B, B * T * ldc).view(B, T, ldc)[:, :, :C] = o
+        o = o + bufs.view(op.res, B, B * T * ldr).view(B, T, ldr)[:, :, :co]
+    bufs.view(op.out, B, B * T * ldc).view(B, T, ldc)[:, :, :co] = o
 
 
 def _resblock_steps(c: int, taps: int):

@@ -137,6 +137,98 @@ def test_row_stationary_conv_as_a_k1024_projection(B, T, C, res, prod):
     assert (ga[B * T * K:].view(B * T, C).double() - y).abs().max() < (2e-5 if f32 else 1e-4)
 
 
+@pytest.mark.parametrize("B,L,ci,co,f", [(37, 64, 64, 128, 4), (1030, 64, 64, 128, 4), (70, 16, 128, 256, 4), (300, 16, 64, 128, 4),
+                                         (9, 4, 128, 256, 4), (2100, 4, 128, 256, 4), (5, 8, 128, 256, 4)])
+def test_strided_convolution_in_patch_form(B, L, ci, co, f, prod):
+    """DownsampleBlock1d's Conv1d(k = 2 f + 1, stride f, padding f) (modules.py:62-75) as k_rconv over PATCHES (f tokens = one row of
+    f ci values; compiler.py::down_patch): 256 -> 128 channels with MDT_R_HALF_OUT, 512 -> 256 with the row's two halves as sources
+    (MDT_R_KSRC = 2); one output token per sample keeps the centre tap only.  Against torch's strided convolution."""
+    from moleculediffusiontransformer_amd.compiler import UNetCompiler
+    f32 = prod == "f32"
+    tile = UNetCompiler._tile_f32 if f32 else UNetCompiler._tile
+    w = rnd(co, ci, 2 * f + 1, seed=1, scale=(ci * (2 * f + 1)) ** -0.5)
+    bias = rnd(co, seed=2)
+    cp, T = ci * f, L // f
+    w3 = torch.zeros(co, cp, 3)
+    for q in range(f):
+        w3[:, q * ci: (q + 1) * ci, 0] = w[:, :, q]
+        w3[:, q * ci: (q + 1) * ci, 1] = w[:, :, f + q]
+    w3[:, :ci, 2] = w[:, :, 2 * f]
+    half, C = cp == 256, 256
+    ks = 0 if half else 2
+    if half:
+        w3 = torch.cat([w3, torch.zeros_like(w3)])
+    taps = 3
+    if T == 1:
+        w3, taps = w3[:, :, 1:2], 1
+    nsrc = max(ks, 1)
+    tiles = [tile(w3[64 * ch: 64 * ch + 64, s_ * C + 128 * kh: s_ * C + 128 * kh + 128, tap])
+             for s_ in range(nsrc) for tap in range(taps) for kh in range(2) for ch in range(4)]
+    wt = torch.cat(tiles)
+    weights = torch.cat([wt, bias])
+    x = rnd(B * L * ci, seed=3)
+    act = torch.cat([x, torch.zeros(B * T * co)])
+    op = rt.MdtOp()
+    op.kind = rt.OP_RCONV
+    op.a, op.out, op.w, op.bias = ref(A, 0), ref(A, L * ci), ref(W, 0), ref(W, wt.numel())
+    i = op.i
+    i[rt.R_T], i[rt.R_C], i[rt.R_LDA], i[rt.R_LDC], i[rt.R_TAPS] = T, C, cp, co, taps
+    i[rt.R_FILM_LD], i[rt.R_WF32], i[rt.R_KSRC], i[rt.R_HALF_OUT] = C, int(f32), ks, int(half)
+    op.f[0], op.f[1] = 1e-5, 1.0
+    (ga, _, _), (ca, _, _) = run_both([op], weights, act, torch.zeros(4), {}, B)
+    assert torch.equal(ga[: B * L * ci], x)
+    assert (ga - ca).abs().max() < 5e-5
+    y = torch.nn.functional.conv1d(x.view(B, L, ci).transpose(1, 2).double(), w.double(), bias.double(), stride=f, padding=f)
+    assert (ga[B * L * ci:].view(B, T, co).double() - y.transpose(1, 2)).abs().max() < (2e-5 if f32 else 1e-4)
+
+
+@pytest.mark.parametrize("B,T,ci,co,f", [(37, 4, 256, 128, 4), (1030, 4, 256, 128, 4), (70, 16, 128, 64, 4), (1100, 16, 128, 64, 4),
+                                         (9, 1, 256, 128, 4), (2100, 1, 256, 128, 4), (5, 8, 128, 64, 4)])
+@pytest.mark.parametrize("res", [False, True])
+def test_transposed_convolution_in_patch_form(B, T, ci, co, f, res, prod):
+    """UpsampleBlock1d's ConvTranspose1d(k = 2 f, stride f, padding f / 2) (modules.py:74-81) as ONE k_rconv launch that writes
+    patches (MDT_R_NB: f co = NB ci output channels per input token; compiler.py::up_patch), residual added in place;
+    against torch's transposed convolution."""
+    from moleculediffusiontransformer_amd.compiler import UNetCompiler
+    f32 = prod == "f32"
+    tile = UNetCompiler._tile_f32 if f32 else UNetCompiler._tile
+    wt = rnd(ci, co, 2 * f, seed=1, scale=(2 * ci) ** -0.5)
+    bias = rnd(co, seed=2)
+    h, C, nb = f // 2, ci, f * co // ci
+    w3 = torch.zeros(f * co, ci, 3)
+    for j in range(f):
+        rows = slice(j * co, (j + 1) * co)
+        if j < h:
+            w3[rows, :, 0], w3[rows, :, 1] = wt[:, :, j + h + f].T, wt[:, :, j + h].T
+        else:
+            w3[rows, :, 1], w3[rows, :, 2] = wt[:, :, j - h + f].T, wt[:, :, j - h].T
+    taps = 3
+    if T == 1:
+        w3, taps = w3[:, :, 1:2], 1
+    tiles = [tile(w3[b_ * C + 64 * ch: b_ * C + 64 * ch + 64, 128 * kh: 128 * kh + 128, tap])
+             for b_ in range(nb) for tap in range(taps) for kh in range(C // 128) for ch in range(C // 64)]
+    wtl = torch.cat(tiles)
+    weights = torch.cat([wtl, bias.repeat(f)])
+    x = rnd(B * T * ci, seed=3)
+    out0 = rnd(B * T * f * co, seed=4)
+    act = torch.cat([x, out0])
+    op = rt.MdtOp()
+    op.kind = rt.OP_RCONV
+    op.a, op.out, op.w, op.bias = ref(A, 0), ref(A, T * ci), ref(W, 0), ref(W, wtl.numel())
+    if res:
+        op.res = ref(A, T * ci)
+    i = op.i
+    i[rt.R_T], i[rt.R_C], i[rt.R_LDA], i[rt.R_LDC], i[rt.R_TAPS], i[rt.R_LDR] = T, C, ci, f * co, taps, (f * co if res else 0)
+    i[rt.R_FILM_LD], i[rt.R_WF32], i[rt.R_NB] = C, int(f32), nb
+    op.f[0], op.f[1] = 1e-5, 1.0
+    (ga, _, _), (ca, _, _) = run_both([op], weights, act, torch.zeros(4), {}, B)
+    assert torch.equal(ga[: B * T * ci], x)
+    assert (ga - ca).abs().max() < 5e-5
+    y = torch.nn.functional.conv_transpose1d(x.view(B, T, ci).transpose(1, 2).double(), wt.double(), bias.double(), stride=f, padding=h)
+    want = y.transpose(1, 2) + (out0.view(B, T * f, co).double() if res else 0)
+    assert (ga[B * T * ci:].view(B, T * f, co).double() - want).abs().max() < (2e-5 if f32 else 1e-4)
+
+
 def test_gemm_strided_conv_and_transposed_phases():
     B, Lin, cin, N, f = 3, 16, 64, 128, 4
     # Conv1d k=9 s=4 p=4 (modules.py:40-51)
