@@ -101,8 +101,12 @@ def test_chained_resnet_blocks_match_the_reference_sample(mode, monkeypatch):
     trace = {"want": (1, 2, 32, 63)}
     out = m.sample(to_t(g["seq"]), DEV, cond_scale=1.0, timesteps=64, clamp=False,
                    noise=NoiseSource(init=init, steps=lambda i: step(i, init)), trace=trace)
-    kinds = [op.kind for op in m._engine.c.programs["eval"]]
-    assert kinds.count(rt.OP_RES256) == 4 and rt.OP_RCONV not in kinds and len(kinds) == 20
+    ops = m._engine.c.programs["eval"]
+    kinds = [op.kind for op in ops]
+    # (the only MDT_OP_RCONV launches left are the four resampling convolutions in patch form: half-output / K-block / output-block ops)
+    rc = [op for op in ops if op.kind == rt.OP_RCONV]
+    assert kinds.count(rt.OP_RES256) == 4 and len(kinds) == 20
+    assert len(rc) == 4 and all(op.i[rt.R_HALF_OUT] or op.i[rt.R_KSRC] or op.i[rt.R_NB] for op in rc) and rt.OP_GEMM not in kinds
     for s_ in (1, 2, 32, 63):
         assert (trace[s_].cpu() - to_t(g[f"x_step{s_}"])).abs().max() < TOL, s_
     assert (out.cpu() - out_ref).abs().max() < TOL
