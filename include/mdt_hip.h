@@ -204,7 +204,7 @@ enum mdt_gemm_i {
                         residual / out 16-byte aligned (bf16 out / copy: 8), otherwise the op is rejected;
                         16 = RING TILES (k_proj.hip, round 5): w holds N / 64 * CIN / 128 tiles of 32 KB, tile (chunk c, K half h)
                         at index c * (CIN / 128) + h = W[64 c .. 64 c + 64)[128 h .. 128 h + 128) as a bf16 hi plane [64][128]
-                        followed by the lo plane (split-bf16 products); CIN in {128, 256}, N % 64 == 0, prologue none or
+                        followed by the lo plane (split-bf16 products); CIN in {128, 256}, N % 64 == 0, N <= 2048, prologue none or
                         LayerNorm (p0 / p1 both unbound = LayerNorm WITHOUT affine: the caller folded gain into the weights and
                         bias into the bias), one tap, bias / residual optional (the residual may alias out), no activation / row mapping;
                         17 = as 16 with fp32 FRAGMENT tiles (the layout of MDT_F_WF32) and exact fp32 MFMA products */

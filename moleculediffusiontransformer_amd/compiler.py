@@ -378,7 +378,7 @@ class UNetCompiler:
         op = rt.MdtOp()
         op.kind = rt.OP_GEMM
         # row-stationary projection on ring tiles (k_proj.hip, MDT_G_WFMT = 16): the K = 128 / 256 layers between the fused kernels
-        ring = (self.use_proj and (self.gemm_mode == "bf16x3" or self.wf32) and cin in (128, 256) and n % 64 == 0 and taps == 1
+        ring = (self.use_proj and (self.gemm_mode == "bf16x3" or self.wf32) and cin in (128, 256) and n % 64 == 0 and n <= 2048 and taps == 1
                 and t_stride == 1 and t_off == 0 and phases <= 1 and o_stride == 1 and o_off == 0 and r_out_ == a.rows
                 and out.rows == r_out_ and act == 0 and pro in (rt.PRO_NONE, rt.PRO_LAYERNORM) and not a.b16 and not out.b16
                 and copy16 is None and a.ld % 4 == 0 and a_col % 4 == 0 and o_col % 4 == 0 and out.ld % 4 == 0

@@ -408,7 +408,9 @@ static hipError_t launch_pj2(const ProjArgs& a, hipStream_t s) {
 }
 
 bool proj_supported(int K, int N, int lda, int ldc, int ldr) {
-  return (K == 128 || K == 256) && N > 0 && N % 64 == 0 && lda % 4 == 0 && ldc % 4 == 0 && ldr % 4 == 0;
+  // (N <= 2048: a workgroup's bias slice in LDS holds 32 chunks, and a workgroup takes all of a row block's chunks when the row blocks
+  //  fill the chip)
+  return (K == 128 || K == 256) && N > 0 && N <= 64 * 4 * PJ_BIAS_PASSES && N % 64 == 0 && lda % 4 == 0 && ldc % 4 == 0 && ldr % 4 == 0;
 }
 
 hipError_t launch_proj(const ProjArgs& a, hipStream_t s) {
