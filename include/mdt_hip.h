@@ -278,14 +278,15 @@ enum mdt_tblock_i {
                                        out = Wout (x + FF(x)) + bout; the W2 tiles hold Wout W2, POST = C/64 extra output
                                        tiles hold Wout (natural k order), the output bias holds Wout b2 + bout; x is left
                                        untouched                                                            */
-  MDT_B_VARIANT = 9                 /* 0: 64-row workgroups, C = 128 (cross: <= 16 keys per 16 rows); 1: removed (round 3);
+  MDT_B_VARIANT = 9,                /* 0: 64-row workgroups, C = 128 (cross: <= 16 keys per 16 rows); 1: removed (round 3);
                                        2: 32-row workgroups, C = 256 (cross: <= 48 keys per 16 rows), weight
                                        stream packed as 128-wide sub-tiles (K halves / output-row halves);
                                        3: as 2, with the heads / hidden chunks of a row block split over two
                                        workgroups: out = scratch [2][B T][C] for their partial sums;
                                        4: chained form of 3 without the reduce launch: block input = a + res (res = the
                                        previous block's second partial | none), out = block output written by head group 0
-                                       (never aliasing a), p2 = second head group's partial | none (one workgroup)   */
+                                       (never aliasing a), p2 = second head group's partial | none (one workgroup);  */
+  MDT_B_WF32 = 12                   /* 1 (variant 0; round 5): w = fp32 FRAGMENT tiles, exact fp32 MFMA products (see MDT_F_WF32)  */
 };
 enum mdt_tblock_f { MDT_BF_EPS = 0, MDT_BF_SCALE = 1 };
 

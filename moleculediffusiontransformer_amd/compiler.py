@@ -825,7 +825,9 @@ class UNetCompiler:
     _SLOT_PERM = [32 * (s >> 5) + 16 * ((s & 7) >> 2) + 4 * ((s >> 3) & 3) + (s & 3) for s in range(64)]
 
     def can_fuse_transformer(self, c: int, rows: int, cross: bool) -> bool:
-        if self.gemm_mode != "bf16x3" or not self.fuse_blocks:      # (the per-sub-block kernels exist with split-bf16 products only)
+        # (exact-fp32 products: the C = 128 sub-block kernel has fp32-fragment instantiations since round 5, MDT_B_WF32; the
+        #  C = 256 ones exist with split-bf16 products only)
+        if not (self.gemm_mode == "bf16x3" or (self.wf32 and c == 128)) or not self.fuse_blocks:
             return False
         if c not in (128, 256) or rows > 16 or 16 % rows or self.cfg.head_features != 64:
             return False
@@ -880,10 +882,10 @@ class UNetCompiler:
                 wout, bout = post[0].reshape(c, c).double(), post[1].double()
                 w2, b2 = (wout @ w2.double()).float(), (wout @ b2.double() + bout).float()
             for h in range(nchunk):
-                tiles += [self._tile(w1[64 * h: 64 * h + 64]), self._tile(w2[:, 64 * h: 64 * h + 64][:, perm])]
+                tiles += [self._wtile(w1[64 * h: 64 * h + 64]), self._wtile(w2[:, 64 * h: 64 * h + 64][:, perm])]
             if post is not None:
                 assert variant in (0, 2, 4) and (x_out is None or (variant == 4 and p_out is None))
-                tiles += [self._tile(post[0].reshape(c, c)[:, 64 * e: 64 * e + 64]) for e in range(c // 64)]
+                tiles += [self._wtile(post[0].reshape(c, c)[:, 64 * e: 64 * e + 64]) for e in range(c // 64)]
                 self.flops += 2 * rows * c * c
             bias = torch.cat([b1, b2])
             self.flops += 2 * 2 * rows * c * w1.shape[0]
@@ -899,9 +901,9 @@ class UNetCompiler:
                 wkv_f, bkv_f = wkv * g_c.unsqueeze(0), wkv @ b_c
                 mid = wq.shape[0]
                 for h in range(nchunk):
-                    tiles += [self._tile(wq_f[64 * h: 64 * h + 64]), self._tile(wkv_f[64 * h: 64 * h + 64]),
-                              self._tile(wkv_f[mid + 64 * h: mid + 64 * h + 64]),
-                              self._tile(wo[:, 64 * h: 64 * h + 64][:, perm])]
+                    tiles += [self._wtile(wq_f[64 * h: 64 * h + 64]), self._wtile(wkv_f[64 * h: 64 * h + 64]),
+                              self._wtile(wkv_f[mid + 64 * h: mid + 64 * h + 64]),
+                              self._wtile(wo[:, 64 * h: 64 * h + 64][:, perm])]
                 # k bias: softmax is invariant to a per-query constant (q . bk), drop it; v bias: sum_j p_j (v_j + bv)
                 # = sum_j p_j v_j + bv, so it moves into the output bias.  The kernels then load only bq per head
                 # (their own global loads queue behind the loader waves' DMA traffic: ~60 cycles of issue stall each).
@@ -910,7 +912,7 @@ class UNetCompiler:
                 self.flops += 2 * rows * c * 3 * mid + 4 * rows * rows * mid + 2 * rows * mid * c
             else:
                 for h in range(nchunk):
-                    tiles += [self._tile(wq_f[64 * h: 64 * h + 64]), self._tile(wo[:, 64 * h: 64 * h + 64][:, perm])]
+                    tiles += [self._wtile(wq_f[64 * h: 64 * h + 64]), self._wtile(wo[:, 64 * h: 64 * h + 64][:, perm])]
                 bias = torch.cat([bq_f, bo])
                 mid = wq.shape[0]
                 self.flops += 2 * rows * c * mid + 4 * rows * self.n_ctx * mid + 2 * rows * mid * c
@@ -941,6 +943,8 @@ class UNetCompiler:
         i[rt.B_MODE], i[rt.B_C], i[rt.B_T], i[rt.B_NCHUNK], i[rt.B_NBIAS] = mode, c, rows, nchunk, bias.numel()
         i[rt.B_TK], i[rt.B_KV_BSTRIDE], i[rt.B_LDKV], i[rt.B_HEADS] = self.n_ctx, self.n_ctx, 2 * cfg.mid_features, cfg.heads
         i[rt.B_VARIANT] = variant
+        i[rt.B_WF32] = int(self.wf32)                # (can_fuse_transformer: exact-fp32 compilations reach this with C = 128, variant 0 only)
+        assert not self.wf32 or variant == 0
         op.f[0], op.f[1] = 1e-5, float(cfg.head_features) ** -0.5
         if mode == rt.TB_CROSS:
             op._kv = ("kv", cross_index)

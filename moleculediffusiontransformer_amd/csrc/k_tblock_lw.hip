@@ -64,12 +64,20 @@ __device__ __forceinline__ float gelu_lw(float x) {   // exact-erf GELU, branch-
   return 0.5f * x * (1.0f + copysignf(erfa, x));
 }
 
+// F32 (round 5, MDT_B_WF32): the values themselves, slots 0..3 in `hi`, 4..7 in `lo` -- operands of exact fp32 MFMAs on fp32 fragment
+// tiles, as in k_tf128.hip (which grew out of this kernel and carries the same branches)
+template <bool F32>
 __device__ __forceinline__ void split8_lw(const float v[8], bf16x8& hi, bf16x8& lo) {
+  if constexpr (F32) {
+    hi = __builtin_bit_cast(bf16x8, f32x4{v[0], v[1], v[2], v[3]});
+    lo = __builtin_bit_cast(bf16x8, f32x4{v[4], v[5], v[6], v[7]});
+  } else {
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const __bf16 h = (__bf16)v[e];
-    hi[e] = h;
-    lo[e] = (__bf16)(v[e] - (float)h);
+    for (int e = 0; e < 8; ++e) {
+      const __bf16 h = (__bf16)v[e];
+      hi[e] = h;
+      lo[e] = (__bf16)(v[e] - (float)h);
+    }
   }
 }
 
@@ -117,7 +125,7 @@ constexpr int NU = 8;           // units (4 fragment reads + 6 MFMAs) per tile, 
 }  // namespace
 
 // NPW (MODE_CROSS only): LDS-DMA pieces per loader wave per K / V tile = ceil(context rows of the workgroup / 16)
-template <int MODE, int NPW>
+template <int MODE, int NPW, bool F32>
 __global__ __launch_bounds__(512) void k_tblock_lw(TBlockArgs a) {
   constexpr int TPC = (MODE == TB_FF) ? 2 : 4;     // tiles per chunk: q k v o | q K V o (K, V = hoisted context rows) | w1 w2
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -148,8 +156,10 @@ __global__ __launch_bounds__(512) void k_tblock_lw(TBlockArgs a) {
     for (int q = 0; q < IPT; ++q) {
       const int inst = iw + 4 * q;
       const int U = 2 * inst;
-      voffP[q] = (unsigned)(U * (2 * C) + ((xP ^ (U & 15)) << 4) + baseP);
-      voffO[q] = (unsigned)(((inst * 8) / C) * (128 * C) + ((inst * 8) % C) * 128 + ((xO ^ (4 * (inst & 1))) << 4) + baseO);
+      // (F32: fp32 fragment tiles are stored in LDS order, a linear copy)
+      voffP[q] = F32 ? (unsigned)(inst * 1024 + lane * 16) : (unsigned)(U * (2 * C) + ((xP ^ (U & 15)) << 4) + baseP);
+      voffO[q] = F32 ? (unsigned)(inst * 1024 + lane * 16)
+                     : (unsigned)(((inst * 8) / C) * (128 * C) + ((inst * 8) % C) * 128 + ((xO ^ (4 * (inst & 1))) << 4) + baseO);
     }
     // MODE_CROSS: tiles 1 and 2 of a head are the K and V rows of the workgroup's samples, head h: row R = (sample,
     // key) concatenated, 256 B (64 fp32) per row, 16-byte chunks XOR-swizzled with R & 15 (conflict-free
@@ -310,7 +320,7 @@ __global__ __launch_bounds__(512) void k_tblock_lw(TBlockArgs a) {
       float v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = mvalid ? (xr[st][e] - mean) * rstd : 0.f;
-      split8_lw(v, xh[st], xl[st]);
+      split8_lw<F32>(v, xh[st], xl[st]);
     }
   }
 
@@ -322,10 +332,10 @@ __global__ __launch_bounds__(512) void k_tblock_lw(TBlockArgs a) {
 #pragma unroll
   for (int st = 0; st < NST; ++st) {
     const int lc = 4 * st + g;
-    aP[st] = i * (4 * C) + ((lc & ~15) | ((lc & 15) ^ i)) * 16;
+    aP[st] = F32 ? lane * 16 : i * (4 * C) + ((lc & ~15) | ((lc & 15) ^ i)) * 16;      // F32: the k-step is in the immediate
   }
 #pragma unroll
-  for (int sp = 0; sp < 2; ++sp) aO[sp] = i * 128 + ((4 * sp + g) ^ ((i >> 1) & 7)) * 16;
+  for (int sp = 0; sp < 2; ++sp) aO[sp] = F32 ? lane * 16 : i * 128 + ((4 * sp + g) ^ ((i >> 1) & 7)) * 16;
 
   bf16x8 fh[3][2], fl[3][2];   // three fragment sets: unit u of a phase with set offset OFF lives in set (OFF + u) % 3
   // Read j (= 2 q + plane) of unit u of a tile of kind KIND; `base` = LDS address of the slot + the lane's swizzled part
@@ -333,8 +343,10 @@ __global__ __launch_bounds__(512) void k_tblock_lw(TBlockArgs a) {
   auto frag_read = [&](auto kind, unsigned base, auto uc, int set, auto jc) {
     constexpr int KIND = decltype(kind)::value, u = decltype(uc)::value, j = decltype(jc)::value;
     constexpr int q = j >> 1, lo = j & 1;
-    constexpr int off = (KIND == K_O) ? ((2 * (u % (NCT / 2)) + q) * 16 * 128 + lo * (C * 128))
-                                      : ((2 * (u & 1) + q) * 16 * 4 * C + lo * (2 * C));
+    constexpr int off = F32 ? ((KIND == K_O) ? ((2 * (u % (NCT / 2)) + q) * 4096 + (u / (NCT / 2)) * 2048 + lo * 1024)
+                                             : ((2 * (u & 1) + q) * 8192 + (u >> 1) * 2048 + lo * 1024))
+                            : ((KIND == K_O) ? ((2 * (u % (NCT / 2)) + q) * 16 * 128 + lo * (C * 128))
+                                             : ((2 * (u & 1) + q) * 16 * 4 * C + lo * (2 * C)));
     lds_read16_off<off>(lo ? fl[set][q] : fh[set][q], base);
   };
   using J0 = std::integral_constant<int, 0>;
@@ -407,12 +419,35 @@ __global__ __launch_bounds__(512) void k_tblock_lw(TBlockArgs a) {
         if constexpr (KIND == K_N) acc[ia + q] = MDT_MFMA_BF16(x, w, acc[ia + q], 0, 0, 0);
         else acc[ia + q] = MDT_MFMA_BF16(w, x, acc[ia + q], 0, 0, 0);
       };
-      mm(fl[s0][0], bh[ib], 0); rd(J0{});
-      mm(fl[s0][1], bh[ib], 1); rd(J1{});
-      mm(fh[s0][0], bl[ib], 0); rd(J2{});
-      mm(fh[s0][1], bl[ib], 1); rd(J3{});
-      mm(fh[s0][0], bh[ib], 0);
-      mm(fh[s0][1], bh[ib], 1);
+      if constexpr (F32) {
+        // exact fp32: fragment (q, half) x operand half, four 16x16x4 MFMAs each (r = contraction sub-step); the two accumulators
+        // alternate so that no MFMA waits for the one issued just before it (k_tf128.hip)
+        auto mm4 = [&](const bf16x8& w0, const bf16x8& w1, const bf16x8& x, auto r0c) {
+          constexpr int r0 = decltype(r0c)::value;
+          const f32x4 a0 = __builtin_bit_cast(f32x4, w0), a1 = __builtin_bit_cast(f32x4, w1), xb = __builtin_bit_cast(f32x4, x);
+#pragma unroll
+          for (int r = r0; r < r0 + 2; ++r) {
+            if constexpr (KIND == K_N) {
+              acc[ia] = MDT_MFMA_F32(xb[r], a0[r], acc[ia], 0, 0, 0);
+              acc[ia + 1] = MDT_MFMA_F32(xb[r], a1[r], acc[ia + 1], 0, 0, 0);
+            } else {
+              acc[ia] = MDT_MFMA_F32(a0[r], xb[r], acc[ia], 0, 0, 0);
+              acc[ia + 1] = MDT_MFMA_F32(a1[r], xb[r], acc[ia + 1], 0, 0, 0);
+            }
+          }
+        };
+        mm4(fh[s0][0], fh[s0][1], bh[ib], J0{}); rd(J0{});
+        mm4(fh[s0][0], fh[s0][1], bh[ib], J2{}); rd(J1{});
+        mm4(fl[s0][0], fl[s0][1], bl[ib], J0{}); rd(J2{});
+        mm4(fl[s0][0], fl[s0][1], bl[ib], J2{}); rd(J3{});
+      } else {
+        mm(fl[s0][0], bh[ib], 0); rd(J0{});
+        mm(fl[s0][1], bh[ib], 1); rd(J1{});
+        mm(fh[s0][0], bl[ib], 0); rd(J2{});
+        mm(fh[s0][1], bl[ib], 1); rd(J3{});
+        mm(fh[s0][0], bh[ib], 0);
+        mm(fh[s0][1], bh[ib], 1);
+      }
       __builtin_amdgcn_sched_barrier(0);
 #ifdef MDT_STAMPS_UNITS
       MDT_STAMP();
@@ -617,7 +652,7 @@ __global__ __launch_bounds__(512) void k_tblock_lw(TBlockArgs a) {
       float v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = oT[2 * sp + (e >> 2)][e & 3];
-      split8_lw(v, oh[sp], ol[sp]);
+      split8_lw<F32>(v, oh[sp], ol[sp]);
     }
     if (NX > 0 && !more) phase(kO, IC1{}, kO, true, accT, oh, ol);   // the folded convolution's tiles follow
     else phase(kO, IC1{}, kT, more, accT, oh, ol);
@@ -652,16 +687,21 @@ __global__ __launch_bounds__(512) void k_tblock_lw(TBlockArgs a) {
   }
 }
 
-template <int MODE, int NPW = 0>
-static hipError_t launch_lw(const TBlockArgs& a, hipStream_t s) {
+template <int MODE, int NPW, bool F32>
+static hipError_t launch_lw2(const TBlockArgs& a, hipStream_t s) {
   const size_t smem = (size_t)NS * SLOT + (size_t)64 * a.nchunk * sizeof(float);   // ring + per-chunk bias vectors
   static DevOnce attr_once;                          // per device (mdt_kernels.h)
   if (attr_once.first()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tblock_lw<MODE, NPW>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tblock_lw<MODE, NPW, F32>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
   }
-  hipLaunchKernelGGL((k_tblock_lw<MODE, NPW>), dim3((unsigned)((a.M + 63) / 64)), dim3(512), smem, s, a);
+  hipLaunchKernelGGL((k_tblock_lw<MODE, NPW, F32>), dim3((unsigned)((a.M + 63) / 64)), dim3(512), smem, s, a);
   return hipGetLastError();
+}
+
+template <int MODE, int NPW = 0>
+static hipError_t launch_lw(const TBlockArgs& a, hipStream_t s) {
+  return a.wf32 ? launch_lw2<MODE, NPW, true>(a, s) : launch_lw2<MODE, NPW, false>(a, s);   // fp32 fragment tiles: exact fp32 products
 }
 
 bool tblock_lw_supported(const TBlockArgs& a) {

@@ -223,6 +223,8 @@ static const char* validate(const mdt_op& o, int idx, char* buf, size_t nbuf) {
         return bad("cross block needs K/V and at most 64 keys per 16 rows");
       if (!o.a.space || !o.w.space || !o.bias.space) return bad("missing operand");
       if (i[MDT_B_VARIANT] < 0 || i[MDT_B_VARIANT] > 4) return bad("unknown fused-block variant");
+      if (i[MDT_B_WF32] != 0 && (i[MDT_B_WF32] != 1 || i[MDT_B_VARIANT] != 0))
+        return bad("WF32 must be 0 (split-bf16 tiles) or 1 (fp32 fragment tiles; variant 0, the C = 128 kernel, only)");
       if (i[MDT_B_VARIANT] == 1) return bad("variant 1 (16-row feature-split workgroups) was removed; C = 256 blocks are variants 2..4");
       if (i[MDT_B_VARIANT] == 0 && (i[MDT_B_C] != 128 || (i[MDT_B_MODE] == MDT_TB_CROSS && (16 / i[MDT_B_T]) * i[MDT_B_TK] > 16)))
         return bad("variant 0 serves C = 128, cross blocks with at most 16 keys per 16 rows (loader-wave kernel)");
@@ -495,7 +497,7 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
           if (!o.p1.space || B % 2 || (B / 2) % (per_wg > 0 ? per_wg : 1))
             return fail("mdt_program_run: a dual-batch cross block needs the shared K/V rows and B = 2 x (a multiple of the samples per workgroup)");
         }
-        a.post = o.i[MDT_B_POST];
+        a.post = o.i[MDT_B_POST]; a.wf32 = o.i[MDT_B_WF32];
         if (a.post) a.xout = ptr(o.out);
         if (o.i[MDT_B_VARIANT] == 3) { a.part = ptr(o.out); a.nsplit = 2; }
         if (o.i[MDT_B_VARIANT] == 4) {

@@ -234,6 +234,7 @@ struct TBlockArgs {
   //   xout = Wout (x + FF(x)) + bout = (Wout W2) gelu(W1 x + b1) + Wout x + (Wout b2 + bout)
   // the host stores Wout W2 as the W2 tiles, Wout as `post` extra output tiles (natural k order) and the fused bias
   int post;            // number of extra [C][64] output tiles (C / 64), 0 = plain residual feed-forward
+  int wf32;            // 1 (variant 0 only): fp32 fragment tiles, exact fp32 MFMA products (MDT_B_WF32)
   int mode, C, M, T, nchunk, nbias, ldx, Tk, kv_bstride, ldkv, nheads, nsamples;
   float eps, scale;
   const void* pf_ptr;  // weight stream of the NEXT launch (ring kernels: pulled into the L2s by the loader waves), or nullptr

@@ -40,7 +40,7 @@ T_HALF, T_LD = range(2)
 R_T, R_C, R_LDA, R_LDC, R_LDR, R_TAPS, R_GSIZE, R_SILU, R_FILM_LD, R_LDA2, R_WF32, R_KSRC, R_HALF_OUT, R_NB = range(14)
 K_T, K_CIN, K_COUT, K_FILM_LD, K_WF32, K_CIN_REAL, K_COUT_REAL, K_PATCH_IN, K_PATCH_OUT = range(9)
 B_MODE, B_C, B_T, B_NCHUNK, B_NBIAS, B_TK, B_KV_BSTRIDE, B_LDKV, B_HEADS, B_VARIANT, B_POST = range(11)
-B_KV2 = 11
+B_KV2, B_WF32 = 11, 12
 # MDT_OP_TF128 (enum mdt_tf128_i)
 (F_C, F_T, F_NT, F_NVEC, F_TK, F_KV_BSTRIDE, F_LDKV, F_HEADS, F_HAS_IN, F_NBLOCKS, F_NFF, F_NPOST, F_KV2, F_CROSS,
  F_KV_LSTRIDE, F_RES_KIND, F_N_RES, F_RES_PAIR1, F_RES_PAIR2, F_NFILM, F_NSPLIT, F_PAIR_STRIDE, F_WF32) = range(23)

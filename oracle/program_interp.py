@@ -386,7 +386,7 @@ def _tblock(op, bufs: Buffers, B: int) -> None:
 
     def tile(k, rows, cols):
         if i[rt.B_VARIANT] not in (2, 3, 4):
-            return _untile(stream, k, rows, cols)
+            return _untile(stream, k, rows, cols, bool(i[rt.B_WF32]))      # (MDT_B_WF32: fp32 fragment tiles)
         # variant 2 (k_tblock32): every tile is stored as two 128-wide sub-tiles (K halves / output-row halves)
         if rows == 64:
             return torch.cat([_untile(stream, 2 * k, 64, 128), _untile(stream, 2 * k + 1, 64, 128)], dim=1)

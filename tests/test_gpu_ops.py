@@ -733,9 +733,12 @@ def test_gemm_bf16_chain_with_bf16_intermediate():
 @pytest.mark.parametrize("variant", [0, 2, 3])
 @pytest.mark.parametrize("mode", [rt.TB_FF, rt.TB_SELF, rt.TB_CROSS])
 @pytest.mark.parametrize("C,T,B", [(128, 16, 5), (256, 4, 37), (128, 4, 16), (256, 16, 3), (128, 1, 70)])
-def test_fused_transformer_sub_block(mode, C, T, B, variant):
-    """MDT_OP_TBLOCK (k_tblock_lw: variant 0, C = 128; k_tblock32: variants 2 / 3, C = 256) against the interpreter: LayerNorm
-    folding, tile packing, DMA ring, MFMA operand chaining."""
+@pytest.mark.parametrize("products", ["bf16x3", "f32"])
+def test_fused_transformer_sub_block(mode, C, T, B, variant, products):
+    """MDT_OP_TBLOCK (k_tblock_lw: variant 0, C = 128, split-bf16 and -- MDT_B_WF32 -- exact-fp32 products; k_tblock32: variants
+    2 / 3, C = 256) against the interpreter: LayerNorm folding, tile packing, DMA ring, MFMA operand chaining."""
+    if products == "f32" and variant != 0:
+        pytest.skip("fp32 fragment tiles: the C = 128 kernel (variant 0) only")
     from moleculediffusiontransformer_amd.compiler import Ten, UNetCompiler
     from moleculediffusiontransformer_amd.netspec import inverse_unet_config
     cfg = inverse_unet_config(16, 64, 128, 12)
@@ -751,9 +754,10 @@ def test_fused_transformer_sub_block(mode, C, T, B, variant):
           p + "attention.to_out.weight": rnd(C, mid, seed=7, scale=mid ** -0.5), p + "attention.to_out.bias": 0.1 * rnd(C, seed=8),
           p + "0.weight": rnd(2 * C, C, seed=9, scale=C ** -0.5), p + "0.bias": 0.1 * rnd(2 * C, seed=10),
           p + "2.weight": rnd(C, 2 * C, seed=11, scale=(2 * C) ** -0.5), p + "2.bias": 0.1 * rnd(C, seed=12)}
-    comp = UNetCompiler(cfg, 64, n_ctx, sd)
+    comp = UNetCompiler(cfg, 64, n_ctx, sd, gemm_mode=products)
     t = Ten(A, 0, T, C)
     comp.tblock(t, mode, p, 0 if mode == rt.TB_CROSS else None, variant=variant)
+    assert comp.ops[0].i[rt.B_WF32] == int(products == "f32")
     op = comp.ops[0]
     kv_off = T * C
     if mode == rt.TB_CROSS:
