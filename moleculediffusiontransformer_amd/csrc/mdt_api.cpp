@@ -175,8 +175,9 @@ static const char* validate(const mdt_op& o, int idx, char* buf, size_t nbuf) {
                                        o.i[MDT_R_KSRC] > 1 || o.i[MDT_R_LDC] < 128))
         return bad("HALF_OUT: a 256 -> 128 channel convolution without prologue (C = 256, one source)");
       if (o.i[MDT_R_NB] < 0 || o.i[MDT_R_NB] > 8 || (o.i[MDT_R_NB] > 1 && (o.i[MDT_R_GSIZE] || o.a2.space || o.p3.space || o.i[MDT_R_KSRC] > 1 ||
-                                                                         o.i[MDT_R_HALF_OUT] || o.i[MDT_R_LDC] < o.i[MDT_R_NB] * o.i[MDT_R_C])))
-        return bad("NB > 1: NB x C output channels of one source without prologue, LDC >= NB * C");
+                                                                         o.i[MDT_R_HALF_OUT] || o.i[MDT_R_LDC] < o.i[MDT_R_NB] * o.i[MDT_R_C] ||
+                                                                         (o.res.space && o.i[MDT_R_LDR] < o.i[MDT_R_NB] * o.i[MDT_R_C]))))
+        return bad("NB > 1: NB x C output channels of one source without prologue, LDC (and LDR) >= NB * C");
       break;
     case MDT_OP_RESBLOCK:
       if (!mdt::resblock_supported(o.i[MDT_K_T], o.i[MDT_K_CIN], o.i[MDT_K_COUT]))
