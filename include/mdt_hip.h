@@ -142,8 +142,8 @@ enum mdt_op_kind {
                           64 channels on a 2C-channel input, 32 otherwise).  Stream: sub-tiles [64 features][128 k] in (tap, K half,
                           chunk) order per convolution; rows 0..31 of chunk c are output channels 32 c .., rows 32..63 channels
                           128 + 32 c ..; K columns in accumulator order (k-slot 32 st + 8 g + e = channel 16 (2 st + (e >> 2)) + 4 g +
-                          (e & 3)).  Descriptors (HEADS of them, NT tiles in all) are SEGMENTS: kind (2 bits: 0 = a RUN of aux consecutive sub-tiles
-                          of the weight stream, which is stored in consumption order, 1 skip rows of block aux, 2 scratch, 3 scratch + the
+                          (e & 3)).  Descriptors (HEADS of them, NT tiles in all) are SEGMENTS: kind (2 bits: 0 = a RUN of aux >= 1 consecutive sub-tiles
+                          of the weight stream, which is stored in consumption order (aux = 0 is read as 1; the runs and single tiles sum to NT), 1 skip rows of block aux, 2 scratch, 3 scratch + the
                           vectors of block aux) | aux << 2; tile sequence: [3 (block 0)], then per block, kind 1: X nt X nt, kind 2: X nt X
                           8 S X 8 S X nt X nt (block1 on x, to_out on x, to_out on the skip, block1 on the skip, block2; X = 2, or 3 with aux = next block at a block's first X; nt = 8 taps; S = 1).  Vectors
                           per block: kind 1 [g1 | b1 | bias1 | g2 | b2 | bias2], kind 2 [g1 (2C) | b1 (2C) | bias1 | bias_to_out | g2 |
@@ -231,7 +231,10 @@ enum mdt_rconv_i { MDT_R_T = 0, MDT_R_C = 1, MDT_R_LDA = 2, MDT_R_LDC = 3, MDT_R
                    MDT_R_NB = 13 /* > 1 (one source, no prologue): NB * C output channels = NB convolutions of the same rows in one launch
                                       (tile streams, bias, residual and output columns of the blocks follow each other): a
                                       ConvTranspose1d(k = 2 f, stride f) in patch form writes f tokens x channels per input token */ };
-enum mdt_rconv_f { MDT_RF_EPS = 0, MDT_RF_IN_SCALE = 1, MDT_RF_IN_SCALE2 = 2 };
+enum mdt_rconv_f { MDT_RF_EPS = 0, MDT_RF_IN_SCALE = 1 /* factor on the rows of a -- with KSRC > 1 on EVERY K block of a */,
+                   MDT_RF_IN_SCALE2 = 2 /* factor on the rows of a2 */ };
+/* The KSRC > 1, HALF_OUT and NB > 1 forms move rows in 16-byte pieces: LDA, LDC and LDR (when res is bound) must be multiples of 4
+   floats; HALF_OUT needs LDC (and LDR) >= 128, NB needs LDC (and LDR) >= NB * C.  mdt_program_create refuses anything else.      */
 enum mdt_resblock_i { MDT_K_T = 0, MDT_K_CIN = 1, MDT_K_COUT = 2, MDT_K_FILM_LD = 3,
                       MDT_K_WF32 = 4 /* 1: w = fp32 MFMA fragments [step][row tile][half lo][64 lanes][4] (lane (i, g) float r =
                                         W[16 rt + i][the step's pair 8 g + 4 lo + r]), exact fp32 MFMA products */,

@@ -26,7 +26,6 @@ SOURCES = [
     ("k_gemm_b16.hip", []),
     ("k_gemm_as.hip", []),
     # VGPR-form MFMA: keeps the persistent accumulators out of the AGPR shuttle (v_accvgpr_write + s_nop per MFMA)
-    ("k_tblock.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("k_tblock_lw.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("k_tblock32.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("k_tf128.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),

@@ -145,27 +145,20 @@ class UNetCompiler:
     def __init__(self, cfg: UNetConfig, length: int, cond_len: int, sd: Dict[str, torch.Tensor],
                  max_time_rows: int = 1024, gemm_mode: str = "bf16x3", fuse_blocks: bool = True, tf256: bool = False):
         self.fuse_blocks = fuse_blocks
-        self.fuse_c256 = os.environ.get("MDT_FUSE_C256", "1") == "1"
-        self.tb_split = os.environ.get("MDT_TB_SPLIT", "1") == "1"   # ... their heads split over two workgroups
-        self.ff_split = os.environ.get("MDT_FF_SPLIT", "1") == "1"   # ... also the feed-forward's hidden chunks
-        # ... partial sums handed to the next sub-block instead of a reduce launch.  Measured: 2511 molecules/s against
-        # 2578 with the 28 reduce launches (the extra dependent loads in every prologue / epilogue and the ping-pong
-        # buffers cost more than 5.4 us per block), so this is not the default.
-        self.tb_chain = os.environ.get("MDT_TB_CHAIN", "1") == "1"
+        # (Round 6: the second-order switches MDT_FUSE_C256 / MDT_TB_SPLIT / MDT_FF_SPLIT / MDT_TB_CHAIN / MDT_FUSE_CROSS /
+        #  MDT_CONVT_MERGE / MDT_GN_ACT -- fallbacks OF fallbacks that no default program reached and no test flipped -- are gone
+        #  with their branches: the C = 256 sub-block launches always split heads / hidden chunks over two workgroups and chain
+        #  their partial sums, the ConvTranspose phases of the GEMM form are one launch, GroupNorm-apply is k_gn_act where it fits.)
         self.use_rconv = os.environ.get("MDT_RCONV", "1") == "1"     # row-stationary convs (k_rconv) at C = 128 / 256
         self.use_resblock = os.environ.get("MDT_RESBLOCK", "1") == "1"   # Patcher / Unpatcher ResNets as ONE launch (k_resblock)
         self.t1_fold = os.environ.get("MDT_T1_FOLD", "1") == "1"   # self-attention over one token per sample as one folded GEMM
         self.ctx_split = os.environ.get("MDT_CTX_SPLIT", "1") == "1"   # k_attn_ctx: split-bf16 scores in the split-bf16 mode
-        self.convt_merge = os.environ.get("MDT_CONVT_MERGE", "1") == "1"   # ConvTranspose phases in one launch
         # Transformer1d's closing 1x1 convolution folded into its last feed-forward block (ring kernels only)
         self.fold_out = os.environ.get("MDT_FOLD_OUT", "1") == "1"
         self.rconv_two = os.environ.get("MDT_RCONV2", "k1") == "1"   # concatenated inputs as ONE two-source launch ...
         self.rconv_two_k1 = os.environ.get("MDT_RCONV2", "k1") in ("1", "k1")   # ... only their 1x1 residual convolution
-        # cross-attention sub-blocks: "1" fuses the shapes whose K/V rows stream through the loader-wave ring
-        # (k_tblock_lw: C = 128, at most 16 context rows per 16 token rows; k_tblock32: C = 256, at most 48),
-        # "all" also the older kernels' shapes
-        self.fuse_cross = os.environ.get("MDT_FUSE_CROSS", "1")
-        self.use_gn_act = os.environ.get("MDT_GN_ACT", "1") == "1"
+        # (cross-attention sub-blocks fuse where their K/V rows stream through the loader-wave ring: k_tblock_lw: C = 128, at most
+        #  16 context rows per 16 token rows; k_tblock32: C = 256, at most 48)
         # cross-attention layers that run layer by layer over MANY keys (QMDiffusionForward: 64): fold the key / value
         # projections into the query / output projections and attend to the normalised context itself
         # ResNet blocks of a 128-channel level inside the transformer launch that follows them (k_tf128 RES = 1 / 2)
@@ -775,7 +768,7 @@ class UNetCompiler:
         h = self._new(x.rows, cout_p, cout)
         w1 = self._conv_w(p + "block1.project.weight", cin_p, cout_p)
         bias1 = self._vec(p + "block1.project.bias", cout_p)
-        if self.use_gn_act and self.gn_act_ok(x.rows, cin_p, groups, cin // groups):
+        if self.gn_act_ok(x.rows, cin_p, groups, cin // groups):
             # fused normalise + SiLU pass, then a plain conv GEMM (the prologue form recomputes the transform
             # 3 taps x N/64 column tiles times per element and is VALU-bound)
             a1 = self.gn_act(x, groups, cin // groups, 1e-5, g1, b1, True)
@@ -801,7 +794,7 @@ class UNetCompiler:
         g2, b2 = self._vec(p + "block2.groupnorm.weight", cout_p), self._vec(p + "block2.groupnorm.bias", cout_p)
         w2 = self._conv_w(p + "block2.project.weight", cout_p, cout_p)
         bias2 = self._vec(p + "block2.project.bias", cout_p)
-        if self.use_gn_act and self.gn_act_ok(h.rows, cout_p, groups, cout // groups):
+        if self.gn_act_ok(h.rows, cout_p, groups, cout // groups):
             a2 = self.gn_act(h, groups, cout // groups, 1e-5, g2, b2, True, film=("ss", ss_off))
             self.gemm(a2, w2, cout_p, y, cin=cout_p, bias_off=bias2, taps=3, t_dj=1, t_off=-1, res=r)
             self._free(a2)
@@ -821,7 +814,7 @@ class UNetCompiler:
     # ------------------------------------------------------------------ fused transformer sub-blocks
     # slot order of the output-projection K dimension: the kernel takes the B operand straight from the
     # accumulator registers of the previous MFMA, which hold feature d = 32 sp + 16 (e >> 2) + 4 g + (e & 3)
-    # in k-slot sigma = 32 sp + 8 g + e (csrc/k_tblock.hip)
+    # in k-slot sigma = 32 sp + 8 g + e (csrc/k_tblock_lw.hip)
     _SLOT_PERM = [32 * (s >> 5) + 16 * ((s & 7) >> 2) + 4 * ((s >> 3) & 3) + (s & 3) for s in range(64)]
 
     def can_fuse_transformer(self, c: int, rows: int, cross: bool) -> bool:
@@ -830,8 +823,6 @@ class UNetCompiler:
         if not (self.gemm_mode == "bf16x3" or (self.wf32 and c == 128)) or not self.fuse_blocks:
             return False
         if c not in (128, 256) or rows > 16 or 16 % rows or self.cfg.head_features != 64:
-            return False
-        if c == 256 and not self.fuse_c256:
             return False
         if (c * self.cfg.ff_mult) % 64:
             return False
@@ -1533,7 +1524,7 @@ class UNetCompiler:
         if self.rconv_ok(x.rows, c, 1, c // 32):
             self.rconv(x, self.sd[p + "to_in.1.weight"], p + "to_in.1.weight", t, taps=1, bias_off=bias_i,
                        gn=(gi, bi, c // 32, 1e-6, False))
-        elif self.use_gn_act and self.gn_act_ok(x.rows, c, 32, c // 32):
+        elif self.gn_act_ok(x.rows, c, 32, c // 32):
             xa = self.gn_act(x, 32, c // 32, 1e-6, gi, bi, False)
             self.gemm(xa, wi, c, t, cin=c, bias_off=bias_i)
             self._free(xa)
@@ -1552,12 +1543,12 @@ class UNetCompiler:
         #   C = 256, 32-row workgroups + loader waves (k_tblock32, self-attention / feed-forward only): the 16-row form
         #                         sits on the L2 -> LDS bandwidth roof (its weight stream is read by 256 workgroups)
         variant = 2 if c == 256 else 0
-        split = 3 if (variant == 2 and self.tb_split) else variant     # self / cross: two workgroups per row block
+        split = 3 if variant == 2 else variant     # self / cross: two workgroups per row block
         keys16 = (16 // t.rows) * self.n_ctx                        # context rows per 16 token rows
         ring_x = (c == 128 and keys16 <= 16) or (variant == 2 and keys16 <= 48)
         # C = 256: the sub-blocks of a transformer hand the residual stream on as (x, second head group's partial)
         # through ping-pong buffers, so the head split needs no reduce launch (every sub-block must be a ring kernel)
-        chain = fused and split == 3 and self.tb_chain and (not cross or (self.fuse_cross == "1" and ring_x))
+        chain = fused and split == 3 and (not cross or ring_x)
         pend: Optional[Ten] = None
         y_fold: Optional[Ten] = None
         for i in range(layers):
@@ -1567,9 +1558,9 @@ class UNetCompiler:
                 if cross:
                     self.cross_layers.append(bp + "cross_attention.")
                     steps.append((rt.TB_CROSS, bp + "cross_attention.", len(self.cross_layers) - 1, True))
-                # the hidden chunks of a feed-forward block split like heads (MDT_FF_SPLIT), except in the transformer's last
+                # the hidden chunks of a feed-forward block split like heads, except in the transformer's last
                 # block, whose output leaves the chain (and may carry the folded closing convolution)
-                steps.append((rt.TB_FF, bp + "feed_forward.", None, self.ff_split and i + 1 < layers))
+                steps.append((rt.TB_FF, bp + "feed_forward.", None, i + 1 < layers))
                 for mode, name, ci, two in steps:
                     last_ff = mode == rt.TB_FF and i == layers - 1 and self.fold_out
                     nxt = y_out if (last_ff and y_out is not None) else self._new(t.rows, c)
@@ -1594,7 +1585,7 @@ class UNetCompiler:
                 if cross:
                     self.cross_layers.append(bp + "cross_attention.")
                     xv = split
-                    if self.fuse_cross == "1" and ring_x:
+                    if ring_x:
                         self.tblock(t, rt.TB_CROSS, bp + "cross_attention.", len(self.cross_layers) - 1,
                                     variant=xv)
                     elif self.fold_ok():
@@ -1604,7 +1595,7 @@ class UNetCompiler:
                         # q-GEMM + attention + out-GEMM (the pre-ring fused cross kernels measured slower than this:
                         # 78 us against ~62 us, their per-head K/V loads were not pipelined)
                         self.attention_layer(t, bp + "cross_attention.", len(self.cross_layers) - 1)
-                ffv = split if self.ff_split else variant
+                ffv = split
                 if i == layers - 1 and self.fold_out and ffv in (0, 2):
                     y_fold = y_out if y_out is not None else self._new(t.rows, c)
                     self.tblock(t, rt.TB_FF, bp + "feed_forward.", variant=ffv,
@@ -1825,20 +1816,13 @@ class UNetCompiler:
             res = skips_list[0][0] if last else None       # `x += skips_list.pop()` (modules.py:1176)
             if self.up_patch_ok(x, ci, co, f, res):
                 self.up_patch(x, up, ci, co, f, y, res)
-            elif self.convt_merge:
+            else:
                 # all f phases in ONE launch (grid.z = phase): each phase alone is a 64..256-workgroup GEMM that runs
                 # at launch latency, and the phases are independent
                 wall = torch.cat([torch.stack((wt[:, :, ph], wt[:, :, ph + f]), dim=0).permute(2, 0, 1).reshape(co, 2 * ci)
                                   for ph in range(f)])                                       # [f * Cout][2 * Cin]
                 self.gemm(x, (f"{up}upsample.weight/phases", wall), co, y, cin=ci, bias_off=bias, taps=2, t_stride=1,
                           t_dj=-1, t_off=0, r_out=x.rows, o_stride=f, o_off=0, res=res, phases=f)
-            else:
-                for ph in range(f):
-                    shift = 1 if ph < f // 2 else 0
-                    wp = torch.stack((wt[:, :, ph], wt[:, :, ph + f]), dim=0).permute(2, 0, 1)   # [Cout][2][Cin]
-                    self.gemm(x, (f"{up}upsample.weight/phase{ph}", wp.reshape(co, 2 * ci)), co, y, cin=ci, bias_off=bias,
-                              taps=2, t_stride=1, t_dj=-1, t_off=shift, r_out=x.rows, o_stride=f,
-                              o_off=f * shift + ph - f // 2, res=res)
             self._free(x)
             x = y
         self._free(skips_list.pop()[0])

@@ -220,7 +220,7 @@ static hipError_t launch_as(const GemmArgs& g, hipStream_t s) {
   const int nsteps = (g.N + AS_BN - 1) / AS_BN;
   int nsplit = 1;
   while (mt * nsplit < 256 && nsplit * 2 <= nsteps) nsplit *= 2;    // fill the 256 CUs when M is small
-  static const int dbg = getenv("MDT_DBG") ? atoi(getenv("MDT_DBG")) : 0;   // ablation switches (tuning aid)
+  static const int dbg = mdt_tuning_env("MDT_DBG") ? atoi(mdt_tuning_env("MDT_DBG")) : 0;   // ablation switches (tuning aid)
   hipLaunchKernelGGL((k_gemm_as<PRO, KC>), dim3((unsigned)(mt * nsplit)), dim3(256), smem, s, g, nsplit, dbg);
   return hipGetLastError();
 }

@@ -253,7 +253,7 @@ hipError_t launch_gemm_b16(const Gemm16Args& g, hipStream_t s) {
   static int force0 = -2;
   if (force0 == -2) {
     force0 = -1;
-    if (const char* e = getenv("MDT_TILE16")) force0 = atoi(e);
+    if (const char* e = mdt_tuning_env("MDT_TILE16")) force0 = atoi(e);
   }
   const int force = g_force_tile16 >= 0 ? g_force_tile16 : force0;
   auto tiles = [&](int bm, int bn) { return (int64_t)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn); };

@@ -342,7 +342,7 @@ template <int PRO>
 static hipError_t launch3_pro(const GemmArgs& g, hipStream_t s) {
   if (g_force_cfg == -2) {
     g_force_cfg = -1;
-    if (const char* e = getenv("MDT_TILE")) sscanf(e, "%d,%d", &g_force_cfg, &g_force_stages);
+    if (const char* e = mdt_tuning_env("MDT_TILE")) sscanf(e, "%d,%d", &g_force_cfg, &g_force_stages);
   }
   // Tile choice: the largest tile that still yields >= 2 workgroups per CU (256 CUs); otherwise 64x64 tiles
   // with the deepest K chunk the channel count allows (fewest iterations for the latency-bound small layers).
@@ -384,7 +384,7 @@ static hipError_t launch1_pro(const GemmArgs& g, hipStream_t s) {
   static int force_cfg = -2, force_stages = 0;
   if (force_cfg == -2) {
     force_cfg = -1;
-    if (const char* e = getenv("MDT_TILE1")) sscanf(e, "%d,%d", &force_cfg, &force_stages);
+    if (const char* e = mdt_tuning_env("MDT_TILE1")) sscanf(e, "%d,%d", &force_cfg, &force_stages);
   }
   auto tiles = [&](int bm, int bn) {
     return (int64_t)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * (g.phases > 1 ? g.phases : 1);

@@ -237,7 +237,7 @@ __global__ __launch_bounds__(512) void k_res256(TFArgs a) {
         const unsigned d = tiles[c.seg];
         c.kind = d & 3u;
         c.aux = d >> 2;
-        c.rem = c.kind == D_W ? (int)c.aux : 1;
+        c.rem = c.kind == D_W ? max((int)c.aux, 1) : 1;   // a weight segment has aux >= 1 (mdt_hip.h); a 0 would never count down
       } else {
         c.kind = D_X;                                  // past the end: nothing to issue, nothing in flight
         c.aux = 0;

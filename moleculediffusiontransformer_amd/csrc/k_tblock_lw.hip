@@ -1,4 +1,4 @@
-// Fused transformer sub-blocks (see k_tblock.hip for the maths and the register-chained layout), C = 128,
+// Fused transformer sub-blocks (MDT_OP_TBLOCK variant 0; the maths and the register-chained layout: DESIGN.md 3.1), C = 128,
 // 64-row workgroups, restructured around two measurements on gfx950 (tools/ubench/proj_phase.hip):
 //
 //   * with one wave per SIMD, an LDS-DMA instruction costs its issuing wave ~60 cycles, so the 8 pieces per tile
@@ -56,7 +56,7 @@ enum { K_T = 0, K_N = 1, K_O = 2 };   // transposed projection, un-transposed pr
 #define MDT_MFMA_BF16 __builtin_amdgcn_mfma_f32_16x16x32_bf16
 #define MDT_MFMA_F32 __builtin_amdgcn_mfma_f32_16x16x4f32
 
-__device__ __forceinline__ float gelu_lw(float x) {   // exact-erf GELU, branch-free erf (A&S 7.1.26), see k_tblock.hip
+__device__ __forceinline__ float gelu_lw(float x) {   // exact-erf GELU, branch-free erf (A&S 7.1.26, |error| < 1.5e-7)
   const float z = fabsf(x) * 0.70710678118654752440f;
   const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
   const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(512) void k_tblock_lw(TBlockArgs a) {
     // ================= loader waves: the weight stream =================
     // Piece `inst` (= iw + 4 q) fills slot bytes [inst*1024, +1024), lane l supplies bytes inst*1024 + 16 l.  The
     // XOR swizzle that makes the fragment reads conflict-free is applied through the SOURCE address
-    // (k_tblock.hip spells out the factorisation into a lane-only and a wave-uniform part).
+    // (the address factors into a lane-only and a wave-uniform part).
     const int iw = wave - 4;
     __builtin_amdgcn_s_setprio(3);   // few instructions, all on the critical path of the stream: issue ahead of the MFMA waves
     const int lpP = lane >> 5;

@@ -95,7 +95,7 @@ enum { D_P = 0, D_O = 1, D_K = 2, D_V = 3, D_SCRATCH = 4, D_SCRATCH_VEC = 5 };  
 #define MDT_MFMA_BF16 __builtin_amdgcn_mfma_f32_16x16x32_bf16
 #define MDT_MFMA_F32 __builtin_amdgcn_mfma_f32_16x16x4f32
 
-__device__ __forceinline__ float gelu_tf(float x) {   // exact-erf GELU, branch-free erf (A&S 7.1.26), see k_tblock.hip
+__device__ __forceinline__ float gelu_tf(float x) {   // exact-erf GELU, branch-free erf (A&S 7.1.26, |error| < 1.5e-7)
   const float z = fabsf(x) * 0.70710678118654752440f;
   const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
   const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));

@@ -122,8 +122,10 @@ static const char* validate(const mdt_op& o, int idx, char* buf, size_t nbuf) {
         if (!mdt::proj_supported(i[MDT_G_CIN], i[MDT_G_N], i[MDT_G_LDA], i[MDT_G_LDC], o.res.space ? i[MDT_G_LDR] : 0) || o.a2.space)
           return bad("ring-tile projection needs cin in {128, 256}, N % 64 == 0, 16-byte aligned rows and no lo plane (the tiles hold both)");
         if (i[MDT_G_PRO] > 1 || i[MDT_G_TAPS] != 1 || i[MDT_G_T_STRIDE] != 1 || i[MDT_G_T_OFF] || i[MDT_G_PHASES] > 1 || i[MDT_G_O_STRIDE] != 1 ||
-            i[MDT_G_O_OFF] || i[MDT_G_R_OUT] != i[MDT_G_R_IN] || i[MDT_G_O_ROWS] != i[MDT_G_R_OUT] || i[MDT_G_ACT] || i[MDT_G_O_COL] % 4)
-          return bad("ring-tile projection: LayerNorm or no prologue, one tap, no stride / phases / output row mapping / activation");
+            i[MDT_G_O_OFF] || i[MDT_G_R_OUT] != i[MDT_G_R_IN] || i[MDT_G_O_ROWS] != i[MDT_G_R_OUT] || i[MDT_G_ACT] || i[MDT_G_O_COL] % 4 ||
+            i[MDT_G_A_COL] % 4)
+          return bad("ring-tile projection: LayerNorm or no prologue, one tap, no stride / phases / output row mapping / activation, "
+                     "A_COL and O_COL multiples of 4 (16-byte row pieces)");
       }
       if (i[MDT_G_WFMT] == 10 && (!o.p0.space || i[MDT_G_O_COL] || i[MDT_G_N] % 2)) return bad("bf16 copy needs its tensor (p0) and whole rows");
       if (i[MDT_G_WFMT] & 2) {
@@ -172,8 +174,12 @@ static const char* validate(const mdt_op& o, int idx, char* buf, size_t nbuf) {
                                                                o.a2.space || o.p3.space || o.i[MDT_R_LDA] < 1024)))
         return bad("KSRC > 2 is a plain K = 1024 projection: KSRC * C == 1024, one tap, no GroupNorm / FiLM / second source");
       if (o.i[MDT_R_HALF_OUT] != 0 && (o.i[MDT_R_HALF_OUT] != 1 || o.i[MDT_R_C] != 256 || o.i[MDT_R_GSIZE] || o.a2.space || o.p3.space ||
-                                       o.i[MDT_R_KSRC] > 1 || o.i[MDT_R_LDC] < 128))
-        return bad("HALF_OUT: a 256 -> 128 channel convolution without prologue (C = 256, one source)");
+                                       o.i[MDT_R_KSRC] > 1 || o.i[MDT_R_LDC] < 128 || (o.res.space && o.i[MDT_R_LDR] < 128)))
+        return bad("HALF_OUT: a 256 -> 128 channel convolution without prologue (C = 256, one source), LDC (and LDR) >= 128");
+      // the K-block / half-output / output-block forms read and write rows in 16-byte pieces at out + m * LDC (res + m * LDR)
+      if ((o.i[MDT_R_KSRC] > 1 || o.i[MDT_R_HALF_OUT] || o.i[MDT_R_NB] > 1) &&
+          (o.i[MDT_R_LDC] % 4 || o.i[MDT_R_LDA] % 4 || (o.res.space && o.i[MDT_R_LDR] % 4)))
+        return bad("KSRC / HALF_OUT / NB forms: LDA, LDC and LDR must be multiples of 4 floats (16-byte row pieces)");
       if (o.i[MDT_R_NB] < 0 || o.i[MDT_R_NB] > 8 || (o.i[MDT_R_NB] > 1 && (o.i[MDT_R_GSIZE] || o.a2.space || o.p3.space || o.i[MDT_R_KSRC] > 1 ||
                                                                          o.i[MDT_R_HALF_OUT] || o.i[MDT_R_LDC] < o.i[MDT_R_NB] * o.i[MDT_R_C] ||
                                                                          (o.res.space && o.i[MDT_R_LDR] < o.i[MDT_R_NB] * o.i[MDT_R_C]))))
@@ -345,7 +351,7 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
     }
   };
 
-  static const bool no_prefetch = getenv("MDT_NO_PREFETCH") != nullptr;     // tuning aid: no next-launch weight prefetch
+  static const bool no_prefetch = mdt_tuning_env("MDT_NO_PREFETCH") != nullptr;     // tuning aid: no next-launch weight prefetch
   for (int idx = first; idx < last; ++idx) {
     const mdt_op& o = p->ops[idx];
     hipError_t e = hipSuccess;
@@ -392,7 +398,7 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
           h.copy16 = (i[MDT_G_WFMT] & 8) ? reinterpret_cast<unsigned short*>(ptr(o.p0)) : nullptr;
           e = mdt::launch_gemm_b16(h, stream);
         } else if (!missing) {
-          static const bool no_as = getenv("MDT_NO_AS") != nullptr;   // tuning aid: disable the A-stationary kernel
+          static const bool no_as = mdt_tuning_env("MDT_NO_AS") != nullptr;   // tuning aid: disable the A-stationary kernel
           if (i[MDT_G_WFMT] == 1) e = mdt::launch_gemm_bf16(g, stream);
           else if (!g.W_lo) e = mdt::launch_gemm(g, stream);
           else if (!no_as && mdt::gemm_as_eligible(g)) e = mdt::launch_gemm_as(g, stream);
@@ -506,7 +512,7 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
           a.nsplit = o.p2.space ? 2 : 1;
         }
         if (!missing)
-          e = o.i[MDT_B_VARIANT] >= 2 ? mdt::launch_tblock32(a, stream) : mdt::launch_tblock(a, stream);
+          e = o.i[MDT_B_VARIANT] >= 2 ? mdt::launch_tblock32(a, stream) : mdt::launch_tblock_lw(a, stream);
         break;
       }
       case MDT_OP_TF128:

@@ -16,6 +16,19 @@
 #endif
 #define MDT_ABI_TUNING_BIT 0x40000000
 
+#include <cstdlib>
+// Environment switches of the TUNING tools (MDT_TILE / MDT_TILE1 / MDT_TILE16: force a GEMM tile; MDT_NO_AS / MDT_NO_PREFETCH:
+// disable a kernel form; MDT_DBG: ablation bits of k_gemm_as): read by -DMDT_TUNING builds only.  The shipped library ignores
+// them -- a configuration nobody tests cannot be reached by setting a variable.
+static inline const char* mdt_tuning_env(const char* name) {
+#ifdef MDT_TUNING
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
+
 // priority of the loader waves of the ring kernels (s_setprio): 3 = their few instructions issue ahead of the MFMA waves
 #ifndef MDT_LOADER_PRIO
 #define MDT_LOADER_PRIO 3
@@ -240,7 +253,6 @@ struct TBlockArgs {
   const void* pf_ptr;  // weight stream of the NEXT launch (ring kernels: pulled into the L2s by the loader waves), or nullptr
   int pf_lines;
 };
-hipError_t launch_tblock(const TBlockArgs& a, hipStream_t s);     // variant 0: k_tblock_lw where it applies (k_tblock.hip)
 bool tblock_lw_supported(const TBlockArgs& a);                  // k_tblock_lw.hip: C = 128 self-attention / feed-forward
 hipError_t launch_tblock_lw(const TBlockArgs& a, hipStream_t s);
 hipError_t launch_tblock32(const TBlockArgs& a, hipStream_t s);   // 32-row workgroups, C = 256, sub-tile stream (k_tblock32.hip)

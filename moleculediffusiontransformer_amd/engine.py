@@ -113,7 +113,11 @@ class UNetEngine:
         if torch.cuda.is_current_stream_capturing():
             # inside a user's graph capture (torch.ops.mdt.unet_eval in a captured region): a host wait would invalidate the
             # capture, and the copy would be replayed into stale pinned memory.  The status word stays on the device; the next
-            # un-captured call -- or handoff_status() -- reports a time-out of the replays.
+            # un-captured call -- or handoff_status() -- reports a time-out of the replays.  The capture is REMEMBERED:
+            # the next un-captured note_handoff() / handoff_check() says that the word may stem from replays of that graph
+            # (without this, the next plain call was blamed for a time-out that happened in a replay).  Sticky: the
+            # engine cannot know when that graph is replayed.
+            self._xstat_captured = True
             return
         self._xstat_host.copy_(self.xflags[:1], non_blocking=True)
         self._xstat_event.record()
@@ -124,7 +128,14 @@ class UNetEngine:
     def handoff_check(self, wait: bool = False) -> None:
         """Raises RuntimeError if a call noted by note_handoff() had a hand-off time-out (and clears the word)."""
         if not getattr(self, "_xstat_pending", False):
-            return
+            if getattr(self, "_xstat_captured", False) and wait and getattr(self, "xflags", None) is not None \
+                    and not torch.cuda.is_current_stream_capturing():
+                # evaluations were captured into a caller's graph and nothing has looked at the status word since: look now
+                self._xstat_host.copy_(self.xflags[:1], non_blocking=True)
+                self._xstat_event.record()
+                self._xstat_pending = True
+            else:
+                return
         if wait:
             self._xstat_event.synchronize()
         if not self._xstat_event.query():
@@ -134,6 +145,8 @@ class UNetEngine:
             if getattr(self, "xflags", None) is not None:
                 self.xflags[0] = 0
             when = "this" if wait else "the PREVIOUS"
+            if getattr(self, "_xstat_captured", False):
+                when = "this call OR of a replay of a graph that captured evaluations of this engine since the last check; every such"
             raise RuntimeError(f"a pair hand-off inside a 256-channel transformer launch timed out (a partner workgroup was not "
                                f"scheduled within 0.3 s): the results of {when} call are invalid.  The pair-split launches need "
                                "their workgroups resident at the same time (compute units taken by another stream or process?); "

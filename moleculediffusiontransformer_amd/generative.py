@@ -396,16 +396,18 @@ def tokens_to_forward_input(tokens: Tensor, max_length: int, X_norm_factor: floa
     predict_properties_from_SMILES :425-429 texts_to_sequences + pad_sequences(maxlen, padding='post',
     truncating='post') / X_norm_factor), restated on token ids: id 0 is "no character" (keras' sequences_to_texts skips
     it), so every row is compacted to its non-zero ids in order, truncated / zero-padded at the end to ``max_length`` and
-    scaled.  Assumes every id 1..pred_dim-1 is in the tokenizer's vocabulary (as produced by the one-hot training data)."""
+    scaled.  Assumes every id 1..pred_dim-1 is in the tokenizer's vocabulary (as produced by the one-hot training data).
+    Pinned bit for bit by tests/golden/token_chain.npz (the reference's own two functions over a restated keras tokenizer)."""
     tok = tokens.long()
     B, L = tok.shape
     keep = tok != 0
     order = torch.argsort((~keep).to(torch.int8), dim=1, stable=True)          # non-zero ids first, original order kept
     packed = torch.gather(tok * keep, 1, order)
-    out = torch.zeros(B, max_length, dtype=torch.float32, device=tok.device)
+    out = torch.zeros(B, max_length, dtype=torch.float64, device=tok.device)
     n = min(L, max_length)
-    out[:, :n] = packed[:, :n].float()
-    return out / X_norm_factor
+    out[:, :n] = packed[:, :n].double()
+    # the reference divides the int32 array by X_norm_factor in float64 (numpy) and torch.Tensor() rounds to fp32 (generative.py:428-429)
+    return (out / X_norm_factor).float()
 
 
 def predict_properties_from_tokens(model_forward: "QMDiffusionForward", tokens: Tensor, device, cond_scale: float = 1.0,

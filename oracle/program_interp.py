@@ -254,7 +254,7 @@ def _rconv(op, bufs: Buffers, B: int) -> None:
     ksrc = i[rt.R_KSRC]
     if ksrc > 1:                                        # K = ksrc C projection: consecutive C-channel blocks of ONE tensor
         xa = bufs.view(op.a, B, B * T * lda).view(B, T, lda)
-        srcs = [xa[:, :, s_ * C: (s_ + 1) * C] for s_ in range(ksrc)]
+        srcs = [xa[:, :, s_ * C: (s_ + 1) * C] * float(f[1]) for s_ in range(ksrc)]      # every K block x IN_SCALE, as k_rconv does
     else:
         srcs = [(bufs.view(op.a, B, B * T * lda).view(B, T, lda)[:, :, :C] * float(f[1]))]
     if ksrc <= 1 and op.a2.space != rt.SP_NONE:         # second half of a concatenated input

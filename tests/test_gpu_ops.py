@@ -953,6 +953,34 @@ def test_fused_resnet_block(cin, cout, B, film, prod):
     assert (og.view(B, 64, cout_p)[:, :, cout:] == 0).all()
 
 
+@pytest.mark.parametrize("cin,cout,pin,pout", [(16, 64, 1, 4), (64, 16, 4, 1), (16, 16, 2, 2), (2, 16, 1, 2), (16, 1, 2, 1), (8, 16, 1, 4),
+                                               (16, 8, 4, 1)])
+@pytest.mark.parametrize("B", [1, 7, 1030])
+def test_fused_resnet_block_with_folded_patch_rearranges(cin, cout, pin, pout, B, prod):
+    """MDT_K_PATCH_IN / MDT_K_PATCH_OUT: the Unpatcher's / Patcher's `b (c p) l <-> b c (l p)` rearranges
+    (modules.py:208-257) as the load / store pattern of k_resblock, op by op against the interpreter AND against the closed form
+    with the rearrange applied by torch: odd B (half a workgroup idle, the B - 1 clamp of the two-samples-per-workgroup tail),
+    1030 samples (the persistent loop wraps), p in {2, 4}, padded channel counts together with patching."""
+    comp, op, shr, closed_form = _resblock_case(cin, cout, True)
+    op.i[rt.K_PATCH_IN], op.i[rt.K_PATCH_OUT] = pin, pout
+    cin_p, cout_p = (cin + 15) // 16 * 16, (cout + 15) // 16 * 16
+    n_in, n_out = B * 64 * cin_p, B * 64 * cout_p
+    x = torch.zeros(B, 64, cin_p)                        # the block's input in plain [T][C] form
+    x[:, :, :cin] = (rnd(B * 64 * cin, seed=12) * 1.5 + 0.3).view(B, 64, cin)
+    # PATCH_IN: a[l][c p + q] = x[l p + q][c]
+    a = x.view(B, 64 // pin, pin, cin_p).permute(0, 1, 3, 2).reshape(B, 64, cin_p) if pin > 1 else x
+    act = torch.cat([a.reshape(-1), torch.full((n_out,), 7.0)])
+    (ga, _, _), (ca, _, _) = run_both([op], comp.W.pack(), act, shr, {}, B)
+    og, oc = ga[n_in:], ca[n_in:]
+    scale = max(1.0, oc.abs().max().item())
+    assert torch.isfinite(og).all() and (og - oc).abs().max() < 1e-4 * scale, (og - oc).abs().max().item()
+    assert torch.equal(ga[:n_in], ca[:n_in])
+    y = closed_form(x[:, :, :cin])                       # [B, 64, cout]
+    o = og.view(B, 64 // pout, cout_p, pout).permute(0, 1, 3, 2).reshape(B, 64, cout_p) if pout > 1 else og.view(B, 64, cout_p)
+    assert (o[:, :, :cout] - y).abs().max() < 1e-4 * scale
+    assert (o[:, :, cout:] == 0).all()
+
+
 @pytest.mark.parametrize("mode,split,with_pin", [(rt.TB_SELF, True, False), (rt.TB_SELF, True, True), (rt.TB_CROSS, True, True),
                                                  (rt.TB_FF, False, True), (rt.TB_FF, False, False)])
 @pytest.mark.parametrize("T,B", [(4, 37), (16, 3)])

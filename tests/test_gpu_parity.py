@@ -33,6 +33,7 @@ def models(request):
             cache[case] = make_model(case)
             cache[case].gemm_mode = mode
         return cache[case]
+    get.mode = mode
     yield get
     if old is None:
         del os.environ["MDT_F32_FUSED"]
@@ -51,11 +52,18 @@ def test_unet_eval_and_denoise_match_reference(models, case):
         y = m.unet(x[b:b + 1], t[b:b + 1], embedding=emb[b:b + 1], embedding_scale=1.0)
         assert (y.cpu() - to_t(g["y_scale1"])[b:b + 1]).abs().max() < 5e-5, (case, b)
         y = m.unet(x[b:b + 1], t[b:b + 1], embedding=emb[b:b + 1], embedding_scale=7.5)
-        # guidance multiplies the difference of two passes by 7.5: the bound is 7.5 x (error of either pass, < 5e-5 above), measured
-        # 0.4e-4 .. 2.7e-4 over the seven models (rounding noise: 1.8e-4 / 2.7e-4 for the same row with the round-4 / round-5 projections)
-        assert (y.cpu() - to_t(g["y_scale7p5"])[b:b + 1]).abs().max() < 4e-4, (case, b)
+        # Guidance returns 7.5 out - 6.5 out_masked (modules.py:1248-1253) of two passes.  Exact-fp32 products hold the 1e-4 contract on
+        # this raw network output too.  Split-bf16: each pass is within 5e-5 (asserted above), so the mix is within 14 x 5e-5 = 7e-4 in the
+        # worst case and 7.5 x 5e-5 = 3.75e-4 when the two passes' errors are alike; measured 0.4e-4 .. 2.7e-4 over the seven models.
+        # The quantity with a contract is what the sampler consumes -- c_skip x + c_out net(), asserted at 1e-4 for every mode below.
+        bound = 1e-4 if models.mode == "f32" else 4e-4
+        assert (y.cpu() - to_t(g["y_scale7p5"])[b:b + 1]).abs().max() < bound, (case, b, models.mode)
     d = m.diffusion.diffusion.denoise_fn(x * 2.5, sigma=torch.tensor(2.5), embedding=emb, embedding_scale=1.0)
     assert (d.cpu() - to_t(g["denoise_sigma2p5"])).abs().max() < 5e-5
+    # denoise_fn UNDER GUIDANCE (diffusion.py:798-814 over modules.py:1248-1253) against the reference: the 1e-4 contract, all modes
+    d = m.diffusion.diffusion.denoise_fn(x * 2.5, sigma=torch.tensor(2.5), embedding=emb, embedding_scale=7.5)
+    gd = load_golden("guided_denoise.npz")[f"{case}_denoise_sigma2p5_scale7p5"]
+    assert (d.cpu() - to_t(gd)).abs().max() < TOL, (case, models.mode)
 
 
 @pytest.mark.parametrize("name,case,want", [

@@ -98,6 +98,47 @@ def test_inverse_to_forward_chain_stays_on_the_device():
     assert torch.equal(again, props)
 
 
+def test_token_chain_matches_the_reference_fixture():
+    """SURVEY 8 (f3), second half, PINNED: token ids -> forward input -> forward model -> properties against
+    tests/golden/token_chain.npz, which the reference's own reverse_tokenize / predict_properties_from_SMILES
+    (generative.py:1069-1078, :404-451) produced over a restated keras tokenizer (tests/golden/make_golden_r6.py)."""
+    from moleculediffusiontransformer_amd import tokens_to_forward_input
+    g = load_golden("token_chain.npz")
+    ids, L, xn, T = to_t(g["ids"]), int(g["max_length"]), float(g["X_norm_factor"]), int(g["timesteps"])
+    data = tokens_to_forward_input(ids.to(DEV), L, xn)
+    assert torch.equal(data.cpu(), to_t(g["forward_input"]))               # integer / byte work: bit-exact
+    fwd = make_model("cfg3")
+    init, step = noise_fns("r6_chain_t10", (ids.shape[0], 1, L))
+    props = predict_properties_from_tokens(fwd, ids, DEV, cond_scale=1.0, timesteps=T, X_norm_factor=xn,
+                                           context_embedding_max_length=12,
+                                           noise=NoiseSource(init=init, steps=lambda i: step(i, init)))
+    assert props.shape == (5, 12) and (props.cpu() - to_t(g["result"])).abs().max() < 1e-4
+
+
+def test_handoff_status_of_captured_evaluations_is_reported_as_such(monkeypatch):
+    """an evaluation noted inside a caller's stream capture cannot be waited for; the engine remembers the capture and
+    the next look (handoff_check(wait=True) or the next plain call) reads the word and says that a replay may be the culprit."""
+    m = make_model("cfg1")
+    m.kernel_choice = "narrow"                           # the pair-split program: the one with in-launch hand-offs
+    g = load_golden("cfg1_unet.npz")
+    emb = m._embed(to_t(g["seq"]), DEV)
+    x, t = to_t(g["x"]).to(DEV), to_t(g["t"])
+    y0 = m.unet(x[:1], t[:1], embedding=emb[:1], embedding_scale=1.0)
+    eng = m._engine
+    assert eng.xflags is not None and eng.handoff_status() == 0 and not getattr(eng, "_xstat_captured", False)
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: True)
+    eng.note_handoff()                                   # what an evaluation inside a capture does: nothing but remember
+    monkeypatch.undo()
+    assert eng._xstat_captured and not getattr(eng, "_xstat_pending", False)
+    eng.handoff_check(wait=True)                         # replays were fine: no error
+    y1 = m.unet(x[:1], t[:1], embedding=emb[:1], embedding_scale=1.0)
+    assert torch.equal(y0, y1)
+    eng.xflags[0] = 1                                    # a poll of some replay ran into its time-out
+    with pytest.raises(RuntimeError, match="replay"):
+        eng.handoff_check(wait=True)
+    assert eng.handoff_status() == 0                     # cleared by the report
+
+
 def test_doubled_guidance_batch_never_straddles_a_workgroup():
     """max_length=32, channels=64, 6 conditioning tokens: the C = 256 level has 2 tokens per sample, i.e. 16 samples per
     32-row cross-attention workgroup.  B = 16 runs both guidance passes as one doubled batch; B = 24 would put conditional

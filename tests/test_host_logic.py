@@ -508,3 +508,63 @@ def test_torch_library_ops_are_registered_and_refuse_cpu_tensors():
         torch.ops.mdt.precond_in(torch.zeros(3, 16, 64), 0.5, 16)
     with pytest.raises(RuntimeError):
         torch.ops.mdt.unet_eval(torch.zeros(1, 64, 16), torch.zeros(1, 12, 128), 0.0, 1.0, 987654)
+
+
+# Every compile-time switch of compiler.py / DESIGN.md 10 that turns a fused form back into its previous form: (variable, value, cases).
+# "a switch that no test flips is a dead configuration" -- each is flipped here (lowering against the reference's golden
+# U-Net output through the CPU interpreter) and on the GPU (tests/test_gpu_parity.py::test_every_fallback_switch_matches_reference).
+FALLBACK_SWITCHES = [
+    ("MDT_TF128", "0", ("cfg1",)), ("MDT_RES128", "0", ("cfg1",)), ("MDT_TF256_PAIR", "0", ("cfg1",)), ("MDT_PAIR_STRIDE", "1", ("cfg1",)),
+    ("MDT_RCONV", "0", ("cfg1",)), ("MDT_RCONV2", "1", ("cfg1",)), ("MDT_RCONV2", "0", ("cfg1",)), ("MDT_RESBLOCK", "0", ("cfg1", "cfg3")),
+    ("MDT_RES256", "1", ("cfg1",)), ("MDT_RES256", "0", ("cfg3",)), ("MDT_PROJ", "0", ("cfg1", "cfg3")), ("MDT_FOLD_PATCH", "0", ("cfg3", "full")),
+    ("MDT_PATCH_CONV", "0", ("cfg1", "cfg3")), ("MDT_FOLD_CTX", "0", ("cfg3",)), ("MDT_T1_FOLD", "0", ("cfg3",)), ("MDT_CTX_SPLIT", "0", ("cfg3",)),
+    ("MDT_FOLD_OUT", "0", ("cfg1",)), ("MDT_QKV_MERGE", "0", ("cfg3",)), ("MDT_B16", "0", ("cfg1",)), ("MDT_CFG_DUAL", "0", ("cfg1",)),
+]
+
+
+def _lowered_eval(case, mode, extra_env, monkeypatch, rows=(0,), wide=False):
+    for k, v in extra_env.items():
+        monkeypatch.setenv(k, v)
+    kind, kw = CASES[case]
+    if kind == "full":
+        ucfg = sparse_unet_config(kw["pred_dim"], kw["channels"], 64, kw["context_embedding_max_length"], patch_size=4, num_blocks=(3, 3))
+    else:
+        mk = {"inverse": inverse_unet_config, "forward": forward_unet_config, "sparse": sparse_unet_config}[kind]
+        ucfg = mk(kw["pred_dim"], kw["channels"], 128, kw["context_embedding_max_length"])
+    usd = {k[5:]: v for k, v in synth_sd(case).items() if k.startswith("unet.")}
+    cu = compile_unet(ucfg, kw["max_length"], kw["context_embedding_max_length"], usd, max_time_rows=4, gemm_mode=mode, tf256=wide)
+    g = load_golden(f"{case}_unet.npz")
+    x, t, emb = (torch.from_numpy(g[k]) for k in ("x", "t", "emb"))
+    _, C, L = x.shape
+    outs = []
+    for b in rows:
+        act, shr = torch.zeros(cu.act_floats), torch.zeros(cu.shr_floats)
+        xin = torch.zeros(1, L, cu.in_pad)
+        xin[0, :, :C] = x[b].T
+        out = torch.zeros(1, L, cu.in_pad)
+        bufs = Buffers(cu.weights, act, shr, {0: xin.view(-1), 1: emb[b:b + 1].contiguous().view(-1), 2: out.view(-1)})
+        shr[cu.shr["c_noise"]] = t[b]
+        run_program(cu.programs["time"], bufs, 1, 1)
+        ss = cu.ss_total
+        shr[cu.shr["ss_cur"]: cu.shr["ss_cur"] + ss] = shr[cu.shr["ss_all"]: cu.shr["ss_all"] + ss].clone()
+        run_program(cu.programs["ctx"], bufs, 1)
+        run_program(cu.programs["eval"], bufs, 1)
+        outs.append(out[0, :, :C].T.clone())
+    return cu, (torch.stack(outs) if outs else None), torch.from_numpy(g["y_scale1"])[list(rows)]
+
+
+@pytest.mark.parametrize("var,value,cases", FALLBACK_SWITCHES, ids=[f"{v}={x}" for v, x, _ in FALLBACK_SWITCHES])
+def test_every_fallback_switch_lowers_to_the_reference_result(var, value, cases, monkeypatch):
+    """Each switch changes the op program (or is recorded as having no effect on that configuration) and the changed program
+    still reproduces the reference's U-Net output."""
+    changed = False
+    for case in cases:
+        mode = "bf16" if var in ("MDT_B16", "MDT_QKV_MERGE") else "bf16x3"        # the two switches of the reduced-precision mode
+        base, _, _ = _lowered_eval(case, mode, {}, monkeypatch, rows=())
+        cu, y, ref = _lowered_eval(case, mode, {var: value}, monkeypatch)
+        sig = lambda c: [(op.kind, tuple(op.i)) for name in ("eval", "ctx") for op in c.programs[name]] + \
+            [len(c.programs.get("eval_dual", []))]                                # noqa: E731
+        changed |= sig(base) != sig(cu)
+        assert (y - ref).abs().max() < (2e-2 if mode == "bf16" else 5e-5), (var, value, case)
+        monkeypatch.delenv(var)
+    assert changed, f"{var}={value} changes nothing in {cases}: a dead switch"

@@ -116,3 +116,35 @@ def test_dynamic_thresholding_matches_reference():
     init, step = noise_fns("tiny_dyn_t6", tuple(ref.shape))
     out = O.sample(sd, cfg, to_t(g["seq"]), init, step, 6, 1.0, False, None, 0.9)
     assert (out - ref).abs().max() <= TOL
+
+
+@pytest.mark.parametrize("case", ["cfg1", "cfg3", "tiny", "pd22", "nb", "sparse", "full"])
+def test_guided_denoise_matches_reference(case):
+    """denoise_fn under embedding_scale = 7.5 (diffusion.py:798-814 over modules.py:1248-1253): what the sampler consumes of a
+    guided evaluation (tests/golden/make_golden_r6.py guided_denoise)."""
+    g, gd = load_golden(f"{case}_unet.npz"), load_golden("guided_denoise.npz")
+    sd, cfg = synth_sd(case), oracle_cfg(case)
+    with torch.no_grad():
+        emb = O.cond_embed(sd, cfg, to_t(g["seq"]))
+        d = O.denoise(sd, cfg, to_t(g["x"]) * 2.5, torch.tensor(2.5), emb, 7.5)
+    assert (d - to_t(gd[f"{case}_denoise_sigma2p5_scale7p5"])).abs().max() <= TOL
+
+
+def test_token_chain_matches_reference():
+    """SURVEY 8 (f3), second half: ids -> reverse_tokenize -> texts_to_sequences -> pad_sequences(post, post) -> / X_norm_factor ->
+    forward model, as the reference's own functions computed it (tests/golden/make_golden_r6.py token_chain: the keras
+    tokenizer restated there, generative.py:1069-1078 and :404-451 themselves executed).  The host restatement is BIT-EQUAL on the
+    forward input; the oracle's forward model reproduces the predicted properties."""
+    from moleculediffusiontransformer_amd import tokens_to_forward_input
+    g = load_golden("token_chain.npz")
+    ids, L, xn = to_t(g["ids"]), int(g["max_length"]), float(g["X_norm_factor"])
+    data = tokens_to_forward_input(ids, L, xn)
+    assert data.dtype == torch.float32 and torch.equal(data, to_t(g["forward_input"]))
+    # the strings in between are what the ids say: zeros dropped, order kept
+    alphabet = "".join(g["alphabet"].tolist())
+    assert ["".join(alphabet[i - 1] for i in row if i) for row in g["ids"].tolist()] == g["smiles"].tolist()
+    sd, cfg = synth_sd("cfg3"), oracle_cfg("cfg3")
+    T = int(g["timesteps"])
+    init, step = noise_fns("r6_chain_t10", (ids.shape[0], 1, L))
+    out = O.sample(sd, cfg, data, init, step, T, 1.0, False)
+    assert (out[:, 0, :12] - to_t(g["result"])).abs().max() <= TOL
