@@ -161,12 +161,31 @@ def pmc_summary(variant=""):
     if not files:
         return None, []
     rows = []
+    digest = None
     for line in open(files[-1]):
+        if line.startswith("# csrc_digest:"):
+            digest = line.split()[2]
         if line.startswith("#") or line.startswith("kernel,"):
             continue
         name, rest = line.rsplit(",", 5)[0].strip('"'), line.strip().rsplit(",", 5)[1:]
         rows.append((name, int(rest[0]), float(rest[4])))
+    PMC_DIGEST[os.path.basename(files[-1])] = digest
     return os.path.basename(files[-1]), rows
+
+
+PMC_DIGEST = {}
+
+
+def pmc_is_current(fname):
+    """(bool, reason): does the committed PMC summary stem from THIS library's kernel sources?  tools/pmc_summary.py stamps
+    every summary with build._digest() of the sources it profiled; a summary of other code is not quoted (VERDICT r5 #8)."""
+    from moleculediffusiontransformer_amd import build as b
+    want, have = b._digest(), PMC_DIGEST.get(fname)
+    if have is None:
+        return False, f"profiles/{fname} carries no csrc_digest stamp (recorded before round 6): not quoted"
+    if have != want:
+        return False, f"profiles/{fname} was recorded on other kernel sources (csrc digest {have[:12]}, this library {want[:12]}): not quoted"
+    return True, ""
 
 
 def pmc_traffic(kernel_class, variant=""):
@@ -175,10 +194,13 @@ def pmc_traffic(kernel_class, variant=""):
     prefixes = ("mdt::k_tblock", "mdt::k_tf128", "mdt::k_tf256") if kernel_class == "k_tblock" else ("mdt::" + kernel_class,)
     n = sum(r[1] for r in rows if r[0].startswith(prefixes))
     if not n:
-        return None, None
+        return None, "no PMC summary of this kernel class under profiles/"
+    ok, why = pmc_is_current(fname)
+    if not ok:
+        return None, why
     mb = sum(r[1] * r[2] for r in rows if r[0].startswith(prefixes))
-    return round(mb / n * 1e6), ("bytes per launch; profiles/" + fname +
-                                 " (rocprofv3 PMC passes of this workload, recorded earlier, not collected live)")
+    return round(mb / n * 1e6), ("bytes per launch; profiles/" + fname + " (rocprofv3 PMC passes of this workload on THESE kernel "
+                                 "sources -- csrc digest checked --, recorded earlier, not collected live)")
 
 
 def cpu_baseline_leg(torch, model, device, evals):
@@ -204,12 +226,10 @@ def cpu_baseline_leg(torch, model, device, evals):
     ncpu = os.cpu_count() or 1
     cands = sorted({n for n in (4, 8, 16, 32, 64) if n <= ncpu})
     sweep = {}
-    for n in cands:                                   # short sweep: one 2-timestep call (2 evaluations) at B = 256
-        torch.set_num_threads(n)
-        run(256, 2, "sweep")
+    for n in cands:                                   # sweep to the END (4 .. 64 threads): one 2-timestep call (2 evaluations) at
+        torch.set_num_threads(n)                      # B = 256, warm-up + one timed; the fastest point is the baseline (more than
+        run(256, 2, "sweep")                          # 64 threads only oversubscribe these small GEMMs: 256 threads took 370 s)
         sweep[n] = round(run(256, 2, "sweep")[0], 3)
-        if sweep[n] > 1.5 * min(sweep.values()):      # past the knee: more threads only oversubscribe (256 threads: 370 s)
-            break
     threads = min(sweep, key=sweep.get)
     torch.set_num_threads(threads)
     points = {}
@@ -335,12 +355,22 @@ def main():
     evals = 2 * (T - 1)
     eval_timer = rt.EventTimer(evals * (a.steps + a.warmup) + 8)
 
+    phase_ev = []          # N > 1: (sample start, sample end = gather start, gather end) HIP events of every timed step, this rank
+
     def one_step(step_idx, timed):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if (grouped and timed) else None
+        if ev:
+            ev[0].record()
         out = model.sample(seq, device, cond_scale=a.cond_scale, timesteps=T, clamp=False,
                            noise=NoiseSource(seed=1234 + step_idx, sample0=rank * B),
                            timer=eval_timer if timed else None)
         if grouped:
+            if ev:
+                ev[1].record()
             out = all_gather_samples(out, world * B, force_collective=True)
+            if ev:
+                ev[2].record()
+                phase_ev.append(ev)
         return out
 
     for w in range(a.warmup):
@@ -362,7 +392,16 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     power = sampler.summary() if sampler else None
+    per_rank = None
     if grouped:
+        # per rank: wall time of its K steps, GPU time inside sample() (compute, no collective) and inside the all-gather (which
+        # includes waiting for the slowest rank), gathered to every rank (a K-independent 3 x N table; outside the timed region)
+        smp = sum(e[0].elapsed_time(e[1]) for e in phase_ev) * 1e-3
+        gth = sum(e[1].elapsed_time(e[2]) for e in phase_ev) * 1e-3
+        mine = torch.tensor([elapsed, smp, gth], dtype=torch.float64, device="cpu" if share else device)
+        table = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(table, mine)
+        per_rank = [[float(v) for v in t_] for t_ in table]
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -416,8 +455,14 @@ def main():
             alg = flops_exec * B / (avg_eval_ms * 1e-3) / 1e12
             roof.update({"kernel": "whole U-Net eval", "achieved": round(alg * mult, 2),
                          "frac": round(alg * mult / peak, 4)})
+        med_eval = sorted(eval_ms)[len(eval_ms) // 2]
+        slow = [(i, t) for i, t in enumerate(eval_ms) if t > 1.25 * med_eval]
         ue = {"ms_avg_graph_replay": round(avg_eval_ms, 4), "ms_min_graph_replay": round(min(eval_ms), 4),
-              "ms_max_graph_replay": round(max(eval_ms), 4), "evals_timed": len(eval_ms),
+              "ms_max_graph_replay": round(max(eval_ms), 4), "ms_median_graph_replay": round(med_eval, 4),
+              # evaluations more than 25 % over the median, as (index in the timed run, evaluation of its call 0..evals-1, ms):
+              # an index that repeats at the same evaluation of every call is the path's own; a scattered one is the box's
+              "outliers_over_1p25_median": {"count": len(slow), "first": [(i, i % evals, round(t, 3)) for i, t in slow[:8]]},
+              "evals_timed": len(eval_ms),
               "launches": len(eng.c.programs["eval"]),
               "flops_per_sample_executed": flops_exec,
               "tflops_executed_fp32_equiv": round(flops_exec * B / (avg_eval_ms * 1e-3) / 1e12, 2)}
@@ -437,7 +482,7 @@ def main():
                 eval_kernels = ("mdt::k_tf128", "mdt::k_tf256", "mdt::k_tblock", "mdt::k_tb_reduce", "mdt::k_rconv", "mdt::k_gemm3",
                                 "mdt::k_resblock", "mdt::k_attn", "mdt::k_gn_", "mdt::k_concat", "mdt::k_patch")
                 evals_profiled = sum(n for nm, n, mb in rows if nm.startswith("mdt::k_resblock<16, 64>")) or None
-                if rows and evals_profiled:
+                if rows and evals_profiled and pmc_is_current(fname)[0]:
                     unet_mb = sum(n * mb for nm, n, mb in rows if nm.startswith(eval_kernels))
                     per_eval = unet_mb / evals_profiled
                     ue["hbm_measured_mb_per_eval"] = round(per_eval, 1)
@@ -474,10 +519,23 @@ def main():
             alone = model.sample(seq_of(r_last)[:probe].to(device), device, cond_scale=a.cond_scale, timesteps=T, clamp=False,
                                  noise=NoiseSource(seed=1234 + a.warmup + a.steps - 1, sample0=r_last * B))
             rows = out[r_last * B: r_last * B + probe]
+            rates = [B * a.steps / r_[1] for r_ in per_rank]          # molecules/s of each rank's sample() calls alone
+            gms = [1e3 * r_[2] / a.steps for r_ in per_rank]
             result["multi_gpu"] = {
                 "backend": "gloo (test hook: ranks share cuda:0)" if share else "nccl (RCCL over xGMI)",
                 "rccl_ranks_seen": dist.get_world_size(), "gathered_rows": int(out.shape[0]),
                 "collectives_per_step": 1, "all_gather_bytes_per_rank": int(B * out.shape[1] * out.shape[2] * 4),
+                # the ONE collective of a step, timed apart from the compute (HIP events on the rank's stream; a rank's figure
+                # includes its wait for the slowest rank to arrive)
+                "all_gather_ms_per_step": {"min_over_ranks": round(min(gms), 3), "max_over_ranks": round(max(gms), 3),
+                                           "share_of_step_time_max": round(max(gms) * a.steps / (1e3 * elapsed), 4)},
+                "sample_ms_per_step_per_rank": [round(1e3 * r_[1] / a.steps, 2) for r_ in per_rank],
+                "per_rank_molecules_per_s": {"min": round(min(rates), 1), "max": round(max(rates), 1),
+                                             "ranks": [round(v, 1) for v in rates]},
+                # what ONE of these GPUs delivers without the collective: compare with the N = 1 line (BENCH) -- value / N below it
+                # is what the all-gather and the slowest rank cost
+                "n1_equivalent_value": round(sum(rates) / len(rates), 1),
+                "value_per_gpu": round(value / world, 1),
                 "shard_invariance": {"rank": r_last, "rows": probe, "bitwise_equal_to_1_rank_run": bool(torch.equal(rows, alone))}}
 
         if not a.no_exact_f32 and world == 1:

@@ -198,7 +198,15 @@ class _QMBase(nn.Module):
 
     # ------------------------------------------------------------------ engine management
     def _param_key(self, device, n_ctx):
-        return (str(device), n_ctx, self.gemm_mode, tuple((p.data_ptr(), p._version) for p in self.unet.parameters()))
+        # every call asks whether the compiled engine still belongs to the parameter VALUES (an optimiser step or load_state_dict
+        # bumps _version, .to() moves the storage).  The Parameter objects themselves are fixed once the module is built, so the
+        # walk over the module tree (766 parameters in ~400 modules: milliseconds, visible to net() / denoise_fn seam users at
+        # small batches) happens once; per call only data_ptr / _version of the cached list are read.
+        cached = self.__dict__.get("_plist")
+        if cached is None or cached[0] is not self.unet:                 # (a caller may assign another U-Net module)
+            cached = self.__dict__["_plist"] = (self.unet, list(self.unet.parameters()))
+        ps = cached[1]
+        return (str(device), n_ctx, self.gemm_mode, tuple((p.data_ptr(), p._version) for p in ps))
 
     def _wide(self, batch: Optional[int]) -> bool:
         """Which form of the 256-channel transformers to run (compiler.py: MDT_TF256).  With the heads split over workgroup PAIRS

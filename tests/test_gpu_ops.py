@@ -341,7 +341,7 @@ def test_attention(B, T, Tk, shared):
 
 
 @pytest.mark.parametrize("B,T,Tk,shared", [(3, 32, 32, False), (2, 8, 8, False), (3, 32, 12, True), (2, 8, 12, True), (1, 100, 70, False)])
-@pytest.mark.parametrize("in16", [1, 2, 3])
+@pytest.mark.parametrize("in16", [pytest.param(1, marks=pytest.mark.slow), 2, 3])      # default: k | v in bf16, and q | k | v
 @pytest.mark.parametrize("out16", [0, 1])
 def test_attention_with_bf16_operands(B, T, Tk, shared, in16, out16):
     """MDT_A_IN16 (plain-bf16 mode): q and / or k | v arrive as bf16 (written so by their GEMM), are widened exactly and contracted in
@@ -1050,7 +1050,7 @@ def _handoff_ext(B, T):
     return {3: torch.zeros(64 + 64 * nrb), 4: torch.zeros(2 * nrb * 2 * 32 * 256)}
 
 
-@pytest.mark.parametrize("form", ["whole", "pair8", "pair1"])
+@pytest.mark.parametrize("form", ["whole", "pair8", pytest.param("pair1", marks=pytest.mark.slow)])    # (pair1 at model level: the pair-stride switch test)
 @pytest.mark.parametrize("C,T,B,layers,cross,fixed", [
     (128, 16, 5, 2, False, False), (128, 16, 70, 4, True, False), (128, 4, 16, 2, False, False), (128, 16, 3, 2, True, True),
     (128, 8, 9, 1, False, False), (128, 2, 33, 1, False, False), (128, 16, 1030, 1, True, False),

@@ -93,6 +93,41 @@ def test_sample_matches_reference(models, name, case, want):
     assert (out.cpu() - out_ref).abs().max() < TOL
 
 
+def _switch_cases():
+    from test_host_logic import FALLBACK_SWITCHES
+    return [pytest.param(var, value, case, id=f"{var}={value}-{case}") for var, value, cases in FALLBACK_SWITCHES for case in cases]
+
+
+@pytest.mark.parametrize("var,value,case", _switch_cases())
+def test_every_fallback_switch_matches_reference(var, value, case, monkeypatch):
+    """every MDT_* switch that turns a fused form back into its previous form is FLIPPED here and
+    the program it selects evaluated on the GPU against the reference's golden U-Net output (CPU half:
+    tests/test_host_logic.py::test_every_fallback_switch_lowers_to_the_reference_result) -- a switch nobody flips is a dead
+    configuration.  MDT_B16 / MDT_QKV_MERGE belong to the reduced-precision mode (budget 2e-2 per evaluation)."""
+    monkeypatch.setenv(var, value)
+    monkeypatch.setenv("MDT_F32_FUSED", "1")
+    g = load_golden(f"{case}_unet.npz")
+    m = make_model(case)
+    bf16 = var in ("MDT_B16", "MDT_QKV_MERGE")
+    if bf16:
+        m.gemm_mode = "bf16"
+    emb = m._embed(to_t(g["seq"]), DEV)
+    x, t = to_t(g["x"]).to(DEV), to_t(g["t"])
+    scale = 2.0 if var == "MDT_CFG_DUAL" else 1.0                 # (the dual / two-pass choice exists under guidance only)
+    want = to_t(g["y_scale1"])
+    for b in range(x.shape[0]):
+        y = m.unet(x[b:b + 1], t[b:b + 1], embedding=emb[b:b + 1], embedding_scale=1.0)
+        assert (y.cpu() - want[b:b + 1]).abs().max() < (2e-2 if bf16 else 5e-5), (var, value, case, b)
+    if scale != 1.0:
+        name = "cfg1_b2_t12_cfg7p5"
+        gs = load_golden(f"{name}_sample.npz")
+        init, step = noise_fns(name, tuple(gs["out"].shape))
+        out = m.sample(to_t(gs["seq"]), DEV, cond_scale=7.5, timesteps=int(gs["timesteps"]), clamp=False,
+                       noise=NoiseSource(init=init, steps=lambda i: step(i, init)))
+        assert not m._engine.has_dual and (out.cpu() - to_t(gs["out"])).abs().max() < TOL
+    assert m._engine.handoff_status() == 0
+
+
 @pytest.mark.parametrize("mode", ["bf16x3", "f32"])
 def test_chained_resnet_blocks_match_the_reference_sample(mode, monkeypatch):
     """MDT_OP_RES256 forced on (MDT_RES256=1) in the NARROW program of configs[1] -- the automatic policy uses it in the wide program
@@ -309,6 +344,11 @@ def test_bench_two_rank_logic_on_one_gpu():
     mg = d["multi_gpu"]
     assert mg["rccl_ranks_seen"] == 2 and mg["gathered_rows"] == 128 and mg["collectives_per_step"] == 1
     assert mg["shard_invariance"]["bitwise_equal_to_1_rank_run"] is True and mg["shard_invariance"]["rank"] == 1
+    # round 6: the collective timed apart from the compute, per-rank rates, the N = 1 equivalent
+    pr = mg["per_rank_molecules_per_s"]
+    assert len(pr["ranks"]) == 2 and len(mg["sample_ms_per_step_per_rank"]) == 2 and 0 < pr["min"] <= mg["n1_equivalent_value"] <= pr["max"]
+    assert 0 <= mg["all_gather_ms_per_step"]["min_over_ranks"] <= mg["all_gather_ms_per_step"]["max_over_ranks"]
+    assert abs(mg["value_per_gpu"] * 2 - d["value"]) < 0.2 and mg["value_per_gpu"] <= pr["max"] * 1.001
 
 
 def test_bench_eight_rank_logic_on_one_gpu():

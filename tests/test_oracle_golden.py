@@ -148,3 +148,20 @@ def test_token_chain_matches_reference():
     init, step = noise_fns("r6_chain_t10", (ids.shape[0], 1, L))
     out = O.sample(sd, cfg, data, init, step, T, 1.0, False)
     assert (out[:, 0, :12] - to_t(g["result"])).abs().max() <= TOL
+
+
+@pytest.mark.parametrize("name,case,tag,B,shape,T,uniform", [("cfg3_t100", "cfg3", "full3", 4096, (1, 64), 100, True),
+                                                             ("cfg5_t16", "cfg5", "full5", 32, (32, 128), 16, False)])
+def test_fullsize_probe_rows_match_reference(name, case, tag, B, shape, T, uniform):
+    """tests/golden/fullsize_rows.npz (the reference's result for the probe rows of tests/test_gpu_fullsize.py's BASELINE-size runs,
+    tests/golden/make_golden_r6.py fullsize_rows) against the oracle on the same named draws.  (cfg5_t256 -- 510 evaluations of the
+    deep U-Net -- takes the oracle ~7 minutes of host time: it is checked on the GPU only.)"""
+    from moleculediffusiontransformer_amd.synth import synth_normal, synth_uniform
+    g = load_golden("fullsize_rows.npz")
+    rows = torch.from_numpy(g[name + "_rows"])
+    n_cond = CASES[case][1]["context_embedding_max_length"]
+    seq = (synth_uniform if uniform else synth_normal)(f"{tag}/seq", (B, n_cond))[rows]
+    init = synth_normal(f"{tag}/init", (B,) + shape)[rows]
+    out = O.sample(synth_sd(case), oracle_cfg(case), seq, init, lambda i, x: synth_normal(f"{tag}/step{i}", (B,) + shape)[rows],
+                   T, 1.0, False)
+    assert (out - to_t(g[name])).abs().max() <= TOL

@@ -35,6 +35,12 @@ def main():
     os.makedirs(dst, exist_ok=True)
     what = open(os.path.join(src, "args.txt")).read().strip() if os.path.exists(os.path.join(src, "args.txt")) else \
         "bench.py --batch 1024 --timesteps 4"
+    # stamp: the digest of the kernel sources the profiled library was built from (moleculediffusiontransformer_amd/build.py)
+    # and the commit, so that bench.py can refuse a summary of other code
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from moleculediffusiontransformer_amd import build as _b
+    head = os.environ.get("MDT_GIT_HEAD", "")          # no .git on the GPU box: tools/profile_round.sh callers pass it in
+    stamp = f"# csrc_digest: {_b._digest()}" + (f"  git: {head}" if head else "") + "\n"
     for kind in ("kernel_stats", "domain_stats"):
         fs = glob.glob(os.path.join(src, "trace", "**", f"*_{kind}.csv"), recursive=True)
         if fs:
@@ -46,6 +52,7 @@ def main():
     wr, wn = counters(os.path.join(src, "pmc_write"), "WRITE_SIZE")
     with open(os.path.join(dst, f"{tag}_pmc_hbm_traffic.csv"), "w") as f:
         f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), " + what + "\n")
+        f.write(stamp)
         f.write("# FETCH_SIZE is in KB and reads exactly 1/2 of the bytes of wide coalesced reads on gfx950 "
                 "(MI355X_MICROARCH.md, HBM): corrected = 2 x raw\n")
         f.write("kernel,dispatches,fetch_raw_KB_per_dispatch,fetch_corrected_MB_per_dispatch,"
@@ -66,6 +73,7 @@ def main():
     if vals["SQ_WAVE_CYCLES"][0]:
         with open(os.path.join(dst, f"{tag}_pmc_sq.csv"), "w") as f:
             f.write("# rocprofv3 --pmc " + " ".join(names) + " (one pass, --kernel-trace only), " + what + "\n")
+            f.write(stamp)
             f.write("# SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are quad-cycles summed over waves; WAIT_ANY = parked on "
                     "s_waitcnt / s_barrier, WAIT_INST_ANY = issue stall, ACTIVE_INST_ANY = issuing; MFMA busy in cycles; "
                     "GRBM_GUI_ACTIVE summed over the 8 XCDs (per-launch cycles = value / 8)\n")
