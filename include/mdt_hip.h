@@ -289,7 +289,8 @@ enum mdt_tblock_i {
                                        4: chained form of 3 without the reduce launch: block input = a + res (res = the
                                        previous block's second partial | none), out = block output written by head group 0
                                        (never aliasing a), p2 = second head group's partial | none (one workgroup);  */
-  MDT_B_WF32 = 12                   /* 1 (variant 0; round 5): w = fp32 FRAGMENT tiles, exact fp32 MFMA products (see MDT_F_WF32)  */
+  MDT_B_WF32 = 12                   /* 1: w = fp32 FRAGMENT tiles (variant 0, round 5) / fp32 fragment SUB-tiles in the layout of MDT_OP_TF256
+                                       (variants 2..4, round 6), exact fp32 MFMA products (see MDT_F_WF32)                      */
 };
 enum mdt_tblock_f { MDT_BF_EPS = 0, MDT_BF_SCALE = 1 };
 

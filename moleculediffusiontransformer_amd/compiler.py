@@ -818,9 +818,9 @@ class UNetCompiler:
     _SLOT_PERM = [32 * (s >> 5) + 16 * ((s & 7) >> 2) + 4 * ((s >> 3) & 3) + (s & 3) for s in range(64)]
 
     def can_fuse_transformer(self, c: int, rows: int, cross: bool) -> bool:
-        # (exact-fp32 products: the C = 128 sub-block kernel has fp32-fragment instantiations since round 5, MDT_B_WF32; the
-        #  C = 256 ones exist with split-bf16 products only)
-        if not (self.gemm_mode == "bf16x3" or (self.wf32 and c == 128)) or not self.fuse_blocks:
+        # (exact-fp32 products: the C = 128 sub-block kernel has fp32-fragment instantiations since round 5, the C = 256 ones
+        #  (k_tblock32) since round 6: MDT_B_WF32)
+        if not (self.gemm_mode == "bf16x3" or self.wf32) or not self.fuse_blocks:
             return False
         if c not in (128, 256) or rows > 16 or 16 % rows or self.cfg.head_features != 64:
             return False
@@ -860,6 +860,11 @@ class UNetCompiler:
         c, rows = t.ld, t.rows
         perm = torch.tensor(self._SLOT_PERM)
         tiles: List[torch.Tensor] = []
+        mats: List[torch.Tensor] = []                # the matrices behind `tiles` (the fp32 sub-tile packing below starts from them)
+
+        def wtile(w: torch.Tensor) -> torch.Tensor:  # self._wtile that remembers its argument
+            mats.append(w)
+            return self._wtile(w)
         if variant in (2, 3, 4):
             assert c == 256, "variants 2 / 3 / 4 (32-row workgroups, sub-tile stream) serve C = 256"
             assert mode != rt.TB_CROSS or (16 // rows) * self.n_ctx <= 48, "at most 48 context rows per 16 token rows"
@@ -873,10 +878,10 @@ class UNetCompiler:
                 wout, bout = post[0].reshape(c, c).double(), post[1].double()
                 w2, b2 = (wout @ w2.double()).float(), (wout @ b2.double() + bout).float()
             for h in range(nchunk):
-                tiles += [self._wtile(w1[64 * h: 64 * h + 64]), self._wtile(w2[:, 64 * h: 64 * h + 64][:, perm])]
+                tiles += [wtile(w1[64 * h: 64 * h + 64]), wtile(w2[:, 64 * h: 64 * h + 64][:, perm])]
             if post is not None:
                 assert variant in (0, 2, 4) and (x_out is None or (variant == 4 and p_out is None))
-                tiles += [self._wtile(post[0].reshape(c, c)[:, 64 * e: 64 * e + 64]) for e in range(c // 64)]
+                tiles += [wtile(post[0].reshape(c, c)[:, 64 * e: 64 * e + 64]) for e in range(c // 64)]
                 self.flops += 2 * rows * c * c
             bias = torch.cat([b1, b2])
             self.flops += 2 * 2 * rows * c * w1.shape[0]
@@ -892,9 +897,9 @@ class UNetCompiler:
                 wkv_f, bkv_f = wkv * g_c.unsqueeze(0), wkv @ b_c
                 mid = wq.shape[0]
                 for h in range(nchunk):
-                    tiles += [self._wtile(wq_f[64 * h: 64 * h + 64]), self._wtile(wkv_f[64 * h: 64 * h + 64]),
-                              self._wtile(wkv_f[mid + 64 * h: mid + 64 * h + 64]),
-                              self._wtile(wo[:, 64 * h: 64 * h + 64][:, perm])]
+                    tiles += [wtile(wq_f[64 * h: 64 * h + 64]), wtile(wkv_f[64 * h: 64 * h + 64]),
+                              wtile(wkv_f[mid + 64 * h: mid + 64 * h + 64]),
+                              wtile(wo[:, 64 * h: 64 * h + 64][:, perm])]
                 # k bias: softmax is invariant to a per-query constant (q . bk), drop it; v bias: sum_j p_j (v_j + bv)
                 # = sum_j p_j v_j + bv, so it moves into the output bias.  The kernels then load only bq per head
                 # (their own global loads queue behind the loader waves' DMA traffic: ~60 cycles of issue stall each).
@@ -903,7 +908,7 @@ class UNetCompiler:
                 self.flops += 2 * rows * c * 3 * mid + 4 * rows * rows * mid + 2 * rows * mid * c
             else:
                 for h in range(nchunk):
-                    tiles += [self._wtile(wq_f[64 * h: 64 * h + 64]), self._wtile(wo[:, 64 * h: 64 * h + 64][:, perm])]
+                    tiles += [wtile(wq_f[64 * h: 64 * h + 64]), wtile(wo[:, 64 * h: 64 * h + 64][:, perm])]
                 bias = torch.cat([bq_f, bo])
                 mid = wq.shape[0]
                 self.flops += 2 * rows * c * mid + 4 * rows * self.n_ctx * mid + 2 * rows * mid * c
@@ -913,6 +918,13 @@ class UNetCompiler:
             tpc = 4 if mode == rt.TB_SELF else 2
             sub: List[torch.Tensor] = []
             for k, tl in enumerate(tiles):
+                out_tile = k % tpc == tpc - 1 or k >= nchunk * tpc      # output tiles (incl. a folded closing convolution's)
+                if self.wf32:
+                    # fp32 fragment sub-tiles (k_tf256.hip's format): [64][128] K halves, [128][64] row halves
+                    m_ = mats[k]
+                    for hm in ((m_[:128], m_[128:]) if out_tile else (m_[:, :128], m_[:, 128:])):
+                        sub.append(self._tile_f32(hm.contiguous()))
+                    continue
                 raw = tl.view(torch.bfloat16)
                 n = raw.numel() // 2
                 if k % tpc == tpc - 1 or k >= nchunk * tpc:      # output tiles (incl. a folded closing convolution's)
@@ -934,8 +946,7 @@ class UNetCompiler:
         i[rt.B_MODE], i[rt.B_C], i[rt.B_T], i[rt.B_NCHUNK], i[rt.B_NBIAS] = mode, c, rows, nchunk, bias.numel()
         i[rt.B_TK], i[rt.B_KV_BSTRIDE], i[rt.B_LDKV], i[rt.B_HEADS] = self.n_ctx, self.n_ctx, 2 * cfg.mid_features, cfg.heads
         i[rt.B_VARIANT] = variant
-        i[rt.B_WF32] = int(self.wf32)                # (can_fuse_transformer: exact-fp32 compilations reach this with C = 128, variant 0 only)
-        assert not self.wf32 or variant == 0
+        i[rt.B_WF32] = int(self.wf32)
         op.f[0], op.f[1] = 1e-5, float(cfg.head_features) ** -0.5
         if mode == rt.TB_CROSS:
             op._kv = ("kv", cross_index)

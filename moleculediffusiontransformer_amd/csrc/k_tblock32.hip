@@ -60,12 +60,20 @@ __device__ __forceinline__ float gelu_32(float x) {   // exact-erf GELU, branch-
   return 0.5f * x * (1.0f + copysignf(erfa, x));
 }
 
+// F32 (round 6, MDT_B_WF32 for variants 2..4): the values themselves, slots 0..3 in `hi`, 4..7 in `lo` -- operands of exact fp32
+// MFMAs on fp32 fragment sub-tiles, as in k_tblock_lw.hip / k_tf256.hip
+template <bool F32>
 __device__ __forceinline__ void split8_32(const float v[8], bf16x8& hi, bf16x8& lo) {
+  if constexpr (F32) {
+    hi = __builtin_bit_cast(bf16x8, f32x4{v[0], v[1], v[2], v[3]});
+    lo = __builtin_bit_cast(bf16x8, f32x4{v[4], v[5], v[6], v[7]});
+  } else {
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const __bf16 h = (__bf16)v[e];
-    hi[e] = h;
-    lo[e] = (__bf16)(v[e] - (float)h);
+    for (int e = 0; e < 8; ++e) {
+      const __bf16 h = (__bf16)v[e];
+      hi[e] = h;
+      lo[e] = (__bf16)(v[e] - (float)h);
+    }
   }
 }
 
@@ -134,7 +142,11 @@ __global__ __launch_bounds__(256) void k_tb_reduce(float* x, const float* part, 
 // NPW (MODE_CROSS only): LDS-DMA pieces per loader wave per K / V tile = ceil(context rows of the workgroup / 16)
 // CHAIN: variant 4 (input = x + pin, outputs xout / pout); a separate instantiation so that the in-place kernels
 // keep their exact code (the chained form costs them 1.8 % when folded in as run-time branches)
-template <int MODE, int NPW, bool CHAIN>
+// F32 (round 6): fp32 FRAGMENT sub-tiles and exact fp32 MFMA products (v_mfma_f32_16x16x4_f32), the format of k_tf256.hip: a [64][128]
+// projection sub-tile is fragments (feature tile ft, k-step st, half lo) at ft * 8192 + st * 2048 + lo * 1024, a [128][64] output
+// sub-tile (row tile ct, k-step sp, half lo) at ct * 4096 + sp * 2048 + lo * 1024; lane (i, g) float r of a fragment =
+// W[16 rt + i][k-slot 32 st + 8 g + 4 lo + r].  The loader waves copy such a sub-tile linearly; the attention core is fp32 either way.
+template <int MODE, int NPW, bool CHAIN, bool F32>
 __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
   // sub-tiles per chunk: q0 q1 k0 k1 v0 v1 o0 o1 | q0 q1 K V o0 o1 (K, V = hoisted context rows) | w1a w1b w2a w2b
   constexpr int SPC = (MODE == TB_SELF) ? 8 : (MODE == TB_CROSS) ? 6 : 4;
@@ -167,8 +179,9 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
     for (int q = 0; q < IPT; ++q) {
       const int inst = iw + 4 * q;
       const int U = 2 * inst;
-      voffP[q] = (unsigned)(U * (2 * CS) + ((xP ^ (U & 15)) << 4) + baseP);
-      voffO[q] = (unsigned)(((inst * 8) / CS) * (128 * CS) + ((inst * 8) % CS) * 128 + ((xO ^ (4 * (inst & 1))) << 4) + baseO);
+      voffP[q] = F32 ? (unsigned)(inst * 1024 + lane * 16) : (unsigned)(U * (2 * CS) + ((xP ^ (U & 15)) << 4) + baseP);
+      voffO[q] = F32 ? (unsigned)(inst * 1024 + lane * 16)
+                     : (unsigned)(((inst * 8) / CS) * (128 * CS) + ((inst * 8) % CS) * 128 + ((xO ^ (4 * (inst & 1))) << 4) + baseO);
     }
     // MODE_CROSS: sub-tiles 2 and 3 of a head are the K and V rows (row = (sample, key), 256 B, chunks swizzled with
     // the row index) of the workgroup's samples -- layout and padding as in k_tblock_lw.hip
@@ -368,7 +381,7 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
       float v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = mvalid ? (xr[st][e] - mean) * rstd : 0.f;
-      split8_32(v, xh[st], xl[st]);
+      split8_32<F32>(v, xh[st], xl[st]);
     }
   }
   else
@@ -461,7 +474,7 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = (xr[st][e] - mean) * rs;
       bf16x8 hh, ll;
-      split8_32(v, hh, ll);
+      split8_32<F32>(v, hh, ll);
       *reinterpret_cast<bf16x8*>(xch + (NH * fh + st) * 2048) = hh;
       *reinterpret_cast<bf16x8*>(xch + (NH * fh + st) * 2048 + 1024) = ll;
     }
@@ -479,9 +492,10 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
 #pragma unroll
   for (int st = 0; st < 4; ++st) {
     const int lc = 4 * st + g;
-    aP[st] = fh * (2 * 16 * 4 * CS) + i * (4 * CS) + ((lc & ~15) | ((lc & 15) ^ i)) * 16;
+    // F32: the lane's 16 bytes of a fragment, this wave's feature tiles ft = 2 fh + q (q in the immediate) and the k-step
+    aP[st] = F32 ? lane * 16 + fh * 16384 + st * 2048 : fh * (2 * 16 * 4 * CS) + i * (4 * CS) + ((lc & ~15) | ((lc & 15) ^ i)) * 16;
   }
-  const int aO = i * 128 + ((4 * fh + g) ^ ((i >> 1) & 7)) * 16;
+  const int aO = F32 ? lane * 16 + fh * 2048 : i * 128 + ((4 * fh + g) ^ ((i >> 1) & 7)) * 16;   // F32: this wave's k-step sp = fh
 
   bf16x8 frh[3][2], frl[3][2];
   // read j (= 2 q + plane) of unit u; `base` = LDS address of the slot + the lane's swizzled part (projection
@@ -489,7 +503,8 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
   auto frag_read = [&](auto kind, unsigned base, auto uc, int set, auto jc) {
     constexpr int KIND = decltype(kind)::value, u = decltype(uc)::value, j = decltype(jc)::value;
     constexpr int q = j >> 1, lo = j & 1;
-    constexpr int off = (KIND == K_O) ? ((2 * u + q) * 16 * 128 + lo * (CS * 128)) : (q * 16 * 4 * CS + lo * (2 * CS));
+    constexpr int off = F32 ? ((KIND == K_O) ? ((2 * u + q) * 4096 + lo * 1024) : (q * 8192 + lo * 1024))
+                            : ((KIND == K_O) ? ((2 * u + q) * 16 * 128 + lo * (CS * 128)) : (q * 16 * 4 * CS + lo * (2 * CS)));
     lds_read16_off<off>(lo ? frl[set][q] : frh[set][q], base);
   };
   using J0 = std::integral_constant<int, 0>;
@@ -544,12 +559,35 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
         if constexpr (KIND == K_N) acc[ia + q] = MDT_MFMA_BF16(x, w, acc[ia + q], 0, 0, 0);
         else acc[ia + q] = MDT_MFMA_BF16(w, x, acc[ia + q], 0, 0, 0);
       };
-      mm(frl[s0][0], bh[ib], 0); rd(J0{});
-      mm(frl[s0][1], bh[ib], 1); rd(J1{});
-      mm(frh[s0][0], bl[ib], 0); rd(J2{});
-      mm(frh[s0][1], bl[ib], 1); rd(J3{});
-      mm(frh[s0][0], bh[ib], 0);
-      mm(frh[s0][1], bh[ib], 1);
+      if constexpr (F32) {
+        // exact fp32: fragment (q, half) x operand half, four 16x16x4 MFMAs each (r = contraction sub-step); the two accumulators
+        // alternate so that no MFMA waits for the one issued just before it (k_tblock_lw.hip)
+        auto mm4 = [&](const bf16x8& w0, const bf16x8& w1, const bf16x8& x, auto r0c) {
+          constexpr int r0 = decltype(r0c)::value;
+          const f32x4 a0 = __builtin_bit_cast(f32x4, w0), a1 = __builtin_bit_cast(f32x4, w1), xb = __builtin_bit_cast(f32x4, x);
+#pragma unroll
+          for (int r = r0; r < r0 + 2; ++r) {
+            if constexpr (KIND == K_N) {
+              acc[ia] = MDT_MFMA_F32(xb[r], a0[r], acc[ia], 0, 0, 0);
+              acc[ia + 1] = MDT_MFMA_F32(xb[r], a1[r], acc[ia + 1], 0, 0, 0);
+            } else {
+              acc[ia] = MDT_MFMA_F32(a0[r], xb[r], acc[ia], 0, 0, 0);
+              acc[ia + 1] = MDT_MFMA_F32(a1[r], xb[r], acc[ia + 1], 0, 0, 0);
+            }
+          }
+        };
+        mm4(frh[s0][0], frh[s0][1], bh[ib], J0{}); rd(J0{});
+        mm4(frh[s0][0], frh[s0][1], bh[ib], J2{}); rd(J1{});
+        mm4(frl[s0][0], frl[s0][1], bl[ib], J0{}); rd(J2{});
+        mm4(frl[s0][0], frl[s0][1], bl[ib], J2{}); rd(J3{});
+      } else {
+        mm(frl[s0][0], bh[ib], 0); rd(J0{});
+        mm(frl[s0][1], bh[ib], 1); rd(J1{});
+        mm(frh[s0][0], bl[ib], 0); rd(J2{});
+        mm(frh[s0][1], bl[ib], 1); rd(J3{});
+        mm(frh[s0][0], bh[ib], 0);
+        mm(frh[s0][1], bh[ib], 1);
+      }
       __builtin_amdgcn_sched_barrier(0);
 #ifdef MDT_STAMPS_UNITS
       MDT_STAMP();
@@ -790,7 +828,7 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
       float v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = oT[e >> 2][e & 3];
-      split8_32(v, oh[0], ol[0]);
+      split8_32<F32>(v, oh[0], ol[0]);
     }
     phase(kO, IC1{}, kO, true, accT, oh, ol);               // output rows 0..127
     if (NX > 0 && !more) phase(kO, IC2{}, kO, true, accT + 8, oh, ol);   // the folded convolution's sub-tiles follow
@@ -892,22 +930,27 @@ __global__ __launch_bounds__(512) void k_tblock32(TBlockArgs a) {
 #endif
 }
 
-template <int MODE, int NPW, bool CHAIN>
-static hipError_t launch_32c(const TBlockArgs& a, hipStream_t s) {
+template <int MODE, int NPW, bool CHAIN, bool F32>
+static hipError_t launch_32f(const TBlockArgs& a, hipStream_t s) {
   const size_t smem = (size_t)NS * SLOT + (MODE == TB_CROSS ? 3 : 1) * 4 * 64 * 16 + (size_t)64 * a.nchunk * sizeof(float);
   static DevOnce attr_once;                          // per device (mdt_kernels.h)
   if (attr_once.first()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tblock32<MODE, NPW, CHAIN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tblock32<MODE, NPW, CHAIN, F32>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
   }
   const int nsplit = a.nsplit > 1 ? a.nsplit : 1;
-  hipLaunchKernelGGL((k_tblock32<MODE, NPW, CHAIN>), dim3((unsigned)((a.M + 31) / 32), (unsigned)nsplit), dim3(512), smem, s, a);
+  hipLaunchKernelGGL((k_tblock32<MODE, NPW, CHAIN, F32>), dim3((unsigned)((a.M + 31) / 32), (unsigned)nsplit), dim3(512), smem, s, a);
   if (nsplit > 1 && !a.xout) {                        // variant 3: separate fixed-order reduce (the chained form needs none)
     const int bo_off = (MODE == TB_SELF) ? 3 * 64 * a.nchunk : 64 * a.nchunk;
     const int64_t n4 = (int64_t)a.M * (C / 4);
     hipLaunchKernelGGL(k_tb_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, a.x, a.part, a.bias + bo_off, a.M, nsplit);
   }
   return hipGetLastError();
+}
+
+template <int MODE, int NPW, bool CHAIN>
+static hipError_t launch_32c(const TBlockArgs& a, hipStream_t s) {
+  return a.wf32 ? launch_32f<MODE, NPW, CHAIN, true>(a, s) : launch_32f<MODE, NPW, CHAIN, false>(a, s);   // fp32 fragment sub-tiles: exact products
 }
 
 template <int MODE, int NPW = 0>

@@ -230,8 +230,7 @@ static const char* validate(const mdt_op& o, int idx, char* buf, size_t nbuf) {
         return bad("cross block needs K/V and at most 64 keys per 16 rows");
       if (!o.a.space || !o.w.space || !o.bias.space) return bad("missing operand");
       if (i[MDT_B_VARIANT] < 0 || i[MDT_B_VARIANT] > 4) return bad("unknown fused-block variant");
-      if (i[MDT_B_WF32] != 0 && (i[MDT_B_WF32] != 1 || i[MDT_B_VARIANT] != 0))
-        return bad("WF32 must be 0 (split-bf16 tiles) or 1 (fp32 fragment tiles; variant 0, the C = 128 kernel, only)");
+      if (i[MDT_B_WF32] != 0 && i[MDT_B_WF32] != 1) return bad("WF32 must be 0 (split-bf16 tiles) or 1 (fp32 fragment tiles)");
       if (i[MDT_B_VARIANT] == 1) return bad("variant 1 (16-row feature-split workgroups) was removed; C = 256 blocks are variants 2..4");
       if (i[MDT_B_VARIANT] == 0 && (i[MDT_B_C] != 128 || (i[MDT_B_MODE] == MDT_TB_CROSS && (16 / i[MDT_B_T]) * i[MDT_B_TK] > 16)))
         return bad("variant 0 serves C = 128, cross blocks with at most 16 keys per 16 rows (loader-wave kernel)");

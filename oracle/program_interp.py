@@ -388,9 +388,10 @@ def _tblock(op, bufs: Buffers, B: int) -> None:
         if i[rt.B_VARIANT] not in (2, 3, 4):
             return _untile(stream, k, rows, cols, bool(i[rt.B_WF32]))      # (MDT_B_WF32: fp32 fragment tiles)
         # variant 2 (k_tblock32): every tile is stored as two 128-wide sub-tiles (K halves / output-row halves)
+        f32 = bool(i[rt.B_WF32])                 # (round 6: fp32 fragment sub-tiles for the C = 256 variants too)
         if rows == 64:
-            return torch.cat([_untile(stream, 2 * k, 64, 128), _untile(stream, 2 * k + 1, 64, 128)], dim=1)
-        return torch.cat([_untile(stream, 2 * k, 128, 64), _untile(stream, 2 * k + 1, 128, 64)], dim=0)
+            return torch.cat([_untile(stream, 2 * k, 64, 128, f32), _untile(stream, 2 * k + 1, 64, 128, f32)], dim=1)
+        return torch.cat([_untile(stream, 2 * k, 128, 64, f32), _untile(stream, 2 * k + 1, 128, 64, f32)], dim=0)
 
     def proj(k0):          # stack of P tiles k0, k0 + tpc, ... -> [mid, C]
         return torch.cat([tile(h * tpc + k0, 64, C) for h in range(nchunk)])

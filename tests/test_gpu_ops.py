@@ -735,10 +735,9 @@ def test_gemm_bf16_chain_with_bf16_intermediate():
 @pytest.mark.parametrize("C,T,B", [(128, 16, 5), (256, 4, 37), (128, 4, 16), (256, 16, 3), (128, 1, 70)])
 @pytest.mark.parametrize("products", ["bf16x3", "f32"])
 def test_fused_transformer_sub_block(mode, C, T, B, variant, products):
-    """MDT_OP_TBLOCK (k_tblock_lw: variant 0, C = 128, split-bf16 and -- MDT_B_WF32 -- exact-fp32 products; k_tblock32: variants
-    2 / 3, C = 256) against the interpreter: LayerNorm folding, tile packing, DMA ring, MFMA operand chaining."""
-    if products == "f32" and variant != 0:
-        pytest.skip("fp32 fragment tiles: the C = 128 kernel (variant 0) only")
+    """MDT_OP_TBLOCK (k_tblock_lw: variant 0, C = 128; k_tblock32: variants 2 / 3, C = 256; both with split-bf16 and -- MDT_B_WF32,
+    k_tblock32 since round 6 -- exact-fp32 products) against the interpreter: LayerNorm folding, tile packing, DMA ring, MFMA
+    operand chaining."""
     from moleculediffusiontransformer_amd.compiler import Ten, UNetCompiler
     from moleculediffusiontransformer_amd.netspec import inverse_unet_config
     cfg = inverse_unet_config(16, 64, 128, 12)
@@ -984,7 +983,7 @@ def test_fused_resnet_block_with_folded_patch_rearranges(cin, cout, pin, pout, B
 @pytest.mark.parametrize("mode,split,with_pin", [(rt.TB_SELF, True, False), (rt.TB_SELF, True, True), (rt.TB_CROSS, True, True),
                                                  (rt.TB_FF, False, True), (rt.TB_FF, False, False)])
 @pytest.mark.parametrize("T,B", [(4, 37), (16, 3)])
-def test_chained_split_sub_block(mode, split, with_pin, T, B):
+def test_chained_split_sub_block(mode, split, with_pin, T, B, prod):
     """MDT_OP_TBLOCK variant 4 (k_tblock32): block input = x + p_in, head group 0 writes x_out = input + its partial
     + bias, head group 1 leaves its bare partial in p_out; no reduce launch, x itself is not touched."""
     from moleculediffusiontransformer_amd.compiler import Ten, UNetCompiler

@@ -60,6 +60,14 @@ def test_unet_eval_and_denoise_match_reference(models, case):
         assert (y.cpu() - to_t(g["y_scale7p5"])[b:b + 1]).abs().max() < bound, (case, b, models.mode)
     d = m.diffusion.diffusion.denoise_fn(x * 2.5, sigma=torch.tensor(2.5), embedding=emb, embedding_scale=1.0)
     assert (d.cpu() - to_t(g["denoise_sigma2p5"])).abs().max() < 5e-5
+    if models.mode == "f32":
+        # 'exact fp32' is exact on EVERY fused op (round 6: the C = 256 sub-block kernel k_tblock32 has fp32 instantiations too): no
+        # ring-kernel op of an f32 program may carry split-bf16 tiles
+        from moleculediffusiontransformer_amd import runtime as rt
+        wf = {rt.OP_TF128: rt.F_WF32, rt.OP_TF256: rt.F_WF32, rt.OP_RES256: rt.F_WF32, rt.OP_RCONV: rt.R_WF32, rt.OP_RESBLOCK: rt.K_WF32,
+              rt.OP_TBLOCK: rt.B_WF32}
+        for name in ("eval", "ctx"):
+            assert all(op.i[wf[op.kind]] == 1 for op in m._engine.c.programs[name] if op.kind in wf), (case, name)
     # denoise_fn UNDER GUIDANCE (diffusion.py:798-814 over modules.py:1248-1253) against the reference: the 1e-4 contract, all modes
     d = m.diffusion.diffusion.denoise_fn(x * 2.5, sigma=torch.tensor(2.5), embedding=emb, embedding_scale=7.5)
     gd = load_golden("guided_denoise.npz")[f"{case}_denoise_sigma2p5_scale7p5"]
