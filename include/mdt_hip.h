@@ -147,7 +147,15 @@ enum mdt_op_kind {
                           vectors of block aux) | aux << 2; tile sequence: [3 (block 0)], then per block, kind 1: X nt X nt, kind 2: X nt X
                           8 S X 8 S X nt X nt (block1 on x, to_out on x, to_out on the skip, block1 on the skip, block2; X = 2, or 3 with aux = next block at a block's first X; nt = 8 taps; S = 1).  Vectors
                           per block: kind 1 [g1 | b1 | bias1 | g2 | b2 | bias2], kind 2 [g1 (2C) | b1 (2C) | bias1 | bias_to_out | g2 |
-                          b2 | bias2].  WF32 as MDT_OP_TF256 (fp32 fragment sub-tiles)                                                  */
+                          b2 | bias2].  WF32 as MDT_OP_TF256 (fp32 fragment sub-tiles).
+                          NSPLIT = 2 (round 6; batches whose 32-row blocks do not fill the chip): a PAIR of workgroups per row block as
+                          MDT_OP_TF256's pair split; a2 = the hand-off flags, p1 = the hand-off blocks (the SAME buffers as the
+                          MDT_OP_TF256 ops of the level: shared flag lines, 32 KB blocks of which this op uses 16 KB), PAIR_STRIDE
+                          as there, NFF = weight sub-tiles of ONE half.  Half hh streams output chunks 2 hh, 2 hh + 1 of every
+                          convolution: sub-tiles in (tap, K half, chunk of the half) order, half 1's NFF sub-tiles behind half
+                          0's; ONE descriptor table (the runs of both halves are equal, the tile sequence is the unsplit one with
+                          half the weight runs); the pair's hand-offs use words 4..7 of the flag lines (one per compute wave; word 0
+                          is MDT_OP_TF256's).  The result does not depend on where the two workgroups run.                     */
   MDT_OP_TBLOCK = 7    /* fused transformer sub-block, in place on x (TransformerBlock.forward, modules.py:456-461):
                           x += Attention(x) | x += Attention(x, context) | x += FeedForward(x); LayerNorm affine
                           folded into the projection weights, q/k/v/probabilities/hidden never leave registers */

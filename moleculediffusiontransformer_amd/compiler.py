@@ -163,11 +163,12 @@ class UNetCompiler:
         # projections into the query / output projections and attend to the normalised context itself
         # ResNet blocks of a 128-channel level inside the transformer launch that follows them (k_tf128 RES = 1 / 2)
         self.res128 = os.environ.get("MDT_RES128", "1") == "1"
-        # MDT_RES256: the 256-channel level's ResNet blocks as chained launches (MDT_OP_RES256, csrc/k_res256.hip) -- 1 always, 0 never
-        # (one k_rconv launch per convolution), auto (default) = where it measured faster: in the wide program (batches whose
-        # 256-channel level does not fit one pair-split launch: +2.1 ... +3.3 % same-box at B = 2048 / 8192 / guidance) and on a
-        # one-token level (configs[2]: +0.7 %); at BASELINE configs[1]'s B = 1024 the per-convolution launches, which split the
-        # output channels over two workgroups, are 0.4 % faster than the chain on half the compute units (profiles/r5_res256_ab.txt)
+        # MDT_RES256: the 256-channel level's ResNet blocks as chained launches (MDT_OP_RES256, csrc/k_res256.hip) -- auto (default):
+        # the unsplit chain in the wide program (+2.1 ... +3.3 % same-box at B = 2048 / 8192 / guidance, round 5) and the PAIR-SPLIT
+        # chain (round 6, res256_split()) in the narrow one; 1: the unsplit chain always; 0: never (one k_rconv launch per convolution);
+        # whole: round 5's policy (unsplit chain in the wide program and on one-token levels, k_rconv launches at configs[1]'s
+        # B = 1024 -- there the per-convolution launches, which split the output channels over two workgroups, were 0.4 % faster than
+        # the unsplit chain on half the compute units, profiles/r5_res256_ab.txt); split: the pair-split chain always
         self.res256_mode = os.environ.get("MDT_RES256", "auto")
         self.patch_conv = os.environ.get("MDT_PATCH_CONV", "1") != "0"   # resampling convolutions in patch form on k_rconv
         self.fold_patch = os.environ.get("MDT_FOLD_PATCH", "1") != "0"   # Patcher / Unpatcher rearranges folded into k_resblock
@@ -1317,7 +1318,9 @@ class UNetCompiler:
             return False
         if c != 256 or rows > 16 or 16 % rows or groups <= 0:
             return False
-        if self.res256_mode != "1" and not (self.tf256 or rows == 1):
+        if self.res256_mode not in ("1", "auto", "split", "whole"):
+            return False
+        if self.res256_mode == "whole" and not (self.tf256 or rows == 1):      # round 5's policy: the unsplit chain where it won
             return False
         cin = 2 * c if two_source else c
         if cin % groups or c % groups or cin // groups != (64 if two_source else 32) or c // groups != 32:
@@ -1327,15 +1330,34 @@ class UNetCompiler:
             return False
         return ((p + "to_out.weight") in self.sd) == two_source
 
+    def res256_split(self) -> bool:
+        """Form of the MDT_OP_RES256 chains: pair-split (k_res256 NSPLIT = 2: two workgroups per 32-row block, half the weight stream
+        each, hand-offs inside the launch) in the NARROW program -- batches whose 32-row blocks do not fill the chip, where the
+        unsplit chain ran on half the compute units and one k_rconv launch per convolution (26 per evaluation at configs[1]) was
+        the faster form through round 5 -- and the unsplit chain in the wide program.  MDT_RES256: auto (default) | split | whole
+        (never split; in the narrow program: k_rconv launches, round 5's policy) | 1 (unsplit chain everywhere) | 0 (no chains)."""
+        if self.res256_mode in ("1", "whole"):
+            return False
+        if self.res256_mode == "split":
+            return True
+        return not self.tf256 and self.tf256_pair
+
     def resnet_chain256(self, x: Ten, blocks: List[str], kind: int, skips: List[Ten], scale_b: float, y: Ten,
-                        free_input: bool) -> Ten:
+                        free_input: bool, nsplit: Optional[int] = None) -> Ten:
         """ResnetBlock1d.forward (modules.py:193-205) for every prefix in `blocks`, ONE MDT_OP_RES256 launch.  kind 1: x = Block(x),
         block rb's output also stored to skips[rb] (whole tensors apart, ascending); kind 2: x = Block(cat([x, scale_b * skips[rb]]))
         (modules.py:828-829; skips descending, in order of consumption).  Sub-tiles [64][128]: rows 0..31 = output channels 32 ch ..,
         rows 32..63 = channels 128 + 32 ch .. (a wave of the kernel owns a contiguous half of the channels); K columns in
-        accumulator order; one token per sample: only the centre tap of the k = 3 convolutions is streamed."""
+        accumulator order; one token per sample: only the centre tap of the k = 3 convolutions is streamed.
+        nsplit = 2 (round 6; default in the narrow program): the pair-split form -- every row block is served by a PAIR of workgroups,
+        half hh streams output chunks 2 hh, 2 hh + 1 of every convolution (its sub-tiles `NFF` sub-tiles behind half 0's), the pair
+        hands its chunks to each other inside the launch behind every completed accumulator set (wave by wave, no tile of the stream)."""
         sd, c, rows = self.sd, 256, x.rows
         taps = 1 if rows == 1 else 3
+        if nsplit is None:
+            nsplit = 2 if self.res256_split() else 1
+        split = nsplit == 2
+        tiles1: List[torch.Tensor] = []                            # half 1's sub-tiles (split form), appended behind half 0's
         acc = torch.tensor([16 * (2 * (k >> 5) + ((k & 7) >> 2)) + 4 * ((k >> 3) & 3) + (k & 3) for k in range(c)])
         W_, S_, X_, XV_ = 0, 1, 2, 3
         tiles: List[torch.Tensor] = []
@@ -1350,13 +1372,15 @@ class UNetCompiler:
             for tap in tp:
                 wt = w[:, :, tap][:, acc]
                 for kh in range(2):
-                    for ch in range(4):
-                        rws = torch.cat([torch.arange(32 * ch, 32 * ch + 32), torch.arange(128 + 32 * ch, 128 + 32 * ch + 32)])
+                    for cl in range(2 if split else 4):
                         if desc and (desc[-1] & 3) == W_ and len(desc) > 1:
                             desc[-1] += 1 << 2                  # run-length: one descriptor per RUN of weight sub-tiles
                         else:
                             desc.append(W_ | (1 << 2))
-                        tiles.append(self._wtile(wt[rws][:, 128 * kh: 128 * kh + 128].contiguous()))
+                        for hh in range(2 if split else 1):      # split: ONE table, chunk 2 hh + cl in half hh's stream
+                            ch = 2 * hh + cl if split else cl
+                            rws = torch.cat([torch.arange(32 * ch, 32 * ch + 32), torch.arange(128 + 32 * ch, 128 + 32 * ch + 32)])
+                            (tiles1 if hh else tiles).append(self._wtile(wt[rws][:, 128 * kh: 128 * kh + 128].contiguous()))
 
         film0 = None
         for rb, bp in enumerate(blocks):
@@ -1399,14 +1423,21 @@ class UNetCompiler:
         op.kind = rt.OP_RES256
         op.a, op.out, op.res = x.ref(), y.ref(), skips[0].ref()
         op._film = ("ss", film0)
-        op.w = _ref(rt.SP_WEIGHT, self.W.add(blocks[0] + "res256.tiles", torch.cat(tiles)))
+        n_half = len(tiles)
+        tiles = tiles + tiles1
+        op.w = _ref(rt.SP_WEIGHT, self.W.add(blocks[0] + f"res256.tiles{nsplit}", torch.cat(tiles)))
         op.i[rt.W_KB] = min(sum(t.numel() for t in tiles) * 4 // 1024, 4096)
         op.bias = _ref(rt.SP_WEIGHT, self.W.add(blocks[0] + "res256.vec", v))
-        op.p0 = _ref(rt.SP_WEIGHT, self.W.add(blocks[0] + "res256.desc", torch.tensor(desc, dtype=torch.int32).view(torch.float32)))
+        op.p0 = _ref(rt.SP_WEIGHT, self.W.add(blocks[0] + f"res256.desc{nsplit}", torch.tensor(desc, dtype=torch.int32).view(torch.float32)))
         i = op.i
         ntiles = sum((d >> 2) if (d & 3) == W_ else 1 for d in desc)
         i[rt.F_C], i[rt.F_T], i[rt.F_NT], i[rt.F_NVEC], i[rt.F_NPOST], i[rt.F_HEADS] = c, rows, ntiles, v.numel(), taps, len(desc)
         i[rt.F_RES_KIND], i[rt.F_N_RES], i[rt.F_NFILM], i[rt.F_WF32] = kind, n, 2 * c * n, int(self.wf32)
+        if split:
+            # hand-off flags / blocks: the engine's buffers of the pair-split MDT_OP_TF256 ops (same row blocks, same flag lines)
+            i[rt.F_NSPLIT], i[rt.F_PAIR_STRIDE], i[rt.F_NFF] = 2, self.pair_stride, n_half
+            op.a2, op.p1 = _ref(rt.SP_EXT0 + EXT_XFLAGS, 0), _ref(rt.SP_EXT0 + EXT_XBUF, 0)
+            self.xchg_tokens = max(self.xchg_tokens, rows)
         op.f[rt.FF_EPS_RES], op.f[rt.FF_SKIP_SCALE] = 1e-5, float(scale_b if kind == 2 else 1.0)
         self._emit(op)
         if free_input:

@@ -36,6 +36,17 @@
 //   kind 1:  X  nt (block1)  X  nt (block2)
 //   kind 2:  X  nt (block1 on x)  X  8 (to_out on x)  S  X  8 (to_out on skip)  S  X  nt (block1 on skip)  X  nt (block2)
 // preceded by ONE vector tile (kind 3, block 0).  X = scratch tile (kind 2, or 3 = + the NEXT block's vectors), S = skip rows.
+//
+// NSPLIT = 2 (round 6; the form of batches whose 32-row blocks do not fill the chip: the narrow program, B <= 1024 at 4 tokens per
+// sample): a PAIR of workgroups per row block, as k_tf256.hip's pair split.  Half hh streams only the sub-tiles of output chunks
+// 2 hh, 2 hh + 1 of every convolution (half the weight stream per compute unit -- what the per-convolution launches of k_rconv.hip
+// bought by splitting the output channels over two workgroups -- without their 26 launches); behind every COMPLETED accumulator
+// set (the first convolution's output; the block's output sum) the two workgroups hand each other their chunks inside the launch
+// (16 KB each way, wave by wave: 16-byte sc1 stores, s_waitcnt vmcnt(0), the wave's flag store; poll of the partner wave's flag,
+// sc1 loads -- the forms, the flag lines and the hand-off blocks of k_tf256.hip, which see for the safety argument; see handoff()),
+// so both hold identical full rows for GroupNorm and the next convolution's operands.  The tile stream is the unsplit one with half
+// the weight runs; the chain's last output leaves the kernel by halves, without a hand-off.
+// One descriptor table serves both halves (equal run lengths); half hh's sub-tiles start at w + hh * (sub-tiles per half).
 #include <cstdlib>
 #include <type_traits>
 
@@ -125,13 +136,19 @@ constexpr int NST = C / 32;     // k-steps of the input channels
 constexpr int NU = 4;           // units (4 fragment reads + 6 MFMAs) per sub-tile per wave
 constexpr int NCH = C / 64;     // 64-feature chunks of an output
 constexpr int VPAR = 12 * 1024; // bytes of one parity of the vector area (kind 2: 9 C + 2 C floats = 11 KB)
+// pair hand-off (NSPLIT = 2): k_tf256.hip's blocks and flag lines (one 32 KB block per (parity, row block, half); this kernel fills
+// the first 16 KB), its cache policies (sc1 stores / sc1 loads: the measured-valid row of MI355X_MICROARCH.md) and its time-out
+constexpr unsigned XBLOCK = 32 * C * 4;
+constexpr int AUX_ST = 16, AUX_LD = 16;
+constexpr unsigned long long POLL_TIMEOUT = 30000000ull;   // s_memrealtime ticks (100 MHz): 0.3 s
 
 }  // namespace
 
 // RES: 1 single source + skip stores, 2 two sources (see the head of the file).  TAPS: 3, or 1 for one token per sample (the
 // block convolutions' centre tap only; the residual convolution of kind 2 is always k = 1).  F32: fp32 fragment sub-tiles and
 // exact fp32 MFMA products, as k_tf256.hip.
-template <int RES, int TAPS, bool F32>
+// NSPLIT: 1 = one workgroup per 32-row block; 2 = a pair of workgroups per block (head of the file).
+template <int RES, int TAPS, bool F32, int NSPLIT>
 __global__ __launch_bounds__(512) void k_res256(TFArgs a) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   unsigned char* vec_b = smem + NS * SLOT;             // two parities of VPAR bytes: [block vectors | FiLM row (2 C)]
@@ -142,7 +159,17 @@ __global__ __launch_bounds__(512) void k_res256(TFArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int NT = a.NT;
   const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(a.w);
-  const int rowb = blockIdx.x * 32;
+  // row block and half of this workgroup (k_tf256.hip): linear id = (group, half, member), partners PAIR_STRIDE ids apart
+  int rb_ = blockIdx.x, hh = 0;
+  const int nrb = (a.M + 31) / 32;
+  if constexpr (NSPLIT == 2) {
+    const int S = a.pair_stride, id = blockIdx.x;
+    const int grp = id / (2 * S), w = id - grp * 2 * S;
+    hh = w / S;
+    rb_ = a.rb_base + grp * S + (w - hh * S);
+    if (rb_ >= nrb) return;                            // padding of the last group: both partners leave
+  }
+  const int rowb = rb_ * 32;
 
   if (wave >= 4) {
     // ================= loader waves: descriptor-driven stream (k_tf128.hip / k_tf256.hip) =================
@@ -250,7 +277,7 @@ __global__ __launch_bounds__(512) void k_res256(TFArgs a) {
         load_seg(c);
       }
     };
-    unsigned wnext = 0;                                // next sub-tile of the weight stream to issue
+    unsigned wnext = NSPLIT == 2 ? (unsigned)(hh * a.nff) : 0u;   // next sub-tile of the weight stream to issue (a.nff = sub-tiles of one half)
     auto issue_cur = [&](int tau, const Cur& c) {      // the tile under the issue cursor -> slot of tile tau
       if (c.kind == D_W) {
         issue_w(smem + MDT_SLOT_IDX(tau) * SLOT + iw * 1024, wsrc + (int64_t)wnext * SLOT);
@@ -603,15 +630,29 @@ __global__ __launch_bounds__(512) void k_res256(TFArgs a) {
 
   // A convolution of NTAPS taps on the operands xh / xl into dst (tile order: tap, K half, chunk).  Starts the fragment pipeline
   // afresh (the operands were not there while the previous convolution's last sub-tiles streamed) and drains it at the end.
+  // NSPLIT = 2: half hh streams chunks 2 hh, 2 hh + 1 only; they are computed in a local pair of chunk accumulators (register
+  // arrays cannot be indexed by hh) that starts from and returns to dst by selects on the wave-uniform hh.
+  auto sel4 = [](bool c_, const f32x4& x, const f32x4& y) __attribute__((always_inline)) {
+    return f32x4{c_ ? x[0] : y[0], c_ ? x[1] : y[1], c_ ? x[2] : y[2], c_ ? x[3] : y[3]};
+  };
   auto conv = [&](auto ntaps, f32x4 (&dst)[NCH][2]) __attribute__((always_inline)) {
     constexpr int NTAPS = decltype(ntaps)::value;
+    constexpr int NCL = NCH / NSPLIT;                  // chunks this workgroup streams per (tap, K half)
+    f32x4 dl[NCL][2];
+#pragma unroll
+    for (int k = 0; k < NCL; ++k)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        if constexpr (NSPLIT == 2) dl[k][q] = sel4(hh != 0, dst[NCL + k][q], dst[k][q]);
+        else dl[k][q] = dst[k][q];
+      }
     MDT_STAMP();                                     // operands ready
     __builtin_amdgcn_s_barrier();                    // B(first sub-tile)
     prefetch2(slot_of(tau));
     MDT_STAMP();                                     // first sub-tile there
     auto tap_kh = [&](auto pc) __attribute__((always_inline)) {
-      constexpr int P0 = decltype(pc)::value;          // first phase of this (tap, K half): 4 phases follow
-      constexpr int tap = P0 / (2 * NCH), kh = (P0 / NCH) & 1;
+      constexpr int P0 = decltype(pc)::value;          // first phase of this (tap, K half): NCL phases follow
+      constexpr int tap = P0 / (2 * NCL), kh = (P0 / NCL) & 1;
       bf16x8 oph[4], opl[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -620,20 +661,97 @@ __global__ __launch_bounds__(512) void k_res256(TFArgs a) {
         else if (tap == 0) { oph[k] = row_shift_rs<true>(xh[st], has_prev); opl[k] = row_shift_rs<true>(xl[st], has_prev); }
         else { oph[k] = row_shift_rs<false>(xh[st], has_next_row); opl[k] = row_shift_rs<false>(xl[st], has_next_row); }
       }
-      constexpr int LAST = NTAPS * 2 * NCH - 1;
-      phase(std::integral_constant<int, (P0 + 0) % 3>{}, P0 + 0 < LAST, dst[0], oph, opl);
-      phase(std::integral_constant<int, (P0 + 1) % 3>{}, P0 + 1 < LAST, dst[1], oph, opl);
-      phase(std::integral_constant<int, (P0 + 2) % 3>{}, P0 + 2 < LAST, dst[2], oph, opl);
-      phase(std::integral_constant<int, (P0 + 3) % 3>{}, P0 + 3 < LAST, dst[3], oph, opl);
-      MDT_STAMP();                                     // four sub-tiles of one (tap, K half)
+      constexpr int LAST = NTAPS * 2 * NCL - 1;
+      phase(std::integral_constant<int, (P0 + 0) % 3>{}, P0 + 0 < LAST, dl[0], oph, opl);
+      phase(std::integral_constant<int, (P0 + 1) % 3>{}, P0 + 1 < LAST, dl[1], oph, opl);
+      if constexpr (NCL == 4) {
+        phase(std::integral_constant<int, (P0 + 2) % 3>{}, P0 + 2 < LAST, dl[2], oph, opl);
+        phase(std::integral_constant<int, (P0 + 3) % 3>{}, P0 + 3 < LAST, dl[3], oph, opl);
+      }
+      MDT_STAMP();                                     // the sub-tiles of one (tap, K half)
     };
     tap_kh(std::integral_constant<int, 0>{});
-    tap_kh(std::integral_constant<int, 4>{});
+    tap_kh(std::integral_constant<int, NCL>{});
     if constexpr (NTAPS == 3) {
-      tap_kh(std::integral_constant<int, 8>{});
-      tap_kh(std::integral_constant<int, 12>{});
-      tap_kh(std::integral_constant<int, 16>{});
-      tap_kh(std::integral_constant<int, 20>{});
+      tap_kh(std::integral_constant<int, 2 * NCL>{});
+      tap_kh(std::integral_constant<int, 3 * NCL>{});
+      tap_kh(std::integral_constant<int, 4 * NCL>{});
+      tap_kh(std::integral_constant<int, 5 * NCL>{});
+    }
+#pragma unroll
+    for (int k = 0; k < NCL; ++k)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        if constexpr (NSPLIT == 2) {
+          dst[k][q] = sel4(hh != 0, dst[k][q], dl[k][q]);
+          dst[NCL + k][q] = sel4(hh != 0, dl[k][q], dst[NCL + k][q]);
+        } else {
+          dst[k][q] = dl[k][q];
+        }
+      }
+  };
+
+  // ---- NSPLIT = 2: the pair hands each other the chunks it computed of a COMPLETED accumulator set ----
+  // k_tf256.hip's protocol PER WAVE: wave w of half hh needs exactly what wave w of half hh ^ 1 computed (same rows, same feature
+  // half, the other two chunks), so every wave owns a 4 KB piece of the pair's hand-off blocks and a flag word of its own (words
+  // 4 + w of the (row block, half) flag line whose word 0 is MDT_OP_TF256's): 16-byte sc1 stores, s_waitcnt vmcnt(0), the wave's flag
+  // store; poll of the partner wave's flag with sc1 loads; 16-byte sc1 loads.  No workgroup barrier, no wave waits for another wave
+  // of its own workgroup, no tile of the stream is spent on it (first version: the two barriers + one polling wave of k_tf256 --
+  // ~6 us per hand-off with the waves' skew added up at the barriers; profiles/r6_res256_split_ab.txt).
+  unsigned xround = 0;                               // this wave's flag value = hand-offs it has completed, ever
+  int xn = 0;                                        // hand-offs of this launch (buffer parity)
+  __amdgpu_buffer_rsrc_t xres, fres;
+  const unsigned fown = (64u + 32u * (unsigned)(2 * rb_ + hh) + 4u + (unsigned)wave) * 4u;
+  if constexpr (NSPLIT == 2) {
+    xres = __builtin_amdgcn_make_buffer_rsrc(a.xbuf, 0, 0x7fffffff, 0x00020000);
+    fres = __builtin_amdgcn_make_buffer_rsrc(a.xflags, 0, 0x7fffffff, 0x00020000);
+    xround = (unsigned)__builtin_amdgcn_readfirstlane(__builtin_amdgcn_raw_buffer_load_b32(fres, fown, 0, AUX_LD));   // written by an earlier LAUNCH
+  }
+  auto handoff = [&](f32x4 (&dst)[NCH][2]) __attribute__((always_inline)) {
+    if constexpr (NSPLIT == 2) {
+      // block of (parity, row block, half): [wave][chunk k of the half][q][lane] f32x4 = 16 KB; the whole byte offset goes into
+      // the instructions' VECTOR offset (a rewritten SGPR as scalar offset lost pieces: k_tf256.hip, round 3)
+      const unsigned sbase = __builtin_amdgcn_readfirstlane(
+          (((unsigned)(xn & 1) * (unsigned)nrb + (unsigned)rb_) * 2u + (unsigned)hh) * XBLOCK + (unsigned)wave * 4096u);
+      const unsigned vlane = (unsigned)lane * 16u;
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const f32x4 v = sel4(hh != 0, dst[2 + k][q], dst[k][q]);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), xres, vlane + sbase + (unsigned)(2 * k + q) * 1024u, 0, AUX_ST);
+        }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores are drained in front of ITS flag store
+      ++xround;
+      __builtin_amdgcn_raw_buffer_store_b32((int)xround, fres, fown, 0, AUX_ST);
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      for (;;) {
+        asm volatile("" ::: "memory");                 // a fresh load every turn
+        const unsigned got = (unsigned)__builtin_amdgcn_readfirstlane(__builtin_amdgcn_raw_buffer_load_b32(fres, fown ^ 128u, 0, AUX_LD));
+        if ((int)(got - xround) >= 0) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > POLL_TIMEOUT) {   // never hang the GPU: flag the launch and go on
+          if (lane == 0) atomicOr(a.xflags, 1u);
+          break;
+        }
+      }
+      asm volatile("" ::: "memory");
+      const unsigned sother = sbase ^ XBLOCK;            // the same piece of half hh ^ 1
+      f32x4 o[2][2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          o[k][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, vlane + sother + (unsigned)(2 * k + q) * 1024u, 0, AUX_LD));
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          dst[k][q] = sel4(hh != 0, o[k][q], dst[k][q]);              // half 1 receives chunks 0, 1
+          dst[2 + k][q] = sel4(hh != 0, dst[2 + k][q], o[k][q]);      // half 0 receives chunks 2, 3
+        }
+      ++xn;
+      MDT_STAMP();                                     // partner's chunks received
     }
   };
   using N1 = std::integral_constant<int, 1>;
@@ -687,17 +805,21 @@ __global__ __launch_bounds__(512) void k_res256(TFArgs a) {
       make_operands(acc, mu, rs, pv, pv + C, nullptr, 1.0f);
       set_vec(hT, pv + 2 * C, false);
       conv(NB{}, hT);
+      handoff(hT);
       gn_stats(hT, false, mu, rs);
       make_operands(hT, mu, rs, pv + 3 * C, pv + 4 * C, film_s, 1.0f);
       set_vec(acc, pv + 5 * C, true);                  // the stream is the block's residual
       conv(NB{}, acc);
-      if (mvalid) {                                    // every block's output is a skip of the up path
-        float* so = a.skip + (int64_t)rb * a.skip_stride + (int64_t)m * C + ch0;
+      if (rb + 1 < a.n_res) handoff(acc);              // (the last block's output leaves by halves, below)
+      if (mvalid) {                                    // every block's output is a skip of the up path (NSPLIT = 2: the chunks this half
+        float* so = a.skip + (int64_t)rb * a.skip_stride + (int64_t)m * C + ch0;      // computed; BEHIND the hand-off: its drain does not wait for them)
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
+          if (NSPLIT == 1 || (c >> 1) == hh) {
 #pragma unroll
-          for (int q = 0; q < 2; ++q)
-            store_nt(so + 32 * c + 16 * q, make_float4(acc[c][q][0], acc[c][q][1], acc[c][q][2], acc[c][q][3]));
+            for (int q = 0; q < 2; ++q)
+              store_nt(so + 32 * c + 16 * q, make_float4(acc[c][q][0], acc[c][q][1], acc[c][q][2], acc[c][q][3]));
+          }
       }
     } else {
       // vectors: [g1 (2C) | b1 (2C) | bias1 | bias_r | g2 | b2 | bias2]; groups of block1's 2C-channel input are 64 channels wide.
@@ -725,32 +847,62 @@ __global__ __launch_bounds__(512) void k_res256(TFArgs a) {
         make_operands(xb, mu, rs, pv + C, pv + 3 * C, nullptr, a.skip_scale);
       }
       conv(NB{}, hT);                                                          // block1 on the skip
+      handoff(hT);
       gn_stats(hT, false, mu, rs);
       make_operands(hT, mu, rs, pv + 6 * C, pv + 7 * C, film_s, 1.0f);
       conv(NB{}, acc);                                                         // block2
+      if (rb + 1 < a.n_res) handoff(acc);                                      // (the last block's output leaves by halves, below)
     }
   }
 
-  // ---- the residual stream leaves the kernel ----
+  // ---- the residual stream leaves the kernel (NSPLIT = 2: every half stores the chunks it owns; kind 1 has exchanged them, both hold
+  // the same values) ----
   if (mvalid) {
     float* xo = a.out + (int64_t)m * C + ch0;
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
+      if (NSPLIT == 1 || (c >> 1) == hh) {
 #pragma unroll
-      for (int q = 0; q < 2; ++q)
-        store_nt(xo + 32 * c + 16 * q, make_float4(acc[c][q][0], acc[c][q][1], acc[c][q][2], acc[c][q][3]));
+        for (int q = 0; q < 2; ++q)
+          store_nt(xo + 32 * c + 16 * q, make_float4(acc[c][q][0], acc[c][q][1], acc[c][q][2], acc[c][q][3]));
+      }
+  }
+}
+
+template <int RES, int TAPS, bool F32, int NSPLIT>
+static hipError_t launch_rs2(const TFArgs& a, hipStream_t s) {
+  const size_t smem = (size_t)NS * SLOT + 2 * VPAR;              // ring, vector areas
+  static DevOnce attr_once;                          // per device (mdt_kernels.h)
+  if (attr_once.first())
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_res256<RES, TAPS, F32, NSPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(160 * 1024));
+  const int nrb = (a.M + 31) / 32;
+  if constexpr (NSPLIT == 1) {
+    hipLaunchKernelGGL((k_res256<RES, TAPS, F32, NSPLIT>), dim3((unsigned)nrb), dim3(512), smem, s, a);
+    return hipGetLastError();
+  } else {
+    // Both workgroups of a pair must be resident at the same time: never more workgroups in a launch than the device runs at once;
+    // a larger batch runs as several launches over consecutive row-block ranges (k_tf256.hip::launch_tf2, same reasoning)
+    const int cap = tf256_pair_capacity();           // (one 512-thread workgroup per compute unit for either kernel: the LDS ring)
+    const int S = a.pair_stride;
+    const int groups_fit = cap / (2 * S);
+    if (groups_fit < 1) return hipErrorLaunchOutOfResources;
+    const int ngroups = (nrb + S - 1) / S;
+    for (int g0 = 0; g0 < ngroups; g0 += groups_fit) {
+      TFArgs b = a;
+      b.rb_base = g0 * S;
+      const int ng = ngroups - g0 < groups_fit ? ngroups - g0 : groups_fit;
+      hipLaunchKernelGGL((k_res256<RES, TAPS, F32, NSPLIT>), dim3(2u * (unsigned)S * (unsigned)ng), dim3(512), smem, s, b);
+      const hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
   }
 }
 
 template <int RES, int TAPS, bool F32>
 static hipError_t launch_rs(const TFArgs& a, hipStream_t s) {
-  const size_t smem = (size_t)NS * SLOT + 2 * VPAR;              // ring, vector areas
-  static DevOnce attr_once;                          // per device (mdt_kernels.h)
-  if (attr_once.first())
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_res256<RES, TAPS, F32>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(160 * 1024));
-  hipLaunchKernelGGL((k_res256<RES, TAPS, F32>), dim3((unsigned)((a.M + 31) / 32)), dim3(512), smem, s, a);
-  return hipGetLastError();
+  return a.nsplit == 2 ? launch_rs2<RES, TAPS, F32, 2>(a, s) : launch_rs2<RES, TAPS, F32, 1>(a, s);
 }
 
 bool res256_supported(int T, int kind, int n_res, int taps) {
@@ -759,11 +911,13 @@ bool res256_supported(int T, int kind, int n_res, int taps) {
 }
 
 // a.res_kind / n_res / T as MDT_OP_TF128's; a.npost carries the taps of the block convolutions (1 | 3); a.nvec = floats of ALL
-// blocks' vectors (n_res x 6 C | 9 C), a.nfilm >= 2 C n_res
+// blocks' vectors (n_res x 6 C | 9 C), a.nfilm >= 2 C n_res; a.nsplit = 2: the pair-split form (a.nff = weight sub-tiles of ONE half,
+// a.xflags / a.xbuf / a.pair_stride as MDT_OP_TF256's)
 hipError_t launch_res256(const TFArgs& a, hipStream_t s) {
   if (a.M <= 0) return hipSuccess;
   const int taps = a.npost;
   if (!res256_supported(a.T, a.res_kind, a.n_res, taps) || a.NT <= 0 || a.nheads <= 0 || !a.skip || !a.film || !a.vec || !a.tiles) return hipErrorInvalidValue;
+  if (a.nsplit == 2 && (!a.xbuf || !a.xflags || a.pair_stride <= 0 || a.pair_stride > 64 || a.nff <= 0)) return hipErrorInvalidValue;
   if (a.wf32) {                                       // exact fp32 products on fp32 fragment sub-tiles (MDT_F_WF32)
     if (a.res_kind == 1) return taps == 3 ? launch_rs<1, 3, true>(a, s) : launch_rs<1, 1, true>(a, s);
     return taps == 3 ? launch_rs<2, 3, true>(a, s) : launch_rs<2, 1, true>(a, s);

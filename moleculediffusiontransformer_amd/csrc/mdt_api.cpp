@@ -287,6 +287,11 @@ static const char* validate(const mdt_op& o, int idx, char* buf, size_t nbuf) {
         return bad("ResNet chain: tokens per sample must divide 16, kind 1 | 2, 1..255 blocks, taps 3 (or 1 with one token per sample)");
       if (i[MDT_F_NT] <= 0 || i[MDT_F_HEADS] <= 0 || i[MDT_F_HEADS] > i[MDT_F_NT] || i[MDT_F_NBLOCKS] || i[MDT_F_HAS_IN] || i[MDT_F_CROSS])
         return bad("ResNet chain: bad tile / segment count or stray transformer fields");
+      if (i[MDT_F_NSPLIT] != 0 && i[MDT_F_NSPLIT] != 1 && i[MDT_F_NSPLIT] != 2) return bad("NSPLIT must be 1 or 2");
+      if (i[MDT_F_NSPLIT] == 2 && (!o.a2.space || !o.p1.space || i[MDT_F_PAIR_STRIDE] < 0 || i[MDT_F_PAIR_STRIDE] > 64 || i[MDT_F_NFF] <= 0))
+        return bad("the pair-split chain needs the hand-off flags (a2), the hand-off blocks (p1), a pair stride of 1..64 and NFF = the "
+                   "weight sub-tiles of one half");
+      if (i[MDT_F_NSPLIT] != 2 && i[MDT_F_NFF]) return bad("ResNet chain: stray transformer fields");
       if (i[MDT_F_WF32] != 0 && i[MDT_F_WF32] != 1) return bad("WF32 must be 0 (split-bf16 tiles) or 1 (fp32 fragment tiles)");
       if (i[MDT_F_NVEC] != i[MDT_F_N_RES] * (i[MDT_F_RES_KIND] == 1 ? 6 : 9) * 256 || i[MDT_F_NFILM] < 512 * i[MDT_F_N_RES])
         return bad("ResNet chain: NVEC must be N_RES x (6 | 9) x 256 floats and NFILM >= 512 N_RES");
@@ -564,7 +569,12 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
         a.skip_stride = (int64_t)B * a.T * 256 * (a.res_kind == 2 ? -1 : 1);
         a.skip_scale = o.f[MDT_FF_SKIP_SCALE]; a.eps_res = o.f[MDT_FF_EPS_RES];
         a.pf_ptr = pf_ptr; a.pf_lines = pf_lines;
-        a.nsplit = 1; a.wf32 = i[MDT_F_WF32];
+        a.nsplit = i[MDT_F_NSPLIT] == 2 ? 2 : 1; a.wf32 = i[MDT_F_WF32];
+        // pair-split chain (round 6): hand-off flags (a2) / blocks (p1) and pair stride as MDT_OP_TF256's, NFF = sub-tiles of ONE half
+        a.pair_stride = g_pair_stride > 0 ? g_pair_stride : (i[MDT_F_PAIR_STRIDE] > 0 ? i[MDT_F_PAIR_STRIDE] : 8);
+        a.xflags = a.nsplit == 2 ? reinterpret_cast<unsigned*>(const_cast<float*>(ptr(o.a2))) : nullptr;
+        a.xbuf = a.nsplit == 2 ? const_cast<float*>(ptr(o.p1)) : nullptr;
+        a.nff = i[MDT_F_NFF]; a.rb_base = 0;
         a.dbgbuf = ptr(o.p2);                            // (tuning builds with -DMDT_STAMPS: clock stamps of workgroup 0; else unused)
         if (!missing) e = mdt::launch_res256(a, stream);
         break;

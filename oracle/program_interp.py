@@ -727,7 +727,12 @@ def _res256(op, bufs: Buffers, B: int) -> None:
         else:
             desc.append(d)
     assert len(desc) == NT, (len(desc), NT)
-    stream = bufs.view(op.w, B, nw * 64 * 128)
+    # NSPLIT = 2 (pair-split form): ONE descriptor table walked by both halves; half hh streams only output chunks 2 hh, 2 hh + 1 of
+    # every convolution -- (tap, K half, chunk of the half) order, half 1's sub-tiles NFF sub-tiles behind half 0's (the hand-offs
+    # between the two workgroups take no tile of the stream)
+    split = i[rt.F_NSPLIT] == 2
+    assert not split or nw == i[rt.F_NFF], (nw, i[rt.F_NFF])
+    stream = bufs.view(op.w, B, (2 if split else 1) * nw * 64 * 128)
     vec = bufs.view(op.bias, B, i[rt.F_NVEC])
     film = bufs.view(op.p3, B, i[rt.F_NFILM])
     acc = torch.tensor([16 * (2 * (k >> 5) + ((k & 7) >> 2)) + 4 * ((k >> 3) & 3) + (k & 3) for k in range(C)])
@@ -755,10 +760,13 @@ def _res256(op, bufs: Buffers, B: int) -> None:
         w = torch.zeros(C, C, k)
         for tap in range(k):
             for kh in range(2):
-                for ch in range(4):
-                    t = _untile(stream, expect(0), 64, 128, wf32)
-                    rows = torch.cat([torch.arange(32 * ch, 32 * ch + 32), torch.arange(128 + 32 * ch, 128 + 32 * ch + 32)])
-                    w[rows[:, None], acc[128 * kh: 128 * kh + 128][None, :], tap] = t
+                for cl in range(2 if split else 4):
+                    idx = expect(0)
+                    for hh in range(2 if split else 1):
+                        ch = 2 * hh + cl if split else cl
+                        t = _untile(stream, idx + hh * nw, 64, 128, wf32)
+                        rows = torch.cat([torch.arange(32 * ch, 32 * ch + 32), torch.arange(128 + 32 * ch, 128 + 32 * ch + 32)])
+                        w[rows[:, None], acc[128 * kh: 128 * kh + 128][None, :], tap] = t
         return w
 
     def V(n):

@@ -1304,11 +1304,15 @@ def test_resnet_blocks_inside_the_transformer_launch(kind, T, B, n_res, layers, 
     (2, 1, 50, 2),
     (2, 8, 5, 2),
 ])
-def test_resnet_chain_256(kind, T, B, n_res, prod, monkeypatch):
+@pytest.mark.parametrize("form", ["whole", "pair8", "pair1"])
+def test_resnet_chain_256(kind, T, B, n_res, form, prod, monkeypatch):
     """MDT_OP_RES256 (k_res256.hip): a chain of ResnetBlock1d blocks of a 256-channel level in one launch, against (i) the CPU
     interpreter of the op and (ii) the reference's module arithmetic (modules.py:145-205: GroupNorm -> [FiLM] -> SiLU -> Conv1d(k =
     3), twice, + to_out(x) | x; :828-829: cat with the scaled skip).  Kind 1 also stores every block's output; kind 2 reads its
-    skips in reverse order.  Both product types."""
+    skips in reverse order.  Both product types.  form: 'whole' = one workgroup per 32-row block; 'pair8' / 'pair1' (round 6) = the
+    PAIR-SPLIT chain (NSPLIT = 2: half hh streams output chunks 2 hh, 2 hh + 1 of every convolution, the pair hands its chunks to each
+    other inside the launch) with the partners 8 workgroup ids apart or neighbours -- the result must not depend on the placement
+    and equals the unsplit chain's BIT FOR BIT (every output channel is the same MFMA sequence)."""
     from moleculediffusiontransformer_amd.compiler import Ten, UNetCompiler
     from moleculediffusiontransformer_amd.netspec import inverse_unet_config
     import torch.nn.functional as F
@@ -1326,17 +1330,28 @@ def test_resnet_chain_256(kind, T, B, n_res, prod, monkeypatch):
     skips = [Ten(A, (2 + k) * T * C, T, C) for k in range(n_res)]
     if kind == 2:
         skips = skips[::-1]                  # consumed from the highest address downwards
-    comp.resnet_chain256(x, blocks, kind, skips, 2 ** -0.5, y, False)
+    comp.pair_stride = 1 if form == "pair1" else 8
+    comp.resnet_chain256(x, blocks, kind, skips, 2 ** -0.5, y, False, nsplit=1 if form == "whole" else 2)
     op = comp.ops[0]
     assert op.kind == rt.OP_RES256 and len(comp.ops) == 1 and op.i[rt.F_NPOST] == (1 if T == 1 else 3)
+    assert op.i[rt.F_NSPLIT] == (0 if form == "whole" else 2)
+    ext = {} if form == "whole" else _handoff_ext(B, T)
     film_off = 64
     op.p3 = ref(S, film_off)
     act_x = rnd(B * T * C, seed=13) * 1.5 + 0.3
     sk_in = rnd(n_res * B * T * C, seed=16) * 1.2 - 0.1 if kind == 2 else torch.zeros(n_res * B * T * C)
     act = torch.cat([act_x, torch.zeros(B * T * C), sk_in])
     shr = torch.cat([torch.zeros(film_off), 0.3 * rnd(n_res * 2 * C, seed=15), torch.zeros(256)])
-    (ga, _, _), (ca, _, _) = run_both([op], comp.W.pack(), act, shr, {}, B)
+    (ga, _, ge), (ca, _, _) = run_both([op], comp.W.pack(), act, shr, ext, B)
     n = B * T * C
+    if form != "whole":
+        assert int(ge[3].view(torch.int32)[0]) == 0                 # no hand-off poll timed out
+        # the unsplit chain on the same inputs: bitwise equal
+        comp1 = UNetCompiler(cfg, 64, 12, sd, gemm_mode="f32" if prod == "f32" else "bf16x3")
+        comp1.resnet_chain256(x, blocks, kind, skips, 2 ** -0.5, y, False, nsplit=1)
+        comp1.ops[0].p3 = ref(S, film_off)
+        (gw, _, _), _ = run_both([comp1.ops[0]], comp1.W.pack(), act, shr, {}, B)
+        assert torch.equal(ga, gw)
     yg, yc = ga[n: 2 * n].view(B, T, C), ca[n: 2 * n].view(B, T, C)
     assert torch.isfinite(yg).all()
     tol = 2e-4 * max(1.0, yc.abs().max().item())
@@ -1348,7 +1363,7 @@ def test_resnet_chain_256(kind, T, B, n_res, prod, monkeypatch):
     else:
         assert torch.equal(ga[2 * n: (2 + n_res) * n], sk_in)
     # repeated launches return the same bits
-    (gb, _, _), _ = run_both([op], comp.W.pack(), act, shr, {}, B)
+    (gb, _, _), _ = run_both([op], comp.W.pack(), act, shr, ext, B)
     assert torch.equal(ga, gb)
     # ---- the reference's arithmetic ----
     h = act_x.view(B, T, C).transpose(1, 2).double()

@@ -103,7 +103,7 @@ def test_sample_matches_reference(models, name, case, want):
 
 def _switch_cases():
     from test_host_logic import FALLBACK_SWITCHES
-    return [pytest.param(var, value, case, id=f"{var}={value}-{case}") for var, value, cases in FALLBACK_SWITCHES for case in cases]
+    return [pytest.param(var, value, case, id=f"{var}={value}-{case}") for var, value, cases in FALLBACK_SWITCHES for case in cases]      # ("case+VAR=v": on top of that fallback)
 
 
 @pytest.mark.parametrize("var,value,case", _switch_cases())
@@ -114,6 +114,9 @@ def test_every_fallback_switch_matches_reference(var, value, case, monkeypatch):
     configuration.  MDT_B16 / MDT_QKV_MERGE belong to the reduced-precision mode (budget 2e-2 per evaluation)."""
     monkeypatch.setenv(var, value)
     monkeypatch.setenv("MDT_F32_FUSED", "1")
+    case, _, under = case.partition("+")
+    if under:
+        monkeypatch.setenv(*under.split("="))
     g = load_golden(f"{case}_unet.npz")
     m = make_model(case)
     bf16 = var in ("MDT_B16", "MDT_QKV_MERGE")
@@ -180,7 +183,9 @@ def test_wide_batch_kernel_choice_matches_reference():
         assert forms == ({1} if choice == "wide" else {2}) and m._engine.c.tf256 == (choice == "wide")
         # round 5: the wide program chains the 256-channel level's ResNet blocks (MDT_OP_RES256: 4 launches instead of 26)
         kinds = [op.kind for op in m._engine.c.programs["eval"]]
-        assert (rt.OP_RES256 in kinds) == (choice == "wide") and len(kinds) == (20 if choice == "wide" else 42)
+        # ... and since round 6 the narrow program too, as PAIR-SPLIT chains (k_res256 NSPLIT = 2, hand-offs inside the launch)
+        assert len(kinds) == 20 and kinds.count(rt.OP_RES256) == 4
+        assert {op.i[rt.F_NSPLIT] for op in m._engine.c.programs["eval"] if op.kind == rt.OP_RES256} == ({0} if choice == "wide" else {2})
         assert m._engine.handoff_status() == 0
         assert (outs[choice] - to_t(g["out"])).abs().max() < TOL
     m.kernel_choice = "auto"
@@ -446,7 +451,8 @@ def test_repeated_sampling_is_bitwise_stable(B, cs, mode, monkeypatch):
     assert m._engine.handoff_status() == 0
     from moleculediffusiontransformer_amd import runtime as rt
     ev = m._engine.c.programs["eval"]
-    assert len(ev) == 42 and all(op.i[rt.F_WF32] == int(mode == "f32") for op in ev if op.kind in (rt.OP_TF128, rt.OP_TF256, rt.OP_RES256))
+    assert len(ev) == 20 and all(op.i[rt.F_WF32] == int(mode == "f32") for op in ev if op.kind in (rt.OP_TF128, rt.OP_TF256, rt.OP_RES256))
+    assert all(op.i[rt.F_NSPLIT] == 2 for op in ev if op.kind in (rt.OP_TF256, rt.OP_RES256))      # narrow program: every 256-channel launch pair-split
 
 
 def test_handoff_timeout_is_reported_before_the_call_returns():

@@ -30,10 +30,14 @@ for B in (8, 1024, int(os.environ.get("MDT_BIG", "4096"))):
             skips = [Ten(A, base + k * T * C, T, C) for k in range(n)]
         else:
             skips = [Ten(A, base + (n - 1 - k) * T * C, T, C) for k in range(n)]
-        comp.resnet_chain256(x, blocks, kind, skips, 2 ** -0.5, y, False)
+        nsplit = int(os.environ.get("MDT_NSPLIT", "1"))              # 2: the pair-split chain (round 6)
+        comp.resnet_chain256(x, blocks, kind, skips, 2 ** -0.5, y, False, nsplit=nsplit)
         op = comp.ops[0]
         op.p3 = ref(rt.SP_SHR, 0)
         dbg = torch.zeros(1024, device=dev)
+        nrb = (B * T + 31) // 32
+        xflags = torch.zeros(64 + 64 * nrb, dtype=torch.int32, device=dev)
+        xbuf = torch.empty(2 * nrb * 2 * 32 * 256, device=dev)
         if os.environ.get("MDT_DBG", "0") == "8":
             op.p2 = ref(rt.SP_EXT0, 0)
         W = comp.W.pack()
@@ -41,7 +45,7 @@ for B in (8, 1024, int(os.environ.get("MDT_BIG", "4096"))):
         act = torch.randn(B * (2 + n) * T * C, device=dev)
         shr = torch.randn(2 * C * n, device=dev) * 0.1
         prog = rt.Program([op])
-        b = rt.MdtBindings(); b.weights, b.act, b.shr = rt.ptr(W), rt.ptr(act), rt.ptr(shr); b.ext[0] = rt.ptr(dbg)
+        b = rt.MdtBindings(); b.weights, b.act, b.shr = rt.ptr(W), rt.ptr(act), rt.ptr(shr); b.ext[0] = rt.ptr(dbg); b.ext[3], b.ext[4] = rt.ptr(xflags), rt.ptr(xbuf)
         with torch.cuda.device(dev):
             for _ in range(3): prog.run(b, B)
             torch.cuda.synchronize()
@@ -49,7 +53,7 @@ for B in (8, 1024, int(os.environ.get("MDT_BIG", "4096"))):
             for _ in range(20): prog.run(b, B)
             t.stop(); ms = t.collect()[0] / 20
         nt = op.i[rt.F_NT]
-        print(f"{name:10s} kind {kind} blocks {n} B={B:5d}: {ms * 1e3:7.1f} us  ({nt} tiles)", flush=True)
+        print(f"{name:10s} kind {kind} blocks {n} B={B:5d} nsplit {nsplit}: {ms * 1e3:7.1f} us  ({nt} tiles)  status {int(xflags[0])}", flush=True)
         if os.environ.get("MDT_DBG", "0") == "8":
             st = dbg.cpu().view(torch.int64)[:120].tolist()
             st = [v for v in st if v]
