@@ -8,10 +8,24 @@
 //   hipcc -O3 --offload-arch=gfx950 tools/ubench/two_row_own_dma.hip -o /tmp/two_row_own_dma && /tmp/two_row_own_dma
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA __builtin_amdgcn_mfma_f32_16x16x32_bf16
+// Round 6: the tables of round 5 were CYCLES on an all-zero weight stream and small-integer rows.  MI355X_MICROARCH.md (DVFS give-back,
+// items 1 and 7): zero or trivial operands rank two MFMA shapes by cycles and miss the clock the chip holds under load -- on random
+// data a 16x16x32 loop delivered ~1.15x the FLOP/s of the 32x32x16 loop at equal cycles per FLOP.  `RANDOM_DATA` (main: second pass)
+// fills the weight stream with random finite bf16 pairs and the row operands with a per-lane pseudo-random sequence, and every
+// variant is also timed in WALL time (hipEvents over >= 0.2 s of back-to-back launches, every CU busy): ns per 32 KB tile and 16 rows,
+// and the clock the kernel ran at (in-kernel cycles / wall).
+__device__ int g_random_rows = 0;
+__device__ __forceinline__ float row_value(int a, int b) {
+  if (!g_random_rows) return (float)(a + b);
+  unsigned h = (unsigned)(a * 2654435761u) ^ (unsigned)(b * 40503u + 0x9e3779b9u);
+  h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+  return (float)(int)(h & 0xffffu) * (1.0f / 32768.0f) - 1.0f;      // [-1, 1)
+}
 
 constexpr int C = 128, SLOT = 256 * C, NS = 4, IPT = 8;   // 32 KB tiles, 8 DMA pieces per wave per tile (4 issuing waves)
 
@@ -26,13 +40,17 @@ __global__ __launch_bounds__(DMA == 0 ? 512 : 256) void kpipe_rt(const unsigned 
   const bool loader = DMA == 0 && wave >= 4;
   const int iw = wave & 3;
   bf16x8 xh[RT][4], xl[RT][4];                       // RT row tiles of 16 rows per compute wave
+#pragma unroll
   for (int t = 0; t < RT; ++t)
+#pragma unroll
     for (int st = 0; st < 4; ++st)
-      for (int e = 0; e < 8; ++e) { xh[t][st][e] = (__bf16)(float)(lane + e + st + t); xl[t][st][e] = (__bf16)(float)(lane - e - t); }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { xh[t][st][e] = (__bf16)row_value(lane + e + st + t, 7 * t + e); xl[t][st][e] = (__bf16)row_value(lane - e - t, 13 * st + 1); }
   for (int t = tid; t < NS * SLOT / 4; t += blockDim.x) ((float*)smem)[t] = 0.f;
   __syncthreads();
   unsigned long long t0 = 0, t1 = 0;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+  unsigned long long r0 = 0, r1 = 0;
+  asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(r0), "=s"(t0)::"memory");
   const unsigned voff = (unsigned)(iw * 1024 + lane * 16);
   auto issue_piece = [&](int tau, unsigned d, int q) {
     const unsigned char* tile = w + (int64_t)d * SLOT;
@@ -162,8 +180,8 @@ __global__ __launch_bounds__(DMA == 0 ? 512 : 256) void kpipe_rt(const unsigned 
     s += accb[0] + accb[1] + accb[2] + accb[3];
     out[blockIdx.x * 256 + (tid & 255)] = s[0] + s[1] + s[2] + s[3];
   }
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
-  if (tid == 0) cyc[blockIdx.x] = t1 - t0;
+  asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(r1), "=s"(t1)::"memory");
+  if (tid == 0) { cyc[blockIdx.x] = t1 - t0; cyc[512 + blockIdx.x] = r1 - r0; }
 }
 
 // The same pipeline with v_mfma_f32_32x32x16_bf16 on ONE 32-row tile per wave (the rows of two 16-row tiles): per unit still 4
@@ -179,13 +197,17 @@ __global__ __launch_bounds__(DMA == 0 ? 512 : 256) void kpipe_m32(const unsigned
   const bool loader = DMA == 0 && wave >= 4;
   const int iw = wave & 3;
   bf16x8 xh[4][2], xl[4][2];                         // k32-step, k16-half: the 32 rows' operand (B)
+#pragma unroll
   for (int st = 0; st < 4; ++st)
+#pragma unroll
     for (int hf = 0; hf < 2; ++hf)
-      for (int e = 0; e < 8; ++e) { xh[st][hf][e] = (__bf16)(float)(lane + e + st + hf); xl[st][hf][e] = (__bf16)(float)(lane - e - hf); }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { xh[st][hf][e] = (__bf16)row_value(lane + e + st + hf, 7 * hf + e); xl[st][hf][e] = (__bf16)row_value(lane - e - hf, 13 * st + 1); }
   for (int t = tid; t < NS * SLOT / 4; t += blockDim.x) ((float*)smem)[t] = 0.f;
   __syncthreads();
   unsigned long long t0 = 0, t1 = 0;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+  unsigned long long r0 = 0, r1 = 0;
+  asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(r0), "=s"(t0)::"memory");
   const unsigned voff = (unsigned)(iw * 1024 + lane * 16);
   auto issue_piece = [&](int tau, unsigned d, int q) {
     const unsigned char* tile = w + (int64_t)d * SLOT;
@@ -290,14 +312,14 @@ __global__ __launch_bounds__(DMA == 0 ? 512 : 256) void kpipe_m32(const unsigned
       for (int r = 0; r < 16; ++r) s += acc[n][r];
     out[blockIdx.x * 256 + (tid & 255)] = s;
   }
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
-  if (tid == 0) cyc[blockIdx.x] = t1 - t0;
+  asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(r1), "=s"(t1)::"memory");
+  if (tid == 0) { cyc[blockIdx.x] = t1 - t0; cyc[512 + blockIdx.x] = r1 - r0; }
 }
 
 int main() {
   unsigned char* w; float* out; unsigned long long* cyc; unsigned* desc;
   const int wtiles = 64;
-  (void)hipMalloc(&w, (size_t)(wtiles + 8) * SLOT); (void)hipMalloc(&out, 1 << 22); (void)hipMalloc(&cyc, 8 * 1024);
+  (void)hipMalloc(&w, (size_t)(wtiles + 8) * SLOT); (void)hipMalloc(&out, 1 << 22); (void)hipMalloc(&cyc, 8 * 1024); (void)hipMemset(cyc, 0, 8 * 1024);
   (void)hipMalloc(&desc, 4 * wtiles);
   unsigned hd[64]; for (int k = 0; k < wtiles; ++k) hd[k] = (unsigned)k;
   (void)hipMemcpy(desc, hd, 4 * wtiles, hipMemcpyHostToDevice);
@@ -313,6 +335,51 @@ int main() {
     printf("%-64s blocks %4d : %7.1f cycles per 32 KB tile for %3d rows = %6.2f per 16 rows ; MFMA pipe %4.1f %% busy\n", name, blocks,
            per_tile, rows, per_tile / (rows / 16), 100.0 * (rows / 64) * 768.0 / per_tile);
   };
+  auto wall = [&](const char* name, auto kern, int threads, int ntiles, int rows) {
+    // every CU busy (256 workgroups), back-to-back launches for >= 0.2 s, hipEvent wall time; cycles from the kernel's own stamps
+    const int blocks = 256;
+    const size_t smem = NS * SLOT;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int rep = 0; rep < 50; ++rep) hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), smem, 0, w, out, cyc, ntiles, wtiles, desc);
+    (void)hipDeviceSynchronize();
+    const int reps = 400;
+    (void)hipEventRecord(e0, 0);
+    for (int rep = 0; rep < reps; ++rep) hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), smem, 0, w, out, cyc, ntiles, wtiles, desc);
+    (void)hipEventRecord(e1, 0);
+    (void)hipDeviceSynchronize();
+    float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
+    static unsigned long long c[1024]; (void)hipMemcpy(c, cyc, 8 * 1024, hipMemcpyDeviceToHost);
+    double s = 0, sr = 0; for (int b = 0; b < blocks; ++b) { s += c[b]; sr += c[512 + b]; }
+    // in-kernel: shader cycles (s_memtime) and 100 MHz ticks (s_memrealtime) of every workgroup's timed region; wall: hipEvents over
+    // the back-to-back launches (includes each launch's LDS fill, drain and the gap to the next launch)
+    const double cyc_launch = s / blocks, ns_kernel = 10.0 * sr / blocks, ns_launch = 1e6 * ms / reps;
+    printf("%-58s : %7.1f cycles = %7.1f ns per tile in the kernel (clock %4.2f GHz) ; %6.2f ns per 16 rows ; %6.1f TFLOP/s in the kernel ; "
+           "wall %7.1f ns per tile\n", name, cyc_launch / ntiles, ns_kernel / ntiles, cyc_launch / ns_kernel, ns_kernel / ntiles / (rows / 16),
+           256.0 * rows * 8192.0 * 2 * 3 * ntiles / (ns_kernel * 1e-9) / 1e12, ns_launch / ntiles);
+  };
+  for (int random = 0; random < 2; ++random) {
+    if (random) {
+      // random finite bf16 pairs: exponent field 0x3c..0x3f, random sign and mantissa
+      const size_t n16 = (size_t)(wtiles + 8) * SLOT / 2;
+      unsigned short* hw = (unsigned short*)malloc(n16 * 2);
+      unsigned st = 12345u;
+      for (size_t k = 0; k < n16; ++k) { st = st * 1664525u + 1013904223u; hw[k] = (unsigned short)(((st >> 16) & 0x81ffu) | (0x3c00u + ((st >> 8) & 0x0300u))); }
+      (void)hipMemcpy(w, hw, n16 * 2, hipMemcpyHostToDevice);
+      free(hw);
+      int one = 1; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_random_rows), &one, sizeof one);
+    }
+    printf("== WALL time, 256 workgroups, %s\n", random ? "RANDOM weight stream and rows" : "all-zero weight stream, small-integer rows (round 5's setting)");
+    wall("4 compute + 4 loader waves, 1 row tile / wave (shipped)", kpipe_rt<0, 1>, 512, 510, 64);
+    wall("4 compute + 4 loader waves, 2 row tiles / wave", kpipe_rt<0, 2>, 512, 510, 128);
+    wall("4 compute waves, own DMA one piece per unit, 2 row tiles", kpipe_rt<2, 2>, 256, 510, 128);
+    wall("32x32x16 MFMAs, one 32-row tile / wave, 4 loader waves", kpipe_m32<0>, 512, 510, 128);
+    wall("32x32x16 MFMAs, one 32-row tile / wave, own DMA per unit", kpipe_m32<2>, 256, 510, 128);
+    wall("4 compute + 4 loader waves, 1 row tile / wave (again)", kpipe_rt<0, 1>, 512, 510, 64);
+  }
+  if (getenv("WALL_ONLY")) return 0;
+  (void)hipMemset(w, 0, (size_t)(wtiles + 8) * SLOT);
+  { int zero = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_random_rows), &zero, sizeof zero); }
   for (int blocks : {1, 256}) {
     report("4 compute + 4 loader waves, 1 row tile / wave (shipped)", kpipe_rt<0, 1>, 512, blocks, 510, 64);
     report("  ... 1 row tile, four accumulators per unit instead of two", kpipe_rt<0, 1, 1>, 512, blocks, 510, 64);
