@@ -114,6 +114,10 @@ def op_flops(op, rt, B):
         if i[rt.F_CROSS]:
             blk += 2.0 * t * c * mid + 4.0 * t * tk * mid + 2.0 * t * mid * c
         return B * (i[rt.F_NBLOCKS] * blk + (2.0 * t * c * c if i[rt.F_HAS_IN] else 0.0) + (2.0 * t * c * c if i[rt.F_NPOST] else 0.0))
+    if op.kind == rt.OP_RES256:                       # a chain of ResnetBlock1d blocks at C = 256 (NPOST = live taps of the k = 3 convolutions)
+        c, t, taps, n = 256, i[rt.F_T], i[rt.F_NPOST], i[rt.F_N_RES]
+        per_block = 2 * taps * c * c if i[rt.F_RES_KIND] == 1 else (taps * 2 * c * c + taps * c * c + 2 * c * c)
+        return 2.0 * B * t * n * per_block
     return 0.0
 
 
