@@ -443,6 +443,11 @@ int mdt_adpm2_euler(const float *x_base, const float *x_from, const float *denoi
 /* x = sigma0 * noise (diffusion.py:520); noise == NULL: counter-based generator as above. */
 int mdt_init_noise(float *x, const float *noise, float sigma0, uint64_t seed, uint32_t step,
                    int64_t sample0, int32_t B, int32_t C, int32_t L, void *stream);
+/* dst[0..n) = src[0..n) on the caller's stream (non-overlapping device buffers): selects the (scale | shift) rows of ONE evaluation out
+ * of the table the time program fills for every evaluation of a call at once -- MappingToScaleShift of all 18 ResnetBlock1d blocks,
+ * modules.py:125-142, evaluated per U-Net call in the reference (:1166-1170), once per sampling call here (rows are identical across the
+ * batch: sigma is a scalar, diffusion.py:91-102).  Round 6, an addition inside ABI version 5. */
+int mdt_copy_f32(float *dst, const float *src, int64_t n, void *stream);
 /* DiffusionSampler final clamp (diffusion.py:590). */
 int mdt_clamp(float *x, float lo, float hi, int64_t n, void *stream);
 /* Inpainting merge (diffusion.py:539-542, :549): out = where(mask, src + sigma*noise, x);

@@ -319,6 +319,18 @@ __global__ __launch_bounds__(256) void k_inpaint_merge(float* x, const float* sr
   }
 }
 
+// dst[0..n) = src[0..n): the FiLM rows of ONE evaluation out of the table the time program fills once per call.  One small launch on
+// the caller's stream (hipMemcpyAsync of the same bytes ran as up to three runtime copy kernels of ~4 us each in front of every
+// evaluation graph: profiles/r6_kernel_stats.csv, __amd_rocclr_copyBuffer).
+__global__ __launch_bounds__(256) void k_copy_f32(float* __restrict__ dst, const float* __restrict__ src, int64_t n, int vec) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (vec) {
+    if (t < n / 4) reinterpret_cast<float4*>(dst)[t] = reinterpret_cast<const float4*>(src)[t];
+  } else {
+    for (int64_t k = t; k < n; k += (int64_t)gridDim.x * 256) dst[k] = src[k];
+  }
+}
+
 __global__ __launch_bounds__(256) void k_clamp(float* x, float lo, float hi, int64_t n4) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     float4 v = reinterpret_cast<float4*>(x)[i];
@@ -614,6 +626,15 @@ int mdt_adpm2_euler(const float* x_base, const float* x_from, const float* denoi
   hipLaunchKernelGGL(mdt::k_adpm2_euler, dim3(mdt::grid_for(n4)), dim3(256), 0, (hipStream_t)stream, x_base, x_from,
                      denoised, noise, out, sigma, dt, sigma_up, noise_mode, seed, step, sample0 * C * L, n4);
   return finish("mdt_adpm2_euler");
+}
+
+int mdt_copy_f32(float* dst, const float* src, int64_t n, void* stream) {
+  if (n <= 0) return 0;
+  if (!dst || !src) return bad("mdt_copy_f32: null pointer");
+  const bool vec = n % 4 == 0 && ((reinterpret_cast<size_t>(dst) | reinterpret_cast<size_t>(src)) & 15) == 0;
+  const int64_t items = vec ? n / 4 : (n < 65536 ? n : 65536);
+  hipLaunchKernelGGL(mdt::k_copy_f32, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dst, src, n, vec ? 1 : 0);
+  return finish("mdt_copy_f32");
 }
 
 int mdt_clamp(float* x, float lo, float hi, int64_t n, void* stream) {

@@ -86,6 +86,7 @@ SYMBOLS = {
     "mdt_adpm2_euler": (_I, [_P, _P, _P, _P, _P, _F, _F, _F, _I, _U64, _U32, _L, _I, _I, _I, _P]),
     "mdt_init_noise": (_I, [_P, _P, _F, _U64, _U32, _L, _I, _I, _I, _P]),
     "mdt_clamp": (_I, [_P, _F, _F, _L, _P]),
+    "mdt_copy_f32": (_I, [_P, _P, _L, _P]),
     "mdt_inpaint_merge": (_I, [_P, _P, _P, _P, _F, _U64, _U32, _L, _I, _I, _I, _P]),
     "mdt_add_noise": (_I, [_P, _P, _F, _U64, _U32, _L, _I, _I, _I, _P]),
     "mdt_argmax_tokens": (_I, [_P, _P, _I, _I, _I, _P]),

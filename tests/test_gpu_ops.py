@@ -456,6 +456,22 @@ def test_concat_patch_time_embed():
     assert (gs - cs).abs().max() < 2e-6
 
 
+def test_row_copy_of_the_film_table():
+    """mdt_copy_f32 (engine.select_time: the FiLM rows of one evaluation out of the per-call table): aligned rows take the 16-byte
+    path, odd offsets / lengths the scalar one; bit-exact either way, nothing outside [dst, dst + n) is touched."""
+    lib = rt.load_library()
+    buf = rnd(20000, seed=3).to(DEV)
+    for dst, src, n in ((0, 8192, 5120), (4, 10001, 4097), (3, 9000, 7), (16, 8192, 4)):
+        b = buf.clone()
+        want = b.clone()
+        want[dst: dst + n] = want[src: src + n]
+        with torch.cuda.device(DEV):
+            rt.check(lib.mdt_copy_f32(b.data_ptr() + 4 * dst, b.data_ptr() + 4 * src, n, rt.current_stream()))
+            torch.cuda.synchronize()
+        assert torch.equal(b, want), (dst, src, n)
+    assert lib.mdt_copy_f32(0, 0, 0, 0) == 0 and lib.mdt_copy_f32(0, buf.data_ptr(), 4, 0) != 0
+
+
 def test_sampler_kernels_match_reference_arithmetic():
     lib = rt.load_library()
     B, C, L, Cp = 5, 22, 32, 32
