@@ -883,7 +883,20 @@ static hipError_t launch_rs2(const TFArgs& a, hipStream_t s) {
   } else {
     // Both workgroups of a pair must be resident at the same time: never more workgroups in a launch than the device runs at once;
     // a larger batch runs as several launches over consecutive row-block ranges (k_tf256.hip::launch_tf2, same reasoning)
-    const int cap = tf256_pair_capacity();           // (one 512-thread workgroup per compute unit for either kernel: the LDS ring)
+    // (one 512-thread workgroup per compute unit for either kernel -- the LDS ring --: k_tf256's capacity, asked once per device;
+    //  the test override, mdt_set_tuning("pair_capacity"), is looked at on every launch)
+    static int cap_of[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    int cap = g_pair_capacity_override;
+    if (cap <= 0) {
+      if (cap_of[dev] == 0) {
+        const int c_ = tf256_pair_capacity();
+        cap_of[dev] = c_ > 0 ? c_ : -1;
+      }
+      cap = cap_of[dev];
+    }
+    if (cap <= 0) return hipErrorLaunchOutOfResources;
     const int S = a.pair_stride;
     const int groups_fit = cap / (2 * S);
     if (groups_fit < 1) return hipErrorLaunchOutOfResources;
