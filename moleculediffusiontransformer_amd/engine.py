@@ -179,8 +179,8 @@ class UNetEngine:
         c = self.c
         src = c.shr["ss_all"] + row * c.ss_total
         dst = c.shr["ss_cur"]
-        # one small launch of the library (a torch copy_ of the same bytes ran as up to three runtime copy kernels of ~4 us each in
-        # front of EVERY evaluation graph: 1 % of configs[1]'s evaluation)
+        # one small launch of the library (a torch copy_ of the same bytes showed up as ~3 runtime copy kernels of ~4 us per evaluation
+        # in the kernel trace, between the evaluation graphs; measured gain ~0.2 ms per 64-step call)
         base = self.shr.data_ptr()
         rt.check(rt.load_library().mdt_copy_f32(base + 4 * dst, base + 4 * src, c.ss_total, rt.current_stream()))
 
