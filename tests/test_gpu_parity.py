@@ -388,6 +388,41 @@ def test_bench_eight_rank_logic_on_one_gpu():
     assert mg["shard_invariance"]["bitwise_equal_to_1_rank_run"] is True and mg["shard_invariance"]["rank"] == 7
 
 
+@pytest.mark.slow
+def test_bench_eight_ranks_at_the_configs3_shard_size_on_one_gpu():
+    """BASELINE configs[3] EXACTLY as the driver will invoke it -- `python bench.py --gpus 8 --batch 8192` = 65,536
+    molecules, the wide program on every rank -- as a dry run with the eight ranks sharing cuda:0 over gloo (test hook; ~10 GB of
+    activations per rank).  Not a scaling measurement (the ranks take turns on one GPU): it checks the N > 1 line at the real shard
+    size -- global batch, one collective per step, the all-gather timed apart from the compute, eight per-rank rates, the N = 1
+    equivalent, bitwise shard invariance of the last rank's rows.  `-m "gpu and slow"` (about a minute)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MDT_BENCH_SHARE_GPU="1", OMP_NUM_THREADS="4")
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1",
+                        "--batch", "8192", "--no-breakdown", "--master-port", "29547"],
+                       capture_output=True, text=True, timeout=1500, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 65536 and d["config"]["timesteps"] == 64 and d["scaling"] == "weak"
+    mg = d["multi_gpu"]
+    assert mg["rccl_ranks_seen"] == 8 and mg["gathered_rows"] == 65536 and mg["collectives_per_step"] == 1
+    assert mg["all_gather_bytes_per_rank"] == 8192 * 16 * 64 * 4
+    assert len(mg["per_rank_molecules_per_s"]["ranks"]) == 8 and mg["n1_equivalent_value"] > 0
+    assert mg["shard_invariance"]["bitwise_equal_to_1_rank_run"] is True and mg["shard_invariance"]["rank"] == 7
+    assert d["unet_eval"]["launches"] == 20
+    out = os.path.join(root, "gpurun_out", "r6")
+    if os.path.isdir(os.path.join(root, "gpurun_out")):
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "bench_8ranks_shared_gpu.json"), "w") as f:
+            f.write(lines[0] + "\n")
+
+
 def test_rccl_all_gather_runs_on_one_gpu():
     """the RCCL path had never executed anywhere.  On a one-GPU box: (i) backend "nccl" (= RCCL) at world size 1
     with all_gather_into_tensor FORCED through all_gather_samples / all_gather_tokens on device tensors; (ii) bench.py as one
