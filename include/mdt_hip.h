@@ -126,7 +126,9 @@ enum mdt_op_kind {
                           (row block, half), counting hand-offs monotonically across launches -- zero them once, never between
                           launches.  The result does not depend on where the two workgroups run (k_tf256.hip)          */
   MDT_OP_PREP16 = 14,  /* A operand of a bf16 x bf16 GEMM: out (bf16 [B][R_IN][CIN], CIN / 2 floats per row) = bf16(prologue(a[.., A_COL +
-                          c])); ints R_IN, LDA, CIN, A_COL, PRO, GROUPS, GSIZE, PRO_SILU and p0..p3 / eps as MDT_OP_GEMM          */
+                          c])); ints R_IN, LDA, CIN, A_COL, PRO, GROUPS, GSIZE, PRO_SILU and p0..p3 / eps as MDT_OP_GEMM;
+                          WFMT = 2 (round 6): a is bf16 itself (LDA / A_COL in bf16 elements) -- LayerNorm (PRO 1) of the bf16
+                          residual stream, statistics in fp32 on the exactly widened values; CIN <= 1024                     */
   MDT_OP_ATTN_CTX = 13, /* cross-attention core against the NORMALISED CONTEXT itself (K = V = c, shared by all heads and layers;
                           the per-layer key / value projections are folded into the query / output projections by the host):
                           a = q' [B][T * heads][128] (rows (token, head)), a2 = c [B | 1][Tk <= 64][LDKV], out [B][T * heads][128]
@@ -207,7 +209,10 @@ enum mdt_gemm_i {
                         operands stream through LDS-DMA; no prologue, stride, phases or output row mapping, cin % 64 == 0;
                         6 = as 2 and the OUTPUT is bf16 too (LDC / O_COL in bf16 elements): a tensor whose only reader is the next
                         bf16 x bf16 GEMM (feed-forward hidden layer); 10 = as 2 and ALSO a bf16 copy [rows][N] of the fp32 output
-                        into p0 (the residual stream as the A operand of the next GEMM, written where it is produced).
+                        into p0 (the residual stream as the A operand of the next GEMM, written where it is produced);
+                        38 (round 6) = as 6 and the RESIDUAL is bf16 too (LDR in bf16 elements; res may alias out): the bf16
+                        residual stream of the plain-bf16 mode's transformer blocks -- one bf16 tensor is residual, output and the
+                        next GEMM's A operand.
                         Formats 2 / 6 / 10 end in a float4 epilogue: N, LDC, O_COL and LDR must be multiples of 4 and bias /
                         residual / out 16-byte aligned (bf16 out / copy: 8), otherwise the op is rejected;
                         16 = RING TILES (k_proj.hip, round 5): w holds N / 64 * CIN / 128 tiles of 32 KB, tile (chunk c, K half h)

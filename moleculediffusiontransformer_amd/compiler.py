@@ -174,6 +174,11 @@ class UNetCompiler:
         self.fold_patch = os.environ.get("MDT_FOLD_PATCH", "1") != "0"   # Patcher / Unpatcher rearranges folded into k_resblock
         self.use_proj = os.environ.get("MDT_PROJ", "1") != "0"      # K = 128 / 256 projections on ring tiles (k_proj.hip)
         self.b16 = os.environ.get("MDT_B16", "1") == "1"
+        # plain-bf16 mode: the TRANSFORMER blocks' residual stream as ONE bf16 tensor (round 6): residual, output and the next GEMM's A
+        # operand at once -- no fp32 read + write of the stream per projection, no conversion pass in front of the feed-forward and
+        # cross-attention GEMMs.  Priced on the oracle at 2e-4 .. 5e-4 of the final sample (tools/res16_experiment.py; the mode's bf16
+        # operands cost 1.2e-3 .. 1.6e-3, its budget is 1e-2).  MDT_RES16=0: the fp32 stream of rounds 3-5.
+        self.res16 = os.environ.get("MDT_RES16", "1") == "1"
         self.qkv_merge = os.environ.get("MDT_QKV_MERGE", "1") == "1"   # ... and self-attention's q | k | v as one GEMM     # bf16 mode: regular layers as PREP16 + bf16 x bf16 GEMM
         self.fold_ctx = os.environ.get("MDT_FOLD_CTX", "1") == "1"
         self.has_chat = False                # some layer attends to the normalised context (ctx program emits it)
@@ -310,8 +315,8 @@ class UNetCompiler:
         a16 = None
         regular = (self.b16_ok(cin) and t_stride == 1 and phases <= 1 and o_stride == 1 and o_off == 0 and r_out_ == a.rows
                    and out.rows == r_out_ and m_mode == 0)
-        assert not (a.b16 or out.b16) or (regular and (not a.b16 or (pro == rt.PRO_NONE and a_col == 0))), "bf16 operand"
-        if regular and not a.b16:
+        assert not (a.b16 or out.b16) or (regular and (not a.b16 or (pro in (rt.PRO_NONE, rt.PRO_LAYERNORM) and a_col == 0))), "bf16 operand"
+        if regular and (not a.b16 or pro == rt.PRO_LAYERNORM):
             # plain-bf16 mode, regular layer: the prologue runs once per element in a pass of its own that writes the bf16 A
             # operand (MDT_OP_PREP16), the GEMM streams both operands by LDS-DMA (k_gemm_b16.hip)
             a16 = self._new16(a.rows, cin)
@@ -333,6 +338,9 @@ class UNetCompiler:
             pi = pre.i
             pi[rt.G_R_IN], pi[rt.G_LDA], pi[rt.G_CIN], pi[rt.G_A_COL] = a.rows, a.ld, cin, a_col
             pi[rt.G_PRO], pi[rt.G_GROUPS], pi[rt.G_GSIZE], pi[rt.G_PRO_SILU] = pro, groups, gsize, pro_silu
+            if a.b16:                            # LayerNorm of the bf16 residual stream (MDT_OP_PREP16 with a bf16 input)
+                assert pro == rt.PRO_LAYERNORM and cin <= 1024 and a.ld % 8 == 0
+                pi[rt.G_WFMT] = 2
             pre.f[0] = eps
             self._emit(pre)
             a = a16
@@ -402,6 +410,9 @@ class UNetCompiler:
             w_off, wlo_off, *wfmt = self._pack_w(wt, cin)
         op.a, op.w, op.out = a.ref(), _ref(rt.SP_WEIGHT, w_off), out.ref()
         op.i[rt.G_WFMT] = ((2 | (4 if out.b16 else 0) | (8 if copy16 is not None else 0)) if a.b16 else wfmt[0]) if wfmt else 0
+        if res is not None and res.b16:      # the bf16 residual stream: A, residual and output all bf16 (MDT_G_WFMT 38)
+            assert a.b16 and out.b16 and copy16 is None and o_col == 0
+            op.i[rt.G_WFMT] = 38
         if copy16 is not None:               # a bf16 copy of the fp32 output, written by the epilogue (MDT_G_WFMT 10)
             assert a.b16 and copy16.b16 and not out.b16 and o_col == 0 and copy16.ld == n and copy16.rows == out.rows
             op.p0 = copy16.ref()
@@ -1560,7 +1571,13 @@ class UNetCompiler:
             return self.transformer_fused128(x, p, c, layers, cross, free_input, y=y_out)
         if self.tf256_ok(c, x.rows, layers, cross):
             return self.transformer_fused256(x, p, c, layers, cross, free_input, y=y_out)
-        t = self._new(x.rows, c)
+        # plain-bf16 mode (round 6, MDT_RES16): the blocks' residual stream as ONE bf16 tensor -- to_in writes it, every residual
+        # projection reads and writes it (MDT_G_WFMT 38), the LayerNorm passes read it (MDT_OP_PREP16 with a bf16 input), the
+        # feed-forward up-projection and to_out consume it as their A operand directly
+        stream16 = (self.res16 and self.gemm_mode == "bf16" and self.b16_ok(c) and self.b16_ok(c * cfg.ff_mult)
+                    and self.b16_ok(cfg.mid_features) and self.qkv_merge and c <= 1024 and not (cross and self.fold_ok())
+                    and not (x.rows == 1 and self.t1_fold))
+        t = self._new16(x.rows, c) if stream16 else self._new(x.rows, c)
         gi, bi = self._vec(p + "to_in.0.weight", c), self._vec(p + "to_in.0.bias", c)
         wi, bias_i = self._conv_w(p + "to_in.1.weight", c, c), self._vec(p + "to_in.1.bias", c)
         if self.rconv_ok(x.rows, c, 1, c // 32):
@@ -1649,7 +1666,7 @@ class UNetCompiler:
             ff16 = self.b16_ok(c) and self.b16_ok(hid) and self.b16_ok(cfg.mid_features)
             folded = cross and self.fold_ok()
             # plain-bf16 mode: the attention block in front of the feed-forward block hands it x as bf16 (no conversion pass)
-            t16 = self._new16(t.rows, c) if (ff16 and not folded) else None
+            t16 = self._new16(t.rows, c) if (ff16 and not folded and not t.b16) else None      # (a bf16 stream IS that operand)
             if t.rows == 1 and self.t1_fold and t16 is None:
                 t = self.attention_single_token(t, bp + "attention.")
             else:

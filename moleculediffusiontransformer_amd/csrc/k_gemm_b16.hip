@@ -37,11 +37,18 @@ __device__ __forceinline__ float gelu16(float x) {
   return 0.5f * x * (1.0f + copysignf(erfa, x));
 }
 
+#ifndef MDT_B16_EP8_PAD
+#define MDT_B16_EP8_PAD 4         // W16 epilogue: parked-row pitch 32 TN + 4 floats (two rows' 8-column pieces interleave over the banks)
+#endif
 #ifndef MDT_B16_EPI_GROUPS
 #define MDT_B16_EPI_GROUPS 8      // (4: the residual of half a 32-row block in flight per wave -- the epilogue was bound by bytes in flight)
 #endif
 
-template <int WM, int WN, int TM, int TN>
+// W16 (round 6): the all-bf16 epilogue -- bf16 output, bf16 residual or none, no second copy.  A lane owns 8 columns of a row
+// (16-byte accesses) and the residual of the tile is REQUESTED UNDER THE MAIN LOOP: the generic epilogue asks for a block's
+// residual, waits a round trip, stores, and does that TM times per wave -- with 8 bytes per lane in flight it was bound by
+// latency, not bytes (K = 512, M = 65,536: 82-86 us with a residual, bf16 or fp32, against 48-50 us without).
+template <int WM, int WN, int TM, int TN, bool W16>
 __global__ __launch_bounds__(64 * WM * WN) void k_gemm_b16(Gemm16Args g) {
   constexpr int NW = WM * WN, BM = 32 * TM * WM, BN = 32 * TN * WN, BK = 64;
   constexpr int NA = BM / 8 / NW, NB = BN / 8 / NW;          // DMA instructions per wave and tile (8 rows each)
@@ -137,12 +144,56 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_b16(Gemm16Args g) {
     }
   };
 
+  // ---- W16: the wave's residual, 8 columns (16 bytes) per lane, LPR8 lanes per row, NP8 requests per 32-row block.  Blocks
+  // 0 and 1 are requested two chunks before the end of the main loop (32 registers), blocks 2 and 3 when the loop is over (the
+  // fragment and DMA-pointer registers are dead by then).
+  // The requests are unconditional on clamped addresses: their COUNT is what the hand-written vmcnt below relies on.
+  constexpr int LPR8 = 4 * TN, RP8 = 64 / LPR8, NP8 = 32 / RP8;
+  static_assert(TM <= 4 && NP8 <= 4, "residual registers");
+  const int er8 = lane / LPR8, ec8 = (lane % LPR8) * 8;
+  const bool res8 = W16 && g.res != nullptr;
+  uint4 rq[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) rq[a][p] = make_uint4(0u, 0u, 0u, 0u);
+  auto prefetch = [&](int a) {
+    const int n = min(n0 + wc * 32 * TN + ec8, g.N - 8);
+#pragma unroll
+    for (int p = 0; p < NP8; ++p) {
+      const int m = min(m0 + wr * 32 * TM + a * 32 + p * RP8 + er8, g.M - 1);
+      rq[a][p] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(g.res) + (int64_t)m * g.ldr + n);
+    }
+  };
+  constexpr int NPRE = (TM < 2 ? TM : 2) * NP8;     // requests in flight behind the last chunk's DMA
+  float bia8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (W16 && g.bias) {                              // requested before the first chunk: no round trip in the epilogue
+    const int n = min(n0 + wc * 32 * TN + ec8, g.N - 8);
+    const float4 b0 = *reinterpret_cast<const float4*>(g.bias + n), b1 = *reinterpret_cast<const float4*>(g.bias + n + 4);
+    bia8[0] = b0.x; bia8[1] = b0.y; bia8[2] = b0.z; bia8[3] = b0.w; bia8[4] = b1.x; bia8[5] = b1.y; bia8[6] = b1.z; bia8[7] = b1.w;
+  }
+
   const int nk = K / BK;
   issue(0, 0);
+  if (res8 && nk == 1) {
+    prefetch(0);
+    if (TM > 1) prefetch(1);
+  }
   for (int kc = 0; kc < nk; ++kc) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();          // chunk kc has landed for every wave; every wave is done reading the other stage
+    // (a bare s_barrier behind hand-written counters: __syncthreads() makes the compiler wait for vmcnt(0), residual included)
+    if (res8 && kc == nk - 1) {
+      // loads retire in order: the last chunk's DMA was issued before the NPRE residual requests
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NPRE) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();          // chunk kc has landed for every wave; every wave is done reading the other stage
+    asm volatile("" ::: "memory");
     if (kc + 1 < nk) issue(kc + 1, (kc + 1) & 1);
+    if (res8 && kc == nk - 2) {
+      prefetch(0);
+      if (TM > 1) prefetch(1);
+    }
     compute(kc & 1);
   }
 
@@ -154,10 +205,64 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_b16(Gemm16Args g) {
   // fp32 rows of pitch 72 floats (both the accumulator-order writes and the row-order reads are conflict-free) and walks it row
   // by row: 16 lanes per row, float4 each -- bias, GELU, residual (float4 loads, all requested before the first store of the
   // pass) and the fp32 store and / or the bf16 store as 16- / 8-byte accesses of 256- / 128-byte row segments.
-  __syncthreads();                                  // every wave is done reading the last stage
-  constexpr int EP = 32 * TN + 8;                   // floats per parked row (72 / 136: pitch = 8 mod 32 banks)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                     // every wave is done reading the last stage (no DMA is in flight any more)
+  asm volatile("" ::: "memory");
+  constexpr int EP = 32 * TN + (W16 ? MDT_B16_EP8_PAD : 8);   // floats per parked row (72 / 136: pitch = 8 mod 32 banks)
   float* ws = reinterpret_cast<float*>(smem) + wave * (32 * EP);
   static_assert(NW * 32 * EP * 4 <= 2 * STAGE, "parking area inside the staging buffers");
+  if constexpr (W16) {
+    unsigned short* o8 = reinterpret_cast<unsigned short*>(g.out);
+    const int ncol = n0 + wc * 32 * TN + ec8;
+    const bool cok = ncol < g.N;                    // (N % 8 == 0, gemm_b16_w16_ok)
+    {
+      // The compiler guards the first LDS read after an LDS-DMA stream with vmcnt(0) (the DMA's LDS writes may alias it).  Take
+      // that wait HERE, where only the requests of blocks 0 / 1 are in flight (two chunks old), and request the other blocks
+      // behind it: they land under the first blocks' passes, and every later wait is counted exactly.
+      const float first = *reinterpret_cast<volatile float*>(ws);
+      asm volatile("" ::"v"(first) : "memory");
+      if (res8) {
+        if (TM > 2) prefetch(2);
+        if (TM > 3) prefetch(3);
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ws[((r & 3) + 8 * (r >> 2) + 4 * lh) * EP + b * 32 + li] = acc[a][b][r];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int mrow0 = m0 + wr * 32 * TM + a * 32;
+#pragma unroll
+      for (int p = 0; p < NP8; ++p) {
+        const int row = p * RP8 + er8, m = mrow0 + row;
+        const float4 v0 = *reinterpret_cast<const float4*>(ws + row * EP + ec8);
+        const float4 v1 = *reinterpret_cast<const float4*>(ws + row * EP + ec8 + 4);
+        float x[8] = {v0.x + bia8[0], v0.y + bia8[1], v0.z + bia8[2], v0.w + bia8[3],
+                      v1.x + bia8[4], v1.y + bia8[5], v1.z + bia8[6], v1.w + bia8[7]};
+        if (g.act == 1) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) x[k] = gelu16(x[k]);
+        }
+        const unsigned w[4] = {rq[a][p].x, rq[a][p].y, rq[a][p].z, rq[a][p].w};       // zeros without a residual
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          x[2 * q] += __uint_as_float(w[q] << 16);
+          x[2 * q + 1] += __uint_as_float(w[q] & 0xffff0000u);
+        }
+        if (cok && m < g.M) {
+          unsigned short h[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) h[k] = __builtin_bit_cast(unsigned short, (__bf16)x[k]);
+          *reinterpret_cast<uint4*>(o8 + (int64_t)m * g.ldc + g.o_col + ncol) =
+              make_uint4(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16), h[4] | ((unsigned)h[5] << 16), h[6] | ((unsigned)h[7] << 16));
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the block has been read before the next one is parked
+    }
+    return;
+  }
   unsigned short* o16 = g.out16 ? reinterpret_cast<unsigned short*>(g.out) : g.copy16;
   const int ld16 = g.out16 ? g.ldc : g.N, oc16 = g.out16 ? g.o_col : 0;
   constexpr int LPR = 8 * TN;                       // lanes per parked row (float4 each)
@@ -186,7 +291,15 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_b16(Gemm16Args g) {
         ok[u] = cok && m < g.M;
         v[u] = *reinterpret_cast<const float4*>(ws + row * EP + ec);
         rs[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (g.res && ok[u]) rs[u] = *reinterpret_cast<const float4*>(g.res + (int64_t)m * g.ldr + ncol);
+        if (g.res && ok[u]) {
+          if (g.res16) {                                          // bf16 residual stream: 8 bytes per lane, widened exactly
+            const uint2 rb = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(g.res) + (int64_t)m * g.ldr + ncol);
+            rs[u] = make_float4(__uint_as_float(rb.x << 16), __uint_as_float(rb.x & 0xffff0000u),
+                                __uint_as_float(rb.y << 16), __uint_as_float(rb.y & 0xffff0000u));
+          } else {
+            rs[u] = *reinterpret_cast<const float4*>(g.res + (int64_t)m * g.ldr + ncol);
+          }
+        }
       }
 #pragma unroll
       for (int u = 0; u < NB; ++u) {
@@ -213,18 +326,40 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_b16(Gemm16Args g) {
   }
 }
 
-template <int WM, int WN, int TM, int TN>
-static hipError_t launch16(const Gemm16Args& g, hipStream_t s) {
+template <int WM, int WN, int TM, int TN, bool W16>
+static hipError_t launch16w(const Gemm16Args& g, hipStream_t s) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   const int mt = (g.M + BM - 1) / BM, nt = (g.N + BN - 1) / BN;
   const size_t smem = 2 * (size_t)(BM + BN) * 128;
   static DevOnce attr_once;                          // per device (mdt_kernels.h)
   if (attr_once.first()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_b16<WM, WN, TM, TN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_b16<WM, WN, TM, TN, W16>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   }
-  hipLaunchKernelGGL((k_gemm_b16<WM, WN, TM, TN>), dim3((unsigned)(mt * nt)), dim3(64 * WM * WN), smem, s, g);
+  hipLaunchKernelGGL((k_gemm_b16<WM, WN, TM, TN, W16>), dim3((unsigned)(mt * nt)), dim3(64 * WM * WN), smem, s, g);
   return hipGetLastError();
+}
+
+// the all-bf16 epilogue (8 columns per lane): bf16 output, no second copy, a bf16 residual or none, every pitch / offset a
+// multiple of 8 elements and the tensors 16-byte aligned; anything else takes the generic epilogue.  MDT_W16=0 (tuning aid) /
+// mdt_set_tuning("w16", 0) turn it off.
+static int g_w16 = -1;
+void set_w16(int v) { g_w16 = v; }
+static bool gemm_b16_w16_ok(const Gemm16Args& g) {
+  auto al16 = [](const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; };
+  if (g_w16 < 0) {
+    const char* e = mdt_tuning_env("MDT_W16");
+    g_w16 = e ? atoi(e) : 1;
+  }
+  if (!g_w16 || !g.out16 || g.copy16 || (g.res && !g.res16)) return false;
+  if (g.N % 8 || g.ldc % 8 || g.o_col % 8 || !al16(g.out)) return false;
+  if (g.res && (g.ldr % 8 || !al16(g.res))) return false;
+  return true;
+}
+
+template <int WM, int WN, int TM, int TN>
+static hipError_t launch16(const Gemm16Args& g, hipStream_t s) {
+  return gemm_b16_w16_ok(g) ? launch16w<WM, WN, TM, TN, true>(g, s) : launch16w<WM, WN, TM, TN, false>(g, s);
 }
 
 bool gemm_b16_supported(int cin, int taps, int lda, int a_col) {
@@ -237,7 +372,7 @@ bool gemm_b16_supported(int cin, int taps, int lda, int a_col) {
 bool gemm_b16_epilogue_ok(const Gemm16Args& g) {
   auto al = [](const void* p, size_t a) { return (reinterpret_cast<size_t>(p) & (a - 1)) == 0; };
   if (g.N <= 0 || g.N % 4 || g.ldc % 4 || g.o_col % 4) return false;
-  if (g.res && (g.ldr % 4 || !al(g.res, 16))) return false;
+  if (g.res && (g.ldr % 4 || !al(g.res, g.res16 ? 8 : 16))) return false;
   if (g.bias && !al(g.bias, 16)) return false;
   if (!al(g.out, g.out16 ? 8 : 16) || (g.copy16 && !al(g.copy16, 8))) return false;
   return true;
@@ -274,6 +409,66 @@ hipError_t launch_gemm_b16(const Gemm16Args& g, hipStream_t s) {
 // the GEMM operator (mdt_hip.h: LayerNorm over the row / GroupNorm from precomputed statistics + FiLM [+ SiLU] / SiLU / none).
 // 16 lanes per row, 8 channels per lane and step: 512 contiguous bytes in, 256 out per row pass.
 // ------------------------------------------------------------------------------------------------------------------
+// bf16 input (round 6: the bf16 residual stream of the plain-bf16 mode): LayerNorm of a bf16 row of up to 1024 channels, statistics and
+// normalisation in fp32 on the exactly widened values; 16 lanes per row, 8 channels (16 bytes) per lane and step
+__global__ __launch_bounds__(256) void k_prep16_ln_in16(Prep16Args g) {
+  const int row = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+  if (row >= g.total_rows) return;
+  const unsigned short* src = reinterpret_cast<const unsigned short*>(g.a) + (int64_t)row * g.lda + g.a_col;
+  unsigned short* dst = g.out + (int64_t)row * g.cin;
+  const int ng = g.cin / 8;
+  float x[8][8];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int e = sub + 16 * k;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (e < ng) v = *reinterpret_cast<const uint4*>(src + 8 * e);
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      x[k][2 * q] = __uint_as_float(w[q] << 16);
+      x[k][2 * q + 1] = __uint_as_float(w[q] & 0xffff0000u);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += x[k][q];
+  }
+#pragma unroll
+  for (int off = 8; off >= 1; off >>= 1) s += __shfl_xor(s, off, 16);
+  const float mean = s / (float)g.cin;
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if (sub + 16 * k < ng) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float d = x[k][q] - mean;
+        ss += d * d;
+      }
+    }
+#pragma unroll
+  for (int off = 8; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 16);
+  const float rstd = 1.0f / sqrtf(ss / (float)g.cin + g.eps);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int e = sub + 16 * k;
+    if (e < ng) {
+      const int c0 = 8 * e;
+      const float4 g0 = *reinterpret_cast<const float4*>(g.p0 + c0), g1 = *reinterpret_cast<const float4*>(g.p0 + c0 + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(g.p1 + c0), b1 = *reinterpret_cast<const float4*>(g.p1 + c0 + 4);
+      const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+      const float be[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      unsigned short h[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) h[q] = __builtin_bit_cast(unsigned short, (__bf16)((x[k][q] - mean) * rstd * ga[q] + be[q]));
+      uint4 o;
+      o.x = h[0] | ((unsigned)h[1] << 16); o.y = h[2] | ((unsigned)h[3] << 16);
+      o.z = h[4] | ((unsigned)h[5] << 16); o.w = h[6] | ((unsigned)h[7] << 16);
+      *reinterpret_cast<uint4*>(dst + c0) = o;
+    }
+  }
+}
+
 template <int PRO>
 __global__ __launch_bounds__(256) void k_prep16(Prep16Args g) {
   const int row = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
@@ -414,6 +609,11 @@ hipError_t launch_prep16(const Prep16Args& g, hipStream_t s) {
   if (g.total_rows <= 0) return hipSuccess;
   if (g.cin % 8 || g.lda % 4 || g.a_col % 4) return hipErrorInvalidValue;
   const dim3 grid((unsigned)((g.total_rows + 15) / 16)), block(256);
+  if (g.in16) {                                        // bf16 input: LayerNorm only (a plain conversion would be a copy), rows <= 1024 channels
+    if (g.pro != 1 || g.cin > 1024 || g.lda % 8 || g.a_col % 8 || !g.p0 || !g.p1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_prep16_ln_in16, grid, block, 0, s, g);
+    return hipGetLastError();
+  }
   switch (g.pro) {
     case 0: hipLaunchKernelGGL(k_prep16<0>, grid, block, 0, s, g); break;
     case 1: hipLaunchKernelGGL(k_prep16<1>, grid, block, 0, s, g); break;

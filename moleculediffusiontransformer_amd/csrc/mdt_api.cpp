@@ -61,6 +61,7 @@ int mdt_set_tuning(const char* key, int32_t value) {
   const std::string k = key ? key : "";
   if (k == "pair_stride") { g_pair_stride = value; return 0; }
   if (k == "tile16") { mdt::set_tile16(value); return 0; }
+  if (k == "w16") { mdt::set_w16(value); return 0; }
   if (k == "pair_capacity") {
     if (value > 0 && !test_hooks_enabled()) return fail("mdt_set_tuning(pair_capacity): a test hook, needs MDT_TEST_HOOKS=1");
     mdt::g_pair_capacity_override = value > 0 ? value : 0;
@@ -117,7 +118,9 @@ static const char* validate(const mdt_op& o, int idx, char* buf, size_t nbuf) {
       if (i[MDT_G_M_MODE] < 0 || i[MDT_G_M_MODE] > 2) return bad("bad m_mode");
       if (o.res.space && i[MDT_G_LDR] <= 0) return bad("residual without ldr");
       if (o.a2.space && i[MDT_G_CIN] % 32) return bad("split-bf16 weights need cin % 32 == 0");
-      if (i[MDT_G_WFMT] < 0 || (i[MDT_G_WFMT] > 2 && i[MDT_G_WFMT] != 6 && i[MDT_G_WFMT] != 10 && i[MDT_G_WFMT] != 16 && i[MDT_G_WFMT] != 17)) return bad("bad weight format");
+      if (i[MDT_G_WFMT] < 0 || (i[MDT_G_WFMT] > 2 && i[MDT_G_WFMT] != 6 && i[MDT_G_WFMT] != 10 && i[MDT_G_WFMT] != 16 && i[MDT_G_WFMT] != 17 &&
+                                i[MDT_G_WFMT] != 38)) return bad("bad weight format");
+      if (i[MDT_G_WFMT] == 38 && !o.res.space) return bad("WFMT 38 (bf16 residual stream) needs the residual");
       if (i[MDT_G_WFMT] == 16 || i[MDT_G_WFMT] == 17) {
         if (!mdt::proj_supported(i[MDT_G_CIN], i[MDT_G_N], i[MDT_G_LDA], i[MDT_G_LDC], o.res.space ? i[MDT_G_LDR] : 0) || o.a2.space)
           return bad("ring-tile projection needs cin in {128, 256}, N % 64 == 0, 16-byte aligned rows and no lo plane (the tiles hold both)");
@@ -145,6 +148,8 @@ static const char* validate(const mdt_op& o, int idx, char* buf, size_t nbuf) {
       if (i[MDT_G_CIN] <= 0 || i[MDT_G_CIN] % 8 || i[MDT_G_R_IN] <= 0) return bad("bad dims");
       if (i[MDT_G_LDA] % 4 || i[MDT_G_A_COL] % 4 || i[MDT_G_LDA] < i[MDT_G_A_COL] + i[MDT_G_CIN]) return bad("bad A rows");
       if (i[MDT_G_PRO] < 0 || i[MDT_G_PRO] > 3) return bad("bad prologue");
+      if (i[MDT_G_WFMT] != 0 && (i[MDT_G_WFMT] != 2 || i[MDT_G_PRO] != MDT_PRO_LAYERNORM || i[MDT_G_CIN] > 1024 || i[MDT_G_LDA] % 8 || i[MDT_G_A_COL] % 8))
+        return bad("PREP16 with a bf16 input (WFMT 2): LayerNorm of rows of at most 1024 channels, LDA / A_COL multiples of 8 elements");
       if (!o.a.space || !o.out.space) return bad("missing operand");
       if (i[MDT_G_PRO] == MDT_PRO_LAYERNORM && (!o.p0.space || !o.p1.space)) return bad("LayerNorm needs gain and bias");
       if (i[MDT_G_PRO] == MDT_PRO_GROUPNORM &&
@@ -398,7 +403,7 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
           h.A = reinterpret_cast<const unsigned short*>(g.A); h.W = reinterpret_cast<const unsigned short*>(g.W);
           h.bias = g.bias; h.res = g.res; h.out = g.out; h.M = g.M; h.N = g.N; h.cin = g.cin; h.taps = g.taps; h.rows = g.r_in;
           h.lda = g.lda; h.a_col = g.a_col; h.t_dj = g.t_dj; h.t_off = g.t_off; h.ldc = g.ldc; h.ldr = g.ldr; h.o_col = g.o_col;
-          h.act = g.act; h.out16 = (i[MDT_G_WFMT] & 4) ? 1 : 0;
+          h.act = g.act; h.out16 = (i[MDT_G_WFMT] & 4) ? 1 : 0; h.res16 = (i[MDT_G_WFMT] & 32) ? 1 : 0;
           h.copy16 = (i[MDT_G_WFMT] & 8) ? reinterpret_cast<unsigned short*>(ptr(o.p0)) : nullptr;
           e = mdt::launch_gemm_b16(h, stream);
         } else if (!missing) {
@@ -416,7 +421,7 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
         g.a = ptr(o.a); g.out = reinterpret_cast<unsigned short*>(ptr(o.out)); g.p0 = ptr(o.p0); g.p1 = ptr(o.p1);
         g.p2 = ptr(o.p2); g.p3 = ptr(o.p3); g.rows = i[MDT_G_R_IN]; g.total_rows = B * g.rows; g.lda = i[MDT_G_LDA];
         g.a_col = i[MDT_G_A_COL]; g.cin = i[MDT_G_CIN]; g.pro = i[MDT_G_PRO]; g.groups = i[MDT_G_GROUPS];
-        g.gsize = i[MDT_G_GSIZE]; g.pro_silu = i[MDT_G_PRO_SILU]; g.eps = o.f[MDT_GF_EPS];
+        g.gsize = i[MDT_G_GSIZE]; g.pro_silu = i[MDT_G_PRO_SILU]; g.eps = o.f[MDT_GF_EPS]; g.in16 = i[MDT_G_WFMT] == 2 ? 1 : 0;
         if (!missing) e = mdt::launch_prep16(g, stream);
         break;
       }

@@ -84,18 +84,21 @@ struct Gemm16Args {
   int lda, a_col;             // bf16 elements
   int t_dj, t_off, ldc, ldr, o_col, act;
   int out16;                  // 1: out is bf16 (ldc / o_col in bf16 elements)
+  int res16;                  // 1: res is bf16 (ldr in bf16 elements): the bf16 residual stream of the plain-bf16 mode (round 6)
   unsigned short* copy16;     // fp32 output: also a bf16 copy [M][N] of it (the next GEMM's A operand), or nullptr
 };
 bool gemm_b16_supported(int cin, int taps, int lda, int a_col);
 bool gemm_b16_epilogue_ok(const Gemm16Args& g);   // N / ldc / o_col / ldr % 4 == 0 and 16-byte aligned tensors (float4 epilogue)
 hipError_t launch_gemm_b16(const Gemm16Args& g, hipStream_t s);
 void set_tile16(int v);          // tuning hook behind mdt_set_tuning("tile16", v)
+void set_w16(int v);             // mdt_set_tuning("w16", 0 / 1): the all-bf16 epilogue of k_gemm_b16 off / on
 struct Prep16Args {
   const float* a;
   unsigned short* out;        // bf16 [total_rows][cin]
   const float* p0; const float* p1; const float* p2; const float* p3;
   int total_rows, rows, lda, a_col, cin, pro, groups, gsize, pro_silu;
   float eps;
+  int in16;                   // 1: a is bf16 (lda / a_col in bf16 elements): LayerNorm of the bf16 residual stream (round 6; PRO 0 / 1)
 };
 hipError_t launch_prep16(const Prep16Args& g, hipStream_t s);
 bool gemm_as_eligible(const GemmArgs& g);                           // wide-N / small-K layers

@@ -48,7 +48,8 @@ def run_program(ops, bufs: Buffers, B: int, n_shared_rows: int = 0) -> None:
             batches = B if (prep or i[rt.G_M_MODE] == 0) else (n_shared_rows if i[rt.G_M_MODE] == 1 else 1)
             r_out, r_in, lda, cin, taps = i[rt.G_R_OUT], i[rt.G_R_IN], i[rt.G_LDA], i[rt.G_CIN], i[rt.G_TAPS]
             n, ldc, o_rows = i[rt.G_N], i[rt.G_LDC], i[rt.G_O_ROWS]
-            if not prep and (i[rt.G_WFMT] & 2):      # A already bf16 (MDT_OP_PREP16): lda / a_col in bf16 elements
+            if i[rt.G_WFMT] & 2 and i[rt.G_WFMT] not in (16, 17):   # A already bf16 (GEMM: written by MDT_OP_PREP16 / a bf16 epilogue;
+                # PREP16 with WFMT 2, round 6: the bf16 residual stream itself): lda / a_col in bf16 elements
                 a = bufs.view(op.a, B, batches * r_in * lda // 2).view(torch.bfloat16).float().view(batches, r_in, lda)
             else:
                 a = bufs.view(op.a, B, batches * r_in * lda).view(batches, r_in, lda)
@@ -78,7 +79,7 @@ def run_program(ops, bufs: Buffers, B: int, n_shared_rows: int = 0) -> None:
                 dst[:] = a.contiguous().to(torch.bfloat16).view(-1).view(torch.float32)
                 continue
             nph = max(int(i[rt.G_PHASES]), 1)         # > 1: ConvTranspose1d phases sharing one op (include/mdt_hip.h)
-            if i[rt.G_WFMT] in (1, 2, 6, 10):              # plain bf16 products: one weight plane, A rounded to bf16 after the prologue
+            if i[rt.G_WFMT] in (1, 2, 6, 10, 38):          # plain bf16 products: one weight plane, A rounded to bf16 after the prologue
                 half = nph * n * taps * cin // 2
                 w_all = bufs.view(op.w, B, half).view(torch.bfloat16).float().view(nph, n, taps, cin)
                 a = a.to(torch.bfloat16).float()
@@ -98,7 +99,7 @@ def run_program(ops, bufs: Buffers, B: int, n_shared_rows: int = 0) -> None:
             else:
                 w_all = bufs.view(op.w, B, nph * n * taps * cin).view(nph, n, taps, cin)
             r = torch.arange(r_out)
-            out = None if i[rt.G_WFMT] == 6 else bufs.view(op.out, B, batches * o_rows * ldc).view(batches, o_rows, ldc)
+            out = None if i[rt.G_WFMT] in (6, 38) else bufs.view(op.out, B, batches * o_rows * ldc).view(batches, o_rows, ldc)
             for ph in range(nph):
                 w = w_all[ph]
                 t_off, o_off = i[rt.G_T_OFF], i[rt.G_O_OFF]
@@ -118,9 +119,12 @@ def run_program(ops, bufs: Buffers, B: int, n_shared_rows: int = 0) -> None:
                 orow = r * i[rt.G_O_STRIDE] + o_off
                 if op.res.space != rt.SP_NONE:
                     ldr = i[rt.G_LDR]
-                    res = bufs.view(op.res, B, batches * o_rows * ldr).view(batches, o_rows, ldr)
+                    if i[rt.G_WFMT] == 38:     # bf16 residual stream (round 6): ldr in bf16 elements, widened exactly
+                        res = bufs.view(op.res, B, batches * o_rows * ldr // 2).view(torch.bfloat16).float().view(batches, o_rows, ldr)
+                    else:
+                        res = bufs.view(op.res, B, batches * o_rows * ldr).view(batches, o_rows, ldr)
                     acc = acc + res[:, orow, :n]
-                if i[rt.G_WFMT] == 6:          # bf16 output (ldc in bf16 elements)
+                if i[rt.G_WFMT] in (6, 38):    # bf16 output (ldc in bf16 elements)
                     assert ldc == n and nph == 1
                     bufs.view(op.out, B, batches * o_rows * ldc // 2)[:] = acc.contiguous().to(torch.bfloat16).view(-1).view(torch.float32)
                     continue

@@ -746,6 +746,93 @@ def test_gemm_bf16_chain_with_bf16_intermediate():
     assert (out_g - out_c).abs().max() < 3e-3 * max(out_c.abs().max().item(), 1.0)
 
 
+@pytest.mark.parametrize("tile,w16", [(-1, 1), (0, 1), (1, 1), (2, 1), (-1, 0), (0, 0)])
+@pytest.mark.parametrize("B,R,C", [(37, 8, 1024), (5, 32, 512), (130, 4, 64)])
+def test_bf16_residual_stream_ops(B, R, C, tile, w16):
+    """Round 6, the bf16 RESIDUAL STREAM of the plain-bf16 mode's transformer blocks: MDT_OP_PREP16 with a bf16 input (WFMT 2: LayerNorm of
+    the bf16 stream, statistics in fp32 on the widened values) -> GEMM -> GEMM with A, residual and output all bf16, IN PLACE on the
+    stream (MDT_G_WFMT 38), against the interpreter.  Shapes: the 1024- and 512-channel levels of configs[4] and a minimal one."""
+    Hd = 2 * C
+    w1 = rnd(Hd, C, seed=1, scale=C ** -0.5).to(torch.bfloat16).contiguous().view(-1).view(torch.float32)
+    w2 = rnd(C, Hd, seed=2, scale=Hd ** -0.5).to(torch.bfloat16).contiguous().view(-1).view(torch.float32)
+    weights = torch.cat([w1, w2, rnd(Hd, seed=3), rnd(C, seed=4), 1 + 0.1 * rnd(C, seed=6), 0.1 * rnd(C, seed=7)])
+    o_w2 = w1.numel()
+    o_b1 = o_w2 + w2.numel()
+    o_b2, o_g, o_be = o_b1 + Hd, o_b1 + Hd + C, o_b1 + Hd + 2 * C
+    # per-sample arena (floats): [x16 (R C / 2) | ln16 (R C / 2) | h16 (R Hd / 2)]
+    xoff, lnoff, hoff = 0, R * C // 2, R * C
+    per = hoff + R * Hd // 2
+    act = torch.zeros(B * per)
+    x16 = (rnd(B * R * C, seed=5) * 1.5 + 0.3).to(torch.bfloat16)
+    act[: B * R * C // 2] = x16.view(-1).view(torch.float32)
+    pre = rt.MdtOp()
+    pre.kind = rt.OP_PREP16
+    pre.a, pre.out, pre.p0, pre.p1 = ref(A, xoff), ref(A, lnoff), ref(W, o_g), ref(W, o_be)
+    pre.i[rt.G_R_IN], pre.i[rt.G_LDA], pre.i[rt.G_CIN], pre.i[rt.G_PRO], pre.i[rt.G_WFMT] = R, C, C, rt.PRO_LAYERNORM, 2
+    pre.f[0] = 1e-5
+    g1 = gemm_op(a=ref(A, lnoff), w=ref(W, 0), bias=ref(W, o_b1), out=ref(A, hoff), r_out=R, r_in=R, lda=C, cin=C, taps=1,
+                 n=Hd, ldc=Hd, o_rows=R, act=1)
+    g1.i[rt.G_WFMT] = 6
+    g2 = gemm_op(a=ref(A, hoff), w=ref(W, o_w2), bias=ref(W, o_b2), out=ref(A, xoff), res=ref(A, xoff), r_out=R, r_in=R,
+                 lda=Hd, cin=Hd, taps=1, n=C, ldc=C, o_rows=R, ldr=C)
+    g2.i[rt.G_WFMT] = 38
+    # every tile of k_gemm_b16 (256 x 256 / 256 x 128 / 128 x 128; ragged M, N below the tile) with the all-bf16 epilogue
+    # (w16 = 1: 8 columns per lane, the residual requested under the main loop) and with the generic one (w16 = 0)
+    lib = rt.load_library()
+    lib.mdt_set_tuning(b"tile16", int(tile))
+    lib.mdt_set_tuning(b"w16", int(w16))
+    try:
+        (ga, _, _), (ca, _, _) = run_both([pre, g1, g2], weights, act, torch.zeros(4), {}, B)
+    finally:
+        lib.mdt_set_tuning(b"tile16", -1)
+        lib.mdt_set_tuning(b"w16", 1)
+    n_x, n_h = B * R * C // 2, B * R * Hd // 2
+    ln_g, ln_c = ga[n_x: 2 * n_x].view(torch.bfloat16).float(), ca[n_x: 2 * n_x].view(torch.bfloat16).float()
+    assert (ln_g - ln_c).abs().max() <= 2.0 ** -7 * max(ln_c.abs().max().item(), 1.0)    # one bf16 ulp (rounding ties)
+    out_g, out_c = ga[:n_x].view(torch.bfloat16).float(), ca[:n_x].view(torch.bfloat16).float()
+    assert torch.isfinite(out_g).all() and not torch.equal(out_c, x16.float())
+    # the stream was updated in place: bf16(x + W2 gelu(W1 LN(x) + b1) + b2); a differently rounded hidden value moves a sum by
+    # less than a bf16 ulp of the result or two
+    assert (out_g - out_c).abs().max() <= 2.0 ** -6 * max(out_c.abs().max().item(), 1.0)
+    # closed form of the three ops on the bf16 inputs
+    xf = x16.float().view(B, R, C)
+    wl1, wl2 = w1.view(torch.bfloat16).float().view(Hd, C), w2.view(torch.bfloat16).float().view(C, Hd)
+    ln = torch.nn.functional.layer_norm(xf, (C,), weights[o_g: o_g + C], weights[o_be: o_be + C], 1e-5).to(torch.bfloat16).float()
+    h = torch.nn.functional.gelu(ln @ wl1.T + weights[o_b1: o_b1 + Hd]).to(torch.bfloat16).float()
+    want = (xf + h @ wl2.T + weights[o_b2: o_b2 + C]).to(torch.bfloat16).float()
+    assert (out_g.view(B, R, C) - want).abs().max() <= 2.0 ** -5 * max(want.abs().max().item(), 1.0)
+
+
+@pytest.mark.parametrize("tile", [-1, 0, 1, 2])
+def test_bf16_gemm_single_chunk_with_bf16_residual(tile):
+    """k_gemm_b16's all-bf16 epilogue with K = 64: ONE chunk, so the residual is requested before the loop instead of two chunks
+    before its end (the hand-counted vmcnt of that case); in place, ragged M, against the interpreter and the closed form."""
+    B, R, C = 83, 4, 64
+    w = rnd(C, C, seed=1, scale=C ** -0.5).to(torch.bfloat16).contiguous().view(-1).view(torch.float32)
+    weights = torch.cat([w, rnd(C, seed=2)])
+    # per-sample arena (floats): [x16 (R C / 2) | a16 (R C / 2)]
+    act = torch.zeros(B * R * C)
+    x16 = (rnd(B * R * C, seed=3) * 1.5 + 0.3).to(torch.bfloat16)
+    a16 = rnd(B * R * C, seed=4).to(torch.bfloat16)
+    act[: B * R * C // 2] = x16.view(-1).view(torch.float32)
+    act[B * R * C // 2:] = a16.view(-1).view(torch.float32)
+    g = gemm_op(a=ref(A, R * C // 2), w=ref(W, 0), bias=ref(W, w.numel()), out=ref(A, 0), res=ref(A, 0), r_out=R, r_in=R,
+                lda=C, cin=C, taps=1, n=C, ldc=C, o_rows=R, ldr=C)
+    g.i[rt.G_WFMT] = 38
+    lib = rt.load_library()
+    lib.mdt_set_tuning(b"tile16", int(tile))
+    try:
+        (ga, _, _), (ca, _, _) = run_both([g], weights, act, torch.zeros(4), {}, B)
+    finally:
+        lib.mdt_set_tuning(b"tile16", -1)
+    n_x = B * R * C // 2
+    out_g, out_c = ga[:n_x].view(torch.bfloat16).float(), ca[:n_x].view(torch.bfloat16).float()
+    assert (out_g - out_c).abs().max() <= 2.0 ** -7 * max(out_c.abs().max().item(), 1.0)
+    want = (x16.float().view(-1, C) + a16.float().view(-1, C) @ w.view(torch.bfloat16).float().view(C, C).T + weights[w.numel():])
+    assert (out_g.view(-1, C) - want.to(torch.bfloat16).float()).abs().max() <= 2.0 ** -7 * max(want.abs().max().item(), 1.0)
+    assert torch.equal(ga[n_x:], act[n_x:])                      # the A operand is untouched
+
+
 @pytest.mark.parametrize("variant", [0, 2, 3])
 @pytest.mark.parametrize("mode", [rt.TB_FF, rt.TB_SELF, rt.TB_CROSS])
 @pytest.mark.parametrize("C,T,B", [(128, 16, 5), (256, 4, 37), (128, 4, 16), (256, 16, 3), (128, 1, 70)])
