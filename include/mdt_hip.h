@@ -34,7 +34,8 @@ int mdt_abi_version(void);
 const char *mdt_last_error(void);
 /* Process-wide tuning / test hooks (NOT part of the stable ABI; not needed for correct results): "pair_stride" = v > 0 places the two workgroups of
  * every pair-split MDT_OP_TF256 v workgroup ids apart whatever the op says (1: neighbours, i.e. different XCDs; 0: back to
- * the ops' own value); "tile16" = 0 | 1 | 2 forces a tile of the bf16 x bf16 GEMM (-1: automatic); "pair_capacity": see
+ * the ops' own value); "tile16" = 0 | 1 | 2 forces a tile of the bf16 x bf16 GEMM (-1: automatic); "w16" = 0 | 1 turns that GEMM's all-bf16
+ * epilogue (bf16 output, bf16 residual or none: 8 columns per lane, the residual requested under the main loop) off | on; "pair_capacity": see
  * mdt_pair_capacity.  Returns 0, or 1 for an unknown key. */
 int mdt_set_tuning(const char *key, int32_t value);
 /* Workgroups of a pair-split MDT_OP_TF256 launch that the current device keeps resident at the same time: compute units x
