@@ -37,6 +37,14 @@ __device__ __forceinline__ float gelu16(float x) {
   return 0.5f * x * (1.0f + copysignf(erfa, x));
 }
 
+// MDT_UB (tools/ubench/gemm16_phases.hip ONLY; the library never defines it): phase ablations of the main loop for timing -- bit 0: only
+// chunk 0 is requested (no DMA stream), bit 1: no MFMAs / fragment reads, bit 2: no epilogue; results are WRONG with any bit set.
+#ifndef MDT_UB
+#define MDT_UB 0
+#endif
+#if MDT_UB != 0 || defined(MDT_UB_CLOCK)
+__device__ unsigned long long g_ub_clk[4];          // shader clock / 100 MHz wall clock at the start and the end of workgroup 0
+#endif
 #ifndef MDT_B16_EP8_PAD
 #define MDT_B16_EP8_PAD 4         // W16 epilogue: parked-row pitch 32 TN + 4 floats (two rows' 8-column pieces interleave over the banks)
 #endif
@@ -70,11 +78,15 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_b16(Gemm16Args g) {
   const unsigned char* zero = reinterpret_cast<const unsigned char*>(g_zero16);
 
   // ---- per-lane DMA sources (lane l of an instruction: LDS row R0 + l / 8, physical slot l % 8) ----
+  // Round 6: a chunk's sources are a wave-UNIFORM base (tap, channel offset) plus per-lane 32-bit byte offsets that never
+  // change, so a DMA instruction takes the scalar-base form (global_load_lds_dwordx4 v_off, s[base]) and a chunk costs 16 DMA
+  // instructions + scalar arithmetic.  Before, every instruction had its own 64-bit VALU add and a zero-source select, and the
+  // chunk's tap came from an integer division: ~100 instructions between the barrier and the chunk's first MFMA, on both waves
+  // of a SIMD at the same time (parked 42 % + issue-stalled 37 % of the wave cycles, profiles/r6_cfg4_pmc_sq.csv).
   // (fixed bounds: hipcc's host pass silently drops the kernel stub when a lambda captures an array of dependent size)
   static_assert(NA <= 8 && NB <= 8, "at most 8 DMA instructions per wave and operand");
-  const unsigned char* abase[8];
+  unsigned aoff[8], woff[8];     // byte offsets from g.A / g.W (launch_gemm_b16 checks that they fit 32 bits)
   int arow[8];                   // row inside the sample, or a large negative number for rows past M
-  const unsigned char* wsrc[8];
 #pragma unroll
   for (int j = 0; j < NA; ++j) {
     const int R = (j * NW + wave) * 8 + (lane >> 3);
@@ -84,33 +96,54 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_b16(Gemm16Args g) {
     const int b = ok ? m / g.rows : 0;
     const int rr = ok ? m - b * g.rows : 0;
     arow[j] = ok ? rr : -(1 << 28);
-    abase[j] = reinterpret_cast<const unsigned char*>(g.A) + (((int64_t)b * g.rows + rr) * g.lda + g.a_col + 8 * c) * 2;
+    aoff[j] = (unsigned)((((int64_t)b * g.rows + rr) * g.lda + g.a_col + 8 * c) * 2);
   }
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     const int R = (j * NW + wave) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((R >> 1) & 7);
     const int n = min(n0 + R, g.N - 1);
-    wsrc[j] = reinterpret_cast<const unsigned char*>(g.W) + ((int64_t)n * K + 8 * c) * 2;
+    woff[j] = (unsigned)(((int64_t)n * K + 8 * c) * 2);
   }
+  // no padded source anywhere: one tap on its own row and whole row tiles
+  const bool plain = g.taps == 1 && g.t_off == 0 && g.M % BM == 0;
+  int nx_tap = 0, nx_ci = 0, nx_k0 = 0;          // the next chunk to request (chunks are requested in order)
 
-  auto issue = [&](int kc, int stage) {
-    const int k0 = kc * BK;
-    const int tap = k0 / g.cin;
-    const int ci = k0 - tap * g.cin;
-    const int delta = tap * g.t_dj + g.t_off;
-    const int64_t aoff = ((int64_t)delta * g.lda + ci) * 2;
+  auto issue = [&](int stage) {
+    const int delta = nx_tap * g.t_dj + g.t_off;
+    const unsigned char* ab = reinterpret_cast<const unsigned char*>(g.A) + ((int64_t)delta * g.lda + nx_ci) * 2;     // wave-uniform
+    const unsigned char* wb = reinterpret_cast<const unsigned char*>(g.W) + (int64_t)nx_k0 * 2;
     unsigned char* sa = smem + stage * STAGE + wave * 1024;
     unsigned char* sb = sa + ABYTES;
+    // (the offsets pass through an empty asm so that their zero-extension stays in this basic block: k_res256.hip, issue_w)
+    unsigned ao[8], wo[8];
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
-      const bool ok = (unsigned)(arow[j] + delta) < (unsigned)g.rows;
-      const unsigned char* src = ok ? abase[j] + aoff : zero;
+      ao[j] = aoff[j];
+      asm volatile("" : "+v"(ao[j]));
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      wo[j] = woff[j];
+      asm volatile("" : "+v"(wo[j]));
+    }
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const unsigned char* src = ab + ao[j];
+      // a padded row (outside its sample for this tap, or past M) reads the zero line; ONE request per piece either way (the
+      // hand-counted vmcnt of the W16 epilogue counts them)
+      if (!plain && !((unsigned)(arow[j] + delta) < (unsigned)g.rows)) src = zero;
       __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(sa + j * NW * 1024), 16, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < NB; ++j)
-      __builtin_amdgcn_global_load_lds(wsrc[j] + (int64_t)k0 * 2, (__attribute__((address_space(3))) void*)(sb + j * NW * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(wb + wo[j], (__attribute__((address_space(3))) void*)(sb + j * NW * 1024), 16, 0, 0);
+    nx_k0 += BK;
+    nx_ci += BK;
+    if (nx_ci == g.cin) {
+      nx_ci = 0;
+      ++nx_tap;
+    }
   };
 
   f32x16 acc[TM][TN];
@@ -126,6 +159,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_b16(Gemm16Args g) {
   const int swz = (li >> 1) & 7;                  // (row >> 1) & 7: tile rows start at multiples of 32
   const int aoffs = (wr * 32 * TM + li) * 128, boffs = ABYTES + (wc * 32 * TN + li) * 128;
 
+  // (Round 6, measured before leaving this loop alone -- tools/ubench/gemm16_phases.hip, profiles/r6_ubench_gemm16_phases.txt: the
+  //  MFMAs alone take 2,400-2,500 cycles per 256 x 256 x 64 chunk at the 1.75-1.95 GHz the chip holds under them, the DMA stream
+  //  alone 2,350 (1,500 with two chunks in flight), together 3,400-3,500 -- and that figure does not move with hand
+  //  double-buffered fragments, a third fewer fragment reads, two chunks in flight, or the requests spread between the MFMAs.)
   auto compute = [&](int stage) {
     const unsigned char* cur = smem + stage * STAGE;
 #pragma unroll
@@ -149,7 +186,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_b16(Gemm16Args g) {
   // fragment and DMA-pointer registers are dead by then).
   // The requests are unconditional on clamped addresses: their COUNT is what the hand-written vmcnt below relies on.
   constexpr int LPR8 = 4 * TN, RP8 = 64 / LPR8, NP8 = 32 / RP8;
-  static_assert(TM <= 4 && NP8 <= 4, "residual registers");
+  static_assert(!W16 || (TM <= 4 && NP8 <= 4), "residual registers");
   const int er8 = lane / LPR8, ec8 = (lane % LPR8) * 8;
   const bool res8 = W16 && g.res != nullptr;
   uint4 rq[4][4];
@@ -160,7 +197,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_b16(Gemm16Args g) {
   auto prefetch = [&](int a) {
     const int n = min(n0 + wc * 32 * TN + ec8, g.N - 8);
 #pragma unroll
-    for (int p = 0; p < NP8; ++p) {
+    for (int p = 0; p < (NP8 < 4 ? NP8 : 4); ++p) {
       const int m = min(m0 + wr * 32 * TM + a * 32 + p * RP8 + er8, g.M - 1);
       rq[a][p] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(g.res) + (int64_t)m * g.ldr + n);
     }
@@ -174,7 +211,15 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_b16(Gemm16Args g) {
   }
 
   const int nk = K / BK;
-  issue(0, 0);
+#if MDT_UB != 0 || defined(MDT_UB_CLOCK)
+  if (blockIdx.x == 0 && tid == 0) {
+    unsigned long long c0, r0;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c0), "=s"(r0)::"memory");
+    g_ub_clk[0] = c0;
+    g_ub_clk[2] = r0;
+  }
+#endif
+  issue(0);
   if (res8 && nk == 1) {
     prefetch(0);
     if (TM > 1) prefetch(1);
@@ -189,13 +234,22 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_b16(Gemm16Args g) {
     }
     __builtin_amdgcn_s_barrier();          // chunk kc has landed for every wave; every wave is done reading the other stage
     asm volatile("" ::: "memory");
-    if (kc + 1 < nk) issue(kc + 1, (kc + 1) & 1);
+    if (kc + 1 < nk && !(MDT_UB & 1)) issue((kc + 1) & 1);
     if (res8 && kc == nk - 2) {
       prefetch(0);
       if (TM > 1) prefetch(1);
     }
-    compute(kc & 1);
+    if (!(MDT_UB & 2)) compute(kc & 1);
   }
+#if MDT_UB != 0 || defined(MDT_UB_CLOCK)
+  if (blockIdx.x == 0 && tid == 0) {
+    unsigned long long c1, r1;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1)::"memory");
+    g_ub_clk[1] = c1;
+    g_ub_clk[3] = r1;
+  }
+  if ((MDT_UB & 4) && g.act != 77) return;           // (the accumulators stay live: act is never 77)
+#endif
 
   // ---- epilogue.  32x32 C/D layout: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5): for a fixed register a
   // half-wave holds 32 consecutive columns of ONE row.  Written straight from the accumulators that is 128-byte segments, one
@@ -385,6 +439,8 @@ void set_tile16(int v) { g_force_tile16 = v; }
 hipError_t launch_gemm_b16(const Gemm16Args& g, hipStream_t s) {
   if (g.M <= 0) return hipSuccess;
   if (!gemm_b16_supported(g.cin, g.taps, g.lda, g.a_col) || !gemm_b16_epilogue_ok(g)) return hipErrorInvalidValue;
+  // the kernel addresses both operands with 32-bit byte offsets from their bases (4 GB of bf16 rows: no layer comes near)
+  if (((int64_t)g.M * g.lda + g.a_col) * 2 >= (1ll << 32) || (int64_t)g.N * g.taps * g.cin * 2 >= (1ll << 32)) return hipErrorInvalidValue;
   static int force0 = -2;
   if (force0 == -2) {
     force0 = -1;
@@ -400,6 +456,9 @@ hipError_t launch_gemm_b16(const Gemm16Args& g, hipStream_t s) {
     //  leaves nothing to run under its fragment reads)
     case 0: return launch16<2, 4, 4, 2>(g, s);
     case 1: return launch16<4, 2, 2, 2>(g, s);
+#ifdef MDT_UB_TILE3
+    case 3: return launch16w<2, 2, 4, 4, false>(g, s);       // (ubench only: 256 x 256 on four waves, generic epilogue)
+#endif
     default: return launch16<2, 2, 2, 2>(g, s);
   }
 }
