@@ -214,6 +214,11 @@ enum mdt_gemm_i {
                         38 (round 6) = as 6 and the RESIDUAL is bf16 too (LDR in bf16 elements; res may alias out): the bf16
                         residual stream of the plain-bf16 mode's transformer blocks -- one bf16 tensor is residual, output and the
                         next GEMM's A operand.
+                        134 (round 6) = 6 with the LayerNorm of its A rows FOLDED into the GEMM: A is a raw bf16 row (the residual
+                        stream), out = rstd (A W^T - mean colsum) + bias with the rows' mean / rstd over CIN gathered by the kernel
+                        from the A fragments it multiplies, p0 = colsum [N] = sum_k W[n][k] of the bf16 weights (the host folds
+                        the LayerNorm's gain into W and W bias_ln into bias), eps = f[0]; one tap, no residual, N / LDC / O_COL
+                        multiples of 8.
                         Formats 2 / 6 / 10 end in a float4 epilogue: N, LDC, O_COL and LDR must be multiples of 4 and bias /
                         residual / out 16-byte aligned (bf16 out / copy: 8), otherwise the op is rejected;
                         16 = RING TILES (k_proj.hip, round 5): w holds N / 64 * CIN / 128 tiles of 32 KB, tile (chunk c, K half h)

@@ -179,6 +179,10 @@ class UNetCompiler:
         # cross-attention GEMMs.  Priced on the oracle at 2e-4 .. 5e-4 of the final sample (tools/res16_experiment.py; the mode's bf16
         # operands cost 1.2e-3 .. 1.6e-3, its budget is 1e-2).  MDT_RES16=0: the fp32 stream of rounds 3-5.
         self.res16 = os.environ.get("MDT_RES16", "1") == "1"
+        # ... and the LayerNorm in front of the attention projections FOLDED into the GEMM (second half of round 6, MDT_G_WFMT 134): the
+        # projection reads the RAW stream, gathers the rows' statistics from the fragments it multiplies and scales / shifts its
+        # accumulators per row -- no MDT_OP_PREP16 pass in front of it.  MDT_LNFOLD=0: the PREP16 pass.
+        self.lnfold = os.environ.get("MDT_LNFOLD", "1") == "1"
         self.qkv_merge = os.environ.get("MDT_QKV_MERGE", "1") == "1"   # ... and self-attention's q | k | v as one GEMM     # bf16 mode: regular layers as PREP16 + bf16 x bf16 GEMM
         self.fold_ctx = os.environ.get("MDT_FOLD_CTX", "1") == "1"
         self.has_chat = False                # some layer attends to the normalised context (ctx program emits it)
@@ -316,6 +320,23 @@ class UNetCompiler:
         regular = (self.b16_ok(cin) and t_stride == 1 and phases <= 1 and o_stride == 1 and o_off == 0 and r_out_ == a.rows
                    and out.rows == r_out_ and m_mode == 0)
         assert not (a.b16 or out.b16) or (regular and (not a.b16 or (pro in (rt.PRO_NONE, rt.PRO_LAYERNORM) and a_col == 0))), "bf16 operand"
+        lnf = None
+        if (self.lnfold and regular and a.b16 and pro == rt.PRO_LAYERNORM and taps == 1 and t_off == 0 and out.b16 and res is None
+                and copy16 is None and n % 8 == 0 and o_col % 8 == 0 and out.ld % 8 == 0):
+            # LayerNorm folded around the GEMM (MDT_G_WFMT 134): W (g xn + b) = rstd ((W g) x - mean rowsum(W g)) + W b, fp64 on the host;
+            # the row sums are taken over the bf16 values the MFMAs multiply
+            key = (wt[0], "lnfold", gain, nbias, bias_off)
+            if key not in self._packed:
+                w = wt[1].double()
+                gv, bv = self.W.read(gain, cin).double(), self.W.read(nbias, cin).double()
+                b0 = self.W.read(bias_off, n).double() if bias_off is not None else torch.zeros(n, dtype=torch.float64)
+                w2 = (w * gv.unsqueeze(0)).float()
+                csum = w2.to(torch.bfloat16).double().sum(dim=1).float()
+                self._packed[key] = ((wt[0] + "/lnfold", w2), self.W.add(wt[0] + "/lnfold.bias", (b0 + w @ bv).float()),
+                                     self.W.add(wt[0] + "/lnfold.csum", csum))
+            wt, bias_off, csum_off = self._packed[key]
+            lnf = csum_off
+            pro, gain, nbias = rt.PRO_NONE, None, None
         if regular and (not a.b16 or pro == rt.PRO_LAYERNORM):
             # plain-bf16 mode, regular layer: the prologue runs once per element in a pass of its own that writes the bf16 A
             # operand (MDT_OP_PREP16), the GEMM streams both operands by LDS-DMA (k_gemm_b16.hip)
@@ -413,6 +434,9 @@ class UNetCompiler:
         if res is not None and res.b16:      # the bf16 residual stream: A, residual and output all bf16 (MDT_G_WFMT 38)
             assert a.b16 and out.b16 and copy16 is None and o_col == 0
             op.i[rt.G_WFMT] = 38
+        if lnf is not None:                  # LayerNorm of the raw bf16 A rows folded into the GEMM (MDT_G_WFMT 134)
+            assert op.i[rt.G_WFMT] == 6
+            op.i[rt.G_WFMT] = 134
         if copy16 is not None:               # a bf16 copy of the fp32 output, written by the epilogue (MDT_G_WFMT 10)
             assert a.b16 and copy16.b16 and not out.b16 and o_col == 0 and copy16.ld == n and copy16.rows == out.rows
             op.p0 = copy16.ref()
@@ -428,6 +452,8 @@ class UNetCompiler:
             op.p1 = _ref(rt.SP_WEIGHT, nbias)
         if stats is not None:
             op.p2 = stats.ref()
+        if lnf is not None:
+            op.p0 = _ref(rt.SP_WEIGHT, lnf)
         if isinstance(film, tuple):      # ("ss", offset inside the shared scale/shift row): resolved in build()
             op._film = film
         elif film is not None:

@@ -24,6 +24,7 @@ namespace mdt {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};   // source of padded rows
 
@@ -163,6 +164,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_b16(Gemm16Args g) {
   //  MFMAs alone take 2,400-2,500 cycles per 256 x 256 x 64 chunk at the 1.75-1.95 GHz the chip holds under them, the DMA stream
   //  alone 2,350 (1,500 with two chunks in flight), together 3,400-3,500 -- and that figure does not move with hand
   //  double-buffered fragments, a third fewer fragment reads, two chunks in flight, or the requests spread between the MFMAs.)
+  const bool fold = W16 && g.csum != nullptr;         // LayerNorm of the A rows folded into the GEMM (below, "W16")
+  float st_s[4] = {0.f, 0.f, 0.f, 0.f}, st_q[4] = {0.f, 0.f, 0.f, 0.f};      // this lane's row of each row block: sum, sum of squares
+  static_assert(TM <= 4, "statistics registers");
   auto compute = [&](int stage) {
     const unsigned char* cur = smem + stage * STAGE;
 #pragma unroll
@@ -173,6 +177,17 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_b16(Gemm16Args g) {
       for (int a = 0; a < TM; ++a) af[a] = *reinterpret_cast<const bf16x8*>(cur + aoffs + a * 4096 + slot);
 #pragma unroll
       for (int b = 0; b < TN; ++b) bf[b] = *reinterpret_cast<const bf16x8*>(cur + boffs + b * 4096 + slot);
+      if (fold && (ks % WN) == wc) {                   // the WN waves of a row group share the k-steps of the row statistics
+        const bf16x2 one2 = {(__bf16)1.0f, (__bf16)1.0f};
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const bf16x2 pr = {af[a][2 * e], af[a][2 * e + 1]};
+            st_s[a] = __builtin_amdgcn_fdot2_f32_bf16(pr, one2, st_s[a], false);
+            st_q[a] = __builtin_amdgcn_fdot2_f32_bf16(pr, pr, st_q[a], false);
+          }
+      }
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -208,6 +223,19 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_b16(Gemm16Args g) {
     const int n = min(n0 + wc * 32 * TN + ec8, g.N - 8);
     const float4 b0 = *reinterpret_cast<const float4*>(g.bias + n), b1 = *reinterpret_cast<const float4*>(g.bias + n + 4);
     bia8[0] = b0.x; bia8[1] = b0.y; bia8[2] = b0.z; bia8[3] = b0.w; bia8[4] = b1.x; bia8[5] = b1.y; bia8[6] = b1.z; bia8[7] = b1.w;
+  }
+  // LayerNorm folded into the GEMM (W16 only).  The A operand is the RAW bf16 residual stream and W (g xn + b) = rstd ((W g) x
+  // - mean rowsum(W g)) + W b: the epilogue scales and shifts the accumulators per row.  The rows' (sum, sum of squares) come from
+  // the A fragments the waves read for the MFMAs anyway -- wave column wc takes the k-steps ks = wc mod WN, two v_dot2c_f32_bf16
+  // per pair of values, in the MFMAs' shadow -- and meet in LDS behind the main loop.  What it replaces: an MDT_OP_PREP16 launch
+  // that read the stream and wrote a normalised copy for this GEMM to read again (134 MB of 201 at M = 65,536, C = 512).
+  float cs8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float2* srow = reinterpret_cast<float2*>(smem + 2 * STAGE);          // (mean, rstd) of the tile's BM rows, behind the two stages
+  float2* sred = srow + BM;                                            // [WN][BM] partial (sum, sum of squares)
+  if (fold) {
+    const int n = min(n0 + wc * 32 * TN + ec8, g.N - 8);
+    const float4 c0 = *reinterpret_cast<const float4*>(g.csum + n), c1 = *reinterpret_cast<const float4*>(g.csum + n + 4);
+    cs8[0] = c0.x; cs8[1] = c0.y; cs8[2] = c0.z; cs8[3] = c0.w; cs8[4] = c1.x; cs8[5] = c1.y; cs8[6] = c1.z; cs8[7] = c1.w;
   }
 
   const int nk = K / BK;
@@ -259,9 +287,33 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_b16(Gemm16Args g) {
   // fp32 rows of pitch 72 floats (both the accumulator-order writes and the row-order reads are conflict-free) and walks it row
   // by row: 16 lanes per row, float4 each -- bias, GELU, residual (float4 loads, all requested before the first store of the
   // pass) and the fp32 store and / or the bf16 store as 16- / 8-byte accesses of 256- / 128-byte row segments.
+  if (fold) {                                       // the rows' statistics meet: halves of k (lh), then the WN waves of the row group
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      const float s_ = st_s[a] + __shfl_xor(st_s[a], 32), q_ = st_q[a] + __shfl_xor(st_q[a], 32);
+      if (lh == 0) sred[wc * BM + wr * 32 * TM + a * 32 + li] = make_float2(s_, q_);
+    }
+  }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                     // every wave is done reading the last stage (no DMA is in flight any more)
   asm volatile("" ::: "memory");
+  if (fold) {
+    for (int r = tid; r < BM; r += 64 * NW) {
+      float s_ = 0.f, q_ = 0.f;
+#pragma unroll
+      for (int w = 0; w < WN; ++w) {
+        const float2 v = sred[w * BM + r];
+        s_ += v.x;
+        q_ += v.y;
+      }
+      const float mean = s_ / (float)g.cin;
+      const float var = fmaxf(q_ / (float)g.cin - mean * mean, 0.f);
+      srow[r] = make_float2(mean, 1.0f / sqrtf(var + g.eps));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
   constexpr int EP = 32 * TN + (W16 ? MDT_B16_EP8_PAD : 8);   // floats per parked row (72 / 136: pitch = 8 mod 32 banks)
   float* ws = reinterpret_cast<float*>(smem) + wave * (32 * EP);
   static_assert(NW * 32 * EP * 4 <= 2 * STAGE, "parking area inside the staging buffers");
@@ -293,8 +345,14 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_b16(Gemm16Args g) {
         const int row = p * RP8 + er8, m = mrow0 + row;
         const float4 v0 = *reinterpret_cast<const float4*>(ws + row * EP + ec8);
         const float4 v1 = *reinterpret_cast<const float4*>(ws + row * EP + ec8 + 4);
-        float x[8] = {v0.x + bia8[0], v0.y + bia8[1], v0.z + bia8[2], v0.w + bia8[3],
-                      v1.x + bia8[4], v1.y + bia8[5], v1.z + bia8[6], v1.w + bia8[7]};
+        float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        if (fold) {
+          const float2 mr = srow[wr * 32 * TM + a * 32 + row];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) x[k] = mr.y * (x[k] - mr.x * cs8[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] += bia8[k];
         if (g.act == 1) {
 #pragma unroll
           for (int k = 0; k < 8; ++k) x[k] = gelu16(x[k]);
@@ -305,10 +363,11 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_b16(Gemm16Args g) {
           x[2 * q] += __uint_as_float(w[q] << 16);
           x[2 * q + 1] += __uint_as_float(w[q] & 0xffff0000u);
         }
-        if (cok && m < g.M) {
-          unsigned short h[8];
+        unsigned short h[8];
 #pragma unroll
-          for (int k = 0; k < 8; ++k) h[k] = __builtin_bit_cast(unsigned short, (__bf16)x[k]);
+        for (int k = 0; k < 8; ++k) h[k] = __builtin_bit_cast(unsigned short, (__bf16)x[k]);
+        const bool okrow = cok && m < g.M;
+        if (okrow) {
           *reinterpret_cast<uint4*>(o8 + (int64_t)m * g.ldc + g.o_col + ncol) =
               make_uint4(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16), h[4] | ((unsigned)h[5] << 16), h[6] | ((unsigned)h[7] << 16));
         }
@@ -384,7 +443,7 @@ template <int WM, int WN, int TM, int TN, bool W16>
 static hipError_t launch16w(const Gemm16Args& g, hipStream_t s) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   const int mt = (g.M + BM - 1) / BM, nt = (g.N + BN - 1) / BN;
-  const size_t smem = 2 * (size_t)(BM + BN) * 128;
+  const size_t smem = 2 * (size_t)(BM + BN) * 128 + (W16 ? (1 + WN) * BM * sizeof(float2) : 0);   // + a folded LayerNorm's row statistics
   static DevOnce attr_once;                          // per device (mdt_kernels.h)
   if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_b16<WM, WN, TM, TN, W16>),
@@ -405,7 +464,7 @@ static bool gemm_b16_w16_ok(const Gemm16Args& g) {
     const char* e = mdt_tuning_env("MDT_W16");
     g_w16 = e ? atoi(e) : 1;
   }
-  if (!g_w16 || !g.out16 || g.copy16 || (g.res && !g.res16)) return false;
+  if ((!g_w16 && !g.csum) || !g.out16 || g.copy16 || (g.res && !g.res16)) return false;   // (the folded LayerNorm lives in this epilogue only)
   if (g.N % 8 || g.ldc % 8 || g.o_col % 8 || !al16(g.out)) return false;
   if (g.res && (g.ldr % 8 || !al16(g.res))) return false;
   return true;
@@ -413,7 +472,9 @@ static bool gemm_b16_w16_ok(const Gemm16Args& g) {
 
 template <int WM, int WN, int TM, int TN>
 static hipError_t launch16(const Gemm16Args& g, hipStream_t s) {
-  return gemm_b16_w16_ok(g) ? launch16w<WM, WN, TM, TN, true>(g, s) : launch16w<WM, WN, TM, TN, false>(g, s);
+  if (gemm_b16_w16_ok(g)) return launch16w<WM, WN, TM, TN, true>(g, s);
+  if (g.csum) return hipErrorInvalidValue;          // a folded LayerNorm must not be dropped silently
+  return launch16w<WM, WN, TM, TN, false>(g, s);
 }
 
 bool gemm_b16_supported(int cin, int taps, int lda, int a_col) {
@@ -439,6 +500,8 @@ void set_tile16(int v) { g_force_tile16 = v; }
 hipError_t launch_gemm_b16(const Gemm16Args& g, hipStream_t s) {
   if (g.M <= 0) return hipSuccess;
   if (!gemm_b16_supported(g.cin, g.taps, g.lda, g.a_col) || !gemm_b16_epilogue_ok(g)) return hipErrorInvalidValue;
+  // folded LayerNorm: one tap over the whole normalised row
+  if (g.csum && (g.taps != 1 || g.t_off || (reinterpret_cast<size_t>(g.csum) & 15))) return hipErrorInvalidValue;
   // the kernel addresses both operands with 32-bit byte offsets from their bases (4 GB of bf16 rows: no layer comes near)
   if (((int64_t)g.M * g.lda + g.a_col) * 2 >= (1ll << 32) || (int64_t)g.N * g.taps * g.cin * 2 >= (1ll << 32)) return hipErrorInvalidValue;
   static int force0 = -2;

@@ -119,8 +119,13 @@ static const char* validate(const mdt_op& o, int idx, char* buf, size_t nbuf) {
       if (o.res.space && i[MDT_G_LDR] <= 0) return bad("residual without ldr");
       if (o.a2.space && i[MDT_G_CIN] % 32) return bad("split-bf16 weights need cin % 32 == 0");
       if (i[MDT_G_WFMT] < 0 || (i[MDT_G_WFMT] > 2 && i[MDT_G_WFMT] != 6 && i[MDT_G_WFMT] != 10 && i[MDT_G_WFMT] != 16 && i[MDT_G_WFMT] != 17 &&
-                                i[MDT_G_WFMT] != 38)) return bad("bad weight format");
+                                i[MDT_G_WFMT] != 38 && i[MDT_G_WFMT] != 134))
+        return bad("bad weight format");
       if (i[MDT_G_WFMT] == 38 && !o.res.space) return bad("WFMT 38 (bf16 residual stream) needs the residual");
+      if (i[MDT_G_WFMT] == 134) {      // LayerNorm of the raw bf16 A rows folded into the GEMM
+        if (!o.p0.space || o.res.space || i[MDT_G_TAPS] != 1 || i[MDT_G_T_OFF] || i[MDT_G_N] % 8 || i[MDT_G_LDC] % 8 || i[MDT_G_O_COL] % 8)
+          return bad("WFMT 134 (folded LayerNorm): p0 = column sums of W, one tap, no residual, N / ldc / o_col % 8 == 0");
+      }
       if (i[MDT_G_WFMT] == 16 || i[MDT_G_WFMT] == 17) {
         if (!mdt::proj_supported(i[MDT_G_CIN], i[MDT_G_N], i[MDT_G_LDA], i[MDT_G_LDC], o.res.space ? i[MDT_G_LDR] : 0) || o.a2.space)
           return bad("ring-tile projection needs cin in {128, 256}, N % 64 == 0, 16-byte aligned rows and no lo plane (the tiles hold both)");
@@ -405,6 +410,8 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
           h.lda = g.lda; h.a_col = g.a_col; h.t_dj = g.t_dj; h.t_off = g.t_off; h.ldc = g.ldc; h.ldr = g.ldr; h.o_col = g.o_col;
           h.act = g.act; h.out16 = (i[MDT_G_WFMT] & 4) ? 1 : 0; h.res16 = (i[MDT_G_WFMT] & 32) ? 1 : 0;
           h.copy16 = (i[MDT_G_WFMT] & 8) ? reinterpret_cast<unsigned short*>(ptr(o.p0)) : nullptr;
+          h.csum = (i[MDT_G_WFMT] & 128) ? ptr(o.p0) : nullptr;
+          h.eps = g.eps;
           e = mdt::launch_gemm_b16(h, stream);
         } else if (!missing) {
           static const bool no_as = mdt_tuning_env("MDT_NO_AS") != nullptr;   // tuning aid: disable the A-stationary kernel

@@ -86,6 +86,10 @@ struct Gemm16Args {
   int out16;                  // 1: out is bf16 (ldc / o_col in bf16 elements)
   int res16;                  // 1: res is bf16 (ldr in bf16 elements): the bf16 residual stream of the plain-bf16 mode (round 6)
   unsigned short* copy16;     // fp32 output: also a bf16 copy [M][N] of it (the next GEMM's A operand), or nullptr
+  // LayerNorm folded into the GEMM (round 6, all-bf16 epilogue only): A is the RAW bf16 residual stream (taps == 1); the waves gather
+  // each row's (sum, sum of squares) from the A fragments they feed the MFMAs anyway, and the epilogue applies
+  const float* csum;          //   out = rstd[m] (acc - mean[m] csum[n]) + bias[n], csum[n] = sum_k W[n][k] (the bf16 values); or nullptr
+  float eps;
 };
 bool gemm_b16_supported(int cin, int taps, int lda, int a_col);
 bool gemm_b16_epilogue_ok(const Gemm16Args& g);   // N / ldc / o_col / ldr % 4 == 0 and 16-byte aligned tensors (float4 epilogue)

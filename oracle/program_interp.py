@@ -79,7 +79,8 @@ def run_program(ops, bufs: Buffers, B: int, n_shared_rows: int = 0) -> None:
                 dst[:] = a.contiguous().to(torch.bfloat16).view(-1).view(torch.float32)
                 continue
             nph = max(int(i[rt.G_PHASES]), 1)         # > 1: ConvTranspose1d phases sharing one op (include/mdt_hip.h)
-            if i[rt.G_WFMT] in (1, 2, 6, 10, 38):          # plain bf16 products: one weight plane, A rounded to bf16 after the prologue
+            wbase = i[rt.G_WFMT] & 63          # (round 6: + 128 = the LayerNorm of the A rows folded into the GEMM, MDT_G_WFMT 134)
+            if wbase in (1, 2, 6, 10, 38):          # plain bf16 products: one weight plane, A rounded to bf16 after the prologue
                 half = nph * n * taps * cin // 2
                 w_all = bufs.view(op.w, B, half).view(torch.bfloat16).float().view(nph, n, taps, cin)
                 a = a.to(torch.bfloat16).float()
@@ -99,7 +100,7 @@ def run_program(ops, bufs: Buffers, B: int, n_shared_rows: int = 0) -> None:
             else:
                 w_all = bufs.view(op.w, B, nph * n * taps * cin).view(nph, n, taps, cin)
             r = torch.arange(r_out)
-            out = None if i[rt.G_WFMT] in (6, 38) else bufs.view(op.out, B, batches * o_rows * ldc).view(batches, o_rows, ldc)
+            out = None if wbase in (6, 38) else bufs.view(op.out, B, batches * o_rows * ldc).view(batches, o_rows, ldc)
             for ph in range(nph):
                 w = w_all[ph]
                 t_off, o_off = i[rt.G_T_OFF], i[rt.G_O_OFF]
@@ -112,6 +113,13 @@ def run_program(ops, bufs: Buffers, B: int, n_shared_rows: int = 0) -> None:
                     ok = (src >= 0) & (src < r_in)
                     rows = a[:, src.clamp(0, r_in - 1), :] * ok.view(1, -1, 1)
                     acc = acc + rows @ w[:, t, :].T
+                if i[rt.G_WFMT] & 128:         # MDT_G_WFMT 134: LayerNorm of the raw bf16 A rows folded into the GEMM -- applied to the
+                    # accumulators from the rows' mean / rstd and W's column sums (the statistics in fp32 on the bf16 values, as the kernel's)
+                    assert taps == 1 and nph == 1 and pro == rt.PRO_NONE
+                    mean = a.mean(dim=-1)
+                    var = ((a * a).mean(dim=-1) - mean * mean).clamp(min=0.0)
+                    rstd = 1.0 / torch.sqrt(var + float(f[0]))
+                    acc = rstd.unsqueeze(-1) * (acc - mean.unsqueeze(-1) * bufs.view(op.p0, B, n))
                 if op.bias.space != rt.SP_NONE:
                     acc = acc + bufs.view(op.bias, B, n)
                 if i[rt.G_ACT] == 1:
@@ -119,17 +127,18 @@ def run_program(ops, bufs: Buffers, B: int, n_shared_rows: int = 0) -> None:
                 orow = r * i[rt.G_O_STRIDE] + o_off
                 if op.res.space != rt.SP_NONE:
                     ldr = i[rt.G_LDR]
-                    if i[rt.G_WFMT] == 38:     # bf16 residual stream (round 6): ldr in bf16 elements, widened exactly
+                    if wbase == 38:            # bf16 residual stream (round 6): ldr in bf16 elements, widened exactly
                         res = bufs.view(op.res, B, batches * o_rows * ldr // 2).view(torch.bfloat16).float().view(batches, o_rows, ldr)
                     else:
                         res = bufs.view(op.res, B, batches * o_rows * ldr).view(batches, o_rows, ldr)
                     acc = acc + res[:, orow, :n]
-                if i[rt.G_WFMT] in (6, 38):    # bf16 output (ldc in bf16 elements)
+                if wbase in (6, 38):           # bf16 output (ldc in bf16 elements)
                     assert ldc == n and nph == 1
-                    bufs.view(op.out, B, batches * o_rows * ldc // 2)[:] = acc.contiguous().to(torch.bfloat16).view(-1).view(torch.float32)
+                    o16 = acc.contiguous().to(torch.bfloat16)
+                    bufs.view(op.out, B, batches * o_rows * ldc // 2)[:] = o16.view(-1).view(torch.float32)
                     continue
                 out[:, orow, i[rt.G_O_COL]: i[rt.G_O_COL] + n] = acc
-                if i[rt.G_WFMT] == 10:         # ... and a bf16 copy of the fp32 output (the next GEMM's A operand)
+                if wbase == 10:                # ... and a bf16 copy of the fp32 output (the next GEMM's A operand)
                     bufs.view(op.p0, B, batches * o_rows * n // 2)[:] = acc.contiguous().to(torch.bfloat16).view(-1).view(torch.float32)
         elif op.kind == rt.OP_GN_STATS:
             rows, ld, G, gs = i[rt.N_ROWS], i[rt.N_LD], i[rt.N_GROUPS], i[rt.N_GSIZE]

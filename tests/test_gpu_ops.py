@@ -804,6 +804,57 @@ def test_bf16_residual_stream_ops(B, R, C, tile, w16):
 
 
 @pytest.mark.parametrize("tile", [-1, 0, 1, 2])
+@pytest.mark.parametrize("B,R,C,N", [(37, 8, 1024, 1536), (5, 32, 512, 512), (130, 4, 256, 768), (67, 2, 64, 128)])
+def test_layernorm_folded_into_bf16_gemm(B, R, C, N, tile):
+    """Round 6, MDT_G_WFMT 134: the projection reads the RAW bf16 residual stream (here just written in place by a WFMT 38 GEMM), gathers
+    each row's mean / rstd from the A fragments it multiplies and applies the LayerNorm to its accumulators (column sums of the
+    gain-folded weights in p0): against the interpreter and against LayerNorm + matmul in closed form.  Ragged M, every tile of
+    k_gemm_b16, one chunk (C = 64) to sixteen."""
+    Hd = C
+    w1 = rnd(C, Hd, seed=1, scale=Hd ** -0.5).to(torch.bfloat16)                      # to_out-like: [C][Hd]
+    gam, bet = 1 + 0.2 * rnd(C, seed=2), 0.2 * rnd(C, seed=3)
+    wq = rnd(N, C, seed=4, scale=C ** -0.5)
+    w2 = (wq * gam.unsqueeze(0)).to(torch.bfloat16)                                    # gain folded, as the compiler packs it
+    csum = w2.float().sum(dim=1)
+    bias2 = wq @ bet + 0.1 * rnd(N, seed=5)
+    weights = torch.cat([w1.contiguous().view(-1).view(torch.float32), w2.contiguous().view(-1).view(torch.float32), rnd(C, seed=6), csum, bias2])
+    o_w2 = w1.numel() // 2
+    o_b1 = o_w2 + w2.numel() // 2
+    o_cs, o_b2 = o_b1 + C, o_b1 + C + N
+    # per-sample arena (floats): [x16 (R C / 2) | a16 (R Hd / 2) | q16 (R N / 2)]
+    xoff, aoff = 0, R * C // 2
+    qoff = aoff + R * Hd // 2
+    per = qoff + R * N // 2
+    act = torch.zeros(B * per)
+    x16 = (rnd(B * R * C, seed=7) * 1.5 + 0.7).to(torch.bfloat16)                     # a mean well away from 0: the cancellation case
+    a16 = rnd(B * R * Hd, seed=8).to(torch.bfloat16)
+    act[: B * R * C // 2] = x16.view(-1).view(torch.float32)
+    act[B * aoff: B * qoff] = a16.view(-1).view(torch.float32)
+    g1 = gemm_op(a=ref(A, aoff), w=ref(W, 0), bias=ref(W, o_b1), out=ref(A, xoff), res=ref(A, xoff), r_out=R, r_in=R,
+                 lda=Hd, cin=Hd, taps=1, n=C, ldc=C, o_rows=R, ldr=C)
+    g1.i[rt.G_WFMT] = 38
+    g2 = gemm_op(a=ref(A, xoff), w=ref(W, o_w2), bias=ref(W, o_b2), out=ref(A, qoff), p0=ref(W, o_cs), r_out=R, r_in=R,
+                 lda=C, cin=C, taps=1, n=N, ldc=N, o_rows=R)
+    g2.i[rt.G_WFMT] = 134
+    g2.f[0] = 1e-5
+    lib = rt.load_library()
+    lib.mdt_set_tuning(b"tile16", int(tile))
+    try:
+        (ga, _, _), (ca, _, _) = run_both([g1, g2], weights, act, torch.zeros(4), {}, B)
+    finally:
+        lib.mdt_set_tuning(b"tile16", -1)
+    n_x = B * R * C // 2
+    xg, xc = ga[:n_x].view(torch.bfloat16).float(), ca[:n_x].view(torch.bfloat16).float()
+    assert (xg - xc).abs().max() <= 2.0 ** -7 * max(xc.abs().max().item(), 1.0)         # the new stream: one bf16 ulp (rounding ties)
+    qg, qc = ga[B * qoff:].view(torch.bfloat16).float(), ca[B * qoff:].view(torch.bfloat16).float()
+    scale = max(qc.abs().max().item(), 1.0)
+    assert torch.isfinite(qg).all() and (qg - qc).abs().max() <= 2.0 ** -6 * scale
+    # closed form on the GPU's own stream: LayerNorm (gain, bias) then the fp32 projection
+    want = torch.nn.functional.layer_norm(xg.view(B * R, C), (C,), gam, bet, 1e-5) @ wq.T + 0.1 * rnd(N, seed=5)
+    assert (qg.view(B * R, N) - want).abs().max() <= 3e-2 * scale                        # bf16 weights and output against fp32 ones
+
+
+@pytest.mark.parametrize("tile", [-1, 0, 1, 2])
 def test_bf16_gemm_single_chunk_with_bf16_residual(tile):
     """k_gemm_b16's all-bf16 epilogue with K = 64: ONE chunk, so the residual is requested before the loop instead of two chunks
     before its end (the hand-counted vmcnt of that case); in place, ragged M, against the interpreter and the closed form."""
