@@ -231,8 +231,11 @@ enum mdt_gemm_i {
 enum mdt_gemm_f { MDT_GF_EPS = 0 };
 
 enum mdt_gn_i { MDT_N_ROWS = 0, MDT_N_LD = 1, MDT_N_GROUPS = 2, MDT_N_GSIZE = 3, MDT_N_SILU = 4,
-                MDT_N_OUT16 = 5 /* MDT_OP_GN_ACT: 1 = out is bf16 [rows][ld] (A operand of a bf16 x bf16 GEMM) */ };
-enum mdt_gn_f { MDT_NF_EPS = 0 };
+                MDT_N_OUT16 = 5, /* MDT_OP_GN_ACT: 1 = out is bf16 [rows][ld] (A operand of a bf16 x bf16 GEMM) */
+                MDT_N_CA = 6     /* MDT_OP_GN_ACT with a2 bound (round 6): the input is cat([a (CA channels, pitch CA), SCALE2 * a2 (LD - CA
+                                    channels, pitch LD - CA)]) without the concatenated tensor; CA a multiple of GSIZE.  p2 (optional,
+                                    with or without a2): also a raw bf16 copy [rows][LD] of that input */ };
+enum mdt_gn_f { MDT_NF_EPS = 0, MDT_NF_SCALE2 = 1 };
 
 enum mdt_rconv_i { MDT_R_T = 0, MDT_R_C = 1, MDT_R_LDA = 2, MDT_R_LDC = 3, MDT_R_LDR = 4, MDT_R_TAPS = 5,
                    MDT_R_GSIZE = 6 /* channels per GroupNorm group, 0 = no normalisation */, MDT_R_SILU = 7,

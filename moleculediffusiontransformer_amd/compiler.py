@@ -183,6 +183,9 @@ class UNetCompiler:
         # projection reads the RAW stream, gathers the rows' statistics from the fragments it multiplies and scales / shifts its
         # accumulators per row -- no MDT_OP_PREP16 pass in front of it.  MDT_LNFOLD=0: the PREP16 pass.
         self.lnfold = os.environ.get("MDT_LNFOLD", "1") == "1"
+        # ... and the up path's cat([x, skip]) never written in that mode: block1's GroupNorm pass reads both sources and leaves the raw
+        # bf16 copy for the to_out convolution (MDT_OP_GN_ACT with a2 / p2).  MDT_CAT_FOLD=0: k_concat + a conversion pass.
+        self.cat_fold = os.environ.get("MDT_CAT_FOLD", "1") == "1"
         self.qkv_merge = os.environ.get("MDT_QKV_MERGE", "1") == "1"   # ... and self-attention's q | k | v as one GEMM     # bf16 mode: regular layers as PREP16 + bf16 x bf16 GEMM
         self.fold_ctx = os.environ.get("MDT_FOLD_CTX", "1") == "1"
         self.has_chat = False                # some layer attends to the normalised context (ctx program emits it)
@@ -495,10 +498,12 @@ class UNetCompiler:
         return (rows * (gsize // 4) + tpg - 1) // tpg <= 32
 
     def gn_act(self, x: Ten, groups: int, gsize: int, eps: float, gain: int, nbias: int, silu: bool,
-               film=None) -> Ten:
+               film=None, x2: Optional[Ten] = None, scale2: float = 1.0, raw16: Optional[Ten] = None) -> Ten:
         """GroupNorm + FiLM + SiLU in one pass (MDT_OP_GN_ACT) -> new activated tensor (bf16 in the plain-bf16 mode: its
-        only reader is the convolution GEMM)."""
-        y = self._new16(x.rows, x.ld) if self.b16_ok(x.ld) else self._new(x.rows, x.ld, x.c)
+        only reader is the convolution GEMM).  x2 (round 6): the input is cat([x, scale2 * x2]) read from its two sources; raw16: the
+        op also leaves a raw bf16 copy of its input."""
+        ld = x.ld + (x2.ld if x2 is not None else 0)
+        y = self._new16(x.rows, ld) if self.b16_ok(ld) else self._new(x.rows, ld, ld if x2 is not None else x.c)
         op = rt.MdtOp()
         op.kind = rt.OP_GN_ACT
         op.a, op.out = x.ref(), y.ref()
@@ -506,8 +511,14 @@ class UNetCompiler:
         if isinstance(film, tuple):
             op._film = film
         i = op.i
-        i[rt.N_ROWS], i[rt.N_LD], i[rt.N_GROUPS], i[rt.N_GSIZE], i[rt.N_SILU] = x.rows, x.ld, groups, gsize, int(silu)
+        i[rt.N_ROWS], i[rt.N_LD], i[rt.N_GROUPS], i[rt.N_GSIZE], i[rt.N_SILU] = x.rows, ld, groups, gsize, int(silu)
         i[rt.N_OUT16] = int(y.b16)
+        if x2 is not None:
+            assert x2.rows == x.rows and x.ld % gsize == 0 and not x.b16 and not x2.b16
+            op.a2, i[rt.N_CA], op.f[1] = x2.ref(), x.ld, scale2
+        if raw16 is not None:
+            assert raw16.b16 and raw16.rows == x.rows and raw16.ld == ld
+            op.p2 = raw16.ref()
         op.f[0] = eps
         self._emit(op)
         return y
@@ -704,6 +715,12 @@ class UNetCompiler:
         """ResnetBlock1d on cat([xa, scale_b * xb]) (2c -> c channels); frees both inputs."""
         if xa.ld == c and xb.ld == c and groups % 2 == 0 and self.rconv_ok(xa.rows, c, 3, 2 * c // groups):
             return self._resnet_rconv(xa, xb, scale_b, p, c, groups, True)
+        if (self.cat_fold and self.gemm_mode == "bf16" and xa.ld == c and xb.ld == c and self.b16_ok(2 * c) and groups > 0
+                and c % (2 * c // groups) == 0 and self.gn_act_ok(xa.rows, 2 * c, groups, 2 * c // groups)
+                and (p + "to_out.weight") in self.sd and not self.resblock_ok(xa.rows, 2 * c, c, groups, p)):
+            # plain-bf16 mode (round 6): the concatenated tensor is never written -- block1's GroupNorm pass reads the two sources and
+            # leaves the raw bf16 copy that the to_out convolution multiplies (was: k_concat + a conversion pass, 81 / 174 us per block)
+            return self.resnet(None, p, 2 * c, c, groups, cat=(xa, xb, scale_b))
         cat = self.concat(xa, xb, scale_b)
         self._free(xa)
         self._free(xb)
@@ -790,9 +807,27 @@ class UNetCompiler:
             self._free(x)
         return y
 
-    def resnet(self, x: Ten, p: str, cin: int, cout: int, groups: int, free_input: bool = True) -> Ten:
-        """ResnetBlock1d.forward (modules.py:193-205); x has `cin` real channels."""
+    def resnet(self, x: Optional[Ten], p: str, cin: int, cout: int, groups: int, free_input: bool = True,
+               cat: Optional[Tuple[Ten, Ten, float]] = None) -> Ten:
+        """ResnetBlock1d.forward (modules.py:193-205); x has `cin` real channels.  cat = (xa, xb, scale) instead of x (resnet_cat, plain-bf16
+        mode): the block's input is cat([xa, scale * xb]), read from its sources; both are freed."""
         cin_p, cout_p = pad16(cin), pad16(cout)
+        if cat is not None:
+            xa, xb, scale_b = cat
+            g1, b1 = self._vec(p + "block1.groupnorm.weight", cin_p), self._vec(p + "block1.groupnorm.bias", cin_p)
+            x16 = self._new16(xa.rows, cin_p)
+            a1 = self.gn_act(xa, groups, cin // groups, 1e-5, g1, b1, True, x2=xb, scale2=scale_b, raw16=x16)
+            self._free(xa)
+            self._free(xb)
+            h = self._new(x16.rows, cout_p, cout)
+            self.gemm(a1, self._conv_w(p + "block1.project.weight", cin_p, cout_p), cout_p, h, cin=cin_p,
+                      bias_off=self._vec(p + "block1.project.bias", cout_p), taps=3, t_dj=1, t_off=-1)
+            self._free(a1)
+            r = self._new(x16.rows, cout_p, cout)
+            self.gemm(x16, self._conv_w(p + "to_out.weight", cin_p, cout_p), cout_p, r, cin=cin_p,
+                      bias_off=self._vec(p + "to_out.bias", cout_p))
+            self._free(x16)
+            return self._resnet_tail(h, r, None, p, cout, cout_p, groups, False)
         assert x.ld == cin_p, (p, x.ld, cin_p)
         if self.resblock_ok(x.rows, cin, cout, groups, p):
             return self.resblock(x, p, cin, cout, free_input)
@@ -824,11 +859,15 @@ class UNetCompiler:
                       bias_off=self._vec(p + "to_out.bias", cout_p))
         else:
             r = x
+        return self._resnet_tail(h, r, x, p, cout, cout_p, groups, free_input)
+
+    def _resnet_tail(self, h: Ten, r: Ten, x: Optional[Ten], p: str, cout: int, cout_p: int, groups: int, free_input: bool) -> Ten:
+        """block2 of a ResnetBlock1d (GroupNorm + FiLM + SiLU + conv) + the skip r; frees h, r (if it is not x) and x (free_input)."""
         # FiLM vectors of this block inside the shared (scale | shift) row
         ss_off = self.ss_total
         self.ss_offsets[p] = ss_off
         self.ss_total += 2 * cout_p
-        y = self._new(x.rows, cout_p, cout)
+        y = self._new(h.rows, cout_p, cout)
         g2, b2 = self._vec(p + "block2.groupnorm.weight", cout_p), self._vec(p + "block2.groupnorm.bias", cout_p)
         w2 = self._conv_w(p + "block2.project.weight", cout_p, cout_p)
         bias2 = self._vec(p + "block2.project.bias", cout_p)
@@ -845,7 +884,7 @@ class UNetCompiler:
         self._free(h)
         if r is not x:
             self._free(r)
-        if free_input:
+        if free_input and x is not None:
             self._free(x)
         return y
 

@@ -72,7 +72,11 @@ __global__ __launch_bounds__(TB) void k_gn_act(GnActArgs a) {
   const int grp = SPLIT ? blockIdx.x % a.groups : tid / tpg, u = SPLIT ? tid : tid % tpg;
   const int q4 = a.gsize / 4;                      // float4 per row of the group's channel span
   const int nf4 = a.rows * q4;                     // float4 per group
-  const float* xb = a.x + (int64_t)b * a.rows * a.ld + grp * a.gsize;
+  // two sources (round 6): a group's channels lie in x (the first ca) or in x2 (scaled), never in both (ca % gsize == 0)
+  const bool second = a.x2 != nullptr && grp * a.gsize >= a.ca;
+  const int pitch = a.x2 ? (second ? a.ld - a.ca : a.ca) : a.ld;
+  const float* xb = second ? a.x2 + (int64_t)b * a.rows * pitch + (grp * a.gsize - a.ca) : a.x + (int64_t)b * a.rows * pitch + grp * a.gsize;
+  const float in_scale = second ? a.scale2 : 1.0f;
   float* yb = a.y + (int64_t)b * a.rows * a.ld + grp * a.gsize;
   float4 v[NF4];
   float s = 0.f;
@@ -82,8 +86,15 @@ __global__ __launch_bounds__(TB) void k_gn_act(GnActArgs a) {
     v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (e < nf4) {
       const int r = e / q4, q = e - r * q4;
-      v[k] = *reinterpret_cast<const float4*>(xb + (int64_t)r * a.ld + 4 * q);
+      v[k] = *reinterpret_cast<const float4*>(xb + (int64_t)r * pitch + 4 * q);
+      if (second) { v[k].x *= in_scale; v[k].y *= in_scale; v[k].z *= in_scale; v[k].w *= in_scale; }
       s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+      if (a.raw16) {                                 // the raw input as bf16 (the A operand of the block's to_out convolution)
+        const unsigned short h0 = __builtin_bit_cast(unsigned short, (__bf16)v[k].x), h1 = __builtin_bit_cast(unsigned short, (__bf16)v[k].y);
+        const unsigned short h2 = __builtin_bit_cast(unsigned short, (__bf16)v[k].z), h3 = __builtin_bit_cast(unsigned short, (__bf16)v[k].w);
+        *reinterpret_cast<uint2*>(a.raw16 + ((int64_t)b * a.rows + r) * a.ld + grp * a.gsize + 4 * q) =
+            make_uint2(h0 | ((unsigned)h1 << 16), h2 | ((unsigned)h3 << 16));
+      }
     }
   }
   auto group_sum = [&](float val) -> float {
@@ -167,6 +178,7 @@ bool gn_act_eligible(int rows, int ld, int groups, int gsize) {
 hipError_t launch_gn_act(const GnActArgs& a, hipStream_t s) {
   if (a.batch <= 0) return hipSuccess;
   if (!gn_act_eligible(a.rows, a.ld, a.groups, a.gsize)) return hipErrorInvalidValue;
+  if (a.x2 && (a.ca <= 0 || a.ca >= a.ld || a.ca % a.gsize || a.ca % 4 || (a.ld - a.ca) % 4)) return hipErrorInvalidValue;
   const int tpg = 256 / a.groups, per = (a.rows * (a.gsize / 4) + tpg - 1) / tpg;
   const int nf4 = a.rows * (a.gsize / 4);
   if (a.groups > 1 && nf4 >= 256 && nf4 <= 2048 && (int64_t)a.batch * a.groups < 0x7fffffffLL) {

@@ -170,6 +170,10 @@ static const char* validate(const mdt_op& o, int idx, char* buf, size_t nbuf) {
       if (!mdt::gn_act_eligible(o.i[MDT_N_ROWS], o.i[MDT_N_LD], o.i[MDT_N_GROUPS], o.i[MDT_N_GSIZE]))
         return bad("shape not supported by the fused GroupNorm-apply kernel");
       if (!o.a.space || !o.out.space || !o.p0.space || !o.p1.space) return bad("missing operand");
+      if (o.a2.space && (o.i[MDT_N_CA] <= 0 || o.i[MDT_N_CA] >= o.i[MDT_N_LD] || o.i[MDT_N_CA] % o.i[MDT_N_GSIZE] || o.i[MDT_N_CA] % 4 ||
+                         (o.i[MDT_N_LD] - o.i[MDT_N_CA]) % 4))
+        return bad("two-source GroupNorm-apply: 0 < CA < LD, CA a multiple of the group size, both parts multiples of 4 channels");
+      if (!o.a2.space && o.i[MDT_N_CA]) return bad("CA without a second source");
       break;
     case MDT_OP_RCONV:
       if (!mdt::rconv_supported(o.i[MDT_R_C], o.i[MDT_R_T], o.i[MDT_R_TAPS], o.i[MDT_R_GSIZE]))
@@ -444,6 +448,7 @@ int mdt_program_run(const mdt_program* p, const mdt_bindings* bd, int32_t B, int
         a.x = ptr(o.a); a.y = ptr(o.out); a.gamma = ptr(o.p0); a.beta = ptr(o.p1); a.film = ptr(o.p3);
         a.batch = B; a.rows = o.i[MDT_N_ROWS]; a.ld = o.i[MDT_N_LD]; a.groups = o.i[MDT_N_GROUPS];
         a.gsize = o.i[MDT_N_GSIZE]; a.silu = o.i[MDT_N_SILU]; a.eps = o.f[MDT_NF_EPS]; a.out16 = o.i[MDT_N_OUT16];
+        a.x2 = ptr(o.a2); a.ca = o.i[MDT_N_CA]; a.scale2 = o.f[MDT_NF_SCALE2]; a.raw16 = reinterpret_cast<unsigned short*>(ptr(o.p2));
         if (!missing) e = mdt::launch_gn_act(a, stream);
         break;
       }

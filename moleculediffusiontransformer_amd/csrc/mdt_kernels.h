@@ -160,6 +160,12 @@ struct GnActArgs {
   int batch, rows, ld, groups, gsize, silu;
   float eps;
   int out16;   // 1: y is bf16 [rows][ld] (the A operand of a bf16 x bf16 GEMM)
+  // round 6: the input as cat([x (ca channels), scale2 * x2 (ld - ca channels)]) without the concatenated tensor (the up path's
+  // ResnetBlock1d, modules.py:828-829), and a raw bf16 copy of that input (the A operand of the block's to_out convolution)
+  const float* x2;          // or nullptr
+  int ca;
+  float scale2;
+  unsigned short* raw16;    // bf16 [rows][ld], or nullptr
 };
 bool gn_act_eligible(int rows, int ld, int groups, int gsize);
 hipError_t launch_gn_act(const GnActArgs& a, hipStream_t s);

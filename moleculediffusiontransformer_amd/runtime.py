@@ -32,7 +32,7 @@ PRO_NONE, PRO_LAYERNORM, PRO_GROUPNORM, PRO_SILU = 0, 1, 2, 3
 # integer slots (enum mdt_gemm_i etc. in mdt_hip.h)
 G_R_OUT, G_R_IN, G_LDA, G_CIN, G_TAPS, G_T_STRIDE, G_T_DJ, G_T_OFF, G_N, G_LDC, G_O_ROWS, G_O_STRIDE, \
     G_O_OFF, G_LDR, G_PRO, G_GROUPS, G_GSIZE, G_PRO_SILU, G_ACT, G_M_MODE, G_A_COL, G_O_COL, G_PHASES, G_WFMT = range(24)
-N_ROWS, N_LD, N_GROUPS, N_GSIZE, N_SILU, N_OUT16 = range(6)
+N_ROWS, N_LD, N_GROUPS, N_GSIZE, N_SILU, N_OUT16, N_CA = range(7)
 A_T, A_TK, A_HEADS, A_LDQ, A_LDKV, A_LDO, A_KV_BSTRIDE, A_OUT16, A_QCOL, A_KCOL, A_SPLIT, A_IN16 = range(12)
 C_ROWS, C_CA, C_CB = range(3)
 P_ROWS_IN, P_C_IN, P_LD_IN, P_LD_OUT, P_PATCH, P_INVERSE = range(6)

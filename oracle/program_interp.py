@@ -150,7 +150,14 @@ def run_program(ops, bufs: Buffers, B: int, n_shared_rows: int = 0) -> None:
             st[:, :, 1] = 1.0 / torch.sqrt(var + float(f[0]))
         elif op.kind == rt.OP_GN_ACT:
             rows, ld, G, gs = i[rt.N_ROWS], i[rt.N_LD], i[rt.N_GROUPS], i[rt.N_GSIZE]
-            x = bufs.view(op.a, B, B * rows * ld).view(B, rows, ld)
+            if op.a2.space != rt.SP_NONE:      # round 6: cat([a, SCALE2 * a2]) without the concatenated tensor (modules.py:828-829)
+                ca = i[rt.N_CA]
+                x = torch.cat([bufs.view(op.a, B, B * rows * ca).view(B, rows, ca),
+                               bufs.view(op.a2, B, B * rows * (ld - ca)).view(B, rows, ld - ca) * float(f[1])], dim=2)
+            else:
+                x = bufs.view(op.a, B, B * rows * ld).view(B, rows, ld)
+            if op.p2.space != rt.SP_NONE:      # ... and a raw bf16 copy of the input
+                bufs.view(op.p2, B, B * rows * ld // 2)[:] = x.contiguous().to(torch.bfloat16).view(-1).view(torch.float32)
             y = F.group_norm(x.transpose(1, 2), G, bufs.view(op.p0, B, ld), bufs.view(op.p1, B, ld), float(f[0])).transpose(1, 2)
             if op.p3.space != rt.SP_NONE:
                 ss = bufs.view(op.p3, B, 2 * ld)

@@ -963,6 +963,36 @@ def test_gn_act(B, R, C, G, film, silu, eps):
     assert (ga[B * R * C:].view(B, R, C) - h.transpose(1, 2)).abs().max() < 2e-5
 
 
+@pytest.mark.parametrize("B,R,C,G", [(5, 32, 512, 8), (37, 8, 1024, 8), (9, 64, 256, 8), (3, 4, 64, 4), (2, 16, 1024, 8)])
+def test_gn_act_on_two_sources_with_raw_copy(B, R, C, G):
+    """MDT_OP_GN_ACT, round 6: the input is cat([a, SCALE2 * a2]) read from its two sources (the up path's ResnetBlock1d, plain-bf16
+    mode), the normalised + SiLU output is bf16 and a raw bf16 copy of the input goes to p2 -- every kernel form (one workgroup per
+    (sample, group) / per sample, 256 / 1024 threads) against the interpreter and torch's GroupNorm on the concatenated tensor."""
+    ld = 2 * C
+    weights = torch.cat([1 + 0.1 * rnd(ld, seed=2), 0.1 * rnd(ld, seed=3)])
+    # per-sample arena (floats): [a (R C) | a2 (R C) | y16 (R ld / 2) | raw16 (R ld / 2)]
+    aoff, boff, yoff = 0, R * C, 2 * R * C
+    roff = yoff + R * ld // 2
+    act = torch.zeros(B * (roff + R * ld // 2))
+    xa, xb = rnd(B * R * C, seed=4) * 1.5 + 0.3, rnd(B * R * C, seed=5) * 0.8 - 0.2
+    act[: B * R * C], act[B * boff: B * yoff] = xa, xb
+    op = rt.MdtOp()
+    op.kind = rt.OP_GN_ACT
+    op.a, op.a2, op.out, op.p0, op.p1, op.p2 = ref(A, aoff), ref(A, boff), ref(A, yoff), ref(W, 0), ref(W, ld), ref(A, roff)
+    i = op.i
+    i[rt.N_ROWS], i[rt.N_LD], i[rt.N_GROUPS], i[rt.N_GSIZE], i[rt.N_SILU], i[rt.N_OUT16], i[rt.N_CA] = R, ld, G, ld // G, 1, 1, C
+    op.f[0], op.f[1] = 1e-5, 0.7071
+    (ga, _, _), (ca, _, _) = run_both([op], weights, act, torch.zeros(4), {}, B)
+    assert torch.equal(ga[: B * yoff], act[: B * yoff])                                   # the sources are untouched
+    yg, yc = ga[B * yoff: B * roff].view(torch.bfloat16).float(), ca[B * yoff: B * roff].view(torch.bfloat16).float()
+    assert (yg - yc).abs().max() <= 2.0 ** -7 * max(yc.abs().max().item(), 1.0)          # one bf16 ulp (rounding ties)
+    cat = torch.cat([xa.view(B, R, C), 0.7071 * xb.view(B, R, C)], dim=2)
+    rg = ga[B * roff:].view(torch.bfloat16)
+    assert torch.equal(rg.view(B, R, ld), cat.to(torch.bfloat16))                          # the raw copy: bit-exact bf16 of the input
+    want = torch.nn.functional.silu(torch.nn.functional.group_norm(cat.transpose(1, 2), G, weights[:ld], weights[ld:], 1e-5)).transpose(1, 2)
+    assert (yg.view(B, R, ld) - want).abs().max() <= 2.0 ** -7 * max(want.abs().max().item(), 1.0) + 2e-5
+
+
 @pytest.mark.parametrize("C,T,B,taps,gsize,silu,in_scale2", [
     (128, 16, 70, 3, 32, True, 0.7071),    # ResnetBlock1d block1 on cat([x, skip / sqrt 2]) at the 128-channel level
     (256, 4, 37, 3, 64, True, 0.7071),

@@ -119,7 +119,7 @@ def test_every_fallback_switch_matches_reference(var, value, case, monkeypatch):
         monkeypatch.setenv(*under.split("="))
     g = load_golden(f"{case}_unet.npz")
     m = make_model(case)
-    bf16 = var in ("MDT_B16", "MDT_QKV_MERGE", "MDT_RES16", "MDT_LNFOLD")
+    bf16 = var in ("MDT_B16", "MDT_QKV_MERGE", "MDT_RES16", "MDT_LNFOLD", "MDT_CAT_FOLD")
     if bf16:
         m.gemm_mode = "bf16"
     emb = m._embed(to_t(g["seq"]), DEV)

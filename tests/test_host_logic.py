@@ -520,7 +520,7 @@ FALLBACK_SWITCHES = [
     ("MDT_RES256", "1", ("cfg1",)), ("MDT_RES256", "0", ("cfg3",)), ("MDT_RES256", "whole", ("cfg1",)), ("MDT_PROJ", "0", ("cfg1", "cfg3")), ("MDT_FOLD_PATCH", "0", ("cfg3", "full")),
     ("MDT_PATCH_CONV", "0", ("cfg1", "cfg3")), ("MDT_FOLD_CTX", "0", ("cfg3",)), ("MDT_T1_FOLD", "0", ("cfg3",)), ("MDT_CTX_SPLIT", "0", ("cfg3",)),
     ("MDT_FOLD_OUT", "0", ("cfg1",)), ("MDT_QKV_MERGE", "0", ("cfg3",)), ("MDT_B16", "0", ("cfg1",)), ("MDT_CFG_DUAL", "0", ("cfg1",)),
-    ("MDT_RES16", "0", ("cfg1",)), ("MDT_LNFOLD", "0", ("cfg1",)),
+    ("MDT_RES16", "0", ("cfg1",)), ("MDT_LNFOLD", "0", ("cfg1",)), ("MDT_CAT_FOLD", "0", ("cfg1",)),
 ]
 
 
@@ -561,7 +561,7 @@ def test_every_fallback_switch_lowers_to_the_reference_result(var, value, cases,
     still reproduces the reference's U-Net output."""
     changed = False
     for case in cases:
-        mode = "bf16" if var in ("MDT_B16", "MDT_QKV_MERGE", "MDT_RES16", "MDT_LNFOLD") else "bf16x3"   # the switches of the reduced-precision mode
+        mode = "bf16" if var in ("MDT_B16", "MDT_QKV_MERGE", "MDT_RES16", "MDT_LNFOLD", "MDT_CAT_FOLD") else "bf16x3"   # the switches of the reduced-precision mode
         # "case+VAR=v": the switch acts on a form that is itself a fallback since round 6 (the two-source k_rconv launches of the up
         # path: the chains took them over) -- flipped on top of that fallback
         case, _, under = case.partition("+")
