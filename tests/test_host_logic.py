@@ -34,6 +34,30 @@ def test_c_abi_exports_every_declared_symbol():
         rt.Program([bad])
 
 
+def test_header_is_plain_c_and_the_binding_uses_its_numbers(tmp_path):
+    """include/mdt_hip.h compiles as C99 on its own (it is what a cgo / JNI / ctypes binding reads), and every enumerator the Python
+    binding mirrors (runtime.py: OP_*, G_*, N_*, F_*, ...) has the header's value."""
+    import subprocess
+    hdr = open(os.path.join(ROOT, "include", "mdt_hip.h")).read()
+    names = sorted(set(re.findall(r"\b(MDT_[A-Z0-9]+_[A-Z0-9_]+) = -?\d", hdr)))        # enumerators are written "NAME = value"
+    assert len(names) > 150
+    src = tmp_path / "h.c"
+    src.write_text('#include <stdio.h>\n#include "mdt_hip.h"\nint main(void) {\n' +
+                   "".join(f'  printf("{n} %d\\n", (int){n});\n' for n in names) + "  return 0;\n}\n")
+    exe = tmp_path / "h"
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    values = dict(line.split() for line in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    checked = 0
+    for n, v in values.items():
+        py = n[4:]                                   # MDT_G_WFMT -> G_WFMT, MDT_OP_GEMM -> OP_GEMM
+        if hasattr(rt, py) and isinstance(getattr(rt, py), int):
+            assert getattr(rt, py) == int(v), (n, v, getattr(rt, py))
+            checked += 1
+    assert checked > 100
+
+
 def test_plan_matches_reference_scalars():
     g = load_golden("scalars.npz")
     for T in (64, 100, 12):
