@@ -374,7 +374,7 @@ _RING_UNITS = ("k_tblock32", "k_rconv", "k_tf128", "k_tf256", "k_rconv_f32", "k_
 
 @pytest.fixture(scope="module")
 def ring_kernel_reports():
-    """One hipcc run per ring-kernel translation unit (build.py's flags): resource remarks + the ISA lint, in parallel."""
+    """One device-only hipcc run per ring-kernel translation unit (build.py's flags): resource remarks + the assembly for the ISA lint."""
     import shutil
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
@@ -382,9 +382,10 @@ def ring_kernel_reports():
     import isa_lint
     import kernel_resources
     from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=4) as ex:
-        res = list(ex.map(kernel_resources.resources, _RING_UNITS))
-        lint = list(ex.map(isa_lint.lint_unit, _RING_UNITS))
+    with ThreadPoolExecutor(max_workers=4) as ex:          # (one device-only compile per unit serves both)
+        both = list(ex.map(kernel_resources.resources_and_assembly, _RING_UNITS))
+    res = [b[0] for b in both]
+    lint = [isa_lint.lint_unit(u, asm=b[1]) for u, b in zip(_RING_UNITS, both)]
     return dict(zip(_RING_UNITS, res)), dict(zip(_RING_UNITS, lint))
 
 

@@ -182,9 +182,10 @@ def lint_kernel(lines):
     return sorted(set(out))
 
 
-def lint_unit(name: str, defs=()):
-    """{kernel: [violations]} for csrc/<name>.hip; also the number of ds_reads seen (so that an empty parse cannot pass)."""
-    kernels = split_kernels(assembly(name, defs))
+def lint_unit(name: str, defs=(), asm=None):
+    """{kernel: [violations]} for csrc/<name>.hip; also the number of ds_reads seen (so that an empty parse cannot pass).  asm: the
+    unit's device assembly if the caller has it already (kernel_resources.resources_and_assembly)."""
+    kernels = split_kernels(asm if asm is not None else assembly(name, defs))
     if not kernels:
         raise RuntimeError(f"no kernels found in the assembly of {name}")
     report, n_reads = {}, 0

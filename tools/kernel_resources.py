@@ -54,6 +54,30 @@ def resources(name: str, defs=()):
     return out
 
 
+def _parse_remarks(stderr: str):
+    out = []
+    for blk in re.split(r"remark: [^\n]*Function Name: ", stderr)[1:]:
+        fn = blk.split()[0]
+        vals = {}
+        for k, pat in FIELDS.items():
+            m = re.search(pat, blk)
+            vals[k] = int(m.group(1)) if m else -1
+        out.append((fn, vals))
+    return out
+
+
+def resources_and_assembly(name: str, defs=()):
+    """(resources(name), the device assembly) from ONE device-only hipcc run: what tests/test_host_logic.py's fixture needs for the
+    scratch limits and for tools/isa_lint.py (two full compiles per unit before: the CPU suite's longest step)."""
+    src, flags = flags_of(name)
+    flags = [f for f in flags if f != "-fPIC"]
+    r = subprocess.run([hipcc(), *flags, *defs, "-I", os.path.join(ROOT, "include"), "-S", "--cuda-device-only",
+                        "-Rpass-analysis=kernel-resource-usage", os.path.join(CSRC, src), "-o", "-"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(r.stderr[-3000:])
+    return _parse_remarks(r.stderr), r.stdout
+
+
 def demangle(fn: str) -> str:
     try:
         return subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", fn], capture_output=True, text=True).stdout.strip() or fn
