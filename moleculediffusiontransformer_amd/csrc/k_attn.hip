@@ -82,7 +82,7 @@ __device__ __forceinline__ void st_out16(const AttnArgs& a, int b, int h, int i,
   }
 }
 
-template <int KTM, int IN16>   // key tiles held in registers: 1 (Tk <= 16) or 4 (Tk <= 64); IN16: bit 0 = q is bf16, bit 1 = k | v are
+template <int KTM, int IN16>   // key tiles held in registers: 1 (Tk <= 16), 2 (Tk <= 32) or 4 (Tk <= 64); IN16: bit 0 = q is bf16, bit 1 = k | v are
 __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
   constexpr int D = 64;
   constexpr bool HQ = IN16 & 1, HK = (IN16 & 2) != 0;
@@ -272,6 +272,8 @@ static hipError_t launch_attn_in(const AttnArgs& a, hipStream_t s) {
   const int waves = a.batch * a.heads;
   if (a.Tk <= 16)
     hipLaunchKernelGGL((k_attn<1, IN16>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a);
+  else if (a.Tk <= 32)   // (round 6: two key tiles in registers instead of four -- 64 registers fewer, more waves per SIMD under the loads)
+    hipLaunchKernelGGL((k_attn<2, IN16>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a);
   else
     hipLaunchKernelGGL((k_attn<4, IN16>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a);
   return hipGetLastError();
