@@ -132,10 +132,12 @@ def run_program(ops, bufs: Buffers, B: int, n_shared_rows: int = 0) -> None:
                     else:
                         res = bufs.view(op.res, B, batches * o_rows * ldr).view(batches, o_rows, ldr)
                     acc = acc + res[:, orow, :n]
-                if wbase in (6, 38):           # bf16 output (ldc in bf16 elements)
-                    assert ldc == n and nph == 1
-                    o16 = acc.contiguous().to(torch.bfloat16)
-                    bufs.view(op.out, B, batches * o_rows * ldc // 2)[:] = o16.view(-1).view(torch.float32)
+                if wbase in (6, 38):           # bf16 output (ldc / o_col in bf16 elements; a column block of wider rows keeps the rest)
+                    assert nph == 1 and r_out == o_rows
+                    dst = bufs.view(op.out, B, batches * o_rows * ldc // 2)
+                    rows16 = dst.view(torch.bfloat16).view(batches, o_rows, ldc).clone()
+                    rows16[:, :, i[rt.G_O_COL]: i[rt.G_O_COL] + n] = acc.to(torch.bfloat16)
+                    dst[:] = rows16.contiguous().view(-1).view(torch.float32)
                     continue
                 out[:, orow, i[rt.G_O_COL]: i[rt.G_O_COL] + n] = acc
                 if wbase == 10:                # ... and a bf16 copy of the fp32 output (the next GEMM's A operand)

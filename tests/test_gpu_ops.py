@@ -854,6 +854,53 @@ def test_layernorm_folded_into_bf16_gemm(B, R, C, N, tile):
     assert (qg.view(B * R, N) - want).abs().max() <= 3e-2 * scale                        # bf16 weights and output against fp32 ones
 
 
+@pytest.mark.parametrize("w16", [1, 0])
+@pytest.mark.parametrize("fold", [False, True])
+def test_bf16_gemm_bf16_output_into_a_column_block(fold, w16):
+    """k_gemm_b16 with a bf16 output written into a COLUMN BLOCK of wider rows (MDT_G_O_COL, LDC > N: how q | k | v or two
+    projections can share a tensor), with GELU, through the all-bf16 epilogue and the generic one; the columns beside the block stay
+    untouched.  fold: the same with the LayerNorm folded into the GEMM (MDT_G_WFMT 134; always the all-bf16 epilogue)."""
+    if fold and not w16:
+        pytest.skip("a folded LayerNorm lives in the all-bf16 epilogue only")
+    B, R, C, N, LDC, OCOL = 41, 8, 256, 128, 320, 64
+    gam, bet = 1 + 0.2 * rnd(C, seed=2), 0.2 * rnd(C, seed=3)
+    wq = rnd(N, C, seed=4, scale=C ** -0.5)
+    w2 = ((wq * gam.unsqueeze(0)) if fold else wq).to(torch.bfloat16)
+    csum = w2.float().sum(dim=1)
+    bias = (wq @ bet if fold else torch.zeros(N)) + 0.1 * rnd(N, seed=5)
+    weights = torch.cat([w2.contiguous().view(-1).view(torch.float32), csum, bias])
+    o_cs = w2.numel() // 2
+    o_b = o_cs + N
+    # per-sample arena (floats): [x16 (R C / 2) | out16 (R LDC / 2)]
+    ooff = R * C // 2
+    act = torch.zeros(B * (ooff + R * LDC // 2))
+    x16 = (rnd(B * R * C, seed=7) * 1.2 + 0.4).to(torch.bfloat16)
+    act[: B * R * C // 2] = x16.view(-1).view(torch.float32)
+    marker16 = torch.full((B * R * LDC,), 3.0).to(torch.bfloat16)
+    act[B * ooff:] = marker16.view(-1).view(torch.float32)
+    g = gemm_op(a=ref(A, 0), w=ref(W, 0), bias=ref(W, o_b), out=ref(A, ooff), r_out=R, r_in=R, lda=C, cin=C, taps=1, n=N, ldc=LDC,
+                o_rows=R, o_col=OCOL, act=1)
+    g.i[rt.G_WFMT] = 6
+    if fold:
+        g.p0 = ref(W, o_cs)
+        g.i[rt.G_WFMT] = 134
+        g.f[0] = 1e-5
+    lib = rt.load_library()
+    lib.mdt_set_tuning(b"w16", int(w16))
+    try:
+        (ga, _, _), (ca, _, _) = run_both([g], weights, act, torch.zeros(4), {}, B)
+    finally:
+        lib.mdt_set_tuning(b"w16", 1)
+    og = ga[B * ooff:].view(torch.bfloat16).float().view(B * R, LDC)
+    oc = ca[B * ooff:].view(torch.bfloat16).float().view(B * R, LDC)
+    assert torch.equal(og[:, :OCOL], torch.full((B * R, OCOL), 3.0)) and torch.equal(og[:, OCOL + N:], torch.full((B * R, LDC - OCOL - N), 3.0))
+    assert (og - oc).abs().max() <= 2.0 ** -7 * max(oc.abs().max().item(), 1.0)
+    xin = x16.float().view(B * R, C)
+    pre = (torch.nn.functional.layer_norm(xin, (C,), gam, bet, 1e-5) @ wq.T + 0.1 * rnd(N, seed=5)) if fold else (xin @ w2.float().T + bias)
+    want = torch.nn.functional.gelu(pre)
+    assert (og[:, OCOL: OCOL + N] - want).abs().max() <= (3e-2 if fold else 2.0 ** -7) * max(want.abs().max().item(), 1.0)
+
+
 @pytest.mark.parametrize("tile", [-1, 0, 1, 2])
 def test_bf16_gemm_single_chunk_with_bf16_residual(tile):
     """k_gemm_b16's all-bf16 epilogue with K = 64: ONE chunk, so the residual is requested before the loop instead of two chunks
