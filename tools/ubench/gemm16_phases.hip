@@ -4,7 +4,7 @@
 // clock workgroup 0 ran at (s_memtime / s_memrealtime).  Results are wrong with any bit set: timing only.
 //   for b in 0 1 2 4 5 6; do hipcc -O3 -std=c++17 --offload-arch=gfx950 -DMDT_UB=$b -DMDT_UB_CLOCK -DMDT_UB_TILE3 -I moleculediffusiontransformer_amd/csrc \
 //       -I include tools/ubench/gemm16_phases.hip -o tools/ubench/bin/gemm16_phases_$b; done
-//   tools/ubench/bin/gemm16_phases_<b> [tile: -1 auto, 0 256x256, 1 256x128, 2 128x128, 3 256x256 on four waves] [out16: 1 | 0]
+//   tools/ubench/bin/gemm16_phases_<b> [tile: -1 auto, 0 256x256, 1 256x128, 2 128x128, 3 256x256 on four waves] [out16: 1 | 0] [launches per shape]
 // The loop variants profiles/r6_ubench_gemm16_phases.txt also lists (fewer fragment reads, two chunks in flight, hand double-buffered
 // fragments, no fragment reads, spread requests) were temporary edits of the kernel, measured and removed: DESIGN.md section 9.
 #include <hip/hip_runtime.h>
@@ -62,7 +62,7 @@ int main(int argc, char** argv) {
     CK(hipStreamSynchronize(s));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    const int reps = 200;
+    const int reps = argc > 3 ? atoi(argv[3]) : 200;          // (a few thousand for tools/power_clock_sampler.sh: seconds per shape)
     CK(hipEventRecord(e0, s));
     for (int i = 0; i < reps; ++i) CK(mdt::launch_gemm_b16(g, s));
     CK(hipEventRecord(e1, s));
